@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""
+Generate the golden vectors under tests/golden/ by RUNNING THE REAL REFERENCE
+(/root/reference, read-only) in the build container.  The reference never
+travels to the GPU box; only the small ``*.npz`` outputs of this script do.
+
+How the reference is imported: its sibling packages ``smqtk_core``,
+``smqtk_dataprovider`` and ``smqtk_descriptors`` are not installed and cannot
+be (no network), so in-memory module objects with those names are registered
+in ``sys.modules`` that re-export the interface-compatible classes of
+``smqtk_indexing_amd._compat``.  The reference source
+files themselves are imported unmodified from /root/reference.
+
+Inputs are produced from seeds with ``numpy.random.default_rng`` (PCG64) and
+stored explicitly when small; large inputs are stored by seed together with a
+sha256 so the tests can detect generator drift.
+
+Run:  python tests/golden/make_golden.py        (writes tests/golden/*.npz)
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SMQTK_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+
+from smqtk_indexing_amd import _compat as C  # noqa: E402
+from tests.golden import inputs as GI  # noqa: E402
+
+
+def _install_shims() -> None:
+    def mod(name: str, **attrs: object) -> types.ModuleType:
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__path__ = []  # type: ignore[attr-defined]
+        sys.modules[name] = m
+        return m
+
+    mod("smqtk_core", Configurable=C.Configurable, Pluggable=C.Pluggable)
+    mod("smqtk_core.configuration", from_config_dict=C.from_config_dict,
+        make_default_config=C.make_default_config, to_config_dict=C.to_config_dict)
+    mod("smqtk_core.dict", merge_dict=C.merge_dict)
+    mod("smqtk_dataprovider", DataElement=C.DataElement, KeyValueStore=C.KeyValueStore)
+    mod("smqtk_dataprovider.exceptions", ReadOnlyError=C.ReadOnlyError)
+    mod("smqtk_descriptors", DescriptorElement=C.DescriptorElement, DescriptorSet=C.DescriptorSet)
+    mod("smqtk_descriptors.utils", parallel_map=C.parallel_map)
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main() -> None:
+    assert not C.HAVE_SMQTK
+    _install_shims()
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.simplefilter("ignore", DeprecationWarning)
+    from smqtk_indexing.utils import bits as rbits, metrics as rmetrics
+    from smqtk_indexing.impls.hash_index.linear import LinearHashIndex
+    from smqtk_indexing.impls.lsh_functor.itq import ItqFunctor
+    from smqtk_indexing.impls.nn_index.lsh import LSHNearestNeighborIndex
+
+    from oracle import cpu_ref as O
+
+    # ---------------------------------------------------------------- G1 bits
+    rng = np.random.default_rng(101)
+    g1 = {}
+    for b in (1, 3, 64, 65, 256):
+        v = rng.random((16, b)) > 0.5
+        ints = [rbits.bit_vector_to_int_large(r) for r in v]
+        back = np.vstack([rbits.int_to_bit_vector_large(i, b) for i in ints])
+        assert (back == v).all()
+        g1[f"bits_{b}"] = v
+        g1[f"ints_{b}"] = np.array([str(i) for i in ints])
+    # test_bits.py:10-54 known answers
+    g1["kat_zero"] = rbits.int_to_bit_vector_large(0)
+    g1["kat_one"] = rbits.int_to_bit_vector_large(1)
+    g1["kat_2p256m1"] = rbits.int_to_bit_vector_large((2 ** 256) - 1)
+    g1["kat_2p512"] = rbits.int_to_bit_vector_large(2 ** 512)
+    np.savez_compressed(os.path.join(HERE, "g1_bits.npz"), **g1)
+
+    # ------------------------------------------------------------- G2 hamming
+    g2 = {}
+    for b in (64, 256, 1024):
+        w = b // 64
+        a = rng.integers(0, 2 ** 64, size=(1000, w), dtype=np.uint64)
+        c = rng.integers(0, 2 ** 64, size=(1000, w), dtype=np.uint64)
+        d = [rmetrics.hamming_distance(O.packed_to_int(x), O.packed_to_int(y))
+             for x, y in zip(a, c)]
+        g2[f"a_{b}"] = a
+        g2[f"b_{b}"] = c
+        g2[f"d_{b}"] = np.array(d, dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "g2_hamming.npz"), **g2)
+
+    # ------------------------------------------------------------ G3 ITQ hash
+    g3 = {}
+    for tag, (n, d, bits, seed) in GI.ITQ_CASES.items():
+        x32, mean, rot = GI.itq_inputs(n, d, bits, seed)
+        g3[f"{tag}_sha_x"] = sha(x32)
+        g3[f"{tag}_mean"] = mean
+        g3[f"{tag}_rot"] = rot
+        for norm in (None, 2):
+            for dt in (np.float32, np.float64):
+                f = ItqFunctor(bit_length=bits, normalize=norm)
+                f.mean_vec = mean
+                f.rotation = rot
+                x = x32.astype(dt)
+                # the reference is called one descriptor at a time (lsh.py:317)
+                codes = np.vstack([f.get_hash(r) for r in x])
+                codes_b = f.get_hash(x)                       # batched form
+                z = O.itq_z(x, mean, rot, norm)
+                key = f"{tag}_n{norm}_{np.dtype(dt).name}"
+                g3[key + "_packed"] = O.pack_bits_msb(codes)
+                g3[key + "_batched_equal"] = np.array((codes == codes_b).all())
+                g3[key + "_minabsz"] = np.abs(z).min(axis=1)
+    # test_itq.py:304-336 known answers
+    f = ItqFunctor(bit_length=1, random_seed=0)
+    f.mean_vec = np.array([0., 0.])
+    f.rotation = np.array([[1. / np.sqrt(2)], [1. / np.sqrt(2)]])
+    kat_x = np.array([[1, 1], [-1, -1], [-1, 1], [-1.001, 1], [-1, 1.001],
+                      [1, -1], [1, -1.001], [1.001, -1]], dtype=np.float64)
+    g3["kat_x"] = kat_x
+    g3["kat_bits"] = np.vstack([f.get_hash(r) for r in kat_x])
+    np.savez_compressed(os.path.join(HERE, "g3_itq_hash.npz"), **g3)
+
+    # ----------------------------------------------------- G4 LinearHashIndex
+    g4 = {}
+    for tag, (n, bits, seed, mode) in GI.HAMMING_CASES.items():
+        codes, queries = GI.hamming_inputs(n, bits, seed, mode)
+        g4[f"{tag}_sha_codes"] = sha(codes)
+        g4[f"{tag}_sha_queries"] = sha(queries)
+        idx = LinearHashIndex()
+        idx.build_index(O.unpack_bits_msb(codes, bits))
+        assert idx.count() == codes.shape[0]
+        for k in GI.HAMMING_KS[tag]:
+            near_all, dist_all = [], []
+            for q in queries:
+                rows, dists = idx.nn(O.unpack_bits_msb(q[None, :], bits)[0], k)
+                near_all.append(O.pack_bits_msb(rows))
+                dist_all.append(np.asarray(dists, dtype=np.float64))
+            g4[f"{tag}_k{k}_codes"] = np.stack(near_all)          # [nq,k,W]
+            g4[f"{tag}_k{k}_dist"] = np.stack(dist_all)           # [nq,k]
+    np.savez_compressed(os.path.join(HERE, "g4_linear_hash_nn.npz"), **g4)
+
+    # ----------------------------------------------------------- G5 dense kNN
+    g5 = {}
+    for tag, (n, d, nq, seed, dist, dt) in GI.DENSE_CASES.items():
+        db, qs = GI.dense_inputs(n, d, nq, seed, dist, dt)
+        g5[f"{tag}_sha_db"] = sha(db)
+        g5[f"{tag}_sha_q"] = sha(qs)
+        for metric, fn in (("euclidean", rmetrics.euclidean_distance),
+                           ("cosine", rmetrics.cosine_distance)):
+            nq_m = nq if metric == "euclidean" else min(nq, 4)
+            idxs, dists = [], []
+            for q in qs[:nq_m]:
+                # exactly lsh.py:475-476,511: one call per candidate row, query first
+                if metric == "euclidean":
+                    dd = np.array([fn(q, r) for r in db])
+                    assert dd.dtype == db.dtype
+                    # vectorised form of the same function agrees bit for bit
+                    assert np.array_equal(dd, fn(db, q))
+                else:
+                    dd = np.array([fn(q, r) for r in db])
+                order = sorted(range(n), key=lambda i: dd[i])[:GI.DENSE_KMAX]   # stable
+                idxs.append(np.array(order, dtype=np.int64))
+                dists.append(dd[order])
+            g5[f"{tag}_{metric}_idx"] = np.stack(idxs)
+            g5[f"{tag}_{metric}_dist"] = np.stack(dists)
+    np.savez_compressed(os.path.join(HERE, "g5_dense_nn.npz"), **g5)
+
+    # ------------------------------------------------------ G6 LSH end to end
+    g6 = {}
+    for tag, (n, d, bits, seed, metric, ns) in GI.LSH_CASES.items():
+        db, qs = GI.lsh_inputs(n, d, seed)
+        g6[f"{tag}_sha_db"] = sha(db)
+        elems = [C.DescriptorMemoryElement(i).set_vector(db[i]) for i in range(n)]
+        ftor = ItqFunctor(bit_length=bits, random_seed=0)
+        ftor.fit(elems)
+        g6[f"{tag}_mean"] = ftor.mean_vec
+        g6[f"{tag}_rot"] = np.real(ftor.rotation)
+        assert np.isrealobj(ftor.rotation) or np.abs(np.imag(ftor.rotation)).max() == 0
+        index = LSHNearestNeighborIndex(ftor, C.MemoryDescriptorSet(), C.MemoryKeyValueStore(),
+                                        LinearHashIndex(), distance_method=metric)
+        index.build_index(elems)
+        g6[f"{tag}_count"] = np.array(index.count())
+        keys = sorted(index.hash2uuids_kvstore.keys())
+        g6[f"{tag}_ncodes"] = np.array(len(keys))
+        for nn in ns:
+            uu, dd = [], []
+            for qi, q in enumerate(qs):
+                qe = C.DescriptorMemoryElement(("q", qi)).set_vector(q)
+                r, dist = index.nn(qe, nn)
+                u = np.full(nn, -1, dtype=np.int64)
+                u[:len(r)] = [e.uuid() for e in r]
+                dv = np.full(nn, np.nan, dtype=np.float64)
+                dv[:len(r)] = dist
+                uu.append(u)
+                dd.append(dv)
+            g6[f"{tag}_n{nn}_uuids"] = np.stack(uu)
+            g6[f"{tag}_n{nn}_dist"] = np.stack(dd)
+    np.savez_compressed(os.path.join(HERE, "g6_lsh_nn.npz"), **g6)
+
+    # ------------------------------------------------------------ G7 ITQ fit
+    g7 = {}
+    elems = [C.DescriptorMemoryElement(i).set_vector([-2. + i, -2. + i]) for i in range(5)]
+    f = ItqFunctor(bit_length=1, random_seed=0)
+    codes = f.fit(elems)
+    g7["kat_mean"] = f.mean_vec
+    g7["kat_rot"] = f.rotation
+    g7["kat_codes"] = codes
+    x, _ = GI.lsh_inputs(400, 32, 7)
+    elems = [C.DescriptorMemoryElement(i).set_vector(x[i]) for i in range(400)]
+    f = ItqFunctor(bit_length=16, random_seed=3, itq_iterations=10, normalize=2)
+    codes = f.fit(elems)
+    g7["r_mean"] = f.mean_vec
+    g7["r_rot"] = np.real(f.rotation)
+    g7["r_codes"] = codes
+    np.savez_compressed(os.path.join(HERE, "g7_itq_fit.npz"), **g7)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
