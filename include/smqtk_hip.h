@@ -1,0 +1,150 @@
+/*
+ * smqtk_hip.h -- C ABI of libsmqtk_hip.so, the MI355X (gfx950) kNN hot path
+ * behind SMQTK-Indexing's plugin surface.
+ *
+ * The reference (Kitware/SMQTK-Indexing v0.18.0) is pure Python and has no
+ * FFI of its own; each entry point below names the reference code whose
+ * arithmetic it replaces (paths relative to the reference root).  The only
+ * callers are the plugin classes in smqtk_indexing_amd/impls/ (through
+ * ctypes, smqtk_indexing_amd/_lib.py) -- see INTEGRATION.md for the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns SQ_OK (0) or a negative SQ_ERR_* code; the
+ *     message of the last error on the calling thread is sq_last_error().
+ *     Nothing throws across the ABI.
+ *   - `mem` says where caller buffers live: SQ_MEM_HOST (library stages them
+ *     through its own device workspace; the call is synchronous) or
+ *     SQ_MEM_DEVICE (pointers are HIP device pointers on the current device;
+ *     work is enqueued on `stream` and the call returns without syncing).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - all matrices are C-contiguous, row-major.
+ *   - hash codes are uint64[n][words], word 0 most significant, bit 0 of the
+ *     SMQTK bit vector = most significant bit of the code, code right-aligned
+ *     (smqtk_indexing/utils/bits.py:4-20; impls/lsh_functor/itq.py:46-50).
+ *   - result order is (distance ascending, then row id ascending); ids are
+ *     `id_base + local row`.  When k exceeds the number of rows the tail is
+ *     filled with id -1 and distance +inf / INT32_MAX.
+ *   - handles own device memory; they are bound to the device that was
+ *     current at create time and are freed only by *_destroy.
+ */
+#ifndef SMQTK_HIP_H
+#define SMQTK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQ_OK 0
+#define SQ_ERR_INVALID (-1)     /* bad argument */
+#define SQ_ERR_HIP (-2)         /* HIP runtime error (no device, launch failure, ...) */
+#define SQ_ERR_NOMEM (-3)       /* device allocation failed */
+#define SQ_ERR_UNSUPPORTED (-4) /* shape outside what the kernels cover */
+#define SQ_ERR_INTERNAL (-5)    /* invariant violated (bug) */
+
+#define SQ_MEM_HOST 0
+#define SQ_MEM_DEVICE 1
+
+#define SQ_METRIC_L2 0     /* utils/metrics.py:73-86 euclidean_distance */
+#define SQ_METRIC_COSINE 1 /* utils/metrics.py:89-137 cosine_distance (pos_vectors=True) */
+
+#define SQ_DTYPE_F32 0
+#define SQ_DTYPE_F64 1
+
+#define SQ_NORM_NONE (-1) /* ItqFunctor(normalize=None) */
+#define SQ_NORM_L2 2      /* ItqFunctor(normalize=2)    */
+
+#define SQ_MAX_K 16384    /* largest k one search call returns per query */
+
+typedef int64_t sq_handle_t;
+
+typedef struct sq_stats {
+    double scan_ms;        /* last search: duration of the scan kernel(s) (hipEvent, when profiling is on) */
+    double total_ms;       /* last search: whole enqueue-to-done time on the stream (when profiling is on) */
+    int64_t scan_launches; /* kernels that streamed the database in the last search */
+    int64_t candidates;    /* sum over queries of candidates the scan emitted */
+    int64_t fallback_queries; /* queries that took the exact full-keys path */
+    int64_t bytes_scanned; /* algorithmic bytes the scan streamed (rows * row bytes * passes) */
+} sq_stats_t;
+
+/* ------------------------------------------------------------------ misc */
+const char* sq_last_error(void);
+int sq_version(void);
+int sq_device_count(int* out_n);
+int sq_device_name(int device, char* out_name, int name_len, int64_t* out_total_mem, int* out_cu_count);
+/* options: "profile" (0/1: record hipEvents so sq_get_stats reports ms),
+ * "sample_stride" (0 = auto), "candidate_cap" (0 = auto),
+ * "force_fallback" (0/1: every query takes the exact full-keys path). */
+int sq_set_option(const char* name, int64_t value);
+int sq_get_stats(sq_handle_t h, sq_stats_t* out);
+
+/* ------------------------------------------------------------------- ITQ
+ * Replaces ItqFunctor.get_hash + _norm_vector applied to n descriptors
+ * (impls/lsh_functor/itq.py:172-191, 389-408) followed by
+ * bit_vector_to_int_large (utils/bits.py:4-20), i.e. the per-descriptor body
+ * of LSHNearestNeighborIndex._build_index (impls/nn_index/lsh.py:316-321):
+ *   z = (norm(x) - mean) . rotation   (float64),  bit = z >= 0
+ * x: [n][d] of x_dtype; mean: [d] f64; rotation: [d][bits] f64;
+ * out_codes: [n][ceil(bits/64)]. */
+int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d,
+                const double* mean, const double* rotation, int bits, int norm_ord,
+                uint64_t* out_codes, int mem, void* stream);
+
+/* --------------------------------------------------------------- Hamming
+ * Replaces LinearHashIndex._nn (impls/hash_index/linear.py:206-244):
+ * heapq.nsmallest over the set of unique codes keyed by
+ * metrics.hamming_distance (utils/metrics.py:140-155).  `codes` are the
+ * UNIQUE packed codes (the caller dedups, linear.py:163); with
+ * SQ_MEM_DEVICE the buffer is borrowed, not copied, and must outlive the
+ * handle. */
+int sq_hamming_create(const uint64_t* codes, int64_t n, int words, int mem,
+                      int64_t id_base, sq_handle_t* out);
+/* queries: [nq][words]; out_dist int32 [nq][k] (differing bits, NOT yet
+ * divided by the bit length -- linear.py:243 does that on the host);
+ * out_idx int64 [nq][k]. */
+int sq_hamming_search(sq_handle_t h, const uint64_t* queries, int nq, int k,
+                      int32_t* out_dist, int64_t* out_idx, int mem, void* stream);
+int sq_hamming_destroy(sq_handle_t h);
+
+/* ----------------------------------------------------------------- dense
+ * Exact brute-force kNN over a float32 matrix: the contract
+ * FaissNearestNeighborsIndex expresses through faiss "IDMap,Flat"
+ * (impls/nn_index/faiss.py:486-559, 681-701, 751-831) and the exact re-rank
+ * tail of LSHNearestNeighborIndex._nn (impls/nn_index/lsh.py:505-519):
+ * distance per row with metrics.euclidean_distance / cosine_distance, stable
+ * ascending sort, first k.  L2 distances are float32 and bit-identical to
+ * numpy's evaluation of metrics.py:86 (same subtraction, square, pairwise
+ * summation order and sqrt); cosine distances are float64.
+ * With SQ_MEM_DEVICE the matrix is borrowed (row stride d, d % 64 == 0
+ * required for borrowing; otherwise pass host memory and the library pads). */
+int sq_dense_create(const float* db, int64_t n, int d, int metric, int mem,
+                    int64_t id_base, sq_handle_t* out);
+/* queries: [nq][d] f32.  out_dist: float32 [nq][k] for SQ_METRIC_L2,
+ * float64 [nq][k] for SQ_METRIC_COSINE.  out_idx int64 [nq][k]. */
+int sq_dense_search(sq_handle_t h, const float* queries, int nq, int k,
+                    void* out_dist, int64_t* out_idx, int mem, void* stream);
+int sq_dense_destroy(sq_handle_t h);
+
+/* Distances from one query to n gathered candidate rows, in the reference's
+ * arithmetic: the `distances = list(map(comp_descr_dist, neighbor_vectors))`
+ * step of lsh.py:511.  rows: [n][d] f32; out: float32[n] (L2) or float64[n]
+ * (cosine). */
+int sq_dense_distances(const float* query, const float* rows, int64_t n, int d,
+                       int metric, void* out, int mem, void* stream);
+
+/* ----------------------------------------------------------------- merge
+ * Host-side k-way merge of per-shard top-k lists after the RCCL all-gather
+ * (BASELINE.json north_star; no reference counterpart: the reference is
+ * single-process).  dist/idx: [nshards][nq][k_in] (host memory); entries with
+ * idx < 0 are padding.  Order: (distance, id).  dist_dtype: 0 = float32,
+ * 1 = float64, 2 = int32. */
+int sq_merge_topk(const void* dist, const int64_t* idx, int dist_dtype,
+                  int nshards, int nq, int k_in, int k_out,
+                  void* out_dist, int64_t* out_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMQTK_HIP_H */

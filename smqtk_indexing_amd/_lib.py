@@ -1,0 +1,336 @@
+"""
+ctypes binding of ``libsmqtk_hip.so`` (C ABI: ``include/smqtk_hip.h``).
+
+There is deliberately NO fallback: if the shared library is missing or a call
+fails, a :class:`HipError` is raised.  Plugin classes report
+``is_usable() == False`` when the library or a GPU is absent.
+
+Buffers: host calls take C-contiguous numpy arrays; device calls take raw
+device pointers (``int``), e.g. ``torch.Tensor.data_ptr()``, plus a HIP stream
+handle (``torch.cuda.current_stream().cuda_stream``).  ctypes releases the GIL
+for the duration of every call.
+"""
+import ctypes
+import os
+import threading
+from typing import Optional, Tuple
+
+import numpy as np
+
+SQ_OK = 0
+SQ_MEM_HOST = 0
+SQ_MEM_DEVICE = 1
+SQ_METRIC_L2 = 0
+SQ_METRIC_COSINE = 1
+SQ_DTYPE_F32 = 0
+SQ_DTYPE_F64 = 1
+SQ_NORM_NONE = -1
+SQ_NORM_L2 = 2
+SQ_MAX_K = 16384
+
+LIB_NAME = "libsmqtk_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+# every symbol include/smqtk_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "sq_last_error", "sq_version", "sq_device_count", "sq_device_name",
+    "sq_set_option", "sq_get_stats", "sq_itq_hash",
+    "sq_hamming_create", "sq_hamming_search", "sq_hamming_destroy",
+    "sq_dense_create", "sq_dense_search", "sq_dense_destroy",
+    "sq_dense_distances", "sq_merge_topk",
+)
+
+
+class HipError(RuntimeError):
+    """A libsmqtk_hip call failed (or the library could not be loaded)."""
+
+
+class SqStats(ctypes.Structure):
+    _fields_ = [
+        ("scan_ms", ctypes.c_double),
+        ("total_ms", ctypes.c_double),
+        ("scan_launches", ctypes.c_int64),
+        ("candidates", ctypes.c_int64),
+        ("fallback_queries", ctypes.c_int64),
+        ("bytes_scanned", ctypes.c_int64),
+    ]
+
+
+_lib: Optional[ctypes.CDLL] = None
+_lock = threading.Lock()
+
+
+def _declare(lib: ctypes.CDLL) -> None:
+    c_int, c_i64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+    lib.sq_last_error.restype = ctypes.c_char_p
+    lib.sq_last_error.argtypes = []
+    lib.sq_version.restype = c_int
+    lib.sq_version.argtypes = []
+    lib.sq_device_count.argtypes = [ctypes.POINTER(c_int)]
+    lib.sq_device_name.argtypes = [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]
+    lib.sq_set_option.argtypes = [ctypes.c_char_p, c_i64]
+    lib.sq_get_stats.argtypes = [c_i64, ctypes.POINTER(SqStats)]
+    lib.sq_itq_hash.argtypes = [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]
+    lib.sq_hamming_create.argtypes = [c_vp, c_i64, c_int, c_int, c_i64, ctypes.POINTER(c_i64)]
+    lib.sq_hamming_search.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]
+    lib.sq_hamming_destroy.argtypes = [c_i64]
+    lib.sq_dense_create.argtypes = [c_vp, c_i64, c_int, c_int, c_int, c_i64, ctypes.POINTER(c_i64)]
+    lib.sq_dense_search.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]
+    lib.sq_dense_destroy.argtypes = [c_i64]
+    lib.sq_dense_distances.argtypes = [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]
+    lib.sq_merge_topk.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]
+    for name in EXPORTS:
+        if name not in ("sq_last_error",):
+            getattr(lib, name).restype = c_int
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (once).  Raises HipError when it is missing."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.isfile(LIB_PATH):
+                raise HipError(
+                    f"{LIB_NAME} not found at {LIB_PATH}; build it with "
+                    "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                    "`make -C smqtk_indexing_amd/csrc`")
+            try:
+                lib = ctypes.CDLL(LIB_PATH)
+            except OSError as ex:
+                raise HipError(f"cannot load {LIB_PATH}: {ex}") from ex
+            _declare(lib)
+            _lib = lib
+        return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != SQ_OK:
+        msg = load().sq_last_error()
+        raise HipError(f"{what} failed (code {rc}): {msg.decode(errors='replace') if msg else ''}")
+
+
+def library_present() -> bool:
+    return os.path.isfile(LIB_PATH)
+
+
+def device_count() -> int:
+    """Number of visible HIP devices; 0 when the library or driver is absent."""
+    if not library_present():
+        return 0
+    try:
+        lib = load()
+    except HipError:
+        return 0
+    n = ctypes.c_int(0)
+    rc = lib.sq_device_count(ctypes.byref(n))
+    return int(n.value) if rc == SQ_OK else 0
+
+
+def usable() -> bool:
+    return device_count() > 0
+
+
+def device_name(device: int = 0) -> Tuple[str, int, int]:
+    buf = ctypes.create_string_buffer(256)
+    mem = ctypes.c_int64(0)
+    cus = ctypes.c_int(0)
+    _check(load().sq_device_name(device, buf, 256, ctypes.byref(mem), ctypes.byref(cus)), "sq_device_name")
+    return buf.value.decode(), int(mem.value), int(cus.value)
+
+
+def set_option(name: str, value: int) -> None:
+    _check(load().sq_set_option(name.encode(), int(value)), f"sq_set_option({name})")
+
+
+def get_stats(handle: int) -> dict:
+    st = SqStats()
+    _check(load().sq_get_stats(handle, ctypes.byref(st)), "sq_get_stats")
+    return {k: getattr(st, k) for k, _ in SqStats._fields_}
+
+
+def _ptr(a) -> ctypes.c_void_p:
+    if isinstance(a, np.ndarray):
+        return ctypes.c_void_p(a.ctypes.data)
+    return ctypes.c_void_p(int(a))
+
+
+def _host(a: np.ndarray, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+# ----------------------------------------------------------------------- ITQ
+def itq_hash(x: np.ndarray, mean: np.ndarray, rotation: np.ndarray, norm_ord: int = SQ_NORM_NONE) -> np.ndarray:
+    """Packed codes uint64[n, ceil(bits/64)] of the rows of ``x`` (host arrays)."""
+    x = np.asarray(x)
+    if x.ndim != 2:
+        raise ValueError("x must be [n, d]")
+    if x.dtype == np.float32:
+        dt = SQ_DTYPE_F32
+    else:
+        x = x.astype(np.float64, copy=False)
+        dt = SQ_DTYPE_F64
+    x = np.ascontiguousarray(x)
+    mean = _host(mean, np.float64)
+    rotation = _host(rotation, np.float64)
+    n, d = x.shape
+    if mean.shape != (d,) or rotation.ndim != 2 or rotation.shape[0] != d:
+        raise ValueError("mean must be [d] and rotation [d, bits]")
+    bits = rotation.shape[1]
+    out = np.empty((n, (bits + 63) // 64), dtype=np.uint64)
+    if n == 0:
+        return out
+    _check(load().sq_itq_hash(_ptr(x), dt, n, d, _ptr(mean), _ptr(rotation), bits, int(norm_ord), _ptr(out),
+                              SQ_MEM_HOST, None), "sq_itq_hash")
+    return out
+
+
+def itq_hash_device(x_ptr: int, x_dtype: int, n: int, d: int, mean_ptr: int, rot_ptr: int, bits: int,
+                    norm_ord: int, out_ptr: int, stream: int = 0) -> None:
+    _check(load().sq_itq_hash(_ptr(x_ptr), x_dtype, n, d, _ptr(mean_ptr), _ptr(rot_ptr), bits, int(norm_ord),
+                              _ptr(out_ptr), SQ_MEM_DEVICE, ctypes.c_void_p(stream or None)), "sq_itq_hash")
+
+
+# ------------------------------------------------------------------- handles
+class _Handle:
+    _destroy_name = ""
+
+    def __init__(self) -> None:
+        self.handle = 0
+        self._keepalive = None
+
+    def close(self) -> None:
+        if self.handle:
+            h, self.handle = self.handle, 0
+            try:
+                getattr(load(), self._destroy_name)(h)
+            except Exception:
+                pass
+            self._keepalive = None
+
+    def __del__(self) -> None:
+        self.close()
+
+    def stats(self) -> dict:
+        return get_stats(self.handle)
+
+
+class HammingIndex(_Handle):
+    """Device-resident array of unique packed codes + top-k Hamming search."""
+    _destroy_name = "sq_hamming_destroy"
+
+    def __init__(self, codes, n: Optional[int] = None, words: Optional[int] = None, device_ptr: bool = False,
+                 id_base: int = 0, keepalive=None):
+        super().__init__()
+        if device_ptr:
+            assert n is not None and words is not None
+            ptr, mem = _ptr(codes), SQ_MEM_DEVICE
+            self._keepalive = keepalive
+        else:
+            codes = _host(codes, np.uint64)
+            if codes.ndim != 2:
+                raise ValueError("codes must be uint64[n, words]")
+            n, words = codes.shape
+            ptr, mem = _ptr(codes), SQ_MEM_HOST
+        self.n, self.words, self.id_base = int(n), int(words), int(id_base)
+        h = ctypes.c_int64(0)
+        _check(load().sq_hamming_create(ptr, self.n, self.words, mem, self.id_base, ctypes.byref(h)),
+               "sq_hamming_create")
+        self.handle = int(h.value)
+
+    def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        q = _host(queries, np.uint64)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.words:
+            raise ValueError("query code width does not match the index")
+        nq = q.shape[0]
+        dist = np.empty((nq, k), dtype=np.int32)
+        idx = np.empty((nq, k), dtype=np.int64)
+        _check(load().sq_hamming_search(self.handle, _ptr(q), nq, int(k), _ptr(dist), _ptr(idx), SQ_MEM_HOST, None),
+               "sq_hamming_search")
+        return dist, idx
+
+    def search_device(self, q_ptr: int, nq: int, k: int, out_dist_ptr: int, out_idx_ptr: int, stream: int = 0) -> None:
+        _check(load().sq_hamming_search(self.handle, _ptr(q_ptr), int(nq), int(k), _ptr(out_dist_ptr),
+                                        _ptr(out_idx_ptr), SQ_MEM_DEVICE, ctypes.c_void_p(stream or None)),
+               "sq_hamming_search")
+
+
+class DenseIndex(_Handle):
+    """Device-resident float32 matrix + exact L2 / cosine top-k search."""
+    _destroy_name = "sq_dense_destroy"
+
+    def __init__(self, db, n: Optional[int] = None, d: Optional[int] = None, metric: int = SQ_METRIC_L2,
+                 device_ptr: bool = False, id_base: int = 0, keepalive=None):
+        super().__init__()
+        if device_ptr:
+            assert n is not None and d is not None
+            ptr, mem = _ptr(db), SQ_MEM_DEVICE
+            self._keepalive = keepalive
+        else:
+            db = _host(db, np.float32)
+            if db.ndim != 2:
+                raise ValueError("db must be float32[n, d]")
+            n, d = db.shape
+            ptr, mem = _ptr(db), SQ_MEM_HOST
+        self.n, self.d, self.metric, self.id_base = int(n), int(d), int(metric), int(id_base)
+        h = ctypes.c_int64(0)
+        _check(load().sq_dense_create(ptr, self.n, self.d, self.metric, mem, self.id_base, ctypes.byref(h)),
+               "sq_dense_create")
+        self.handle = int(h.value)
+
+    @property
+    def dist_dtype(self):
+        return np.float64 if self.metric == SQ_METRIC_COSINE else np.float32
+
+    def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        q = _host(queries, np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        if q.shape[1] != self.d:
+            raise ValueError("query dimension does not match the index")
+        nq = q.shape[0]
+        dist = np.empty((nq, k), dtype=self.dist_dtype)
+        idx = np.empty((nq, k), dtype=np.int64)
+        _check(load().sq_dense_search(self.handle, _ptr(q), nq, int(k), _ptr(dist), _ptr(idx), SQ_MEM_HOST, None),
+               "sq_dense_search")
+        return dist, idx
+
+    def search_device(self, q_ptr: int, nq: int, k: int, out_dist_ptr: int, out_idx_ptr: int, stream: int = 0) -> None:
+        _check(load().sq_dense_search(self.handle, _ptr(q_ptr), int(nq), int(k), _ptr(out_dist_ptr),
+                                      _ptr(out_idx_ptr), SQ_MEM_DEVICE, ctypes.c_void_p(stream or None)),
+               "sq_dense_search")
+
+
+def dense_distances(query: np.ndarray, rows: np.ndarray, metric: int = SQ_METRIC_L2) -> np.ndarray:
+    """Reference-arithmetic distances from ``query`` to each of ``rows`` (host arrays)."""
+    q = _host(query, np.float32).reshape(-1)
+    r = _host(rows, np.float32)
+    if r.ndim != 2 or r.shape[1] != q.shape[0]:
+        raise ValueError("rows must be [n, d] with d == len(query)")
+    out = np.empty(r.shape[0], dtype=np.float64 if metric == SQ_METRIC_COSINE else np.float32)
+    if r.shape[0] == 0:
+        return out
+    _check(load().sq_dense_distances(_ptr(q), _ptr(r), r.shape[0], r.shape[1], int(metric), _ptr(out), SQ_MEM_HOST,
+                                     None), "sq_dense_distances")
+    return out
+
+
+def merge_topk(dist: np.ndarray, idx: np.ndarray, k_out: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Host merge of per-shard lists: dist/idx [nshards, nq, k_in] -> [nq, k_out]."""
+    idx = _host(idx, np.int64)
+    if dist.dtype == np.float32:
+        dt = 0
+    elif dist.dtype == np.float64:
+        dt = 1
+    elif dist.dtype == np.int32:
+        dt = 2
+    else:
+        raise ValueError("dist must be float32, float64 or int32")
+    dist = np.ascontiguousarray(dist)
+    ns, nq, k_in = dist.shape
+    od = np.empty((nq, k_out), dtype=dist.dtype)
+    oi = np.empty((nq, k_out), dtype=np.int64)
+    _check(load().sq_merge_topk(_ptr(dist), _ptr(idx), dt, ns, nq, k_in, int(k_out), _ptr(od), _ptr(oi)),
+           "sq_merge_topk")
+    return od, oi

@@ -1,0 +1,139 @@
+// Internal helpers shared by the libsmqtk_hip translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+#include "../../include/smqtk_hip.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+namespace sq {
+
+// ------------------------------------------------------------------ errors
+extern thread_local char g_err[512];
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define SQ_HIP(expr)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return sq::fail(e_ == hipErrorOutOfMemory ? SQ_ERR_NOMEM : SQ_ERR_HIP,    \
+                            "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                            __FILE__, __LINE__);                                      \
+    } while (0)
+
+#define SQ_TRY(expr)              \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != SQ_OK) return rc_; \
+    } while (0)
+
+// ----------------------------------------------------------------- options
+struct Options {
+    int profile = 0;
+    int sample_stride = 0;   // 0 = auto
+    int candidate_cap = 0;   // 0 = auto
+    int force_fallback = 0;
+    int dense_stages = 0;    // 0 = auto (LDS ring depth of the dense scan)
+    int dense_blocks = 0;    // 0 = auto (row blocks of the dense scan grid)
+    int dense_builtin_dma = 0;  // 1 = compiler-tracked LDS-DMA builtin instead of asm + counted vmcnt
+};
+extern Options g_opt;
+
+// ------------------------------------------------------- device buffer (RAII)
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return SQ_OK;
+        if (p) {
+            (void)hipFree(p);
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + (bytes >> 3) + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(SQ_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return SQ_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct HostPinned {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return SQ_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc(&p, bytes + 256, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(SQ_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        }
+        cap = bytes + 256;
+        return SQ_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// ------------------------------------------------------------------ handles
+enum HandleKind { H_HAMMING = 1, H_DENSE = 2 };
+
+struct HandleBase {
+    int kind = 0;
+    int device = 0;
+    std::mutex mu;
+    sq_stats_t stats{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    virtual ~HandleBase() {
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+
+sq_handle_t register_handle(HandleBase* h);
+HandleBase* lookup_handle(sq_handle_t id, int kind);
+HandleBase* remove_handle(sq_handle_t id, int kind);
+
+inline int cu_count(int device) {
+    static int cached[64] = {0};
+    if (device >= 0 && device < 64 && cached[device]) return cached[device];
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 256;
+    if (device >= 0 && device < 64) cached[device] = p.multiProcessorCount;
+    return p.multiProcessorCount;
+}
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace sq

@@ -1,0 +1,908 @@
+// Exact brute-force L2 / cosine top-k over a float32 descriptor matrix (gfx950).
+//
+// What it replaces: the per-candidate python distance calls + stable sort of
+// LSHNearestNeighborIndex._nn (smqtk_indexing/impls/nn_index/lsh.py:505-519)
+// and the faiss "IDMap,Flat" search + recompute of
+// FaissNearestNeighborsIndex._nn (impls/nn_index/faiss.py:751-831), both of
+// which evaluate metrics.euclidean_distance / cosine_distance
+// (utils/metrics.py:73-86, 89-137) for every row and keep the n smallest.
+//
+// Structure (DESIGN.md "dense path"):
+//   1. dense_scan_kernel      streams the matrix once per 32-query tile.  Each
+//      wave owns 32-row x 64-float units that it pulls HBM -> LDS with
+//      global_load_lds_dwordx4 into a private ring (no workgroup barrier in
+//      the loop, counted s_waitcnt vmcnt), feeds v_mfma_f32_32x32x2_f32 with
+//      A = rows (ds_read_b128, XOR-swizzled, conflict free) and B = the
+//      pre-scaled query tile held in LDS, and compares the 32x32 scores
+//      s = |x|^2 - 2 x.q (cosine: -x^.q^) with a per-query threshold.
+//      Survivors (row ids) go to per-query candidate lists.
+//      mode SAMPLE writes the raw scores of every S-th tile instead; the
+//      threshold is the ~k-th smallest sample score (kth_threshold_f32_kernel).
+//   2. dense_exact_*_kernel   recomputes the distance of every candidate in
+//      the REFERENCE arithmetic (float32 subtract, square, numpy pairwise
+//      summation order, correctly rounded sqrt; cosine in float64) and forms
+//      (distance, row) keys.
+//   3. select_topk_kernel     sorts the keys; dense_finalize_kernel converts
+//      and CERTIFIES each query: the k-th exact distance must lie below the
+//      smallest distance any non-candidate can have given the threshold and
+//      the float32 error bound of the MFMA score.  Queries that fail (or
+//      overflow their list) are redone on the exact full-keys path.
+#include "sq_pairwise.cuh"
+#include "sq_select.cuh"
+
+namespace sq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int KT = 64;                 // floats per k-unit (one 256-byte LDS bank row per matrix row)
+static constexpr int TILE_ROWS = 32;          // rows per MFMA tile / per wave unit
+static constexpr int UNIT_BYTES = TILE_ROWS * KT * 4;  // 8 KiB
+static constexpr int SCAN_WAVES = 4;
+static constexpr int EBUF_ENTRIES = 256;      // per-wave emission buffer (row, query) pairs
+static constexpr int MAX_DPAD = 512;
+
+struct DenseHandle : HandleBase {
+    const float* db = nullptr;  // device [n][ld]
+    DevBuf owned;
+    DevBuf normalized;          // cosine: rows scaled to unit length (filter operand)
+    long long n = 0;
+    int d = 0;
+    int d_pad = 0;
+    long long ld = 0;
+    int metric = SQ_METRIC_L2;
+    long long id_base = 0;
+    double xn2_max = 0.0;       // max squared row norm (error bound of the L2 filter)
+    // workspace
+    DevBuf q_dev, q_scaled, qn2, thr, cand, cnt, keys, sample, out_keys, status, out_dist_dev, out_idx_dev, big_keys,
+        scratch;
+    HostPinned status_host;
+    ~DenseHandle() override {
+        for (DevBuf* b : {&owned, &normalized, &q_dev, &q_scaled, &qn2, &thr, &cand, &cnt, &keys, &sample, &out_keys,
+                          &status, &out_dist_dev, &out_idx_dev, &big_keys, &scratch})
+            b->release();
+        status_host.release();
+    }
+};
+
+// ------------------------------------------------------- reference arithmetic
+// sum_{i<d} (x[i]-q[i])^2 exactly as numpy evaluates np.square(i - j).sum()
+// (metrics.py:86): float32 subtract, float32 square, pairwise add-reduce.
+__device__ __forceinline__ float np_sqdist_f32(const float* __restrict__ x, const float* __restrict__ q, int d, int j8) {
+    auto term = [x, q](int i) {
+        const float t = __fsub_rn(x[i], q[i]);
+        return __fmul_rn(t, t);
+    };
+    return np_pairwise_sum<float>(term, d, j8);
+}
+
+__device__ __forceinline__ float sqrt_rn_f32(float v) {
+    // correctly rounded: double sqrt is correctly rounded and 53 >= 2*24+2
+    return (float)sqrt((double)v);
+}
+
+// cosine_distance(q, x) of metrics.py:120-137 in float64, following the order
+// of scipy's C kernel behind cdist(..., 'cosine') (scipy/spatial/src/
+// distance_impl.h, scipy 1.15.3 as pinned here): sequential dot products,
+// c = u.v / (|u| |v|) clipped to [-1,1], cdist value 1 - c; the reference then
+// forms sim = 1 - cdist, clips again and returns (1+1) * arccos(sim) / pi.
+__device__ __forceinline__ double cosine_dist_f64(double dot, double nx2, double nq2) {
+    double c = __ddiv_rn(dot, __dmul_rn(sqrt(nq2), sqrt(nx2)));
+    if (fabs(c) > 1.0) c = copysign(1.0, c);
+    double dm = 1.0 - c;
+    double sim = 1.0 - dm;
+    sim = fmax(fmin(sim, 1.0), -1.0);
+    return 2.0 * acos(sim) / 3.141592653589793;
+}
+
+// One lane per row, element order 0..d-1, separate multiply and add.
+__device__ __forceinline__ double cosine_row_f64(const float* __restrict__ x, const float* __restrict__ q, int d) {
+    double dot = 0.0, nx = 0.0, nq = 0.0;
+    for (int i = 0; i < d; ++i) {
+        const double xv = (double)x[i], qq = (double)q[i];
+        dot = __dadd_rn(dot, __dmul_rn(qq, xv));
+        nx = __dadd_rn(nx, __dmul_rn(xv, xv));
+        nq = __dadd_rn(nq, __dmul_rn(qq, qq));
+    }
+    return cosine_dist_f64(dot, nx, nq);
+}
+
+// ------------------------------------------------------------- small kernels
+// Per-row squared norms -> max (as ordered float bits) and, for cosine, the
+// unit-length copy of the matrix used by the filter.
+__global__ __launch_bounds__(256) void dense_rowstats_kernel(const float* __restrict__ db, long long n, long long ld,
+                                                              int d, int d_pad, u32* __restrict__ max_bits,
+                                                              float* __restrict__ normalized) {
+    const int lane8 = threadIdx.x & 7;
+    const long long row = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const long long r = row < n ? row : n - 1;
+    const float* x = db + r * ld;
+    double acc = 0.0;
+    for (int i = lane8; i < d; i += 8) acc += (double)x[i] * (double)x[i];
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    if (row < n) {
+        if (lane8 == 0) atomicMax(max_bits, __float_as_uint((float)(acc * (1.0 + 1e-6))));
+        if (normalized) {
+            const double inv = acc > 0.0 ? 1.0 / sqrt(acc) : 0.0;
+            float* o = normalized + row * (long long)d_pad;
+            for (int i = lane8; i < d_pad; i += 8) o[i] = i < d ? (float)((double)x[i] * inv) : 0.f;
+        }
+    }
+}
+
+// Pad/copy host-layout rows [n][d] into [n][d_pad] (zero padded).
+__global__ void dense_pad_rows_kernel(const float* __restrict__ src, long long n, int d, int d_pad,
+                                      float* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * (long long)d_pad) return;
+    const long long r = i / d_pad;
+    const int c = (int)(i - r * d_pad);
+    dst[i] = c < d ? src[r * d + c] : 0.f;
+}
+
+// Query prep: scaled/padded filter operand [nq_pad][d_pad] and |q|^2 (f64).
+//   L2: -2 q        cosine: -q / |q|
+__global__ void dense_prep_queries_kernel(const float* __restrict__ q, int nq, int d, int d_pad, int nq_pad,
+                                          int metric, float* __restrict__ qs, double* __restrict__ qn2) {
+    const int qi = blockIdx.x;
+    __shared__ double red[4];
+    double acc = 0.0;
+    if (qi < nq)
+        for (int i = threadIdx.x; i < d; i += blockDim.x) acc += (double)q[(long long)qi * d + i] * (double)q[(long long)qi * d + i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+    if (threadIdx.x == 0) qn2[qi] = qi < nq ? tot : 0.0;
+    double scale = -2.0;
+    if (metric == SQ_METRIC_COSINE) scale = tot > 0.0 ? -1.0 / sqrt(tot) : 0.0;
+    for (int i = threadIdx.x; i < d_pad; i += blockDim.x) {
+        float v = 0.f;
+        if (qi < nq && i < d) v = (float)((double)q[(long long)qi * d + i] * scale);
+        qs[(long long)qi * d_pad + i] = v;
+    }
+}
+
+// ------------------------------------------------------------- the scan kernel
+struct DenseScanArgs {
+    const float* db;        // filter operand (the matrix; cosine: its normalized copy)
+    long long n;
+    long long ld;           // row stride in floats (>= d_pad readable columns)
+    int d_pad;              // multiple of KT
+    const float* qs;        // [nqt*32][d_pad] pre-scaled queries
+    const float* thr;       // [nqt*32] score thresholds (mode EMIT)
+    u32* cand;              // [nqt*32][cap] candidate row ids
+    u32* cnt;               // [nqt*32]
+    u32 cap;
+    float* sample_out;      // [nqt*32][ns] (mode SAMPLE)
+    long long ns;
+    long long tile_first, tile_step, n_tiles;  // tile i covers rows (tile_first + i*tile_step)*32 ...
+    int nqt;                // query tiles
+    int nrb;                // row blocks (multiple of 8 when nqt > 1)
+    int mode;               // 0 EMIT, 1 SAMPLE
+    int add_norm;           // 1: L2 (add |x|^2 through one extra MFMA), 0: cosine
+};
+
+// LDS-DMA: 64 lanes x 16 bytes land at lds_dst + lane*16 (wave-uniform base in
+// M0); the global source address is per lane.  Issued from inline asm so that
+// hipcc does not fence every later ds_read with vmcnt(0); completion is
+// tracked by the counted waits below (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16(const float* gsrc, u32 lds_dst) {
+    u32 keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NSTAGE>
+__device__ __forceinline__ void wait_units_in_flight(int units) {
+    // allow `units` younger 8-instruction units to stay outstanding
+    if constexpr (NSTAGE >= 4) {
+        if (units >= 3) {
+            wait_vmcnt<24>();
+            return;
+        }
+    }
+    if constexpr (NSTAGE >= 3) {
+        if (units == 2) {
+            wait_vmcnt<16>();
+            return;
+        }
+    }
+    if (units == 1)
+        wait_vmcnt<8>();
+    else
+        wait_vmcnt<0>();
+}
+
+template <int NSTAGE, bool BUILTIN_DMA>
+__global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ku = a.d_pad / KT;
+    const u32 q_bytes = (u32)TILE_ROWS * a.d_pad * 4;
+    // LDS map: [query tile][ring wave0..3][emission buffers]
+    const u32 lds_base = (u32)(uintptr_t)smem;  // low 32 bits of a flat LDS address = LDS offset
+    const u32 ring_base = lds_base + q_bytes + (u32)wave * (NSTAGE * UNIT_BYTES);
+    unsigned char* ring_ptr = smem + q_bytes + wave * (NSTAGE * UNIT_BYTES);
+    uint2* ebuf = reinterpret_cast<uint2*>(smem + q_bytes + SCAN_WAVES * NSTAGE * UNIT_BYTES) + wave * EBUF_ENTRIES;
+
+    // block -> (row block, query tile); blocks that share an XCD (same id mod 8)
+    // walk the query tiles of the same rows so the matrix is re-read from L2.
+    const int L = blockIdx.x;
+    int qt, rb;
+    if (a.nqt > 1) {
+        const int xcd = L & 7, j = L >> 3;
+        qt = j % a.nqt;
+        rb = (j / a.nqt) * 8 + xcd;
+    } else {
+        qt = 0;
+        rb = L;
+    }
+
+    // stage the query tile: [32][d_pad] floats, 16-byte chunks XOR-swizzled
+    // inside each 256-byte group by (row & 15)
+    {
+        const float* qsrc = a.qs + (long long)qt * TILE_ROWS * a.d_pad;
+        const int chunks_per_row = a.d_pad / 4;
+        for (int c = threadIdx.x; c < TILE_ROWS * chunks_per_row; c += SCAN_WAVES * 64) {
+            const int r = c / chunks_per_row, ch = c - r * chunks_per_row;
+            f32x4 v = *reinterpret_cast<const f32x4*>(qsrc + (long long)r * a.d_pad + ch * 4);
+            const int sw = (ch & ~15) | ((ch & 15) ^ (r & 15));
+            *reinterpret_cast<f32x4*>(smem + (u32)r * a.d_pad * 4 + sw * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    const long long gw = (long long)rb * SCAN_WAVES + wave;
+    const long long nwaves = (long long)a.nrb * SCAN_WAVES;
+    const long long i0 = a.n_tiles * gw / nwaves;
+    const long long i1 = a.n_tiles * (gw + 1) / nwaves;
+    const long long total_units = (i1 - i0) * ku;
+
+    const int r31 = lane & 31, h = lane >> 5;
+    const int qglob = qt * TILE_ROWS + r31;
+    const float thr_l = a.mode == 0 ? a.thr[qglob] : 0.f;
+    int ecnt = 0;  // wave-uniform number of buffered emissions
+
+    auto flush = [&]() {
+        for (int e = lane; e < ecnt; e += 64) {
+            uint2 ent = ebuf[e];
+            u32 pos = atomicAdd(&a.cnt[ent.y], 1u);
+            if (pos < a.cap) a.cand[(long long)ent.y * a.cap + pos] = ent.x;
+        }
+        ecnt = 0;
+    };
+
+    // issue cursor
+    long long iss_tile = i0;
+    int iss_kc = 0, iss_slot = 0;
+    long long issued = 0;
+    auto issue_unit = [&]() {
+        const long long row0 = (a.tile_first + iss_tile * a.tile_step) * TILE_ROWS;
+        const float* colbase = a.db + (long long)iss_kc * KT;
+        const u32 dst = ring_base + (u32)iss_slot * UNIT_BYTES;
+        unsigned char* dst_ptr = ring_ptr + iss_slot * UNIT_BYTES;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 4 * j + (lane >> 4);
+            long long row = row0 + r;
+            row = row < a.n ? row : a.n - 1;
+            const int chunk = (lane & 15) ^ (r & 15);
+            const float* src = colbase + row * a.ld + chunk * 4;
+            if constexpr (BUILTIN_DMA) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst_ptr + j * 1024), 16, 0,
+                                                 0);
+            } else {
+                glds16(src, dst + (u32)j * 1024);
+            }
+        }
+        ++issued;
+        if (++iss_kc == ku) {
+            iss_kc = 0;
+            ++iss_tile;
+        }
+        if (++iss_slot == NSTAGE) iss_slot = 0;
+    };
+
+    for (int p = 0; p < NSTAGE - 1; ++p)
+        if (issued < total_units) issue_unit();
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float nrm = 0.f;
+    long long con_tile = i0;
+    int con_kc = 0, con_slot = 0;
+
+    for (long long u = 0; u < total_units; ++u) {
+        if (issued < total_units) issue_unit();
+        if constexpr (!BUILTIN_DMA) {
+            const long long inflight = issued - u - 1;  // units younger than u
+            wait_units_in_flight<NSTAGE>((int)inflight);
+        }
+        const unsigned char* slot = ring_ptr + con_slot * UNIT_BYTES;
+        const unsigned char* arow = slot + r31 * 256;
+        const unsigned char* brow = smem + (u32)r31 * a.d_pad * 4 + con_kc * 256;
+        f32x4 av[8], bv[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int sw = ((2 * g + h) ^ (r31 & 15)) * 16;
+            av[g] = *reinterpret_cast<const f32x4*>(arow + sw);
+            bv[g] = *reinterpret_cast<const f32x4*>(brow + sw);
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][j], bv[g][j], acc, 0, 0, 0);
+                nrm = __builtin_fmaf(av[g][j], av[g][j], nrm);
+            }
+        }
+        if (++con_slot == NSTAGE) con_slot = 0;
+        if (++con_kc == ku) {
+            // tile complete
+            con_kc = 0;
+            if (a.add_norm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(nrm, 1.0f, acc, 0, 0, 0);
+            const long long row0 = (a.tile_first + con_tile * a.tile_step) * TILE_ROWS;
+            if (a.mode == 0) {
+                float m = acc[0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) m = fminf(m, acc[i]);
+                if (__any(m <= thr_l)) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        const bool p = (acc[i] <= thr_l) && (row < a.n);
+                        const u64 mask = __ballot(p);
+                        if (mask) {
+                            if (ecnt + 64 > EBUF_ENTRIES) flush();
+                            if (p) {
+                                const int off = __popcll(mask & ((1ull << lane) - 1ull));
+                                ebuf[ecnt + off] = make_uint2((u32)row, (u32)qglob);
+                            }
+                            ecnt += __popcll(mask);
+                        }
+                    }
+                }
+            } else {
+                float* so = a.sample_out + (long long)qglob * a.ns + (con_tile - 0) * TILE_ROWS;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ro = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    so[ro] = (row0 + ro < a.n) ? acc[i] : __builtin_inff();
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            nrm = 0.f;
+            ++con_tile;
+        }
+    }
+    if (a.mode == 0 && ecnt > 0) flush();
+}
+
+// ------------------------------------------------------ exact distance keys
+// Candidate j of query q (row = cand[q][j], or j itself when cand == nullptr)
+// -> key (ordered float32 euclidean distance, row).  8 lanes per candidate.
+__global__ __launch_bounds__(256) void dense_exact_l2_kernel(const float* __restrict__ db, long long ld, int d,
+                                                              const float* __restrict__ q_orig,
+                                                              const u32* __restrict__ cand, const u32* __restrict__ cnt,
+                                                              u32 cap, long long implicit_n, long long row_offset,
+                                                              u64* __restrict__ keys, long long key_stride) {
+    const int q = blockIdx.y;
+    const long long M = cand ? (long long)(cnt[q] < cap ? cnt[q] : cap) : implicit_n;
+    const int j8 = threadIdx.x & 7;
+    const float* qv = q_orig + (long long)q * d;
+    for (long long base = (long long)blockIdx.x * 32; base < M; base += (long long)gridDim.x * 32) {
+        const long long j = base + (threadIdx.x >> 3);
+        const long long jc = j < M ? j : M - 1;
+        const long long row = cand ? (long long)cand[(long long)q * cap + jc] : row_offset + jc;
+        const float s = np_sqdist_f32(db + row * ld, qv, d, j8);
+        if (j8 == 0 && j < M) {
+            const float dist = sqrt_rn_f32(s);
+            keys[(long long)q * key_stride + j] = ((u64)ordered_f32(dist) << 32) | (u64)(u32)row;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_exact_cos_kernel(const float* __restrict__ db, long long ld, int d,
+                                                               const float* __restrict__ q_orig,
+                                                               const u32* __restrict__ cand, const u32* __restrict__ cnt,
+                                                               u32 cap, long long implicit_n, long long row_offset,
+                                                               K128* __restrict__ keys, long long key_stride) {
+    const int q = blockIdx.y;
+    const long long M = cand ? (long long)(cnt[q] < cap ? cnt[q] : cap) : implicit_n;
+    const float* qv = q_orig + (long long)q * d;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < M; j += (long long)gridDim.x * 256) {
+        const long long row = cand ? (long long)cand[(long long)q * cap + j] : row_offset + j;
+        const double dist = cosine_row_f64(db + row * ld, qv, d);
+        keys[(long long)q * key_stride + j] = K128{ordered_f64(dist), (u64)(u32)row};
+    }
+}
+
+// Plain distance vectors for sq_dense_distances (one query, n gathered rows).
+__global__ __launch_bounds__(256) void dense_distances_kernel(const float* __restrict__ rows, long long n, int d,
+                                                               const float* __restrict__ q, int metric,
+                                                               float* __restrict__ out32, double* __restrict__ out64) {
+    const int j8 = threadIdx.x & 7;
+    const long long j = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const long long jc = j < n ? j : n - 1;
+    const float* x = rows + jc * d;
+    if (metric == SQ_METRIC_L2) {
+        const float s = np_sqdist_f32(x, q, d, j8);
+        if (j8 == 0 && j < n) out32[j] = sqrt_rn_f32(s);
+    } else {
+        if (j8 == 0 && j < n) out64[j] = cosine_row_f64(x, q, d);
+    }
+}
+
+// --------------------------------------------------------------- finalize
+// status bits: 1 candidate overflow, 2 certification failed, 4 fewer than kk candidates
+__global__ void dense_finalize_l2_kernel(const u64* __restrict__ sorted, const u32* __restrict__ cnt, u32 cap, int k,
+                                         int kk, long long id_base, const float* __restrict__ thr,
+                                         const double* __restrict__ qn2, double xn2_max, double eps_coef,
+                                         int certify, float* __restrict__ out_dist, long long* __restrict__ out_idx,
+                                         u32* __restrict__ status) {
+    const int q = blockIdx.x;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const u64 key = sorted[(long long)q * k + j];
+        const bool pad = key == ~0ull;
+        out_dist[(long long)q * k + j] = pad ? __builtin_inff() : unordered_f32((u32)(key >> 32));
+        out_idx[(long long)q * k + j] = pad ? -1ll : id_base + (long long)(key & 0xffffffffull);
+    }
+    if (threadIdx.x == 0) {
+        u32 st = 0;
+        if (certify) {
+            const u32 c = cnt[q];
+            if (c > cap) st |= 1u;
+            if (c < (u32)kk) st |= 4u;
+            if (st == 0) {
+                const u64 key = sorted[(long long)q * k + (kk - 1)];
+                const double dk = (double)unordered_f32((u32)(key >> 32));
+                const double t = (double)thr[q];
+                const double eps = eps_coef * (xn2_max + 2.0 * sqrt(xn2_max * qn2[q]));
+                const double lo2 = t + qn2[q] - eps;  // smallest squared distance a non-candidate can have
+                const double bound = lo2 > 0.0 ? sqrt(lo2) * (1.0 - 1e-6) : 0.0;
+                if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
+            }
+        }
+        status[q] = st;
+    }
+}
+
+__global__ void dense_finalize_cos_kernel(const K128* __restrict__ sorted, const u32* __restrict__ cnt, u32 cap,
+                                          int k, int kk, long long id_base, const float* __restrict__ thr,
+                                          double eps, int certify, double* __restrict__ out_dist,
+                                          long long* __restrict__ out_idx, u32* __restrict__ status) {
+    const int q = blockIdx.x;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const K128 key = sorted[(long long)q * k + j];
+        const bool pad = key.hi == ~0ull && key.lo == ~0ull;
+        out_dist[(long long)q * k + j] = pad ? (double)__builtin_inff() : unordered_f64(key.hi);
+        out_idx[(long long)q * k + j] = pad ? -1ll : id_base + (long long)(key.lo & 0xffffffffull);
+    }
+    if (threadIdx.x == 0) {
+        u32 st = 0;
+        if (certify) {
+            const u32 c = cnt[q];
+            if (c > cap) st |= 1u;
+            if (c < (u32)kk) st |= 4u;
+            if (st == 0) {
+                const double dk = unordered_f64(sorted[(long long)q * k + (kk - 1)].hi);
+                const double t = (double)thr[q];  // threshold on -sim~
+                // non-candidates: -sim~ > t  =>  sim < -t + eps  =>  dist > 2 acos(min(1,-t+eps))/pi
+                double smax = -t + eps;
+                smax = smax > 1.0 ? 1.0 : (smax < -1.0 ? -1.0 : smax);
+                const double bound = 2.0 * acos(smax) / 3.141592653589793 - 1e-9;
+                if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
+            }
+        }
+        status[q] = st;
+    }
+}
+
+// -------------------------------------------------------------- host driver
+static constexpr int kSelectLdsKeys64 = 16384;
+static constexpr int kSelectLdsKeys128 = 8192;
+
+template <class K>
+static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out,
+                           hipStream_t st) {
+    static bool attr_set = false;
+    const int lds_keys = sizeof(K) == 8 ? kSelectLdsKeys64 : kSelectLdsKeys128;
+    const size_t lds = (size_t)lds_keys * sizeof(K);
+    if (!attr_set) {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<K>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((select_topk_kernel<K>), dim3(nq), dim3(1024), lds, st, keys, cnt, cap, stride, k, lds_keys,
+                       out);
+    return SQ_OK;
+}
+
+template <int NSTAGE, bool BUILTIN>
+static int scan_launch_t(const DenseScanArgs& a, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<NSTAGE, BUILTIN>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dense_scan_kernel<NSTAGE, BUILTIN>), dim3((unsigned)(a.nrb * a.nqt)), dim3(SCAN_WAVES * 64),
+                       lds, st, a);
+    return SQ_OK;
+}
+
+static int scan_stages_for(int d_pad) {
+    // LDS: query tile + 4 waves * NSTAGE * 8 KiB + emission buffers <= 160 KiB
+    const int fixed = TILE_ROWS * d_pad * 4 + SCAN_WAVES * EBUF_ENTRIES * 8;
+    int ns = (160 * 1024 - fixed) / (SCAN_WAVES * UNIT_BYTES);
+    if (ns > 4) ns = 4;
+    if (g_opt.dense_stages >= 2 && g_opt.dense_stages <= ns) ns = g_opt.dense_stages;
+    return ns;
+}
+
+static int scan_launch(DenseScanArgs a, hipStream_t st) {
+    const int ns = scan_stages_for(a.d_pad);
+    if (ns < 2) return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d leaves no room for the LDS ring", a.d_pad);
+    const size_t lds = (size_t)TILE_ROWS * a.d_pad * 4 + (size_t)SCAN_WAVES * ns * UNIT_BYTES +
+                       (size_t)SCAN_WAVES * EBUF_ENTRIES * 8;
+    const bool bi = g_opt.dense_builtin_dma != 0;
+    switch (ns) {
+        case 4: return bi ? scan_launch_t<4, true>(a, lds, st) : scan_launch_t<4, false>(a, lds, st);
+        case 3: return bi ? scan_launch_t<3, true>(a, lds, st) : scan_launch_t<3, false>(a, lds, st);
+        default: return bi ? scan_launch_t<2, true>(a, lds, st) : scan_launch_t<2, false>(a, lds, st);
+    }
+}
+
+static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, void* out_dist, long long* out_idx,
+                               hipStream_t st) {
+    const long long n = h->n;
+    const int d = h->d, d_pad = h->d_pad;
+    const int kk = (int)(k < n ? k : n);
+    const bool cosine = h->metric == SQ_METRIC_COSINE;
+    const bool prof = g_opt.profile != 0;
+    const size_t key_bytes = cosine ? sizeof(K128) : sizeof(u64);
+    u32 cap = g_opt.candidate_cap > 0 ? (u32)g_opt.candidate_cap : 65536u;
+    if (cap < (u32)(4 * kk)) cap = (u32)(4 * kk);
+    const bool force_fb = g_opt.force_fallback != 0;
+    const bool small = n <= (long long)cap;
+    const bool scan_ok = d_pad <= MAX_DPAD && !small;
+    const int nqt = (nq + TILE_ROWS - 1) / TILE_ROWS;
+    const int nq_pad = nqt * TILE_ROWS;
+    h->stats = sq_stats_t{};
+    if (prof) {
+        for (auto& e : h->ev)
+            if (!e) SQ_HIP(hipEventCreate(&e));
+        SQ_HIP(hipEventRecord(h->ev[0], st));
+        SQ_HIP(hipEventRecord(h->ev[1], st));
+        SQ_HIP(hipEventRecord(h->ev[2], st));
+    }
+    SQ_TRY(h->cnt.reserve((size_t)nq_pad * 4));
+    SQ_TRY(h->thr.reserve((size_t)nq_pad * 4));
+    SQ_TRY(h->qn2.reserve((size_t)nq_pad * 8));
+    SQ_TRY(h->q_scaled.reserve((size_t)nq_pad * d_pad * 4));
+    SQ_TRY(h->out_keys.reserve((size_t)nq * k * key_bytes));
+    SQ_TRY(h->status.reserve((size_t)nq * 4));
+    SQ_TRY(h->status_host.reserve((size_t)nq * 8));
+    u32* cnt = h->cnt.as<u32>();
+    float* thr = h->thr.as<float>();
+    double* qn2 = h->qn2.as<double>();
+    float* qs = h->q_scaled.as<float>();
+    u32* status = h->status.as<u32>();
+    u32* hs = reinterpret_cast<u32*>(h->status_host.p);
+    const double eps_coef = 4.0 * (double)(d_pad + 8) * 5.9604644775390625e-08;  // 4 (d+8) 2^-24
+
+    hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, q, nq, d, d_pad, nq_pad, h->metric,
+                       qs, qn2);
+
+    const long long key_stride = small ? n : (long long)cap;
+    bool all_fallback = false;
+    if (small) {
+        // every row is a candidate: exact keys for all rows, no scan
+        SQ_TRY(h->keys.reserve((size_t)nq * key_stride * key_bytes));
+        hipLaunchKernelGGL(fill_u32_kernel, dim3((nq_pad + 255) / 256), dim3(256), 0, st, cnt, (long long)nq_pad, (u32)n);
+        unsigned gx = (unsigned)((n + 31) / 32);
+        if (gx > 4096) gx = 4096;
+        if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
+        if (cosine)
+            hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, nq), dim3(256), 0, st, h->db, h->ld, d, q, nullptr, cnt,
+                               (u32)n, n, 0ll, h->keys.as<K128>(), key_stride);
+        else
+            hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, nq), dim3(256), 0, st, h->db, h->ld, d, q, nullptr, cnt,
+                               (u32)n, n, 0ll, h->keys.as<u64>(), key_stride);
+        if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
+        h->stats.scan_launches = 1;
+        h->stats.bytes_scanned = n * (long long)d * 4;
+        if (cosine) {
+            SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, (u32)n, key_stride, k, nq, h->out_keys.as<K128>(), st));
+            hipLaunchKernelGGL(dense_finalize_cos_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<K128>(), cnt,
+                               (u32)n, k, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx, status);
+        } else {
+            SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, (u32)n, key_stride, k, nq, h->out_keys.as<u64>(), st));
+            hipLaunchKernelGGL(dense_finalize_l2_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<u64>(), cnt, (u32)n,
+                               k, kk, h->id_base, thr, qn2, 0.0, 0.0, 0, (float*)out_dist, out_idx, status);
+        }
+    } else if (scan_ok) {
+        const float* fdb = cosine ? h->normalized.as<float>() : h->db;
+        const long long fld = cosine ? (long long)d_pad : h->ld;
+        const long long n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+        long long stride = g_opt.sample_stride > 0 ? g_opt.sample_stride : (long long)cap / (8ll * kk);
+        if (stride > 64) stride = 64;
+        if (stride < 1) stride = 1;
+        while (stride > 1 && (n_tiles / stride) * TILE_ROWS < 16ll * kk) stride >>= 1;
+        const long long ns_tiles = (n_tiles + stride - 1) / stride;
+        const long long ns = ns_tiles * TILE_ROWS;
+        SQ_TRY(h->sample.reserve((size_t)nq_pad * ns * 4));
+        SQ_TRY(h->cand.reserve((size_t)nq_pad * cap * 4));
+        SQ_TRY(h->keys.reserve((size_t)nq * key_stride * key_bytes));
+        u32* cand = h->cand.as<u32>();
+        const int cus = cu_count(h->device);
+        int nrb = g_opt.dense_blocks > 0 ? g_opt.dense_blocks : cus;
+        nrb = (nrb + 7) / 8 * 8;
+        DenseScanArgs a{};
+        a.db = fdb;
+        a.n = n;
+        a.ld = fld;
+        a.d_pad = d_pad;
+        a.qs = qs;
+        a.thr = thr;
+        a.cand = cand;
+        a.cnt = cnt;
+        a.cap = cap;
+        a.sample_out = h->sample.as<float>();
+        a.ns = ns;
+        a.nqt = nqt;
+        a.add_norm = cosine ? 0 : 1;
+        // sample pass
+        a.mode = 1;
+        a.tile_first = 0;
+        a.tile_step = stride;
+        a.n_tiles = ns_tiles;
+        a.nrb = nrb;
+        if (ns_tiles < (long long)nrb * SCAN_WAVES) a.nrb = (int)(((ns_tiles + SCAN_WAVES - 1) / SCAN_WAVES + 7) / 8 * 8);
+        SQ_TRY(scan_launch(a, st));
+        hipLaunchKernelGGL(fill_f32_kernel, dim3((nq_pad + 255) / 256), dim3(256), 0, st, thr, (long long)nq_pad,
+                           -__builtin_inff());
+        hipLaunchKernelGGL(kth_threshold_f32_kernel, dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr);
+        SQ_HIP(hipMemsetAsync(cnt, 0, (size_t)nq_pad * 4, st));
+        // full pass
+        a.mode = 0;
+        a.tile_step = 1;
+        a.n_tiles = n_tiles;
+        a.nrb = nrb;
+        if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
+        SQ_TRY(scan_launch(a, st));
+        if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
+        h->stats.scan_launches = 2;
+        h->stats.bytes_scanned = n * (long long)d * 4;
+        // exact re-rank of the candidates, select, certify
+        const unsigned gx = 64;
+        if (cosine) {
+            hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, nq), dim3(256), 0, st, h->db, h->ld, d, q, cand, cnt, cap,
+                               0ll, 0ll, h->keys.as<K128>(), key_stride);
+            SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, cap, key_stride, k, nq, h->out_keys.as<K128>(), st));
+            hipLaunchKernelGGL(dense_finalize_cos_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<K128>(), cnt, cap, k,
+                               kk, h->id_base, thr, eps_coef, 1, (double*)out_dist, out_idx, status);
+        } else {
+            hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, nq), dim3(256), 0, st, h->db, h->ld, d, q, cand, cnt, cap,
+                               0ll, 0ll, h->keys.as<u64>(), key_stride);
+            SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, cap, key_stride, k, nq, h->out_keys.as<u64>(), st));
+            hipLaunchKernelGGL(dense_finalize_l2_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<u64>(), cnt, cap, k,
+                               kk, h->id_base, thr, qn2, h->xn2_max, eps_coef, 1, (float*)out_dist, out_idx, status);
+        }
+    } else {
+        all_fallback = true;  // dimension outside the MFMA scan's LDS budget: exact path for every query
+    }
+    if (prof) SQ_HIP(hipEventRecord(h->ev[3], st));
+    if (!all_fallback) {
+        SQ_HIP(hipMemcpyAsync(hs, status, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        SQ_HIP(hipMemcpyAsync(hs + nq, cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        SQ_HIP(hipStreamSynchronize(st));
+        SQ_HIP(hipGetLastError());
+        if (prof) {
+            float t1 = 0, t2 = 0;
+            SQ_HIP(hipEventElapsedTime(&t1, h->ev[1], h->ev[2]));
+            SQ_HIP(hipEventElapsedTime(&t2, h->ev[0], h->ev[3]));
+            h->stats.scan_ms = t1;
+            h->stats.total_ms = t2;
+        }
+        for (int qi = 0; qi < nq; ++qi) h->stats.candidates += hs[nq + qi];
+    }
+    // exact full-keys path, one query at a time: keys for all n rows -> radix select
+    for (int qi = 0; qi < nq; ++qi) {
+        const bool need = all_fallback || (!small && (hs[qi] != 0 || force_fb));
+        if (!need) continue;
+        h->stats.fallback_queries++;
+        SQ_TRY(h->big_keys.reserve((size_t)n * key_bytes));
+        hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, cnt + qi, 1ll, (u32)n);
+        unsigned gx = (unsigned)((n + 31) / 32);
+        if (gx > 8192) gx = 8192;
+        if (cosine) {
+            hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, 1), dim3(256), 0, st, h->db, h->ld, d,
+                               q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<K128>(), n);
+            SQ_TRY(select_launch_t<K128>(h->big_keys.as<K128>(), cnt + qi, (u32)n, n, k, 1,
+                                         h->out_keys.as<K128>() + (long long)qi * k, st));
+            hipLaunchKernelGGL(dense_finalize_cos_kernel, dim3(1), dim3(256), 0, st,
+                               h->out_keys.as<K128>() + (long long)qi * k, cnt + qi, (u32)n, k, kk, h->id_base, thr, 0.0,
+                               0, (double*)out_dist + (long long)qi * k, out_idx + (long long)qi * k, status + qi);
+        } else {
+            hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, 1), dim3(256), 0, st, h->db, h->ld, d,
+                               q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<u64>(), n);
+            SQ_TRY(select_launch_t<u64>(h->big_keys.as<u64>(), cnt + qi, (u32)n, n, k, 1,
+                                        h->out_keys.as<u64>() + (long long)qi * k, st));
+            hipLaunchKernelGGL(dense_finalize_l2_kernel, dim3(1), dim3(256), 0, st,
+                               h->out_keys.as<u64>() + (long long)qi * k, cnt + qi, (u32)n, k, kk, h->id_base, thr, qn2,
+                               0.0, 0.0, 0, (float*)out_dist + (long long)qi * k, out_idx + (long long)qi * k,
+                               status + qi);
+        }
+        h->stats.scan_launches++;
+    }
+    if (h->stats.fallback_queries) {
+        SQ_HIP(hipStreamSynchronize(st));
+        SQ_HIP(hipGetLastError());
+    }
+    return SQ_OK;
+}
+
+}  // namespace sq
+
+using namespace sq;
+
+extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, int mem, int64_t id_base,
+                               sq_handle_t* out) {
+    if (!db || !out || n <= 0 || d <= 0) return fail(SQ_ERR_INVALID, "sq_dense_create: bad argument");
+    if (metric != SQ_METRIC_L2 && metric != SQ_METRIC_COSINE)
+        return fail(SQ_ERR_INVALID, "sq_dense_create: unknown metric %d", metric);
+    if (n >= (1ll << 32)) return fail(SQ_ERR_UNSUPPORTED, "sq_dense_create: more than 2^32-1 rows per shard");
+    const int d_pad = (d + KT - 1) / KT * KT;
+    if (mem == SQ_MEM_DEVICE && d != d_pad)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_dense_create: borrowing a device matrix needs d %% 64 == 0 (d=%d)", d);
+    auto* h = new DenseHandle();
+    h->kind = H_DENSE;
+    h->n = n;
+    h->d = d;
+    h->d_pad = d_pad;
+    h->ld = d_pad;
+    h->metric = metric;
+    h->id_base = id_base;
+    if (hipGetDevice(&h->device) != hipSuccess) {
+        delete h;
+        return fail(SQ_ERR_HIP, "sq_dense_create: no HIP device");
+    }
+    auto bail = [&](int rc) {
+        delete h;
+        return rc;
+    };
+    if (mem == SQ_MEM_DEVICE) {
+        h->db = db;
+    } else {
+        const size_t bytes = (size_t)n * d_pad * 4;
+        int rc = h->owned.reserve(bytes);
+        if (rc != SQ_OK) return bail(rc);
+        hipError_t e;
+        if (d == d_pad) {
+            e = hipMemcpy(h->owned.p, db, bytes, hipMemcpyHostToDevice);
+        } else {
+            e = hipMemcpy2D(h->owned.p, (size_t)d_pad * 4, db, (size_t)d * 4, (size_t)d * 4, (size_t)n,
+                            hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                // zero the padding columns
+                e = hipMemset2D(reinterpret_cast<char*>(h->owned.p) + (size_t)d * 4, (size_t)d_pad * 4, 0,
+                                (size_t)(d_pad - d) * 4, (size_t)n);
+            }
+        }
+        if (e != hipSuccess) return bail(fail(SQ_ERR_HIP, "sq_dense_create: H2D copy failed: %s", hipGetErrorString(e)));
+        h->db = h->owned.as<float>();
+    }
+    // row statistics (+ unit-length copy for cosine)
+    {
+        int rc = h->scratch.reserve(256);
+        if (rc != SQ_OK) return bail(rc);
+        if (hipMemset(h->scratch.p, 0, 256) != hipSuccess) return bail(fail(SQ_ERR_HIP, "memset failed"));
+        float* norm = nullptr;
+        if (metric == SQ_METRIC_COSINE) {
+            rc = h->normalized.reserve((size_t)n * d_pad * 4);
+            if (rc != SQ_OK) return bail(rc);
+            norm = h->normalized.as<float>();
+        }
+        hipLaunchKernelGGL(dense_rowstats_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, 0, h->db, n, h->ld, d,
+                           d_pad, h->scratch.as<u32>(), norm);
+        u32 bits = 0;
+        hipError_t e = hipMemcpy(&bits, h->scratch.p, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return bail(fail(SQ_ERR_HIP, "sq_dense_create: row statistics failed: %s", hipGetErrorString(e)));
+        float f;
+        memcpy(&f, &bits, 4);
+        h->xn2_max = (double)f;
+    }
+    *out = register_handle(h);
+    return SQ_OK;
+}
+
+extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, int k, void* out_dist, int64_t* out_idx,
+                               int mem, void* stream) {
+    auto* h = static_cast<DenseHandle*>(lookup_handle(hid, H_DENSE));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_dense_search: unknown handle");
+    if (!queries || !out_dist || !out_idx || nq <= 0 || k <= 0) return fail(SQ_ERR_INVALID, "sq_dense_search: bad argument");
+    if (k > SQ_MAX_K) return fail(SQ_ERR_UNSUPPORTED, "sq_dense_search: k=%d exceeds SQ_MAX_K=%d", k, SQ_MAX_K);
+    if (h->metric == SQ_METRIC_COSINE && k > kSelectLdsKeys128)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_dense_search: cosine k=%d exceeds %d", k, kSelectLdsKeys128);
+    std::lock_guard<std::mutex> lock(h->mu);
+    SQ_HIP(hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t dsz = h->metric == SQ_METRIC_COSINE ? 8 : 4;
+    if (mem == SQ_MEM_DEVICE)
+        return dense_search_device(h, queries, nq, k, out_dist, reinterpret_cast<long long*>(out_idx), st);
+    const size_t qb = (size_t)nq * h->d * 4;
+    SQ_TRY(h->q_dev.reserve(qb));
+    SQ_TRY(h->out_dist_dev.reserve((size_t)nq * k * dsz));
+    SQ_TRY(h->out_idx_dev.reserve((size_t)nq * k * 8));
+    SQ_HIP(hipMemcpyAsync(h->q_dev.p, queries, qb, hipMemcpyHostToDevice, st));
+    SQ_TRY(dense_search_device(h, h->q_dev.as<float>(), nq, k, h->out_dist_dev.p, h->out_idx_dev.as<long long>(), st));
+    SQ_HIP(hipMemcpyAsync(out_dist, h->out_dist_dev.p, (size_t)nq * k * dsz, hipMemcpyDeviceToHost, st));
+    SQ_HIP(hipMemcpyAsync(out_idx, h->out_idx_dev.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+    SQ_HIP(hipStreamSynchronize(st));
+    return SQ_OK;
+}
+
+extern "C" int sq_dense_destroy(sq_handle_t hid) {
+    auto* h = remove_handle(hid, H_DENSE);
+    if (!h) return fail(SQ_ERR_INVALID, "sq_dense_destroy: unknown handle");
+    (void)hipSetDevice(h->device);
+    delete h;
+    return SQ_OK;
+}
+
+extern "C" int sq_dense_distances(const float* query, const float* rows, int64_t n, int d, int metric, void* out,
+                                  int mem, void* stream) {
+    if (!query || !rows || !out || n <= 0 || d <= 0) return fail(SQ_ERR_INVALID, "sq_dense_distances: bad argument");
+    if (metric != SQ_METRIC_L2 && metric != SQ_METRIC_COSINE) return fail(SQ_ERR_INVALID, "sq_dense_distances: unknown metric");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t osz = metric == SQ_METRIC_COSINE ? 8 : 4;
+    const unsigned gx = (unsigned)((n + 31) / 32);
+    if (mem == SQ_MEM_DEVICE) {
+        hipLaunchKernelGGL(dense_distances_kernel, dim3(gx), dim3(256), 0, st, rows, (long long)n, d, query, metric,
+                           (float*)out, (double*)out);
+        SQ_HIP(hipGetLastError());
+        return SQ_OK;
+    }
+    DevBuf dq, dr, dout;
+    int rc = SQ_OK;
+    auto done = [&](int code) {
+        dq.release();
+        dr.release();
+        dout.release();
+        return code;
+    };
+    if ((rc = dq.reserve((size_t)d * 4)) != SQ_OK) return done(rc);
+    if ((rc = dr.reserve((size_t)n * d * 4)) != SQ_OK) return done(rc);
+    if ((rc = dout.reserve((size_t)n * osz)) != SQ_OK) return done(rc);
+    if (hipMemcpyAsync(dq.p, query, (size_t)d * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(dr.p, rows, (size_t)n * d * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+        return done(fail(SQ_ERR_HIP, "sq_dense_distances: H2D copy failed"));
+    hipLaunchKernelGGL(dense_distances_kernel, dim3(gx), dim3(256), 0, st, dr.as<float>(), (long long)n, d,
+                       dq.as<float>(), metric, dout.as<float>(), dout.as<double>());
+    if (hipMemcpyAsync(out, dout.p, (size_t)n * osz, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return done(fail(SQ_ERR_HIP, "sq_dense_distances: kernel or D2H copy failed: %s",
+                         hipGetErrorString(hipGetLastError())));
+    return done(SQ_OK);
+}

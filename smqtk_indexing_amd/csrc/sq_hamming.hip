@@ -1,0 +1,486 @@
+// Hamming top-k over packed unique hash codes (gfx950).
+//
+// Replaces the hot loop of LinearHashIndex._nn
+// (smqtk_indexing/impls/hash_index/linear.py:235-240): one python call of
+// metrics.hamming_distance (utils/metrics.py:140-155) per stored code inside
+// heapq.nsmallest.  Here: one streaming pass over the code array
+// (uint64[N][W], coalesced 16-byte loads), XOR + v_bcnt popcount per
+// (code, query) with the query words in scalar registers, a per-query
+// distance threshold taken from a histogram of a 1/S sample of the codes, and
+// emission of (distance, row) keys for everything within the threshold;
+// `select_topk_kernel` then sorts the few survivors.  Integer-exact.
+#include "sq_select.cuh"
+
+namespace sq {
+
+struct HammingHandle : HandleBase {
+    const u64* codes = nullptr;  // device, [n][words]
+    DevBuf owned;                // backing store when the library owns the copy
+    long long n = 0;
+    int words = 0;
+    long long id_base = 0;
+    // workspace
+    DevBuf q_dev, keys, cnt, hist, thr, out_keys, status, out_dist_dev, out_idx_dev, big_keys;
+    HostPinned status_host;
+    ~HammingHandle() override {
+        owned.release();
+        q_dev.release();
+        keys.release();
+        cnt.release();
+        hist.release();
+        thr.release();
+        out_keys.release();
+        status.release();
+        out_dist_dev.release();
+        out_idx_dev.release();
+        big_keys.release();
+        status_host.release();
+    }
+};
+
+// ------------------------------------------------------------------ kernels
+// Row handled by register slot i of thread t in the block that starts at code bb.
+// W <= 2: every 16-byte vector load is fully coalesced across the wave (lane t
+// takes vector j*256+t of the block); wider codes stay contiguous per thread.
+template <int W, int C>
+__device__ __forceinline__ long long code_row(long long bb, int t, int i) {
+    if constexpr (W <= 2) {
+        constexpr int CPV = 2 / W;  // codes per 16-byte vector
+        return bb + ((long long)(i / CPV) * 256 + t) * CPV + (i % CPV);
+    } else {
+        return bb + (long long)t * C + i;
+    }
+}
+
+template <int W, int C>
+__device__ __forceinline__ void load_codes(const u64* __restrict__ codes, long long n, long long bb, int t,
+                                           u64 (&c)[C][W], bool (&valid)[C]) {
+    if (bb + 256ll * C <= n) {
+        if constexpr (W <= 2) {
+            constexpr int CPV = 2 / W;
+            constexpr int NV = C / CPV;
+            const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(codes + bb * W);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                ulonglong2 v = p2[j * 256 + t];
+                if constexpr (W == 1) {
+                    c[2 * j][0] = v.x;
+                    c[2 * j + 1][0] = v.y;
+                } else {
+                    c[j][0] = v.x;
+                    c[j][1] = v.y;
+                }
+            }
+        } else if constexpr ((W % 2) == 0) {
+            const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(codes + (bb + (long long)t * C) * W);
+#pragma unroll
+            for (int i = 0; i < C * W / 2; ++i) {
+                ulonglong2 v = p2[i];
+                c[(2 * i) / W][(2 * i) % W] = v.x;
+                c[(2 * i + 1) / W][(2 * i + 1) % W] = v.y;
+            }
+        } else {
+            const u64* p = codes + (bb + (long long)t * C) * W;
+#pragma unroll
+            for (int i = 0; i < C * W; ++i) c[i / W][i % W] = p[i];
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i) valid[i] = true;
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const long long r = code_row<W, C>(bb, t, i);
+            valid[i] = r < n;
+#pragma unroll
+            for (int w = 0; w < W; ++w) c[i][w] = valid[i] ? codes[r * W + w] : 0ull;
+        }
+    }
+}
+
+// mode 0: emit keys with dist <= thr[q] through per-query atomic counters.
+// mode 1: write the key of EVERY code at its own position (keys[q][row]).
+template <int W, int C>
+__global__ __launch_bounds__(256) void hamming_scan_kernel(const u64* __restrict__ codes, long long n,
+                                                            const u64* __restrict__ qs, int nq,
+                                                            const int* __restrict__ thr,
+                                                            u64* __restrict__ keys, u32* __restrict__ cnt,
+                                                            u32 cap, long long key_stride, int mode) {
+    const long long bb = (long long)blockIdx.x * 256 * C;
+    const int tid = threadIdx.x;
+    u64 c[C][W];
+    bool valid[C];
+    load_codes<W, C>(codes, n, bb, tid, c, valid);
+    for (int q = 0; q < nq; ++q) {
+        const u64* qp = qs + (long long)q * W;  // wave-uniform: scalar loads
+        u64 qw[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) qw[w] = qp[w];
+        const int t = mode == 0 ? thr[q] : 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            int dist = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) dist += __popcll(c[i][w] ^ qw[w]);
+            if (valid[i] && dist <= t) {
+                const long long row = code_row<W, C>(bb, tid, i);
+                const u64 key = ((u64)(u32)dist << 32) | (u64)(u32)row;
+                if (mode == 0) {
+                    u32 pos = atomicAdd(&cnt[q], 1u);
+                    if (pos < cap) keys[(long long)q * key_stride + pos] = key;
+                } else {
+                    keys[(long long)q * key_stride + row] = key;
+                }
+            }
+        }
+    }
+}
+
+// Generic word count (W not specialised): one code per thread.
+__global__ __launch_bounds__(256) void hamming_scan_generic_kernel(const u64* __restrict__ codes, long long n,
+                                                                    int W, const u64* __restrict__ qs, int nq,
+                                                                    const int* __restrict__ thr,
+                                                                    u64* __restrict__ keys, u32* __restrict__ cnt,
+                                                                    u32 cap, long long key_stride, int mode) {
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    const u64* cp = codes + row * W;
+    for (int q = 0; q < nq; ++q) {
+        const u64* qp = qs + (long long)q * W;
+        int dist = 0;
+        for (int w = 0; w < W; ++w) dist += __popcll(cp[w] ^ qp[w]);
+        const int t = mode == 0 ? thr[q] : 0x7fffffff;
+        if (dist <= t) {
+            const u64 key = ((u64)(u32)dist << 32) | (u64)(u32)row;
+            if (mode == 0) {
+                u32 pos = atomicAdd(&cnt[q], 1u);
+                if (pos < cap) keys[(long long)q * key_stride + pos] = key;
+            } else {
+                keys[(long long)q * key_stride + row] = key;
+            }
+        }
+    }
+}
+
+// Histogram of distances over every `block_step`-th 256*C-code block.
+// grid.y chunks the queries so the LDS histogram fits.  hist: [nq][bits+1].
+template <int W, int C>
+__global__ __launch_bounds__(256) void hamming_hist_kernel(const u64* __restrict__ codes, long long n,
+                                                            const u64* __restrict__ qs, int nq, int bits,
+                                                            u32* __restrict__ hist, int block_step, int qchunk) {
+    extern __shared__ u32 lh[];
+    const int nb = bits + 1;
+    const int q0 = blockIdx.y * qchunk;
+    const int qn = (nq - q0) < qchunk ? (nq - q0) : qchunk;
+    for (int i = threadIdx.x; i < qn * nb; i += 256) lh[i] = 0;
+    __syncthreads();
+    const long long bb = ((long long)blockIdx.x * block_step) * 256 * C;
+    if (bb < n) {
+        u64 c[C][W];
+        bool valid[C];
+        load_codes<W, C>(codes, n, bb, (int)threadIdx.x, c, valid);
+        for (int q = 0; q < qn; ++q) {
+            const u64* qp = qs + (long long)(q0 + q) * W;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                int dist = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) dist += __popcll(c[i][w] ^ qp[w]);
+                if (valid[i]) atomicAdd(&lh[q * nb + dist], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < qn * nb; i += 256)
+        if (lh[i]) atomicAdd(&hist[(long long)q0 * nb + i], lh[i]);
+}
+
+__global__ void hamming_hist_generic_kernel(const u64* __restrict__ codes, long long n, int W,
+                                            const u64* __restrict__ qs, int nq, int bits,
+                                            u32* __restrict__ hist, int block_step) {
+    const long long row = ((long long)blockIdx.x * block_step) * 256 + threadIdx.x;
+    if (row >= n) return;
+    const int nb = bits + 1;
+    const u64* cp = codes + row * W;
+    for (int q = 0; q < nq; ++q) {
+        const u64* qp = qs + (long long)q * W;
+        int dist = 0;
+        for (int w = 0; w < W; ++w) dist += __popcll(cp[w] ^ qp[w]);
+        atomicAdd(&hist[(long long)q * nb + dist], 1u);
+    }
+}
+
+// thr[q] = smallest t whose cumulative sample count reaches k (an upper bound
+// of the k-th smallest distance over the whole array); `bits` when the sample
+// holds fewer than k codes.
+__global__ void hamming_thr_kernel(const u32* __restrict__ hist, int nq, int bits, int k, int* __restrict__ thr) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const u32* h = hist + (long long)q * (bits + 1);
+    u32 c = 0;
+    int t = bits;
+    for (int b = 0; b <= bits; ++b) {
+        c += h[b];
+        if (c >= (u32)k) {
+            t = b;
+            break;
+        }
+    }
+    thr[q] = t;
+}
+
+// sorted keys -> (distance, global id); status bit0 = candidate overflow.
+__global__ void hamming_finalize_kernel(const u64* __restrict__ sorted, const u32* __restrict__ cnt, u32 cap,
+                                        int nq, int k, long long id_base, int* __restrict__ out_dist,
+                                        long long* __restrict__ out_idx, u32* __restrict__ status, int kk) {
+    const int q = blockIdx.x;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        u64 key = sorted[(long long)q * k + j];
+        bool pad = key == ~0ull;
+        out_dist[(long long)q * k + j] = pad ? 0x7fffffff : (int)(key >> 32);
+        out_idx[(long long)q * k + j] = pad ? -1ll : id_base + (long long)(key & 0xffffffffull);
+    }
+    if (threadIdx.x == 0) {
+        u32 c = cnt[q];
+        status[q] = (c > cap ? 1u : 0u) | (c < (u32)kk ? 4u : 0u);
+    }
+}
+
+// ------------------------------------------------------------- host driver
+template <int W, int C>
+static void launch_scan(const HammingHandle* h, const u64* qs, int nq, const int* thr, u64* keys, u32* cnt, u32 cap,
+                        long long key_stride, int mode, hipStream_t st) {
+    long long per_block = 256ll * C;
+    unsigned blocks = (unsigned)((h->n + per_block - 1) / per_block);
+    hipLaunchKernelGGL((hamming_scan_kernel<W, C>), dim3(blocks), dim3(256), 0, st, h->codes, h->n, qs, nq, thr, keys,
+                       cnt, cap, key_stride, mode);
+}
+
+static void scan_dispatch(const HammingHandle* h, const u64* qs, int nq, const int* thr, u64* keys, u32* cnt, u32 cap,
+                          long long key_stride, int mode, hipStream_t st) {
+    switch (h->words) {
+        case 1: launch_scan<1, 4>(h, qs, nq, thr, keys, cnt, cap, key_stride, mode, st); break;
+        case 2: launch_scan<2, 2>(h, qs, nq, thr, keys, cnt, cap, key_stride, mode, st); break;
+        case 4: launch_scan<4, 1>(h, qs, nq, thr, keys, cnt, cap, key_stride, mode, st); break;
+        default: {
+            unsigned blocks = (unsigned)((h->n + 255) / 256);
+            hipLaunchKernelGGL(hamming_scan_generic_kernel, dim3(blocks), dim3(256), 0, st, h->codes, h->n, h->words,
+                               qs, nq, thr, keys, cnt, cap, key_stride, mode);
+        }
+    }
+}
+
+template <int W, int C>
+static void launch_hist(const HammingHandle* h, const u64* qs, int nq, int bits, u32* hist, int step, hipStream_t st) {
+    long long per_block = 256ll * C;
+    long long blocks_all = (h->n + per_block - 1) / per_block;
+    unsigned blocks = (unsigned)((blocks_all + step - 1) / step);
+    int nb = bits + 1;
+    int qchunk = (48 * 1024 / 4) / nb;
+    if (qchunk < 1) qchunk = 1;
+    if (qchunk > nq) qchunk = nq;
+    unsigned gy = (unsigned)((nq + qchunk - 1) / qchunk);
+    size_t lds = (size_t)qchunk * nb * 4;
+    hipLaunchKernelGGL((hamming_hist_kernel<W, C>), dim3(blocks, gy), dim3(256), lds, st, h->codes, h->n, qs, nq, bits,
+                       hist, step, qchunk);
+}
+
+static void hist_dispatch(const HammingHandle* h, const u64* qs, int nq, int bits, u32* hist, int step,
+                          hipStream_t st) {
+    switch (h->words) {
+        case 1: launch_hist<1, 4>(h, qs, nq, bits, hist, step, st); break;
+        case 2: launch_hist<2, 2>(h, qs, nq, bits, hist, step, st); break;
+        case 4: launch_hist<4, 1>(h, qs, nq, bits, hist, step, st); break;
+        default: {
+            long long blocks_all = (h->n + 255) / 256;
+            unsigned blocks = (unsigned)((blocks_all + step - 1) / step);
+            hipLaunchKernelGGL(hamming_hist_generic_kernel, dim3(blocks), dim3(256), 0, st, h->codes, h->n, h->words,
+                               qs, nq, bits, hist, step);
+        }
+    }
+}
+
+static constexpr int kSelectLdsKeys64 = 16384;  // 128 KiB of LDS for the sort buffer
+
+static int select_launch(const u64* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, u64* out,
+                         hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)kSelectLdsKeys64 * sizeof(u64);
+    if (!attr_set) {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<u64>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((select_topk_kernel<u64>), dim3(nq), dim3(1024), lds, st, keys, cnt, cap, stride, k,
+                       kSelectLdsKeys64, out);
+    return SQ_OK;
+}
+
+static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k, int* out_dist, long long* out_idx,
+                                 hipStream_t st) {
+    const long long n = h->n;
+    const int W = h->words, bits = W * 64;
+    const int kk = (int)(k < n ? k : n);
+    const bool prof = g_opt.profile != 0;
+    u32 cap = g_opt.candidate_cap > 0 ? (u32)g_opt.candidate_cap : 65536u;
+    if (cap < (u32)(2 * kk)) cap = (u32)(2 * kk);
+    const bool small = n <= (long long)cap;
+    h->stats = sq_stats_t{};
+    if (prof) {
+        for (auto& e : h->ev)
+            if (!e) SQ_HIP(hipEventCreate(&e));
+        SQ_HIP(hipEventRecord(h->ev[0], st));
+    }
+    SQ_TRY(h->cnt.reserve((size_t)nq * 4));
+    SQ_TRY(h->thr.reserve((size_t)nq * 4));
+    SQ_TRY(h->out_keys.reserve((size_t)nq * k * 8));
+    SQ_TRY(h->status.reserve((size_t)nq * 4));
+    SQ_TRY(h->status_host.reserve((size_t)nq * 8));
+    u32* cnt = h->cnt.as<u32>();
+    int* thr = h->thr.as<int>();
+    u64* okeys = h->out_keys.as<u64>();
+    u32* status = h->status.as<u32>();
+    const long long key_stride = small ? n : (long long)cap;
+    SQ_TRY(h->keys.reserve((size_t)nq * key_stride * 8));
+    u64* keys = h->keys.as<u64>();
+    const bool force_fb = g_opt.force_fallback != 0;
+
+    if (small) {
+        hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, cnt, (long long)nq, (u32)n);
+        if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
+        scan_dispatch(h, qs, nq, thr, keys, cnt, (u32)n, key_stride, /*mode*/ 1, st);
+        if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
+        h->stats.scan_launches = 1;
+        h->stats.bytes_scanned = n * W * 8;
+        SQ_TRY(select_launch(keys, cnt, (u32)n, key_stride, k, nq, okeys, st));
+        hipLaunchKernelGGL(hamming_finalize_kernel, dim3(nq), dim3(256), 0, st, okeys, cnt, (u32)n, nq, k, h->id_base,
+                           out_dist, out_idx, status, kk);
+    } else {
+        int step = g_opt.sample_stride > 0 ? g_opt.sample_stride : 64;
+        // keep the sample comfortably larger than k
+        const long long per_block = 256ll * (W == 1 ? 4 : W == 2 ? 2 : 1);
+        const long long blocks_all = (n + per_block - 1) / per_block;
+        while (step > 1 && (blocks_all / step) * per_block < 64ll * kk) step >>= 1;
+        SQ_TRY(h->hist.reserve((size_t)nq * (bits + 1) * 4));
+        u32* hist = h->hist.as<u32>();
+        SQ_HIP(hipMemsetAsync(hist, 0, (size_t)nq * (bits + 1) * 4, st));
+        SQ_HIP(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));
+        hist_dispatch(h, qs, nq, bits, hist, step, st);
+        hipLaunchKernelGGL(hamming_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, hist, nq, bits, kk, thr);
+        if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
+        scan_dispatch(h, qs, nq, thr, keys, cnt, cap, key_stride, /*mode*/ 0, st);
+        if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
+        h->stats.scan_launches = 1;
+        h->stats.bytes_scanned = n * W * 8;
+        SQ_TRY(select_launch(keys, cnt, cap, key_stride, k, nq, okeys, st));
+        hipLaunchKernelGGL(hamming_finalize_kernel, dim3(nq), dim3(256), 0, st, okeys, cnt, cap, nq, k, h->id_base,
+                           out_dist, out_idx, status, kk);
+    }
+    if (prof) SQ_HIP(hipEventRecord(h->ev[3], st));
+    // one small D2H + sync: the host decides whether any query needs the exact path
+    u32* hs = reinterpret_cast<u32*>(h->status_host.p);
+    SQ_HIP(hipMemcpyAsync(hs, status, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    SQ_HIP(hipMemcpyAsync(hs + nq, cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    SQ_HIP(hipStreamSynchronize(st));
+    SQ_HIP(hipGetLastError());
+    if (prof) {
+        float a = 0, b = 0;
+        SQ_HIP(hipEventElapsedTime(&a, h->ev[1], h->ev[2]));
+        SQ_HIP(hipEventElapsedTime(&b, h->ev[0], h->ev[3]));
+        h->stats.scan_ms = a;
+        h->stats.total_ms = b;
+    }
+    for (int q = 0; q < nq; ++q) h->stats.candidates += hs[nq + q];
+    // exact path (candidate overflow): every key of the query, radix-selected from global memory
+    for (int q = 0; q < nq; ++q) {
+        if (!small && (hs[q] != 0 || force_fb)) {
+            h->stats.fallback_queries++;
+            SQ_TRY(h->big_keys.reserve((size_t)n * 8));
+            u64* bk = h->big_keys.as<u64>();
+            hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, cnt + q, 1ll, (u32)(n > 0xffffffffll ? 0xffffffffu : n));
+            scan_dispatch(h, qs + (long long)q * W, 1, thr, bk, cnt + q, (u32)n, n, /*mode*/ 1, st);
+            SQ_TRY(select_launch(bk, cnt + q, (u32)n, n, k, 1, okeys + (long long)q * k, st));
+            hipLaunchKernelGGL(hamming_finalize_kernel, dim3(1), dim3(256), 0, st, okeys + (long long)q * k, cnt + q,
+                               (u32)n, 1, k, h->id_base, out_dist + (long long)q * k, out_idx + (long long)q * k,
+                               status + q, kk);
+            h->stats.scan_launches++;
+        }
+    }
+    if (h->stats.fallback_queries) {
+        SQ_HIP(hipStreamSynchronize(st));
+        SQ_HIP(hipGetLastError());
+    }
+    return SQ_OK;
+}
+
+}  // namespace sq
+
+using namespace sq;
+
+extern "C" int sq_hamming_create(const uint64_t* codes, int64_t n, int words, int mem, int64_t id_base,
+                                 sq_handle_t* out) {
+    if (!codes || !out || n <= 0 || words <= 0) return fail(SQ_ERR_INVALID, "sq_hamming_create: bad argument");
+    if (n >= (1ll << 32)) return fail(SQ_ERR_UNSUPPORTED, "sq_hamming_create: more than 2^32-1 codes per shard");
+    if (words > 64) return fail(SQ_ERR_UNSUPPORTED, "sq_hamming_create: codes wider than 4096 bits");
+    auto* h = new HammingHandle();
+    h->kind = H_HAMMING;
+    h->n = n;
+    h->words = words;
+    h->id_base = id_base;
+    if (hipGetDevice(&h->device) != hipSuccess) {
+        delete h;
+        return fail(SQ_ERR_HIP, "sq_hamming_create: no HIP device");
+    }
+    if (mem == SQ_MEM_DEVICE) {
+        h->codes = reinterpret_cast<const u64*>(codes);
+    } else {
+        size_t bytes = (size_t)n * words * 8;
+        int rc = h->owned.reserve(bytes);
+        if (rc != SQ_OK) {
+            delete h;
+            return rc;
+        }
+        hipError_t e = hipMemcpy(h->owned.p, codes, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            delete h;
+            return fail(SQ_ERR_HIP, "sq_hamming_create: H2D copy failed: %s", hipGetErrorString(e));
+        }
+        h->codes = h->owned.as<u64>();
+    }
+    *out = register_handle(h);
+    return SQ_OK;
+}
+
+extern "C" int sq_hamming_search(sq_handle_t hid, const uint64_t* queries, int nq, int k, int32_t* out_dist,
+                                 int64_t* out_idx, int mem, void* stream) {
+    auto* h = static_cast<HammingHandle*>(lookup_handle(hid, H_HAMMING));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_hamming_search: unknown handle");
+    if (!queries || !out_dist || !out_idx || nq <= 0 || k <= 0)
+        return fail(SQ_ERR_INVALID, "sq_hamming_search: bad argument");
+    if (k > SQ_MAX_K) return fail(SQ_ERR_UNSUPPORTED, "sq_hamming_search: k=%d exceeds SQ_MAX_K=%d", k, SQ_MAX_K);
+    std::lock_guard<std::mutex> lock(h->mu);
+    SQ_HIP(hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (mem == SQ_MEM_DEVICE) {
+        return hamming_search_device(h, reinterpret_cast<const u64*>(queries), nq, k, out_dist,
+                                     reinterpret_cast<long long*>(out_idx), st);
+    }
+    size_t qb = (size_t)nq * h->words * 8;
+    SQ_TRY(h->q_dev.reserve(qb));
+    SQ_TRY(h->out_dist_dev.reserve((size_t)nq * k * 4));
+    SQ_TRY(h->out_idx_dev.reserve((size_t)nq * k * 8));
+    SQ_HIP(hipMemcpyAsync(h->q_dev.p, queries, qb, hipMemcpyHostToDevice, st));
+    SQ_TRY(hamming_search_device(h, h->q_dev.as<u64>(), nq, k, h->out_dist_dev.as<int>(),
+                                 h->out_idx_dev.as<long long>(), st));
+    SQ_HIP(hipMemcpyAsync(out_dist, h->out_dist_dev.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+    SQ_HIP(hipMemcpyAsync(out_idx, h->out_idx_dev.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+    SQ_HIP(hipStreamSynchronize(st));
+    return SQ_OK;
+}
+
+extern "C" int sq_hamming_destroy(sq_handle_t hid) {
+    auto* h = remove_handle(hid, H_HAMMING);
+    if (!h) return fail(SQ_ERR_INVALID, "sq_hamming_destroy: unknown handle");
+    (void)hipSetDevice(h->device);
+    delete h;
+    return SQ_OK;
+}

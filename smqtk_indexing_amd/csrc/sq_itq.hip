@@ -1,0 +1,296 @@
+// ITQ hash-code generation (gfx950): rotation + sign + MSB-first packing.
+//
+// Replaces, for n descriptors at once, ItqFunctor.get_hash
+// (smqtk_indexing/impls/lsh_functor/itq.py:389-408), its _norm_vector
+// (itq.py:172-191) and bit_vector_to_int_large (utils/bits.py:4-20), i.e. the
+// body of the hashing loop of LSHNearestNeighborIndex._build_index
+// (impls/nn_index/lsh.py:316-321):
+//     v = x / ||x||_2 (optional, in x's dtype, zero norm -> 1)
+//     z = (v - mean) . R        float64 (mean, R are float64)
+//     bit_j = z_j >= 0          (exact zero and -0.0 map to 1)
+// The contraction runs on v_mfma_f64_16x16x4_f64 (A = 16 rows x 4 k of v,
+// B = 4 k x 16 hash bits of R from LDS).  Sign bits leave the accumulators
+// through wave ballots and are packed so that hash bit 0 is the most
+// significant bit of the right-aligned uint64[W] code.
+#include "sq_common.hpp"
+#include "sq_pairwise.cuh"
+
+namespace sq {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+struct ItqArgs {
+    const void* x;
+    long long n;
+    int d;
+    const double* mean;
+    const double* rot;  // [d][bits]
+    int bits;
+    int words;          // W = ceil(bits/64)
+    int pad;            // W*64 - bits leading zero columns
+    int norm;           // SQ_NORM_NONE / SQ_NORM_L2
+    u64* out;           // [n][W]
+    int dk;             // k rows of R staged per chunk (multiple of 16)
+    int nchunks;
+    int d16;            // d rounded up to 16
+};
+
+template <class T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct Vec4<double> {
+    typedef double type __attribute__((ext_vector_type(4)));
+};
+
+__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ double div_rn(double a, double b) { return __ddiv_rn(a, b); }
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float sqrt_rn(float a) { return (float)sqrt((double)a); }
+__device__ __forceinline__ double sqrt_rn(double a) { return sqrt(a); }
+
+// CT column tiles of 16 hash bits per pass (CT*16 padded columns), RT = 16/CT
+// row tiles of 16 rows per wave.  grid.y walks groups of CT*16 columns.
+template <class T, int CT>
+__global__ __launch_bounds__(256, 1) void itq_hash_kernel(ItqArgs a) {
+    constexpr int RT = 16 / CT;
+    constexpr int NCOL = CT * 16;
+    constexpr int RSTRIDE = NCOL + 4;        // f64 per staged R row (+32 B: lanes l and l+16 hit different bank halves)
+    constexpr int ROWS_PER_WAVE = RT * 16;
+    constexpr int ROWS_PER_BLOCK = 4 * ROWS_PER_WAVE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* s_mean = reinterpret_cast<double*>(smem);                 // [d16]
+    double* s_rot = s_mean + a.d16;                                    // [dk][RSTRIDE]
+    double* s_nrm = s_rot + (size_t)a.dk * RSTRIDE;                    // [4][ROWS_PER_WAVE]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int j8 = lane & 7;
+    const T* X = reinterpret_cast<const T*>(a.x);
+    const int col0 = blockIdx.y * NCOL;      // first padded column of this group
+
+    for (int i = threadIdx.x; i < a.d16; i += 256) s_mean[i] = i < a.d ? a.mean[i] : 0.0;
+
+    auto stage_rot = [&](int chunk) {
+        const int k0 = chunk * a.dk;
+        for (int e = threadIdx.x; e < a.dk * NCOL; e += 256) {
+            const int kr = e / NCOL, pc = e - kr * NCOL;
+            const int k = k0 + kr;
+            const int b = col0 + pc - a.pad;
+            double v = 0.0;
+            if (k < a.d && b >= 0 && b < a.bits) v = a.rot[(long long)k * a.bits + b];
+            s_rot[kr * RSTRIDE + pc] = v;
+        }
+    };
+    if (a.nchunks == 1) stage_rot(0);
+    __syncthreads();
+
+    const long long nblocks = (a.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const long long wrow0 = blk * ROWS_PER_BLOCK + (long long)wave * ROWS_PER_WAVE;
+        // ---- row norms in numpy's arithmetic (itq.py:185: np.linalg.norm(v, 2, axis, keepdims))
+        if (a.norm == SQ_NORM_L2) {
+            for (int rr = 0; rr < ROWS_PER_WAVE; rr += 8) {
+                const int rloc = rr + (lane >> 3);
+                long long row = wrow0 + rloc;
+                row = row < a.n ? row : a.n - 1;
+                const T* xr = X + row * a.d;
+                auto term = [xr](int i) { return mul_rn(xr[i], xr[i]); };
+                T s = np_pairwise_sum<T>(term, a.d, j8);
+                T nv = sqrt_rn(s);
+                if (nv == (T)0) nv = (T)1;
+                if (j8 == 0) s_nrm[wave * ROWS_PER_WAVE + rloc] = (double)nv;
+            }
+        }
+        f64x4 acc[RT][CT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f64x4{0.0, 0.0, 0.0, 0.0};
+        T nrm_l[RT];
+        const T* xrow[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            long long row = wrow0 + rt * 16 + l15;
+            row = row < a.n ? row : a.n - 1;
+            xrow[rt] = X + row * a.d;
+            nrm_l[rt] = a.norm == SQ_NORM_L2 ? (T)s_nrm[wave * ROWS_PER_WAVE + rt * 16 + l15] : (T)1;
+        }
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+            if (a.nchunks > 1) {
+                __syncthreads();
+                stage_rot(chunk);
+                __syncthreads();
+            }
+            const int k0 = chunk * a.dk;
+            for (int c = 0; c < a.dk; c += 16) {
+                const int kb = k0 + c + 4 * g;  // this lane's 4 consecutive k
+                if (k0 + c >= a.d16) break;
+                double av[RT][4];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = kb + j;
+                        double v = 0.0;
+                        if (k < a.d) {
+                            T xv = xrow[rt][k];
+                            if (a.norm == SQ_NORM_L2) xv = div_rn(xv, nrm_l[rt]);
+                            v = __dsub_rn((double)xv, s_mean[k]);
+                        }
+                        av[rt][j] = v;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double* brow = s_rot + (size_t)(c + 4 * g + j) * RSTRIDE + l15;
+                    double bv[CT];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) bv[ct] = brow[ct * 16];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt][j], bv[ct], acc[rt][ct], 0, 0, 0);
+                }
+            }
+        }
+        // ---- sign bits -> packed words.  D layout: col = lane&15, row = (lane>>4) + 4*reg
+        constexpr int WPG = (CT + 3) / 4;  // words per column group
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            u64 cw[4][WPG];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int w = 0; w < WPG; ++w) cw[r][w] = 0ull;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const u64 m = __ballot(acc[rt][ct][r] >= 0.0);
+                    const u32 m16 = (u32)(m >> (16 * g)) & 0xffffu;
+                    const u64 rev = (u64)(__brev(m16) >> 16);  // column 0 -> most significant of the 16
+                    cw[r][ct / 4] |= rev << (48 - 16 * (ct % 4));
+                }
+            }
+            if (l15 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long row = wrow0 + rt * 16 + g + 4 * r;
+                    if (row < a.n) {
+#pragma unroll
+                        for (int w = 0; w < WPG; ++w) {
+                            const int gw = blockIdx.y * (NCOL / 64) + w;
+                            if (gw < a.words) {
+                                u64 v = cw[r][w];
+                                if (gw == 0 && a.pad > 0) v &= (~0ull) >> a.pad;
+                                a.out[row * a.words + gw] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <class T, int CT>
+static int itq_launch_t(const ItqArgs& a0, hipStream_t st, int device) {
+    ItqArgs a = a0;
+    constexpr int NCOL = CT * 16, RSTRIDE = NCOL + 4, RT = 16 / CT;
+    const size_t fixed = (size_t)a.d16 * 8 + (size_t)4 * RT * 16 * 8;
+    const size_t budget = 150 * 1024;
+    if (fixed + (size_t)16 * RSTRIDE * 8 > budget)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_itq_hash: d=%d too large for the LDS mean vector", a.d);
+    int dk = (int)((budget - fixed) / ((size_t)RSTRIDE * 8));
+    dk = dk / 16 * 16;
+    if (dk > a.d16) dk = a.d16;
+    a.dk = dk;
+    a.nchunks = (a.d16 + dk - 1) / dk;
+    const size_t lds = fixed + (size_t)dk * RSTRIDE * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&itq_hash_kernel<T, CT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const long long rows_per_block = 4ll * RT * 16;
+    const long long nblocks = (a.n + rows_per_block - 1) / rows_per_block;
+    long long gx = cu_count(device);
+    if (gx > nblocks) gx = nblocks;
+    const int groups = (a.words * 64 + NCOL - 1) / NCOL;
+    hipLaunchKernelGGL((itq_hash_kernel<T, CT>), dim3((unsigned)gx, (unsigned)groups), dim3(256), lds, st, a);
+    SQ_HIP(hipGetLastError());
+    return SQ_OK;
+}
+
+template <class T>
+static int itq_launch(const ItqArgs& a, hipStream_t st, int device) {
+    if (a.words == 1) return itq_launch_t<T, 4>(a, st, device);
+    if (a.words == 2) return itq_launch_t<T, 8>(a, st, device);
+    return itq_launch_t<T, 16>(a, st, device);
+}
+
+}  // namespace sq
+
+using namespace sq;
+
+extern "C" int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d, const double* mean, const double* rotation,
+                           int bits, int norm_ord, uint64_t* out_codes, int mem, void* stream) {
+    if (!x || !mean || !rotation || !out_codes || n <= 0 || d <= 0 || bits <= 0)
+        return fail(SQ_ERR_INVALID, "sq_itq_hash: bad argument");
+    if (x_dtype != SQ_DTYPE_F32 && x_dtype != SQ_DTYPE_F64) return fail(SQ_ERR_INVALID, "sq_itq_hash: unknown dtype %d", x_dtype);
+    if (norm_ord != SQ_NORM_NONE && norm_ord != SQ_NORM_L2)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_itq_hash: normalize=%d not supported on the device (None or 2)", norm_ord);
+    int device = 0;
+    SQ_HIP(hipGetDevice(&device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int words = (bits + 63) / 64;
+    const size_t esz = x_dtype == SQ_DTYPE_F32 ? 4 : 8;
+    ItqArgs a{};
+    a.n = n;
+    a.d = d;
+    a.bits = bits;
+    a.words = words;
+    a.pad = words * 64 - bits;
+    a.norm = norm_ord;
+    a.d16 = (d + 15) / 16 * 16;
+    DevBuf dx, dm, dr, dout;
+    auto done = [&](int code) {
+        dx.release();
+        dm.release();
+        dr.release();
+        dout.release();
+        return code;
+    };
+    if (mem == SQ_MEM_DEVICE) {
+        a.x = x;
+        a.mean = mean;
+        a.rot = rotation;
+        a.out = reinterpret_cast<u64*>(out_codes);
+        return x_dtype == SQ_DTYPE_F32 ? itq_launch<float>(a, st, device) : itq_launch<double>(a, st, device);
+    }
+    int rc;
+    if ((rc = dx.reserve((size_t)n * d * esz)) != SQ_OK) return done(rc);
+    if ((rc = dm.reserve((size_t)d * 8)) != SQ_OK) return done(rc);
+    if ((rc = dr.reserve((size_t)d * bits * 8)) != SQ_OK) return done(rc);
+    if ((rc = dout.reserve((size_t)n * words * 8)) != SQ_OK) return done(rc);
+    if (hipMemcpyAsync(dx.p, x, (size_t)n * d * esz, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(dm.p, mean, (size_t)d * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(dr.p, rotation, (size_t)d * bits * 8, hipMemcpyHostToDevice, st) != hipSuccess)
+        return done(fail(SQ_ERR_HIP, "sq_itq_hash: H2D copy failed"));
+    a.x = dx.p;
+    a.mean = dm.as<double>();
+    a.rot = dr.as<double>();
+    a.out = dout.as<u64>();
+    rc = x_dtype == SQ_DTYPE_F32 ? itq_launch<float>(a, st, device) : itq_launch<double>(a, st, device);
+    if (rc != SQ_OK) return done(rc);
+    if (hipMemcpyAsync(out_codes, dout.p, (size_t)n * words * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return done(fail(SQ_ERR_HIP, "sq_itq_hash: kernel or D2H copy failed: %s", hipGetErrorString(hipGetLastError())));
+    return done(SQ_OK);
+}

@@ -1,0 +1,352 @@
+// Top-k selection over per-query candidate keys, and the sample-threshold
+// selector.  Shared by the Hamming and dense paths (gfx950, wave64).
+//
+// Keys are totally ordered and UNIQUE per query: (ordered distance bits, row
+// id).  Sorting keys ascending therefore IS the canonical result order
+// (distance ascending, then row id ascending), which
+// restates the stable `sorted(...)[:n]` of lsh.py:513-518 and the
+// `heapq.nsmallest` of linear.py:235-238 up to their set-iteration tie order.
+#pragma once
+#include "sq_common.hpp"
+
+namespace sq {
+
+// ---------------------------------------------------------------- key types
+// K64: [63:32] ordered distance (f32 bits or integer), [31:0] local row id.
+// K128: hi = ordered f64 distance bits, lo = local row id.
+struct K128 {
+    u64 hi, lo;
+};
+
+__device__ __forceinline__ u32 ordered_f32(float f) {
+    u32 u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unordered_f32(u32 u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ u64 ordered_f64(double f) {
+    u64 u = (u64)__double_as_longlong(f);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double unordered_f64(u64 u) {
+    return __longlong_as_double((long long)((u >> 63) ? (u & 0x7fffffffffffffffull) : ~u));
+}
+
+template <class K>
+struct KeyOps;
+template <>
+struct KeyOps<u64> {
+    static constexpr int NBYTES = 8;
+    __device__ static __forceinline__ u64 maxv() { return ~0ull; }
+    __device__ static __forceinline__ bool less(u64 a, u64 b) { return a < b; }
+    __device__ static __forceinline__ bool is_max(u64 a) { return a == ~0ull; }
+    // byte i, i = 0 most significant
+    __device__ static __forceinline__ u32 byte(u64 a, int i) { return (u32)(a >> (8 * (7 - i))) & 255u; }
+    __device__ static __forceinline__ u64 zero() { return 0ull; }
+    __device__ static __forceinline__ void set_byte(u64& a, int i, u32 v) { a |= (u64)v << (8 * (7 - i)); }
+    // first nb bytes equal
+    __device__ static __forceinline__ bool prefix_eq(u64 a, u64 p, int nb) {
+        return nb == 0 || (a >> (8 * (8 - nb))) == (p >> (8 * (8 - nb)));
+    }
+};
+template <>
+struct KeyOps<K128> {
+    static constexpr int NBYTES = 12;  // 8 bytes of hi + low 4 bytes of lo (row id < 2^32)
+    __device__ static __forceinline__ K128 maxv() { return K128{~0ull, ~0ull}; }
+    __device__ static __forceinline__ bool less(K128 a, K128 b) {
+        return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo);
+    }
+    __device__ static __forceinline__ bool is_max(K128 a) { return a.hi == ~0ull && a.lo == ~0ull; }
+    __device__ static __forceinline__ u32 byte(K128 a, int i) {
+        return i < 8 ? (u32)(a.hi >> (8 * (7 - i))) & 255u : (u32)(a.lo >> (8 * (11 - i))) & 255u;
+    }
+    __device__ static __forceinline__ K128 zero() { return K128{0ull, 0ull}; }
+    __device__ static __forceinline__ void set_byte(K128& a, int i, u32 v) {
+        if (i < 8)
+            a.hi |= (u64)v << (8 * (7 - i));
+        else
+            a.lo |= (u64)v << (8 * (11 - i));
+    }
+    __device__ static __forceinline__ bool prefix_eq(K128 a, K128 p, int nb) {
+        if (nb == 0) return true;
+        if (nb <= 8) return (a.hi >> (8 * (8 - nb))) == (p.hi >> (8 * (8 - nb)));
+        if (a.hi != p.hi) return false;
+        int r = nb - 8;  // 1..4 bytes of the low word's 32-bit id
+        return ((a.lo & 0xffffffffull) >> (8 * (4 - r))) == ((p.lo & 0xffffffffull) >> (8 * (4 - r)));
+    }
+};
+
+// ------------------------------------------------------- LDS bitonic sort
+// Sorts sk[0..P) ascending, P a power of two >= 2; all threads of the block call.
+template <class K>
+__device__ __forceinline__ void bitonic_sort_lds(K* sk, int P) {
+    const int T = blockDim.x;
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < (P >> 1); i += T) {
+                int lo = 2 * i - (i & (stride - 1));
+                int hi = lo + stride;
+                bool asc = (lo & size) == 0;
+                K a = sk[lo], b = sk[hi];
+                if (KeyOps<K>::less(b, a) == asc) {
+                    sk[lo] = b;
+                    sk[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int pow2_ceil(int v) {
+    int p = 2;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// --------------------------------------------------------------- select_topk
+// One workgroup per query.  keys: [nq][stride] candidate keys, cnt[q] of them
+// valid (clamped to cap).  Writes the min(k, M) smallest keys ascending to
+// out[q][0..k) and pads the rest with the max key.
+//   M <= LDS_KEYS : everything is sorted in LDS.
+//   M  > LDS_KEYS : MSB-first radix select (8-bit digits, LDS histogram) finds
+//                   the k-th smallest key reading global memory, the keys
+//                   <= it are gathered (exactly k: keys are unique) and sorted.
+// Requires k <= LDS_KEYS.  Dynamic LDS: LDS_KEYS * sizeof(K).
+template <class K>
+__global__ __launch_bounds__(1024) void select_topk_kernel(const K* __restrict__ keys,
+                                                            const u32* __restrict__ cnt, u32 cap,
+                                                            long long stride, int k, int lds_keys,
+                                                            K* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    K* sk = reinterpret_cast<K*>(smem_raw);
+    __shared__ u32 hist[256];
+    __shared__ u32 sh_sel, sh_rem, sh_n;
+    const int q = blockIdx.x;
+    const int T = blockDim.x;
+    const u32 craw = cnt[q];
+    const int M = (int)(craw < cap ? craw : cap);
+    const K* src = keys + (long long)q * stride;
+    K* dst = out + (long long)q * k;
+    const int kk = k < M ? k : M;
+    int nsort;
+    if (M <= lds_keys) {
+        for (int i = threadIdx.x; i < M; i += T) sk[i] = src[i];
+        nsort = M;
+    } else {
+        K prefix = KeyOps<K>::zero();
+        if (threadIdx.x == 0) sh_rem = (u32)kk;
+        for (int b = 0; b < KeyOps<K>::NBYTES; ++b) {
+            for (int i = threadIdx.x; i < 256; i += T) hist[i] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < M; i += T) {
+                K key = src[i];
+                if (KeyOps<K>::prefix_eq(key, prefix, b)) atomicAdd(&hist[KeyOps<K>::byte(key, b)], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                u32 need = sh_rem, c = 0, v = 0;
+                for (; v < 255; ++v) {
+                    if (c + hist[v] >= need) break;
+                    c += hist[v];
+                }
+                sh_sel = v;
+                sh_rem = need - c;
+            }
+            __syncthreads();
+            KeyOps<K>::set_byte(prefix, b, sh_sel);
+            __syncthreads();
+        }
+        // prefix is now the kk-th smallest key
+        if (threadIdx.x == 0) sh_n = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < M; i += T) {
+            K key = src[i];
+            if (!KeyOps<K>::less(prefix, key)) {
+                u32 pos = atomicAdd(&sh_n, 1u);
+                if ((int)pos < lds_keys) sk[pos] = key;
+            }
+        }
+        __syncthreads();
+        nsort = (int)sh_n < lds_keys ? (int)sh_n : lds_keys;
+    }
+    __syncthreads();
+    if (nsort > 1) {
+        const int P = pow2_ceil(nsort);
+        for (int i = nsort + threadIdx.x; i < P; i += T) sk[i] = KeyOps<K>::maxv();
+        bitonic_sort_lds<K>(sk, P);
+    } else {
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < k; i += T) dst[i] = (i < kk && i < nsort) ? sk[i] : KeyOps<K>::maxv();
+}
+
+// ------------------------------------------------------------ block helpers
+__device__ __forceinline__ float wave_min(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------- kth_threshold_f32
+// Per query (one 1024-thread workgroup): an element T of scores[q][0..ns)
+// whose rank r among the finite scores satisfies k <= r (and r <= ~2k unless
+// the data has that many duplicates).  T upper-bounds the k-th smallest score
+// of ANY superset of the sample, which is all the scan needs (DESIGN.md
+// "threshold").  +inf entries mark padding rows and are ignored; when fewer
+// than k finite scores exist T = +inf (scan emits everything).
+// Method: iterated linear bucketing (2048 buckets over [lo,hi]); bucket index
+// is a monotone function of the score, so everything in lower buckets is
+// strictly smaller than everything in the selected bucket.
+static __global__ __launch_bounds__(1024) void kth_threshold_f32_kernel(const float* __restrict__ scores,
+                                                                  long long ns, int k,
+                                                                  float* __restrict__ thr) {
+    constexpr int NB = 2048;
+    __shared__ u32 hist[NB];
+    __shared__ float red_a[16], red_b[16];
+    __shared__ u32 red_c[16];
+    __shared__ u32 sh_b, sh_below, sh_cin;
+    const int q = blockIdx.x;
+    const int T = blockDim.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = T >> 6;
+    const float* s = scores + (long long)q * ns;
+    const float INF = __builtin_inff();
+
+    // pass 0: min / max / count of finite scores
+    float vmin = INF, vmax = -INF;
+    u32 nfin = 0;
+    for (long long i = threadIdx.x; i < ns; i += T) {
+        float v = s[i];
+        if (v < INF) {
+            vmin = fminf(vmin, v);
+            vmax = fmaxf(vmax, v);
+            ++nfin;
+        }
+    }
+    vmin = wave_min(vmin);
+    vmax = wave_max(vmax);
+    nfin = wave_sum(nfin);
+    if (lane == 0) {
+        red_a[wv] = vmin;
+        red_b[wv] = vmax;
+        red_c[wv] = nfin;
+    }
+    __syncthreads();
+    vmin = INF;
+    vmax = -INF;
+    nfin = 0;
+    for (int w = 0; w < nw; ++w) {
+        vmin = fminf(vmin, red_a[w]);
+        vmax = fmaxf(vmax, red_b[w]);
+        nfin += red_c[w];
+    }
+    __syncthreads();
+    if (nfin < (u32)k) {
+        if (threadIdx.x == 0) thr[q] = INF;
+        return;
+    }
+    float lo = vmin, hi = vmax, result = vmax;
+    u32 base = 0;
+    for (int it = 0; it < 8; ++it) {
+        if (!(lo < hi)) {
+            result = hi;
+            break;
+        }
+        float scale = (float)NB / (hi - lo);
+        if (!(scale > 0.f) || !(scale < INF)) {
+            result = hi;
+            break;
+        }
+        for (int i = threadIdx.x; i < NB; i += T) hist[i] = 0;
+        __syncthreads();
+        for (long long i = threadIdx.x; i < ns; i += T) {
+            float v = s[i];
+            if (v >= lo && v <= hi) {
+                int b = (int)((v - lo) * scale);
+                b = b > NB - 1 ? NB - 1 : b;
+                atomicAdd(&hist[b], 1u);
+            }
+        }
+        __syncthreads();
+        if (wv == 0) {  // wave 0 finds the bucket holding rank k
+            const u32 need = (u32)k - base;
+            u32 mysum = 0;
+            for (int j = 0; j < NB / 64; ++j) mysum += hist[lane * (NB / 64) + j];
+            u32 incl = mysum;
+            for (int o = 1; o < 64; o <<= 1) {
+                u32 t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            u64 m = __ballot(incl >= need);
+            int L = __ffsll((long long)m) - 1;  // nfin >= k guarantees m != 0
+            if (lane == L) {
+                u32 c = incl - mysum;
+                int b = lane * (NB / 64);
+                for (int j = 0; j < NB / 64; ++j, ++b) {
+                    if (c + hist[b] >= need) break;
+                    c += hist[b];
+                }
+                sh_b = (u32)b;
+                sh_below = base + c;
+                sh_cin = hist[b];
+            }
+        }
+        __syncthreads();
+        const int bsel = (int)sh_b;
+        const u32 below = sh_below, cin = sh_cin;
+        // min / max of the selected bucket
+        float bmin = INF, bmax = -INF;
+        for (long long i = threadIdx.x; i < ns; i += T) {
+            float v = s[i];
+            if (v >= lo && v <= hi) {
+                int b = (int)((v - lo) * scale);
+                b = b > NB - 1 ? NB - 1 : b;
+                if (b == bsel) {
+                    bmin = fminf(bmin, v);
+                    bmax = fmaxf(bmax, v);
+                }
+            }
+        }
+        bmin = wave_min(bmin);
+        bmax = wave_max(bmax);
+        if (lane == 0) {
+            red_a[wv] = bmin;
+            red_b[wv] = bmax;
+        }
+        __syncthreads();
+        bmin = INF;
+        bmax = -INF;
+        for (int w = 0; w < nw; ++w) {
+            bmin = fminf(bmin, red_a[w]);
+            bmax = fmaxf(bmax, red_b[w]);
+        }
+        __syncthreads();
+        result = bmax;
+        if (below + cin <= 2u * (u32)k || it == 7) break;
+        base = below;
+        lo = bmin;
+        hi = bmax;
+    }
+    if (threadIdx.x == 0) thr[q] = result;
+}
+
+// ------------------------------------------------------------------ fills
+static __global__ void fill_u32_kernel(u32* p, long long n, u32 v) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+static __global__ void fill_f32_kernel(float* p, long long n, float v) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace sq

@@ -1,0 +1,271 @@
+"""
+GPU parity tests: the HIP path, called through the C ABI (ctypes), against the
+oracle on the same seeded inputs and against the golden vectors produced by the
+real reference.  Integer / index results must be identical; float32 L2
+distances bit-identical; float64 cosine distances within 1e-12 relative
+(north_star allows 1e-5).
+"""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as O
+from smqtk_indexing_amd import _lib
+from tests.golden import inputs as GI
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _reset_options():
+    yield
+    for name in ("candidate_cap", "sample_stride", "force_fallback", "profile", "dense_stages", "dense_blocks",
+                 "dense_builtin_dma"):
+        _lib.set_option(name, 0)
+
+
+# ------------------------------------------------------------------- Hamming
+def _hamming_check(codes, queries, k):
+    idx = _lib.HammingIndex(codes)
+    d, i = idx.search(queries, k)
+    for qi, q in enumerate(queries):
+        rd, ri = O.hamming_topk(codes, q, k)
+        kk = len(rd)
+        np.testing.assert_array_equal(d[qi, :kk], rd)
+        np.testing.assert_array_equal(i[qi, :kk], ri)
+        assert (i[qi, kk:] == -1).all()
+    return idx
+
+
+@pytest.mark.parametrize("tag", list(GI.HAMMING_CASES))
+def test_hamming_golden_cases(golden, tag):
+    g = golden("g4_linear_hash_nn.npz")
+    n, bits, seed, mode = GI.HAMMING_CASES[tag]
+    codes, queries = GI.hamming_inputs(n, bits, seed, mode)
+    lut = {O.packed_to_int(r): i for i, r in enumerate(codes)}
+    for k in GI.HAMMING_KS[tag]:
+        idx = _hamming_check(codes, queries, k)
+        d, i = idx.search(queries, k)
+        # against the reference's own output (tie-group semantics, test_linear.py:150-155)
+        rcodes, rdist = g[f"{tag}_k{k}_codes"], g[f"{tag}_k{k}_dist"]
+        for qi, q in enumerate(queries):
+            ref_d = np.rint(rdist[qi] * bits).astype(np.int32)
+            ref_i = np.array([lut[O.packed_to_int(r)] for r in rcodes[qi]])
+            full = O.popcount_u64(codes ^ q[None, :]).sum(axis=1)
+            kk = len(ref_d)
+            O.assert_topk_equivalent(ref_d, ref_i, d[qi, :kk], i[qi, :kk], all_dist_of=lambda r: full[r])
+
+
+@pytest.mark.parametrize("bits,n,nq,k", [(64, 200_000, 40, 100), (128, 150_000, 7, 10), (256, 120_000, 9, 100),
+                                         (192, 90_000, 5, 33), (64, 70_001, 3, 1)])
+def test_hamming_scan_path(bits, n, nq, k):
+    """n above the candidate cap: sample histogram -> threshold -> emit -> select."""
+    rng = np.random.default_rng(bits + n)
+    w = bits // 64
+    codes = np.unique(rng.integers(0, 2 ** 64, size=(n, w), dtype=np.uint64), axis=0)
+    queries = rng.integers(0, 2 ** 64, size=(nq, w), dtype=np.uint64)
+    queries[0] = codes[17]
+    idx = _hamming_check(codes, queries, k)
+    st = idx.stats()
+    assert st["fallback_queries"] == 0
+    assert st["candidates"] >= nq * k
+
+
+def test_hamming_low_entropy_overflow_and_fallback():
+    """Clustered codes: huge tie groups overflow the candidate list, the exact
+    full-keys path must still give the canonical answer."""
+    codes, queries = GI.hamming_inputs(150_000, 64, 77, "lowent")
+    _lib.set_option("candidate_cap", 2048)
+    idx = _hamming_check(codes, queries, 50)
+    assert idx.stats()["fallback_queries"] > 0
+    _lib.set_option("candidate_cap", 0)
+    _lib.set_option("force_fallback", 1)
+    idx = _hamming_check(codes[:100_000], queries[:3], 20)
+    assert idx.stats()["fallback_queries"] == 3
+
+
+def test_hamming_k_larger_than_n_and_id_base():
+    codes = np.unique(np.random.default_rng(5).integers(0, 2 ** 64, size=(50, 1), dtype=np.uint64), axis=0)
+    idx = _lib.HammingIndex(codes, id_base=1000)
+    d, i = idx.search(codes[:2], 64)
+    rd, ri = O.hamming_topk(codes, codes[0], 64)
+    np.testing.assert_array_equal(i[0, :len(ri)], ri + 1000)
+    assert (i[0, len(ri):] == -1).all() and (d[0, len(ri):] == np.iinfo(np.int32).max).all()
+
+
+# --------------------------------------------------------------------- dense
+def _dense_check(db, qs, k, metric="euclidean", exact_dist=True):
+    m = _lib.SQ_METRIC_L2 if metric == "euclidean" else _lib.SQ_METRIC_COSINE
+    idx = _lib.DenseIndex(db, metric=m)
+    d, i = idx.search(qs, k)
+    for qi, q in enumerate(qs):
+        rd, ri = O.dense_topk(db, q, k, metric)
+        kk = len(rd)
+        if metric == "euclidean":
+            assert d.dtype == np.float32
+            # float32 distances bit-identical to numpy's evaluation of metrics.py:86
+            np.testing.assert_array_equal(d[qi, :kk].view(np.uint32), rd.view(np.uint32))
+            np.testing.assert_array_equal(i[qi, :kk], ri)
+        else:
+            np.testing.assert_allclose(d[qi, :kk], rd, rtol=1e-12, atol=1e-15)
+            full = O.dense_distances(db, q, "cosine")
+            # identical ranks wherever the reference distances are distinguishable
+            mism = i[qi, :kk] != ri
+            if mism.any():
+                assert np.abs(full[i[qi, :kk][mism]] - full[ri[mism]]).max() < 1e-14
+    return idx
+
+
+@pytest.mark.parametrize("tag", list(GI.DENSE_CASES))
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_dense_golden_cases(golden, tag, metric):
+    """Small matrices (every row is a candidate): exact-distance kernel + select."""
+    g = golden("g5_dense_nn.npz")
+    n, d, nq, seed, dist, dt = GI.DENSE_CASES[tag]
+    db, qs = GI.dense_inputs(n, d, nq, seed, dist, dt)
+    k = min(GI.DENSE_KMAX, n)
+    idx = _dense_check(db, qs, k, metric)
+    dd, ii = idx.search(qs, k)
+    ridx, rdist = g[f"{tag}_{metric}_idx"], g[f"{tag}_{metric}_dist"]
+    for qi in range(ridx.shape[0]):
+        if metric == "euclidean":
+            np.testing.assert_array_equal(dd[qi], rdist[qi][:k])   # the real reference's numbers
+            np.testing.assert_array_equal(ii[qi], ridx[qi][:k])
+        else:
+            np.testing.assert_allclose(dd[qi], rdist[qi][:k], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["uni128", "nrm128", "nrm200"])
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_dense_scan_path_small(tag, metric):
+    """Force the MFMA scan path on the golden inputs (tiny candidate cap)."""
+    n, d, nq, seed, dist, dt = GI.DENSE_CASES[tag]
+    db, qs = GI.dense_inputs(n, d, nq, seed, dist, dt)
+    _lib.set_option("candidate_cap", 1024)
+    idx = _dense_check(db, qs, 20, metric)
+    st = idx.stats()
+    assert st["scan_launches"] >= 2
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(300_000, 128, 33, 100), (100_000, 512, 5, 10), (120_000, 64, 64, 1),
+                                      (90_001, 100, 3, 50), (200_000, 256, 2, 100)])
+@pytest.mark.parametrize("variant", ["asm", "builtin"])
+def test_dense_scan_path_l2(n, d, nq, k, variant):
+    rng = np.random.default_rng(n + d)
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    qs[0] = db[12345]
+    db[777] = db[555]
+    _lib.set_option("dense_builtin_dma", 1 if variant == "builtin" else 0)
+    idx = _dense_check(db, qs, k, "euclidean")
+    st = idx.stats()
+    assert st["fallback_queries"] == 0, st
+    assert st["candidates"] >= nq * k
+
+
+def test_dense_scan_path_cosine():
+    rng = np.random.default_rng(99)
+    db = rng.random((150_000, 128)).astype(np.float32)
+    qs = rng.random((6, 128)).astype(np.float32)
+    idx = _dense_check(db, qs, 50, "cosine")
+    assert idx.stats()["fallback_queries"] == 0
+
+
+def test_dense_uncertifiable_data_takes_exact_path():
+    """Many near-duplicate rows: the candidate list overflows / certification
+    fails and the exact full-keys path answers (canonical tie order)."""
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((1, 64)).astype(np.float32)
+    db = np.repeat(base, 100_000, axis=0)
+    db[::7] += 1e-3
+    qs = rng.standard_normal((2, 64)).astype(np.float32)
+    _lib.set_option("candidate_cap", 4096)
+    idx = _dense_check(db, qs, 10, "euclidean")
+    assert idx.stats()["fallback_queries"] == 2
+    _lib.set_option("candidate_cap", 0)
+    _lib.set_option("force_fallback", 1)
+    db = rng.standard_normal((80_000, 96)).astype(np.float32)
+    idx = _dense_check(db, qs[:, :96].copy() if qs.shape[1] >= 96 else rng.standard_normal((2, 96)).astype(np.float32),
+                       10, "euclidean")
+    assert idx.stats()["fallback_queries"] == 2
+
+
+def test_dense_wide_rows_exact_path():
+    """d beyond the scan kernel's LDS budget: exact path, numpy pairwise recursion (d > 128)."""
+    rng = np.random.default_rng(8)
+    db = rng.standard_normal((70_000, 1000)).astype(np.float32)
+    qs = rng.standard_normal((2, 1000)).astype(np.float32)
+    _dense_check(db, qs, 5, "euclidean")
+
+
+@pytest.mark.parametrize("d", [1, 5, 8, 9, 127, 128, 129, 200, 300, 1024, 4100])
+def test_dense_distances_bit_exact(d):
+    rng = np.random.default_rng(d)
+    rows = (rng.standard_normal((257, d)) * 3).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    got = _lib.dense_distances(q, rows, _lib.SQ_METRIC_L2)
+    ref = O.euclidean_distance(rows, q)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    got = _lib.dense_distances(q, rows, _lib.SQ_METRIC_COSINE)
+    ref = np.array([O.cosine_distance(q, r) for r in rows])
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-15)
+
+
+def test_dense_known_answers():
+    # tests/impls/nn_index/test_faiss.py:443-515 / test_lsh.py:837-979 ported to the dense index
+    dim = 5
+    db = np.eye(dim, dtype=np.float32)
+    idx = _lib.DenseIndex(db)
+    d, i = idx.search(np.zeros((1, dim), np.float32), dim)
+    np.testing.assert_array_equal(d[0], np.ones(dim, np.float32))
+    np.testing.assert_array_equal(i[0], np.arange(dim))
+    d, i = idx.search(db[3:4], 1)
+    assert i[0, 0] == 3 and d[0, 0] == 0.0
+    pts = np.array([[j, 2 * j] for j in range(1000)], dtype=np.float32)
+    perm = np.random.default_rng(0).permutation(1000)
+    idx = _lib.DenseIndex(pts[perm])
+    d, i = idx.search(np.zeros((1, 2), np.float32), 1000)
+    np.testing.assert_array_equal(perm[i[0]], np.arange(1000))
+    assert (np.diff(d[0]) > 0).all()
+
+
+# ----------------------------------------------------------------------- ITQ
+@pytest.mark.parametrize("tag", list(GI.ITQ_CASES))
+def test_itq_hash_golden(golden, tag):
+    g = golden("g3_itq_hash.npz")
+    n, d, bits, seed = GI.ITQ_CASES[tag]
+    x32, mean, rot = GI.itq_inputs(n, d, bits, seed)
+    for norm, ordv in ((None, _lib.SQ_NORM_NONE), (2, _lib.SQ_NORM_L2)):
+        for dt in (np.float32, np.float64):
+            key = f"{tag}_n{norm}_{np.dtype(dt).name}"
+            got = _lib.itq_hash(x32.astype(dt), mean, rot, ordv)
+            ref = g[key + "_packed"]
+            bad = (got != ref).any(axis=1)
+            # the reference's own sign is BLAS-order dependent when |z| is at rounding level
+            if bad.any():
+                assert g[key + "_minabsz"][bad].max() < 1e-10, (key, int(bad.sum()))
+            assert bad.sum() <= 1
+
+
+def test_itq_known_answers(golden):
+    g = golden("g3_itq_hash.npz")
+    mean = np.array([0., 0.])
+    rot = np.array([[1. / np.sqrt(2)], [1. / np.sqrt(2)]])
+    got = _lib.itq_hash(g["kat_x"], mean, rot)
+    np.testing.assert_array_equal(O.unpack_bits_msb(got, 1)[:, 0], g["kat_bits"][:, 0])
+
+
+@pytest.mark.parametrize("n,d,bits", [(50_000, 128, 64), (10_000, 512, 256), (3_000, 300, 100), (1000, 40, 33)])
+def test_itq_hash_bulk(n, d, bits):
+    rng = np.random.default_rng(n + bits)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    mean = x[:1000].mean(axis=0).astype(np.float64)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    rot = np.ascontiguousarray(q[:, :bits])
+    for norm, ordv in ((None, _lib.SQ_NORM_NONE), (2, _lib.SQ_NORM_L2)):
+        got = _lib.itq_hash(x, mean, rot, ordv)
+        z = O.itq_z(x, mean, rot, norm)
+        ref = O.pack_bits_msb(z >= 0)
+        bad = (got != ref).any(axis=1)
+        if bad.any():
+            assert np.abs(z[bad]).min(axis=1).max() < 1e-10
+        assert bad.mean() < 1e-3
