@@ -50,7 +50,6 @@ struct Options {
     int force_fallback = 0;
     int dense_stages = 0;    // 0 = auto (LDS ring depth of the dense scan)
     int dense_blocks = 0;    // 0 = auto (row blocks of the dense scan grid)
-    int dense_builtin_dma = 0;  // 1 = compiler-tracked LDS-DMA builtin instead of asm + counted vmcnt
 };
 extern Options g_opt;
 

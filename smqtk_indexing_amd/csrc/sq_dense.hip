@@ -95,11 +95,26 @@ __device__ __forceinline__ double cosine_dist_f64(double dot, double nx2, double
     return 2.0 * acos(sim) / 3.141592653589793;
 }
 
-// One lane per row, element order 0..d-1, separate multiply and add.
+// One lane per row.  The dot products follow the order of the scipy 1.15.3
+// build pinned in this image (two interleaved accumulators over even / odd
+// elements, summed, then the odd tail; established against cdist itself, see
+// tests/test_oracle_golden.py::test_scipy_cosine_order).  Inputs are float32
+// values, so every product is exact in float64 and FMA contraction is moot.
 __device__ __forceinline__ double cosine_row_f64(const float* __restrict__ x, const float* __restrict__ q, int d) {
-    double dot = 0.0, nx = 0.0, nq = 0.0;
-    for (int i = 0; i < d; ++i) {
-        const double xv = (double)x[i], qq = (double)q[i];
+    double dot0 = 0.0, dot1 = 0.0, nx0 = 0.0, nx1 = 0.0, nq0 = 0.0, nq1 = 0.0;
+    const int m = d - (d & 1);
+    for (int i = 0; i < m; i += 2) {
+        const double x0 = (double)x[i], x1 = (double)x[i + 1], q0 = (double)q[i], q1 = (double)q[i + 1];
+        dot0 = __dadd_rn(dot0, __dmul_rn(q0, x0));
+        dot1 = __dadd_rn(dot1, __dmul_rn(q1, x1));
+        nx0 = __dadd_rn(nx0, __dmul_rn(x0, x0));
+        nx1 = __dadd_rn(nx1, __dmul_rn(x1, x1));
+        nq0 = __dadd_rn(nq0, __dmul_rn(q0, q0));
+        nq1 = __dadd_rn(nq1, __dmul_rn(q1, q1));
+    }
+    double dot = __dadd_rn(dot0, dot1), nx = __dadd_rn(nx0, nx1), nq = __dadd_rn(nq0, nq1);
+    if (d & 1) {
+        const double xv = (double)x[m], qq = (double)q[m];
         dot = __dadd_rn(dot, __dmul_rn(qq, xv));
         nx = __dadd_rn(nx, __dmul_rn(xv, xv));
         nq = __dadd_rn(nq, __dmul_rn(qq, qq));
@@ -229,7 +244,7 @@ __device__ __forceinline__ void wait_units_in_flight(int units) {
         wait_vmcnt<0>();
 }
 
-template <int NSTAGE, bool BUILTIN_DMA>
+template <int NSTAGE>
 __global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -297,7 +312,6 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseSca
         const long long row0 = (a.tile_first + iss_tile * a.tile_step) * TILE_ROWS;
         const float* colbase = a.db + (long long)iss_kc * KT;
         const u32 dst = ring_base + (u32)iss_slot * UNIT_BYTES;
-        unsigned char* dst_ptr = ring_ptr + iss_slot * UNIT_BYTES;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = 4 * j + (lane >> 4);
@@ -305,13 +319,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseSca
             row = row < a.n ? row : a.n - 1;
             const int chunk = (lane & 15) ^ (r & 15);
             const float* src = colbase + row * a.ld + chunk * 4;
-            if constexpr (BUILTIN_DMA) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst_ptr + j * 1024), 16, 0,
-                                                 0);
-            } else {
-                glds16(src, dst + (u32)j * 1024);
-            }
+            glds16(src, dst + (u32)j * 1024);
         }
         ++issued;
         if (++iss_kc == ku) {
@@ -333,10 +341,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseSca
 
     for (long long u = 0; u < total_units; ++u) {
         if (issued < total_units) issue_unit();
-        if constexpr (!BUILTIN_DMA) {
-            const long long inflight = issued - u - 1;  // units younger than u
-            wait_units_in_flight<NSTAGE>((int)inflight);
-        }
+        wait_units_in_flight<NSTAGE>((int)(issued - u - 1));  // units younger than u may stay in flight
         const unsigned char* slot = ring_ptr + con_slot * UNIT_BYTES;
         const unsigned char* arow = slot + r31 * 256;
         const unsigned char* brow = smem + (u32)r31 * a.d_pad * 4 + con_kc * 256;
@@ -453,6 +458,29 @@ __global__ __launch_bounds__(256) void dense_distances_kernel(const float* __res
     }
 }
 
+// The sampled threshold T is the score of an actual row.  The scan emits with
+// T + slack so that a query whose k-th neighbour IS that row still certifies:
+// slack covers twice the filter's error bound plus the relative rounding of
+// the exact distance (DESIGN.md "certification").
+__global__ void dense_inflate_thr_kernel(float* __restrict__ thr, const double* __restrict__ qn2, int nq, int cosine,
+                                         double xn2_max, double eps_coef) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const float t = thr[q];
+    if (!(t < __builtin_inff())) return;
+    double slack;
+    if (cosine) {
+        slack = 2.0 * eps_coef + 1e-8;
+    } else {
+        const double eps = eps_coef * (xn2_max + 2.0 * sqrt(xn2_max * qn2[q]));
+        slack = 2.0 * eps + 4e-6 * fabs((double)t + qn2[q]);
+    }
+    // round up so the float threshold is never below T + slack
+    float r = (float)((double)t + slack);
+    if ((double)r < (double)t + slack) r = __uint_as_float(__float_as_uint(r) + (r >= 0.f ? 1 : -1));
+    thr[q] = r;
+}
+
 // --------------------------------------------------------------- finalize
 // status bits: 1 candidate overflow, 2 certification failed, 4 fewer than kk candidates
 __global__ void dense_finalize_l2_kernel(const u64* __restrict__ sorted, const u32* __restrict__ cnt, u32 cap, int k,
@@ -538,15 +566,15 @@ static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long str
     return SQ_OK;
 }
 
-template <int NSTAGE, bool BUILTIN>
+template <int NSTAGE>
 static int scan_launch_t(const DenseScanArgs& a, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<NSTAGE, BUILTIN>),
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<NSTAGE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dense_scan_kernel<NSTAGE, BUILTIN>), dim3((unsigned)(a.nrb * a.nqt)), dim3(SCAN_WAVES * 64),
+    hipLaunchKernelGGL((dense_scan_kernel<NSTAGE>), dim3((unsigned)(a.nrb * a.nqt)), dim3(SCAN_WAVES * 64),
                        lds, st, a);
     return SQ_OK;
 }
@@ -565,11 +593,10 @@ static int scan_launch(DenseScanArgs a, hipStream_t st) {
     if (ns < 2) return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d leaves no room for the LDS ring", a.d_pad);
     const size_t lds = (size_t)TILE_ROWS * a.d_pad * 4 + (size_t)SCAN_WAVES * ns * UNIT_BYTES +
                        (size_t)SCAN_WAVES * EBUF_ENTRIES * 8;
-    const bool bi = g_opt.dense_builtin_dma != 0;
     switch (ns) {
-        case 4: return bi ? scan_launch_t<4, true>(a, lds, st) : scan_launch_t<4, false>(a, lds, st);
-        case 3: return bi ? scan_launch_t<3, true>(a, lds, st) : scan_launch_t<3, false>(a, lds, st);
-        default: return bi ? scan_launch_t<2, true>(a, lds, st) : scan_launch_t<2, false>(a, lds, st);
+        case 4: return scan_launch_t<4>(a, lds, st);
+        case 3: return scan_launch_t<3>(a, lds, st);
+        default: return scan_launch_t<2>(a, lds, st);
     }
 }
 
@@ -683,6 +710,8 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         hipLaunchKernelGGL(fill_f32_kernel, dim3((nq_pad + 255) / 256), dim3(256), 0, st, thr, (long long)nq_pad,
                            -__builtin_inff());
         hipLaunchKernelGGL(kth_threshold_f32_kernel, dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr);
+        hipLaunchKernelGGL(dense_inflate_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, thr, qn2, nq, cosine ? 1 : 0,
+                           h->xn2_max, eps_coef);
         SQ_HIP(hipMemsetAsync(cnt, 0, (size_t)nq_pad * 4, st));
         // full pass
         a.mode = 0;

@@ -18,8 +18,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _reset_options():
     yield
-    for name in ("candidate_cap", "sample_stride", "force_fallback", "profile", "dense_stages", "dense_blocks",
-                 "dense_builtin_dma"):
+    for name in ("candidate_cap", "sample_stride", "force_fallback", "profile", "dense_stages", "dense_blocks"):
         _lib.set_option(name, 0)
 
 
@@ -148,14 +147,14 @@ def test_dense_scan_path_small(tag, metric):
 
 @pytest.mark.parametrize("n,d,nq,k", [(300_000, 128, 33, 100), (100_000, 512, 5, 10), (120_000, 64, 64, 1),
                                       (90_001, 100, 3, 50), (200_000, 256, 2, 100)])
-@pytest.mark.parametrize("variant", ["asm", "builtin"])
-def test_dense_scan_path_l2(n, d, nq, k, variant):
+@pytest.mark.parametrize("stages", [0, 2])
+def test_dense_scan_path_l2(n, d, nq, k, stages):
     rng = np.random.default_rng(n + d)
     db = rng.standard_normal((n, d)).astype(np.float32)
     qs = rng.standard_normal((nq, d)).astype(np.float32)
     qs[0] = db[12345]
     db[777] = db[555]
-    _lib.set_option("dense_builtin_dma", 1 if variant == "builtin" else 0)
+    _lib.set_option("dense_stages", stages)
     idx = _dense_check(db, qs, k, "euclidean")
     st = idx.stats()
     assert st["fallback_queries"] == 0, st

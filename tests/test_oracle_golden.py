@@ -237,3 +237,33 @@ def test_itq_fit_golden(golden):
     np.testing.assert_allclose(mean, g["r_mean"], rtol=1e-12)
     np.testing.assert_allclose(rot, g["r_rot"], rtol=1e-9, atol=1e-12)
     np.testing.assert_array_equal(codes, g["r_codes"])
+
+
+def test_scipy_cosine_order():
+    """Pins the summation order of the scipy build in this image that the HIP
+    cosine kernel mirrors: two interleaved accumulators (even / odd elements),
+    summed, then the odd tail (float32-valued inputs: products are exact)."""
+    import math
+    from scipy.spatial.distance import cdist
+
+    def dot2(u, v):
+        a0 = a1 = 0.0
+        m = len(u) - (len(u) & 1)
+        for i in range(0, m, 2):
+            a0 += u[i] * v[i]
+            a1 += u[i + 1] * v[i + 1]
+        s = a0 + a1
+        if len(u) & 1:
+            s += u[m] * v[m]
+        return s
+
+    rng = np.random.default_rng(1)
+    for t in range(120):
+        d = int(rng.integers(1, 200))
+        u = rng.standard_normal(d).astype(np.float32).astype(np.float64)
+        v = u.copy() if t % 7 == 0 else rng.standard_normal(d).astype(np.float32).astype(np.float64)
+        ul, vl = u.tolist(), v.tolist()
+        c = dot2(ul, vl) / (math.sqrt(dot2(ul, ul)) * math.sqrt(dot2(vl, vl)))
+        if abs(c) > 1:
+            c = math.copysign(1, c)
+        assert cdist(u[None], v[None], "cosine")[0, 0] == 1.0 - c
