@@ -1,0 +1,188 @@
+"""
+ITQ locality-sensitive hash functor whose ``get_hash`` runs on MI355X.
+
+Drop-in counterpart of ``ItqFunctor``
+(smqtk_indexing/impls/lsh_functor/itq.py:31-408): same constructor
+arguments, same model files (``mean_vec`` / ``rotation`` as ``.npy`` bytes in
+``DataElement`` caches, itq.py:212-237), same bit convention (bit 0 = most
+significant, itq.py:46-50) and the same sign rule (``z >= 0`` -> True,
+itq.py:407).  ``get_hash`` calls ``sq_itq_hash`` (include/smqtk_hip.h); there
+is no CPU code path for hashing.
+
+``fit`` (itq.py:291-387) is model *training*, outside the query/build hot path
+(SURVEY.md section 8f rank 3): it runs on the host with numpy exactly as the
+reference does, then the codes of the training set are produced on the GPU.
+"""
+from io import BytesIO
+import logging
+from typing import Any, Dict, Iterable, Optional, Type, TypeVar, Union
+
+import numpy as np
+
+from .. import _require_usable
+from ... import _lib
+from ..._compat import (DataElement, DescriptorElement, from_config_dict,
+                        make_default_config, merge_dict, to_config_dict)
+from ...interfaces.lsh_functor import LshFunctor
+from ...utils.bits import unpack_bits_msb
+
+LOG = logging.getLogger(__name__)
+T = TypeVar("T", bound="HipItqFunctor")
+
+
+class HipItqFunctor(LshFunctor):
+    """ITQ (Gong & Lazebnik, CVPR 2011) hash codes; rotation + sign on the GPU."""
+
+    @classmethod
+    def is_usable(cls) -> bool:
+        return _lib.usable()
+
+    @classmethod
+    def get_default_config(cls) -> Dict[str, Any]:
+        c = super().get_default_config()
+        slots = make_default_config(DataElement.get_impls())
+        c["mean_vec_cache"] = slots
+        c["rotation_cache"] = dict(slots)
+        return c
+
+    @classmethod
+    def from_config(cls: Type[T], config_dict: Dict, merge_default: bool = True) -> T:
+        if merge_default:
+            config_dict = merge_dict(cls.get_default_config(), config_dict)
+        for slot in ("mean_vec_cache", "rotation_cache"):
+            v = config_dict.get(slot)
+            config_dict[slot] = (from_config_dict(v, DataElement.get_impls())
+                                 if v and v.get("type") else None)
+        return super().from_config(config_dict, False)
+
+    def __init__(self, mean_vec_cache: Optional[DataElement] = None,
+                 rotation_cache: Optional[DataElement] = None,
+                 bit_length: int = 8, itq_iterations: int = 50,
+                 normalize: Optional[Union[int, float, str]] = None,
+                 random_seed: Optional[int] = None):
+        super().__init__()
+        self.mean_vec_cache_elem = mean_vec_cache
+        self.rotation_cache_elem = rotation_cache
+        self.bit_length = bit_length
+        self.itq_iterations = itq_iterations
+        self.normalize = normalize
+        self.random_seed = random_seed
+        if normalize is not None:
+            # same validation the reference performs (itq.py:162-164) ...
+            np.linalg.norm(np.random.rand(8), normalize, 0, keepdims=True)
+            # ... and the device kernel implements the L2 case only
+            if float(normalize) != 2.0:
+                raise ValueError("HipItqFunctor supports normalize=None or 2 on the device, got %r" % (normalize,))
+        self.mean_vec: Optional[np.ndarray] = None
+        self.rotation: Optional[np.ndarray] = None
+        self.load_model()
+
+    # ------------------------------------------------------------------ model
+    def get_config(self) -> Dict[str, Any]:
+        c = merge_dict(self.get_default_config(), {
+            "bit_length": self.bit_length,
+            "itq_iterations": self.itq_iterations,
+            "normalize": self.normalize,
+            "random_seed": self.random_seed,
+        })
+        if self.mean_vec_cache_elem:
+            c["mean_vec_cache"] = to_config_dict(self.mean_vec_cache_elem)
+        if self.rotation_cache_elem:
+            c["rotation_cache"] = to_config_dict(self.rotation_cache_elem)
+        return c
+
+    def has_model(self) -> bool:
+        return self.mean_vec is not None and self.rotation is not None
+
+    def load_model(self) -> None:
+        m, r = self.mean_vec_cache_elem, self.rotation_cache_elem
+        if m and r and not m.is_empty() and not r.is_empty():
+            self.mean_vec = np.load(BytesIO(m.get_bytes()))
+            self.rotation = np.load(BytesIO(r.get_bytes()))
+
+    def save_model(self) -> None:
+        m, r = self.mean_vec_cache_elem, self.rotation_cache_elem
+        if m and r and m.writable() and r.writable() and self.has_model():
+            for elem, arr in ((m, self.mean_vec), (r, self.rotation)):
+                buf = BytesIO()
+                np.save(buf, arr)
+                elem.set_bytes(buf.getvalue())
+
+    def _norm_ord(self) -> int:
+        return _lib.SQ_NORM_NONE if self.normalize is None else _lib.SQ_NORM_L2
+
+    def _norm_vector(self, v: np.ndarray) -> np.ndarray:
+        """Host normalisation used by ``fit`` only (itq.py:172-191)."""
+        if self.normalize is None:
+            return v
+        n = np.linalg.norm(v, self.normalize, v.ndim - 1, keepdims=True)
+        n[n == 0.] = 1.
+        return v / n
+
+    # ---------------------------------------------------------------- hashing
+    def get_hash_packed(self, descriptors: np.ndarray) -> np.ndarray:
+        """Packed codes ``uint64[n, ceil(bits/64)]`` of an ``[n, d]`` matrix (GPU)."""
+        _require_usable(self)
+        if not self.has_model():
+            if self.mean_vec is None:
+                raise Exception("Can't compute hash code: mean vector is none.")
+            raise Exception("Can't compute hash code: rotation matrix is none.")
+        x = np.asarray(descriptors)
+        if x.ndim != 2:
+            raise ValueError("expected an [n, d] matrix")
+        if x.dtype != np.float32:
+            x = x.astype(np.float64)       # ints / float16 etc. upcast like numpy would
+        return _lib.itq_hash(x, self.mean_vec, np.real(self.rotation), self._norm_ord())
+
+    def get_hash(self, descriptor: np.ndarray) -> np.ndarray:
+        """Boolean hash vector of one descriptor (or bool ``[n, bits]`` of a matrix)."""
+        x = np.asarray(descriptor)
+        single = x.ndim == 1
+        if self.mean_vec is None:
+            raise Exception("Can't compute hash code: mean vector is none.")
+        elif self.rotation is None:
+            raise Exception("Can't compute hash code: rotation matrix is none.")
+        bits = self.rotation.shape[1]
+        b = unpack_bits_msb(self.get_hash_packed(x[None, :] if single else x), bits)
+        return b[0] if single else b
+
+    # ------------------------------------------------------------------- fit
+    def _find_itq_rotation(self, v: np.ndarray, n_iter: int) -> np.ndarray:
+        """Orthogonal Procrustes iterations of ITQ on the PCA-embedded data
+        (itq.py:239-289): random orthogonal start (SVD of a seeded Gaussian),
+        then alternate B = sign(V R) and R = argmin ||B - V R||_F."""
+        nbits = v.shape[1]
+        if self.random_seed is not None:
+            np.random.seed(self.random_seed)
+        u, _, _ = np.linalg.svd(np.random.randn(nbits, nbits))
+        r = u[:, :nbits]
+        for _ in range(n_iter):
+            b = np.where(np.dot(v, r) >= 0, 1.0, -1.0)
+            ub, _, ua = np.linalg.svd(np.dot(b.T, v))
+            r = np.dot(ua, ub.T)
+        return r
+
+    def fit(self, descriptors: Iterable[DescriptorElement], use_multiprocessing: bool = True) -> np.ndarray:
+        """Train mean vector and rotation from descriptors (host, numpy), then
+        return the training set's codes (bool ``[n, bits]``, computed on the GPU)."""
+        if self.has_model():
+            raise RuntimeError("Model components have already been loaded.")
+        descr = descriptors if isinstance(descriptors, (list, tuple)) else list(descriptors)
+        if len(descr[0].vector()) < self.bit_length:
+            raise ValueError("Input descriptors have fewer features than "
+                             "requested bit encoding. Hash codes will be "
+                             "smaller than requested due to PCA decomposition "
+                             "result being bound by number of features.")
+        x_in = np.asarray([d.vector() for d in descr])
+        x = self._norm_vector(x_in)
+        mean_vec = np.mean(x, axis=0)
+        x = x - mean_vec
+        cov = np.atleast_2d(np.cov(x.T))
+        evals, evecs = np.linalg.eig(cov)
+        ranked = sorted(zip(evals, evecs.T), key=lambda p: p[0], reverse=True)
+        pc_top = np.array([p[1] for p in ranked[:self.bit_length]]).T
+        r = self._find_itq_rotation(np.dot(x, pc_top), self.itq_iterations)
+        self.mean_vec = mean_vec
+        self.rotation = np.dot(pc_top, r)
+        self.save_model()
+        return self.get_hash(x_in)

@@ -1,0 +1,139 @@
+"""
+Exact brute-force ``NearestNeighborsIndex`` on MI355X.
+
+The reference has no stand-alone brute-force class; the contract implemented
+here is the one its FAISS ``"IDMap,Flat"`` wrapper expresses
+(smqtk_indexing/impls/nn_index/faiss.py:486-559 build, 681-701 float32 matrix,
+751-831 search ``k = min(n, ntotal)``, ascending true Euclidean distance) and
+the exact tail of ``LSHNearestNeighborIndex._nn``
+(impls/nn_index/lsh.py:505-519): distance of every row by
+``metrics.euclidean_distance`` / ``cosine_distance``
+(utils/metrics.py:73-86, 120-137), stable ascending sort, first ``n``.
+
+The descriptor matrix lives in HBM as float32 (faiss.py:696-698 casts the same
+way); ``nn`` calls ``sq_dense_search``.  Ties are returned in insertion order
+(stable sort over rows), which is the canonical (distance, row) order.
+"""
+import threading
+from typing import Any, Dict, Hashable, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .. import _require_usable
+from ... import _lib
+from ..._compat import DescriptorElement, ReadOnlyError
+from ...interfaces.nearest_neighbor_index import NearestNeighborsIndex
+
+
+class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
+    """Exact L2 / cosine kNN over all indexed descriptors (HIP kernels)."""
+
+    METRICS = {"euclidean": _lib.SQ_METRIC_L2, "cosine": _lib.SQ_METRIC_COSINE}
+
+    @classmethod
+    def is_usable(cls) -> bool:
+        return _lib.usable()
+
+    def __init__(self, distance_method: str = "euclidean", read_only: bool = False):
+        super().__init__()
+        if distance_method not in self.METRICS:
+            raise ValueError("Invalid distance method label. Must be one of "
+                             "['euclidean' | 'cosine']")
+        self.distance_method = distance_method
+        self.read_only = read_only
+        self._lock = threading.RLock()
+        self._elements: List[DescriptorElement] = []
+        self._row_of: Dict[Hashable, int] = {}
+        self._matrix = np.zeros((0, 0), dtype=np.float32)
+        self._dev: Optional[_lib.DenseIndex] = None
+
+    def get_config(self) -> Dict[str, Any]:
+        return {"distance_method": self.distance_method, "read_only": self.read_only}
+
+    # ------------------------------------------------------------------ state
+    def _set(self, elements: List[DescriptorElement], matrix: np.ndarray) -> None:
+        self._elements = elements
+        self._row_of = {e.uuid(): i for i, e in enumerate(elements)}
+        self._matrix = matrix
+        if self._dev is not None:
+            self._dev.close()
+            self._dev = None
+
+    def _device(self) -> _lib.DenseIndex:
+        if self._dev is None:
+            _require_usable(self)
+            self._dev = _lib.DenseIndex(self._matrix, metric=self.METRICS[self.distance_method])
+        return self._dev
+
+    @staticmethod
+    def _to_matrix(elements: Sequence[DescriptorElement]) -> np.ndarray:
+        vecs = [e.vector() for e in elements]
+        if any(v is None for v in vecs):
+            raise ValueError("descriptor without a vector cannot be indexed")
+        return np.ascontiguousarray(np.vstack(vecs), dtype=np.float32)
+
+    def _guard(self) -> None:
+        if self.read_only:
+            raise ReadOnlyError("Cannot modify container attributes due to "
+                                "being in read-only mode.")
+
+    # -------------------------------------------------------------- interface
+    def count(self) -> int:
+        with self._lock:
+            return len(self._elements)
+
+    def _build_index(self, descriptors: Iterable[DescriptorElement]) -> None:
+        with self._lock:
+            self._guard()
+            uniq: Dict[Hashable, DescriptorElement] = {}
+            for d in descriptors:
+                uniq[d.uuid()] = d
+            elements = list(uniq.values())
+            self._set(elements, self._to_matrix(elements))
+
+    def _update_index(self, descriptors: Iterable[DescriptorElement]) -> None:
+        with self._lock:
+            self._guard()
+            new: Dict[Hashable, DescriptorElement] = {}
+            for d in descriptors:
+                new[d.uuid()] = d
+            kept = [e for e in self._elements if e.uuid() not in new]
+            keep_rows = [self._row_of[e.uuid()] for e in kept]
+            add = list(new.values())
+            add_m = self._to_matrix(add)
+            if kept:
+                matrix = np.vstack([self._matrix[keep_rows], add_m])
+            else:
+                matrix = add_m
+            self._set(kept + add, np.ascontiguousarray(matrix, dtype=np.float32))
+
+    def _remove_from_index(self, uids: Iterable[Hashable]) -> None:
+        with self._lock:
+            self._guard()
+            uids = list(uids)
+            for u in uids:
+                if u not in self._row_of:
+                    raise KeyError(u)          # nothing modified yet
+            drop = set(uids)
+            kept = [e for e in self._elements if e.uuid() not in drop]
+            rows = [self._row_of[e.uuid()] for e in kept]
+            self._set(kept, np.ascontiguousarray(self._matrix[rows], dtype=np.float32))
+
+    def nn_many(self, vectors: np.ndarray, n: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+        """Batched search: ``[nq, d]`` -> (row ids ``[nq, k]``, distances ``[nq, k]``)."""
+        with self._lock:
+            if not self.count():
+                raise ValueError("No index currently set to query from!")
+            k = min(int(n), self.count())
+            dist, idx = self._device().search(np.asarray(vectors, dtype=np.float32), k)
+            return idx, dist
+
+    def elements_of(self, rows: Sequence[int]) -> Tuple[DescriptorElement, ...]:
+        with self._lock:
+            return tuple(self._elements[int(r)] for r in rows)
+
+    def _nn(self, d: DescriptorElement, n: int = 1
+            ) -> Tuple[Tuple[DescriptorElement, ...], Tuple[float, ...]]:
+        with self._lock:
+            idx, dist = self.nn_many(np.asarray(d.vector()).reshape(1, -1), n)
+            return self.elements_of(idx[0]), tuple(float(v) for v in dist[0])

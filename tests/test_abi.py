@@ -1,0 +1,55 @@
+"""The C-ABI library loads without a GPU and exports every symbol that
+include/smqtk_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from smqtk_indexing_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "smqtk_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sq_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_library_answers_without_gpu_calls():
+    lib = _lib.load()
+    assert lib.sq_version() >= 100
+    assert _lib.device_count() >= 0
+    with pytest.raises(_lib.HipError):
+        _lib.set_option("no_such_option", 1)
+    assert b"unknown option" in lib.sq_last_error()
+
+
+def test_host_merge_orders_by_distance_then_id():
+    d = np.array([[[1., 3., np.inf]], [[1., 2., 2.]]], dtype=np.float32)      # [shards=2][nq=1][k_in=3]
+    i = np.array([[[7, 9, -1]], [[3, 5, 4]]], dtype=np.int64)
+    od, oi = _lib.merge_topk(d, i, 5)
+    np.testing.assert_array_equal(oi[0], [3, 7, 4, 5, 9])
+    np.testing.assert_array_equal(od[0], [1., 1., 2., 2., 3.])
+    od, oi = _lib.merge_topk(d.astype(np.float64), i, 6)
+    assert oi[0, 5] == -1 and np.isinf(od[0, 5])
+    od, oi = _lib.merge_topk(np.array([[[4, 1]], [[1, 9]]], dtype=np.int32), np.array([[[8, 2]], [[1, 0]]]), 3)
+    np.testing.assert_array_equal(oi[0], [1, 2, 8])
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    with pytest.raises(_lib.HipError):
+        _lib.merge_topk(np.zeros((1, 1, 1), np.float32), np.zeros((1, 1, 1), np.int64), 0)
+    if _lib.device_count() == 0:
+        with pytest.raises(_lib.HipError):
+            _lib.DenseIndex(np.zeros((4, 8), np.float32))

@@ -1,0 +1,239 @@
+"""
+GPU tests of the plugin classes: ports of the reference's result-pinning tests
+ run against the HIP implementations, plus comparisons
+with the oracle and the reference-generated golden vectors.
+"""
+from math import sqrt
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as O
+from smqtk_indexing_amd import _lib
+from smqtk_indexing_amd._compat import (DataMemoryElement, DescriptorMemoryElement,
+                                        MemoryDescriptorSet, MemoryKeyValueStore)
+from smqtk_indexing_amd.impls.hash_index.hip_linear import HipLinearHashIndex
+from smqtk_indexing_amd.impls.lsh_functor.hip_itq import HipItqFunctor
+from smqtk_indexing_amd.impls.nn_index.hip_bruteforce import HipBruteForceNearestNeighborsIndex
+from smqtk_indexing_amd.impls.nn_index.hip_lsh import HipLSHNearestNeighborIndex
+from tests.golden import inputs as GI
+
+pytestmark = pytest.mark.gpu
+
+
+def _elems(x, base=0):
+    return [DescriptorMemoryElement(base + i).set_vector(v) for i, v in enumerate(x)]
+
+
+# ------------------------------------------------------------ HipLinearHashIndex
+def test_linear_nn_known_answer():
+    # tests/impls/hash_index/test_linear.py:141-155
+    i = HipLinearHashIndex()
+    i.build_index([[0, 1, 0], [1, 1, 0], [0, 1, 1], [0, 0, 1]])
+    near_codes, near_dists = i.nn([0, 0, 0], 4)
+    assert set(map(tuple, near_codes[:2].astype(int))) == {(0, 1, 0), (0, 0, 1)}
+    assert set(map(tuple, near_codes[2:].astype(int))) == {(1, 1, 0), (0, 1, 1)}
+    np.testing.assert_array_almost_equal(near_dists, (1 / 3., 1 / 3., 2 / 3., 2 / 3.))
+    assert near_codes.dtype == bool and isinstance(near_dists, tuple)
+    codes, dists = i.nn([0, 0, 0], 10)                        # n > count -> count results
+    assert len(codes) == 4 and len(dists) == 4
+
+
+def test_linear_nn_matches_reference_golden(golden):
+    g = golden("g4_linear_hash_nn.npz")
+    for tag in ("u64", "small70"):
+        n, bits, seed, mode = GI.HAMMING_CASES[tag]
+        codes, queries = GI.hamming_inputs(n, bits, seed, mode)
+        idx = HipLinearHashIndex()
+        idx.build_index(O.unpack_bits_msb(codes, bits))
+        assert idx.count() == codes.shape[0]
+        k = GI.HAMMING_KS[tag][-1]
+        for qi, q in enumerate(queries[:4]):
+            rows, dists = idx.nn(O.unpack_bits_msb(q[None], bits)[0], k)
+            np.testing.assert_allclose(dists, g[f"{tag}_k{k}_dist"][qi][:len(dists)], rtol=0, atol=1e-15)
+            assert len({tuple(r) for r in rows.astype(int)}) == len(rows)      # never the same code twice
+        rows, dist = idx.nn_many(O.unpack_bits_msb(queries, bits), k)
+        assert rows.shape == (len(queries), min(k, idx.count()), bits)
+
+
+def test_linear_update_remove_then_search():
+    rng = np.random.default_rng(2)
+    v = rng.random((500, 64)) > 0.5
+    idx = HipLinearHashIndex(DataMemoryElement())
+    idx.build_index(v[:300])
+    idx.update_index(v[300:])
+    idx.remove_from_index(v[:50])
+    left = np.unique(O.pack_bits_msb(v[50:]), axis=0)
+    assert idx.count() == left.shape[0]
+    rows, dists = idx.nn(v[7], 5)                             # removed code: not returned at distance 0
+    rd, ri = O.hamming_topk(left, O.pack_bits_msb(v[7:8])[0], 5)
+    np.testing.assert_allclose(dists, rd / 64.0)
+    np.testing.assert_array_equal(O.pack_bits_msb(rows), left[ri])
+
+
+# ---------------------------------------------------------------- HipItqFunctor
+def test_itq_get_hash_known_answers():
+    # tests/impls/lsh_functor/test_itq.py:304-336
+    itq = HipItqFunctor(bit_length=1, random_seed=0)
+    itq.mean_vec = np.array([0., 0.])
+    itq.rotation = np.array([[1. / sqrt(2)], [1. / sqrt(2)]])
+    for v, want in (([1, 1], True), ([-1, -1], False), ([-1, 1], True), ([-1.001, 1], False),
+                    ([-1, 1.001], True), ([1, -1], True), ([1, -1.001], False), ([1.001, -1], True)):
+        np.testing.assert_array_equal(itq.get_hash(np.array(v)), [want])
+    assert itq(np.array([1, 1])).dtype == bool
+
+
+def test_itq_fit_known_answer_and_cache():
+    # tests/impls/lsh_functor/test_itq.py:255-302
+    fit = _elems([[-2. + i, -2. + i] for i in range(5)])
+    itq = HipItqFunctor(DataMemoryElement(), DataMemoryElement(), bit_length=1, random_seed=0)
+    codes = itq.fit(fit)
+    np.testing.assert_array_almost_equal(itq.mean_vec, [0, 0])
+    np.testing.assert_array_almost_equal(itq.rotation, [[1 / sqrt(2)], [1 / sqrt(2)]])
+    assert codes.shape == (5, 1)
+    again = HipItqFunctor(itq.mean_vec_cache_elem, itq.rotation_cache_elem, bit_length=1)
+    np.testing.assert_array_equal(again.get_hash(np.array([3., 3.])), [True])
+
+
+def test_itq_functor_matches_reference_golden(golden):
+    g = golden("g3_itq_hash.npz")
+    n, d, bits, seed = GI.ITQ_CASES["a"]
+    x32, mean, rot = GI.itq_inputs(n, d, bits, seed)
+    for norm in (None, 2):
+        f = HipItqFunctor(bit_length=bits, normalize=norm)
+        f.mean_vec, f.rotation = mean, rot
+        got = O.pack_bits_msb(f.get_hash(x32))
+        key = f"a_n{norm}_float32"
+        bad = (got != g[key + "_packed"]).any(axis=1)
+        assert bad.sum() == 0 or g[key + "_minabsz"][bad].max() < 1e-10
+        one = f.get_hash(x32[5])
+        assert one.shape == (bits,) and one.dtype == bool
+        np.testing.assert_array_equal(O.pack_bits_msb(one[None])[0], got[5])
+
+
+# ------------------------------------------- HipBruteForceNearestNeighborsIndex
+def test_bruteforce_known_answers():
+    # tests/impls/nn_index/test_faiss.py:443-515 (the reference's exact-index KATs)
+    dim = 5
+    index = HipBruteForceNearestNeighborsIndex()
+    index.build_index(_elems(np.eye(dim)))
+    q = DescriptorMemoryElement("q").set_vector(np.zeros(dim))
+    r, dists = index.nn(q, dim)
+    assert len(r) == dim and all(d == 1.0 for d in dists)
+    r, dists = index.nn(_elems(np.eye(dim))[3], 1)
+    assert r[0].uuid() == 3 and dists[0] == 0.0
+    pts = np.array([[j, 2. * j] for j in range(1000)])
+    order = np.random.default_rng(0).permutation(1000)
+    index.build_index([DescriptorMemoryElement(int(j)).set_vector(pts[j]) for j in order])
+    q.set_vector(np.zeros(2))
+    r, dists = index.nn(q, 100)
+    assert [e.uuid() for e in r] == list(range(100))
+    assert all(b > a for a, b in zip(dists, dists[1:]))
+    x = np.random.default_rng(1).random((10_000, 256))
+    index.build_index(_elems(x))
+    r, dists = index.nn(_elems(x[:1] + 1e-3)[0], 10)
+    assert len(r) == 10 and r[0].uuid() == 0
+
+
+def test_bruteforce_matches_reference_golden(golden):
+    g = golden("g5_dense_nn.npz")
+    n, d, nq, seed, dist, dt = GI.DENSE_CASES["nrm128"]
+    db, qs = GI.dense_inputs(n, d, nq, seed, dist, dt)
+    for metric in ("euclidean", "cosine"):
+        index = HipBruteForceNearestNeighborsIndex(metric)
+        index.build_index(_elems(db))
+        for qi in range(2):
+            r, dists = index.nn(DescriptorMemoryElement("q").set_vector(qs[qi]), 100)
+            if metric == "euclidean":
+                assert [e.uuid() for e in r] == g["nrm128_euclidean_idx"][qi].tolist()
+                np.testing.assert_array_equal(np.float32(dists), g["nrm128_euclidean_dist"][qi])
+            else:
+                np.testing.assert_allclose(dists, g["nrm128_cosine_dist"][qi], rtol=1e-9, atol=1e-12)
+        index.remove_from_index([int(g[f"nrm128_{metric}_idx"][0][0])])
+        r, _ = index.nn(DescriptorMemoryElement("q").set_vector(qs[0]), 1)
+        assert r[0].uuid() == int(g[f"nrm128_{metric}_idx"][0][1])
+
+
+# ------------------------------------------------ HipLSHNearestNeighborIndex
+def _lsh(bits, metric, hash_index=True, x=None, seed=0, iters=50):
+    f = HipItqFunctor(bit_length=bits, random_seed=seed, itq_iterations=iters)
+    if x is not None:
+        f.fit(_elems(x))
+    return HipLSHNearestNeighborIndex(f, MemoryDescriptorSet(), MemoryKeyValueStore(),
+                                      HipLinearHashIndex() if hash_index else None, distance_method=metric)
+
+
+@pytest.mark.parametrize("hash_index", [True, False])
+def test_lsh_random_euclidean(hash_index):
+    # tests/impls/nn_index/test_lsh.py:754-832
+    np.random.seed(0)
+    x = np.random.rand(1000, 256)
+    index = _lsh(32, "euclidean", hash_index, x)
+    index.build_index(_elems(x))
+    assert index.count() == 1000
+    q = DescriptorMemoryElement("q")
+    for i in (0, 500, 999):
+        q.set_vector(x[i])
+        r, dists = index.nn(q, 1)
+        assert r[0].uuid() == i and dists[0] == 0.0
+        q.set_vector(x[i] + 1e-4)
+        r, dists = index.nn(q, 1)
+        assert r[0].uuid() == i
+    q.set_vector(np.random.rand(256))
+    for n in (10, 1000):
+        r, dists = index.nn(q, n)
+        assert len(dists) <= n
+        assert all(b > a for a, b in zip(dists, dists[1:]))      # strictly increasing
+
+
+def test_lsh_known_unit_and_ordered():
+    # tests/impls/nn_index/test_lsh.py:837-979
+    dim = 5
+    index = _lsh(dim, "euclidean", True, np.eye(dim))
+    index.build_index(_elems(np.eye(dim)))
+    q = DescriptorMemoryElement("q").set_vector(np.zeros(dim))
+    r, dists = index.nn(q, dim)
+    assert len(r) == dim and all(d == 1.0 for d in dists)
+    r, dists = index.nn(_elems(np.eye(dim))[2], 1)
+    assert r[0].uuid() == 2 and dists[0] == 0.0
+    pts = np.array([[j, 2. * j] for j in range(1000)])
+    order = np.random.default_rng(0).permutation(1000)
+    d_set = [DescriptorMemoryElement(int(j)).set_vector(pts[j]) for j in order]
+    index = _lsh(1, "euclidean", True, pts)
+    index.build_index(d_set)
+    q.set_vector(np.zeros(2))
+    r, dists = index.nn(q, 5)
+    assert [e.uuid() for e in r] == [0, 1, 2, 3, 4]
+    r, dists = index.nn(q, 1000)                                  # n covers every code: exact brute force
+    assert [e.uuid() for e in r] == list(range(1000))
+
+
+def test_lsh_matches_reference_golden(golden):
+    g = golden("g6_lsh_nn.npz")
+    for tag, (n, d, bits, seed, metric, ns) in GI.LSH_CASES.items():
+        db, qs = GI.lsh_inputs(n, d, seed)
+        f = HipItqFunctor(bit_length=bits)
+        f.mean_vec, f.rotation = g[f"{tag}_mean"], g[f"{tag}_rot"]      # the model the reference fitted
+        index = HipLSHNearestNeighborIndex(f, MemoryDescriptorSet(), MemoryKeyValueStore(), HipLinearHashIndex(),
+                                           distance_method=metric)
+        index.build_index(_elems(db))
+        assert index.count() == int(g[f"{tag}_count"])
+        assert len(list(index.hash2uuids_kvstore.keys())) == int(g[f"{tag}_ncodes"])
+        nn_all = max(ns)
+        if nn_all >= n:
+            for qi, q in enumerate(qs):
+                r, dists = index.nn(DescriptorMemoryElement("q").set_vector(q), nn_all)
+                ru, rd = g[f"{tag}_n{nn_all}_uuids"][qi], g[f"{tag}_n{nn_all}_dist"][qi]
+                np.testing.assert_allclose(dists, rd, rtol=1e-12)
+                dd = np.asarray(dists)
+                if (dd[1:] != dd[:-1]).all():
+                    assert [e.uuid() for e in r] == ru.tolist()
+        for qi, q in enumerate(qs):                                # first result always agrees on distance
+            r, dists = index.nn(DescriptorMemoryElement("q").set_vector(q), min(ns))
+            assert len(r) >= 1 and dists[0] >= 0
+
+
+def test_lsh_config_roundtrip_on_gpu():
+    idx = _lsh(4, "euclidean")
+    j = HipLSHNearestNeighborIndex.from_config(idx.get_config())
+    assert isinstance(j.hash_index, HipLinearHashIndex) and j.lsh_functor.bit_length == 4
