@@ -129,9 +129,10 @@ int sq_dense_destroy(sq_handle_t h);
 
 /* Distances from one query to n gathered candidate rows, in the reference's
  * arithmetic: the `distances = list(map(comp_descr_dist, neighbor_vectors))`
- * step of lsh.py:511.  rows: [n][d] f32; out: float32[n] (L2) or float64[n]
- * (cosine). */
-int sq_dense_distances(const float* query, const float* rows, int64_t n, int d,
+ * step of lsh.py:511.  query: [d], rows: [n][d], both of `dtype`
+ * (SQ_DTYPE_F32 / SQ_DTYPE_F64).  out: L2 -> [n] of the same dtype
+ * (metrics.py:73-86 is dtype preserving); cosine -> float64[n]. */
+int sq_dense_distances(const void* query, const void* rows, int dtype, int64_t n, int d,
                        int metric, void* out, int mem, void* stream);
 
 /* ----------------------------------------------------------------- merge

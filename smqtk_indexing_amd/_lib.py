@@ -77,7 +77,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_dense_create.argtypes = [c_vp, c_i64, c_int, c_int, c_int, c_i64, ctypes.POINTER(c_i64)]
     lib.sq_dense_search.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]
     lib.sq_dense_destroy.argtypes = [c_i64]
-    lib.sq_dense_distances.argtypes = [c_vp, c_vp, c_i64, c_int, c_int, c_vp, c_int, c_vp]
+    lib.sq_dense_distances.argtypes = [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_int, c_vp]
     lib.sq_merge_topk.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]
     for name in EXPORTS:
         if name not in ("sq_last_error",):
@@ -303,16 +303,21 @@ class DenseIndex(_Handle):
 
 
 def dense_distances(query: np.ndarray, rows: np.ndarray, metric: int = SQ_METRIC_L2) -> np.ndarray:
-    """Reference-arithmetic distances from ``query`` to each of ``rows`` (host arrays)."""
-    q = _host(query, np.float32).reshape(-1)
-    r = _host(rows, np.float32)
+    """Reference-arithmetic distances from ``query`` to each of ``rows`` (host
+    arrays).  Computed in float32 when both operands are float32, otherwise in
+    float64 (numpy's promotion in metrics.py:86); cosine is always float64."""
+    query, rows = np.asarray(query), np.asarray(rows)
+    dt = np.float32 if (query.dtype == np.float32 and rows.dtype == np.float32) else np.float64
+    q = _host(query, dt).reshape(-1)
+    r = _host(rows, dt)
     if r.ndim != 2 or r.shape[1] != q.shape[0]:
         raise ValueError("rows must be [n, d] with d == len(query)")
-    out = np.empty(r.shape[0], dtype=np.float64 if metric == SQ_METRIC_COSINE else np.float32)
+    out = np.empty(r.shape[0], dtype=np.float64 if metric == SQ_METRIC_COSINE else dt)
     if r.shape[0] == 0:
         return out
-    _check(load().sq_dense_distances(_ptr(q), _ptr(r), r.shape[0], r.shape[1], int(metric), _ptr(out), SQ_MEM_HOST,
-                                     None), "sq_dense_distances")
+    _check(load().sq_dense_distances(_ptr(q), _ptr(r), SQ_DTYPE_F32 if dt == np.float32 else SQ_DTYPE_F64,
+                                     r.shape[0], r.shape[1], int(metric), _ptr(out), SQ_MEM_HOST, None),
+           "sq_dense_distances")
     return out
 
 

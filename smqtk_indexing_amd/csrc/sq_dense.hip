@@ -40,6 +40,7 @@ static constexpr int TILE_ROWS = 32;          // rows per MFMA tile / per wave u
 static constexpr int UNIT_BYTES = TILE_ROWS * KT * 4;  // 8 KiB
 static constexpr int SCAN_WAVES = 4;
 static constexpr int EBUF_ENTRIES = 256;      // per-wave emission buffer (row, query) pairs
+static constexpr int EBUF_FLUSH = 128;        // flush the buffer to the global candidate lists at this fill
 static constexpr int MAX_DPAD = 512;
 
 struct DenseHandle : HandleBase {
@@ -202,10 +203,24 @@ struct DenseScanArgs {
 };
 
 // LDS-DMA: 64 lanes x 16 bytes land at lds_dst + lane*16 (wave-uniform base in
-// M0); the global source address is per lane.  Issued from inline asm so that
-// hipcc does not fence every later ds_read with vmcnt(0); completion is
-// tracked by the counted waits below (cdna_hip_programming.md section 5.7).
-__device__ __forceinline__ void glds16(const float* gsrc, u32 lds_dst) {
+// M0); the global source is a wave-uniform 64-bit base (SGPR pair) plus a
+// per-lane 32-bit byte offset.  Issued from inline asm so that hipcc does not
+// fence every later ds_read with vmcnt(0); completion is tracked by the
+// counted waits below (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16(const float* gbase_uniform, u32 voff, u32 lds_dst) {
+    u32 keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(gbase_uniform), "s"(lds_dst)
+        : "memory");
+}
+// same with a full per-lane 64-bit address (partial last tile: clamped rows)
+__device__ __forceinline__ void glds16_addr(const float* gsrc, u32 lds_dst) {
     u32 keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -244,18 +259,24 @@ __device__ __forceinline__ void wait_units_in_flight(int units) {
         wait_vmcnt<0>();
 }
 
-template <int NSTAGE>
+typedef __attribute__((address_space(3))) u32 lds_u32;
+
+// NSTAGE: ring depth per wave; KU = d_pad / 64 k-units per row tile.
+template <int NSTAGE, int KU>
 __global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseScanArgs a) {
+    constexpr bool QREG = KU <= 2;  // query fragments live in registers for d_pad <= 128
+    constexpr int DPAD = KU * KT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ku = a.d_pad / KT;
-    const u32 q_bytes = (u32)TILE_ROWS * a.d_pad * 4;
-    // LDS map: [query tile][ring wave0..3][emission buffers]
+    constexpr u32 q_bytes = (u32)TILE_ROWS * DPAD * 4;
+    // LDS map: [query tile][ring wave0..3][emission buffers][emission counters]
     const u32 lds_base = (u32)(uintptr_t)smem;  // low 32 bits of a flat LDS address = LDS offset
     const u32 ring_base = lds_base + q_bytes + (u32)wave * (NSTAGE * UNIT_BYTES);
     unsigned char* ring_ptr = smem + q_bytes + wave * (NSTAGE * UNIT_BYTES);
-    uint2* ebuf = reinterpret_cast<uint2*>(smem + q_bytes + SCAN_WAVES * NSTAGE * UNIT_BYTES) + wave * EBUF_ENTRIES;
+    unsigned char* etop = smem + q_bytes + SCAN_WAVES * NSTAGE * UNIT_BYTES;
+    uint2* ebuf = reinterpret_cast<uint2*>(etop) + wave * EBUF_ENTRIES;
+    lds_u32* ecnt_ptr = (lds_u32*)(etop + SCAN_WAVES * EBUF_ENTRIES * 8 + wave * 16);
 
     // block -> (row block, query tile); blocks that share an XCD (same id mod 8)
     // walk the query tiles of the same rows so the matrix is re-read from L2.
@@ -273,58 +294,91 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseSca
     // stage the query tile: [32][d_pad] floats, 16-byte chunks XOR-swizzled
     // inside each 256-byte group by (row & 15)
     {
-        const float* qsrc = a.qs + (long long)qt * TILE_ROWS * a.d_pad;
-        const int chunks_per_row = a.d_pad / 4;
+        const float* qsrc = a.qs + (long long)qt * TILE_ROWS * DPAD;
+        constexpr int chunks_per_row = DPAD / 4;
         for (int c = threadIdx.x; c < TILE_ROWS * chunks_per_row; c += SCAN_WAVES * 64) {
             const int r = c / chunks_per_row, ch = c - r * chunks_per_row;
-            f32x4 v = *reinterpret_cast<const f32x4*>(qsrc + (long long)r * a.d_pad + ch * 4);
+            f32x4 v = *reinterpret_cast<const f32x4*>(qsrc + (long long)r * DPAD + ch * 4);
             const int sw = (ch & ~15) | ((ch & 15) ^ (r & 15));
-            *reinterpret_cast<f32x4*>(smem + (u32)r * a.d_pad * 4 + sw * 16) = v;
+            *reinterpret_cast<f32x4*>(smem + (u32)r * DPAD * 4 + sw * 16) = v;
         }
+        if (lane == 0) *ecnt_ptr = 0u;
     }
     __syncthreads();
 
+    // Tiles are dealt round-robin over all waves of the launch (wave gw takes tiles
+    // gw, gw + nwaves, ...): at any moment the grid reads one compact window of the
+    // matrix, which keeps HBM pages open across waves (a private contiguous range
+    // per wave measured ~20 % slower).
     const long long gw = (long long)rb * SCAN_WAVES + wave;
     const long long nwaves = (long long)a.nrb * SCAN_WAVES;
-    const long long i0 = a.n_tiles * gw / nwaves;
-    const long long i1 = a.n_tiles * (gw + 1) / nwaves;
-    const long long total_units = (i1 - i0) * ku;
+    const long long my_tiles = gw < a.n_tiles ? (a.n_tiles - gw + nwaves - 1) / nwaves : 0;
+    const long long total_units = my_tiles * KU;
 
     const int r31 = lane & 31, h = lane >> 5;
     const int qglob = qt * TILE_ROWS + r31;
-    const float thr_l = a.mode == 0 ? a.thr[qglob] : 0.f;
-    int ecnt = 0;  // wave-uniform number of buffered emissions
+    float thr_l = a.mode == 0 ? a.thr[qglob] : 0.f;
+    // Force hipcc's wait for this load HERE.  Left to its first use inside the
+    // loop the compiler emits s_waitcnt vmcnt(0) there (it cannot see the asm
+    // LDS-DMAs), draining the whole ring once per tile.
+    asm volatile("" : "+v"(thr_l));
 
-    auto flush = [&]() {
-        for (int e = lane; e < ecnt; e += 64) {
+    f32x4 bq[QREG ? KU : 1][8];
+    if constexpr (QREG) {
+#pragma unroll
+        for (int kc = 0; kc < KU; ++kc)
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                bq[kc][g] = *reinterpret_cast<const f32x4*>(smem + (u32)r31 * DPAD * 4 + kc * 256 +
+                                                             ((2 * g + h) ^ (r31 & 15)) * 16);
+    }
+
+    // per-lane byte offsets of the 8 DMA instructions of a unit (row 4j + lane/16, swizzled 16-byte chunk)
+    u32 voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 4 * j + (lane >> 4);
+        voff[j] = (u32)(((long long)r * a.ld + (((lane & 15) ^ (r & 15)) * 4)) * 4);
+    }
+
+    auto emit_global = [&](u32 row, u32 q) {
+        u32 pos = atomicAdd(&a.cnt[q], 1u);
+        if (pos < a.cap) a.cand[(long long)q * a.cap + pos] = row;
+    };
+    auto flush = [&](u32 c) {
+        const u32 n = c < (u32)EBUF_ENTRIES ? c : (u32)EBUF_ENTRIES;
+        for (u32 e = lane; e < n; e += 64) {
             uint2 ent = ebuf[e];
-            u32 pos = atomicAdd(&a.cnt[ent.y], 1u);
-            if (pos < a.cap) a.cand[(long long)ent.y * a.cap + pos] = ent.x;
+            emit_global(ent.x, ent.y);
         }
-        ecnt = 0;
+        if (lane == 0) *ecnt_ptr = 0u;
     };
 
     // issue cursor
-    long long iss_tile = i0;
+    long long iss_tile = gw;
     int iss_kc = 0, iss_slot = 0;
     long long issued = 0;
     auto issue_unit = [&]() {
         const long long row0 = (a.tile_first + iss_tile * a.tile_step) * TILE_ROWS;
-        const float* colbase = a.db + (long long)iss_kc * KT;
         const u32 dst = ring_base + (u32)iss_slot * UNIT_BYTES;
+        if (row0 + TILE_ROWS <= a.n) {
+            const float* base = a.db + row0 * a.ld + (long long)iss_kc * KT;  // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = 4 * j + (lane >> 4);
-            long long row = row0 + r;
-            row = row < a.n ? row : a.n - 1;
-            const int chunk = (lane & 15) ^ (r & 15);
-            const float* src = colbase + row * a.ld + chunk * 4;
-            glds16(src, dst + (u32)j * 1024);
+            for (int j = 0; j < 8; ++j) glds16(base, voff[j], dst + (u32)j * 1024);
+        } else {
+            const float* colbase = a.db + (long long)iss_kc * KT;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 4 * j + (lane >> 4);
+                long long row = row0 + r;
+                row = row < a.n ? row : a.n - 1;
+                glds16_addr(colbase + row * a.ld + ((lane & 15) ^ (r & 15)) * 4, dst + (u32)j * 1024);
+            }
         }
         ++issued;
-        if (++iss_kc == ku) {
+        if (++iss_kc == KU) {
             iss_kc = 0;
-            ++iss_tile;
+            iss_tile += nwaves;
         }
         if (++iss_slot == NSTAGE) iss_slot = 0;
     };
@@ -332,98 +386,186 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseSca
     for (int p = 0; p < NSTAGE - 1; ++p)
         if (issued < total_units) issue_unit();
 
-    f32x16 acc;
+    long long consumed = 0;
+    int con_slot = 0;
+    for (long long tile = gw; tile < a.n_tiles; tile += nwaves) {
+        f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float nrm = 0.f;
-    long long con_tile = i0;
-    int con_kc = 0, con_slot = 0;
-
-    for (long long u = 0; u < total_units; ++u) {
-        if (issued < total_units) issue_unit();
-        wait_units_in_flight<NSTAGE>((int)(issued - u - 1));  // units younger than u may stay in flight
-        const unsigned char* slot = ring_ptr + con_slot * UNIT_BYTES;
-        const unsigned char* arow = slot + r31 * 256;
-        const unsigned char* brow = smem + (u32)r31 * a.d_pad * 4 + con_kc * 256;
-        f32x4 av[8], bv[8];
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        float nrm = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int sw = ((2 * g + h) ^ (r31 & 15)) * 16;
-            av[g] = *reinterpret_cast<const f32x4*>(arow + sw);
-            bv[g] = *reinterpret_cast<const f32x4*>(brow + sw);
-        }
+        for (int kc = 0; kc < KU; ++kc) {
+            if (issued < total_units) issue_unit();
+            wait_units_in_flight<NSTAGE>((int)(issued - consumed - 1));  // younger units may stay in flight
+            const unsigned char* arow = ring_ptr + con_slot * UNIT_BYTES + r31 * 256;
+            f32x4 av[8], bv[8];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][j], bv[g][j], acc, 0, 0, 0);
-                nrm = __builtin_fmaf(av[g][j], av[g][j], nrm);
+            for (int g = 0; g < 8; ++g) {
+                const int sw = ((2 * g + h) ^ (r31 & 15)) * 16;
+                av[g] = *reinterpret_cast<const f32x4*>(arow + sw);
+                if constexpr (QREG)
+                    bv[g] = bq[kc][g];
+                else
+                    bv[g] = *reinterpret_cast<const f32x4*>(smem + (u32)r31 * DPAD * 4 + kc * 256 + sw);
             }
-        }
-        if (++con_slot == NSTAGE) con_slot = 0;
-        if (++con_kc == ku) {
-            // tile complete
-            con_kc = 0;
-            if (a.add_norm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(nrm, 1.0f, acc, 0, 0, 0);
-            const long long row0 = (a.tile_first + con_tile * a.tile_step) * TILE_ROWS;
-            if (a.mode == 0) {
-                float m = acc[0];
 #pragma unroll
-                for (int i = 1; i < 16; ++i) m = fminf(m, acc[i]);
-                if (__any(m <= thr_l)) {
+            for (int g = 0; g < 8; ++g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][j], bv[g][j], acc, 0, 0, 0);
+                    nrm = __builtin_fmaf(av[g][j], av[g][j], nrm);
+                }
+            }
+            ++consumed;
+            if (++con_slot == NSTAGE) con_slot = 0;
+        }
+        // ---- tile complete: scores for 32 rows x 32 queries (lane = query, regs = rows)
+        if (a.add_norm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(nrm, 1.0f, acc, 0, 0, 0);
+        const long long row0 = (a.tile_first + tile * a.tile_step) * TILE_ROWS;
+        if (a.mode == 0) {
+            float m = acc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) m = fminf(m, acc[i]);
+            if (__any(m <= thr_l)) {
+                if (m <= thr_l) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        const bool p = (acc[i] <= thr_l) && (row < a.n);
-                        const u64 mask = __ballot(p);
-                        if (mask) {
-                            if (ecnt + 64 > EBUF_ENTRIES) flush();
-                            if (p) {
-                                const int off = __popcll(mask & ((1ull << lane) - 1ull));
-                                ebuf[ecnt + off] = make_uint2((u32)row, (u32)qglob);
-                            }
-                            ecnt += __popcll(mask);
+                        if (acc[i] <= thr_l && row < a.n) {
+                            const u32 pos = __hip_atomic_fetch_add(ecnt_ptr, 1u, __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (pos < (u32)EBUF_ENTRIES)
+                                ebuf[pos] = make_uint2((u32)row, (u32)qglob);
+                            else
+                                emit_global((u32)row, (u32)qglob);  // buffer full (degenerate thresholds only)
                         }
                     }
                 }
-            } else {
-                float* so = a.sample_out + (long long)qglob * a.ns + (con_tile - 0) * TILE_ROWS;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int ro = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    so[ro] = (row0 + ro < a.n) ? acc[i] : __builtin_inff();
-                }
+                const u32 c = __builtin_amdgcn_readfirstlane(*ecnt_ptr);
+                if (c >= (u32)EBUF_FLUSH) flush(c);
             }
+        } else {
+            // sample mode: the minimum score of this lane's 16 rows (one row's score: a valid
+            // upper bound sample for the k-th smallest, see kth_threshold_f32_kernel)
+            float ml = __builtin_inff();
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            nrm = 0.f;
-            ++con_tile;
+            for (int i = 0; i < 16; ++i) {
+                const int ro = (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (row0 + ro < a.n) ml = fminf(ml, acc[i]);
+            }
+            a.sample_out[(long long)qglob * a.ns + tile * 2 + h] = ml;
         }
     }
-    if (a.mode == 0 && ecnt > 0) flush();
+    if (a.mode == 0) {
+        const u32 c = __builtin_amdgcn_readfirstlane(*ecnt_ptr);
+        if (c > 0) flush(c);
+    }
 }
 
 // ------------------------------------------------------ exact distance keys
-// Candidate j of query q (row = cand[q][j], or j itself when cand == nullptr)
-// -> key (ordered float32 euclidean distance, row).  8 lanes per candidate.
+// One lane per row: numpy's eight interleaved accumulators are eight registers,
+// fed by two 16-byte row loads and two 16-byte LDS (query) reads per 8 elements.
+// Requires 16-byte aligned rows (row stride and base a multiple of 16 bytes).
+struct SqLeafLane {
+    const float* x;
+    const float* q;  // LDS copy of the query
+    __device__ __forceinline__ float term(int i) const {
+        const float t = __fsub_rn(x[i], q[i]);
+        return __fmul_rn(t, t);
+    }
+    __device__ __forceinline__ float leaf(int off, int n) const {
+        if (n < 8) {
+            float r = 0.f;
+            for (int i = 0; i < n; ++i) r = __fadd_rn(r, term(off + i));
+            return r;
+        }
+        float r[8];
+        {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + off), x1 = *reinterpret_cast<const f32x4*>(x + off + 4);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(q + off), q1 = *reinterpret_cast<const f32x4*>(q + off + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t0 = __fsub_rn(x0[j], q0[j]), t1 = __fsub_rn(x1[j], q1[j]);
+                r[j] = __fmul_rn(t0, t0);
+                r[4 + j] = __fmul_rn(t1, t1);
+            }
+        }
+        const int nfull = n - (n % 8);
+        for (int i = 8; i < nfull; i += 8) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + off + i), x1 = *reinterpret_cast<const f32x4*>(x + off + i + 4);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(q + off + i), q1 = *reinterpret_cast<const f32x4*>(q + off + i + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t0 = __fsub_rn(x0[j], q0[j]), t1 = __fsub_rn(x1[j], q1[j]);
+                r[j] = __fadd_rn(r[j], __fmul_rn(t0, t0));
+                r[4 + j] = __fadd_rn(r[4 + j], __fmul_rn(t1, t1));
+            }
+        }
+        float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                              __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+        for (int i = nfull; i < n; ++i) res = __fadd_rn(res, term(off + i));
+        return res;
+    }
+    // numpy pairwise recursion (split at n/2 rounded down to a multiple of 8), explicit stack
+    __device__ float sum(int d) const {
+        if (d <= 128) return leaf(0, d);
+        int s_off[24], s_n[24], s_state[24];
+        float s_left[24];
+        int sp = 1;
+        s_off[0] = 0;
+        s_n[0] = d;
+        s_state[0] = 0;
+        float ret = 0.f;
+        while (sp > 0) {
+            const int top = sp - 1;
+            const int off = s_off[top], m = s_n[top];
+            if (m <= 128) {
+                ret = leaf(off, m);
+                --sp;
+                continue;
+            }
+            int m2 = m / 2;
+            m2 -= m2 % 8;
+            if (s_state[top] == 0) {
+                s_state[top] = 1;
+                s_off[sp] = off;
+                s_n[sp] = m2;
+                s_state[sp] = 0;
+                ++sp;
+            } else if (s_state[top] == 1) {
+                s_left[top] = ret;
+                s_state[top] = 2;
+                s_off[sp] = off + m2;
+                s_n[sp] = m - m2;
+                s_state[sp] = 0;
+                ++sp;
+            } else {
+                ret = __fadd_rn(s_left[top], ret);
+                --sp;
+            }
+        }
+        return ret;
+    }
+};
+
+// Candidate j of query q (row = cand[q][j], or row_offset + j when cand == nullptr)
+// -> key (ordered float32 euclidean distance, row).  Dynamic LDS: round_up(d,4)*4 bytes.
 __global__ __launch_bounds__(256) void dense_exact_l2_kernel(const float* __restrict__ db, long long ld, int d,
                                                               const float* __restrict__ q_orig,
                                                               const u32* __restrict__ cand, const u32* __restrict__ cnt,
                                                               u32 cap, long long implicit_n, long long row_offset,
                                                               u64* __restrict__ keys, long long key_stride) {
+    extern __shared__ __attribute__((aligned(16))) float s_q[];
     const int q = blockIdx.y;
     const long long M = cand ? (long long)(cnt[q] < cap ? cnt[q] : cap) : implicit_n;
-    const int j8 = threadIdx.x & 7;
-    const float* qv = q_orig + (long long)q * d;
-    for (long long base = (long long)blockIdx.x * 32; base < M; base += (long long)gridDim.x * 32) {
-        const long long j = base + (threadIdx.x >> 3);
-        const long long jc = j < M ? j : M - 1;
-        const long long row = cand ? (long long)cand[(long long)q * cap + jc] : row_offset + jc;
-        const float s = np_sqdist_f32(db + row * ld, qv, d, j8);
-        if (j8 == 0 && j < M) {
-            const float dist = sqrt_rn_f32(s);
-            keys[(long long)q * key_stride + j] = ((u64)ordered_f32(dist) << 32) | (u64)(u32)row;
-        }
+    if ((long long)blockIdx.x * 256 >= M) return;
+    for (int i = threadIdx.x; i < d; i += 256) s_q[i] = q_orig[(long long)q * d + i];
+    __syncthreads();
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < M; j += (long long)gridDim.x * 256) {
+        const long long row = cand ? (long long)cand[(long long)q * cap + j] : row_offset + j;
+        const SqLeafLane w{db + row * ld, s_q};
+        const float dist = sqrt_rn_f32(w.sum(d));
+        keys[(long long)q * key_stride + j] = ((u64)ordered_f32(dist) << 32) | (u64)(u32)row;
     }
 }
 
@@ -442,19 +584,59 @@ __global__ __launch_bounds__(256) void dense_exact_cos_kernel(const float* __res
     }
 }
 
-// Plain distance vectors for sq_dense_distances (one query, n gathered rows).
-__global__ __launch_bounds__(256) void dense_distances_kernel(const float* __restrict__ rows, long long n, int d,
-                                                               const float* __restrict__ q, int metric,
-                                                               float* __restrict__ out32, double* __restrict__ out64) {
+// Plain distance vectors for sq_dense_distances (one query, n gathered rows),
+// in the rows' own dtype like metrics.euclidean_distance (float32 in -> float32
+// out, float64 in -> float64 out); cosine is always float64 (scipy cdist).
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(a, b); }
+__device__ __forceinline__ float mul_rn_t(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn_t(double a, double b) { return __dmul_rn(a, b); }
+
+template <class T>
+__device__ __forceinline__ double cosine_row_t(const T* __restrict__ x, const T* __restrict__ q, int d) {
+    double dot0 = 0.0, dot1 = 0.0, nx0 = 0.0, nx1 = 0.0, nq0 = 0.0, nq1 = 0.0;
+    const int m = d - (d & 1);
+    for (int i = 0; i < m; i += 2) {
+        const double x0 = (double)x[i], x1 = (double)x[i + 1], q0 = (double)q[i], q1 = (double)q[i + 1];
+        dot0 = __dadd_rn(dot0, __dmul_rn(q0, x0));
+        dot1 = __dadd_rn(dot1, __dmul_rn(q1, x1));
+        nx0 = __dadd_rn(nx0, __dmul_rn(x0, x0));
+        nx1 = __dadd_rn(nx1, __dmul_rn(x1, x1));
+        nq0 = __dadd_rn(nq0, __dmul_rn(q0, q0));
+        nq1 = __dadd_rn(nq1, __dmul_rn(q1, q1));
+    }
+    double dot = __dadd_rn(dot0, dot1), nx = __dadd_rn(nx0, nx1), nq = __dadd_rn(nq0, nq1);
+    if (d & 1) {
+        const double xv = (double)x[m], qq = (double)q[m];
+        dot = __dadd_rn(dot, __dmul_rn(qq, xv));
+        nx = __dadd_rn(nx, __dmul_rn(xv, xv));
+        nq = __dadd_rn(nq, __dmul_rn(qq, qq));
+    }
+    return cosine_dist_f64(dot, nx, nq);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void dense_distances_kernel(const T* __restrict__ rows, long long n, int d,
+                                                               const T* __restrict__ q, int metric,
+                                                               T* __restrict__ out_t, double* __restrict__ out64) {
     const int j8 = threadIdx.x & 7;
     const long long j = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
     const long long jc = j < n ? j : n - 1;
-    const float* x = rows + jc * d;
+    const T* x = rows + jc * d;
     if (metric == SQ_METRIC_L2) {
-        const float s = np_sqdist_f32(x, q, d, j8);
-        if (j8 == 0 && j < n) out32[j] = sqrt_rn_f32(s);
+        auto term = [x, q](int i) {
+            const T t = sub_rn(x[i], q[i]);
+            return mul_rn_t(t, t);
+        };
+        const T s = np_pairwise_sum<T>(term, d, j8);
+        if (j8 == 0 && j < n) {
+            if constexpr (sizeof(T) == 4)
+                out_t[j] = sqrt_rn_f32(s);
+            else
+                out_t[j] = sqrt(s);
+        }
     } else {
-        if (j8 == 0 && j < n) out64[j] = cosine_row_f64(x, q, d);
+        if (j8 == 0 && j < n) out64[j] = cosine_row_t<T>(x, q, d);
     }
 }
 
@@ -548,14 +730,14 @@ __global__ void dense_finalize_cos_kernel(const K128* __restrict__ sorted, const
 
 // -------------------------------------------------------------- host driver
 static constexpr int kSelectLdsKeys64 = 16384;
-static constexpr int kSelectLdsKeys128 = 8192;
+static constexpr int kSelectLdsKeys128 = 7168;
 
 template <class K>
 static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out,
                            hipStream_t st) {
     static bool attr_set = false;
     const int lds_keys = sizeof(K) == 8 ? kSelectLdsKeys64 : kSelectLdsKeys128;
-    const size_t lds = (size_t)lds_keys * sizeof(K);
+    const size_t lds = (size_t)(lds_keys + SELECT_SORT_MAX) * sizeof(K);
     if (!attr_set) {
         SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<K>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -566,37 +748,53 @@ static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long str
     return SQ_OK;
 }
 
-template <int NSTAGE>
+template <int NSTAGE, int KU>
 static int scan_launch_t(const DenseScanArgs& a, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<NSTAGE>),
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<NSTAGE, KU>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dense_scan_kernel<NSTAGE>), dim3((unsigned)(a.nrb * a.nqt)), dim3(SCAN_WAVES * 64),
+    hipLaunchKernelGGL((dense_scan_kernel<NSTAGE, KU>), dim3((unsigned)(a.nrb * a.nqt)), dim3(SCAN_WAVES * 64),
                        lds, st, a);
     return SQ_OK;
 }
 
+static constexpr int SCAN_LDS_TAIL = SCAN_WAVES * EBUF_ENTRIES * 8 + SCAN_WAVES * 16;  // emission buffers + counters
+
 static int scan_stages_for(int d_pad) {
     // LDS: query tile + 4 waves * NSTAGE * 8 KiB + emission buffers <= 160 KiB
-    const int fixed = TILE_ROWS * d_pad * 4 + SCAN_WAVES * EBUF_ENTRIES * 8;
+    const int fixed = TILE_ROWS * d_pad * 4 + SCAN_LDS_TAIL;
     int ns = (160 * 1024 - fixed) / (SCAN_WAVES * UNIT_BYTES);
     if (ns > 4) ns = 4;
     if (g_opt.dense_stages >= 2 && g_opt.dense_stages <= ns) ns = g_opt.dense_stages;
     return ns;
 }
 
+template <int KU>
+static int scan_launch_ku(const DenseScanArgs& a, int ns, size_t lds, hipStream_t st) {
+    switch (ns) {
+        case 4: return scan_launch_t<4, KU>(a, lds, st);
+        case 3: return scan_launch_t<3, KU>(a, lds, st);
+        default: return scan_launch_t<2, KU>(a, lds, st);
+    }
+}
+
 static int scan_launch(DenseScanArgs a, hipStream_t st) {
     const int ns = scan_stages_for(a.d_pad);
     if (ns < 2) return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d leaves no room for the LDS ring", a.d_pad);
-    const size_t lds = (size_t)TILE_ROWS * a.d_pad * 4 + (size_t)SCAN_WAVES * ns * UNIT_BYTES +
-                       (size_t)SCAN_WAVES * EBUF_ENTRIES * 8;
-    switch (ns) {
-        case 4: return scan_launch_t<4>(a, lds, st);
-        case 3: return scan_launch_t<3>(a, lds, st);
-        default: return scan_launch_t<2>(a, lds, st);
+    const size_t lds = (size_t)TILE_ROWS * a.d_pad * 4 + (size_t)SCAN_WAVES * ns * UNIT_BYTES + SCAN_LDS_TAIL;
+    switch (a.d_pad / KT) {
+        case 1: return scan_launch_ku<1>(a, ns, lds, st);
+        case 2: return scan_launch_ku<2>(a, ns, lds, st);
+        case 3: return scan_launch_ku<3>(a, ns, lds, st);
+        case 4: return scan_launch_ku<4>(a, ns, lds, st);
+        case 5: return scan_launch_ku<5>(a, ns, lds, st);
+        case 6: return scan_launch_ku<6>(a, ns, lds, st);
+        case 7: return scan_launch_ku<7>(a, ns, lds, st);
+        case 8: return scan_launch_ku<8>(a, ns, lds, st);
+        default: return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d", a.d_pad);
     }
 }
 
@@ -637,6 +835,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     u32* status = h->status.as<u32>();
     u32* hs = reinterpret_cast<u32*>(h->status_host.p);
     const double eps_coef = 4.0 * (double)(d_pad + 8) * 5.9604644775390625e-08;  // 4 (d+8) 2^-24
+    const size_t l2_lds = (size_t)((d + 3) / 4 * 4) * 4;
 
     hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, q, nq, d, d_pad, nq_pad, h->metric,
                        qs, qn2);
@@ -654,7 +853,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
             hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, nq), dim3(256), 0, st, h->db, h->ld, d, q, nullptr, cnt,
                                (u32)n, n, 0ll, h->keys.as<K128>(), key_stride);
         else
-            hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, nq), dim3(256), 0, st, h->db, h->ld, d, q, nullptr, cnt,
+            hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, nq), dim3(256), l2_lds, st, h->db, h->ld, d, q, nullptr, cnt,
                                (u32)n, n, 0ll, h->keys.as<u64>(), key_stride);
         if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
         h->stats.scan_launches = 1;
@@ -675,9 +874,9 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         long long stride = g_opt.sample_stride > 0 ? g_opt.sample_stride : (long long)cap / (8ll * kk);
         if (stride > 64) stride = 64;
         if (stride < 1) stride = 1;
-        while (stride > 1 && (n_tiles / stride) * TILE_ROWS < 16ll * kk) stride >>= 1;
+        while (stride > 1 && (n_tiles / stride) * 2 < 8ll * kk) stride >>= 1;
         const long long ns_tiles = (n_tiles + stride - 1) / stride;
-        const long long ns = ns_tiles * TILE_ROWS;
+        const long long ns = ns_tiles * 2;  // one sample (a 16-row group minimum) per lane half per tile
         SQ_TRY(h->sample.reserve((size_t)nq_pad * ns * 4));
         SQ_TRY(h->cand.reserve((size_t)nq_pad * cap * 4));
         SQ_TRY(h->keys.reserve((size_t)nq * key_stride * key_bytes));
@@ -732,7 +931,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
             hipLaunchKernelGGL(dense_finalize_cos_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<K128>(), cnt, cap, k,
                                kk, h->id_base, thr, eps_coef, 1, (double*)out_dist, out_idx, status);
         } else {
-            hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, nq), dim3(256), 0, st, h->db, h->ld, d, q, cand, cnt, cap,
+            hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, nq), dim3(256), l2_lds, st, h->db, h->ld, d, q, cand, cnt, cap,
                                0ll, 0ll, h->keys.as<u64>(), key_stride);
             SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, cap, key_stride, k, nq, h->out_keys.as<u64>(), st));
             hipLaunchKernelGGL(dense_finalize_l2_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<u64>(), cnt, cap, k,
@@ -774,7 +973,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
                                h->out_keys.as<K128>() + (long long)qi * k, cnt + qi, (u32)n, k, kk, h->id_base, thr, 0.0,
                                0, (double*)out_dist + (long long)qi * k, out_idx + (long long)qi * k, status + qi);
         } else {
-            hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, 1), dim3(256), 0, st, h->db, h->ld, d,
+            hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, 1), dim3(256), l2_lds, st, h->db, h->ld, d,
                                q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<u64>(), n);
             SQ_TRY(select_launch_t<u64>(h->big_keys.as<u64>(), cnt + qi, (u32)n, n, k, 1,
                                         h->out_keys.as<u64>() + (long long)qi * k, st));
@@ -805,6 +1004,8 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
     const int d_pad = (d + KT - 1) / KT * KT;
     if (mem == SQ_MEM_DEVICE && d != d_pad)
         return fail(SQ_ERR_UNSUPPORTED, "sq_dense_create: borrowing a device matrix needs d %% 64 == 0 (d=%d)", d);
+    if (mem == SQ_MEM_DEVICE && (reinterpret_cast<uintptr_t>(db) & 15u) != 0)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_dense_create: device matrix must be 16-byte aligned");
     auto* h = new DenseHandle();
     h->kind = H_DENSE;
     h->n = n;
@@ -900,16 +1101,27 @@ extern "C" int sq_dense_destroy(sq_handle_t hid) {
     return SQ_OK;
 }
 
-extern "C" int sq_dense_distances(const float* query, const float* rows, int64_t n, int d, int metric, void* out,
-                                  int mem, void* stream) {
+template <class T>
+static void distances_launch(const void* rows, long long n, int d, const void* q, int metric, void* out,
+                             hipStream_t st) {
+    const unsigned gx = (unsigned)((n + 31) / 32);
+    hipLaunchKernelGGL((dense_distances_kernel<T>), dim3(gx), dim3(256), 0, st, (const T*)rows, n, d, (const T*)q,
+                       metric, (T*)out, (double*)out);
+}
+
+extern "C" int sq_dense_distances(const void* query, const void* rows, int dtype, int64_t n, int d, int metric,
+                                  void* out, int mem, void* stream) {
     if (!query || !rows || !out || n <= 0 || d <= 0) return fail(SQ_ERR_INVALID, "sq_dense_distances: bad argument");
     if (metric != SQ_METRIC_L2 && metric != SQ_METRIC_COSINE) return fail(SQ_ERR_INVALID, "sq_dense_distances: unknown metric");
+    if (dtype != SQ_DTYPE_F32 && dtype != SQ_DTYPE_F64) return fail(SQ_ERR_INVALID, "sq_dense_distances: unknown dtype");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t osz = metric == SQ_METRIC_COSINE ? 8 : 4;
-    const unsigned gx = (unsigned)((n + 31) / 32);
+    const size_t esz = dtype == SQ_DTYPE_F32 ? 4 : 8;
+    const size_t osz = (metric == SQ_METRIC_COSINE || dtype == SQ_DTYPE_F64) ? 8 : 4;
     if (mem == SQ_MEM_DEVICE) {
-        hipLaunchKernelGGL(dense_distances_kernel, dim3(gx), dim3(256), 0, st, rows, (long long)n, d, query, metric,
-                           (float*)out, (double*)out);
+        if (dtype == SQ_DTYPE_F32)
+            distances_launch<float>(rows, n, d, query, metric, out, st);
+        else
+            distances_launch<double>(rows, n, d, query, metric, out, st);
         SQ_HIP(hipGetLastError());
         return SQ_OK;
     }
@@ -921,14 +1133,16 @@ extern "C" int sq_dense_distances(const float* query, const float* rows, int64_t
         dout.release();
         return code;
     };
-    if ((rc = dq.reserve((size_t)d * 4)) != SQ_OK) return done(rc);
-    if ((rc = dr.reserve((size_t)n * d * 4)) != SQ_OK) return done(rc);
+    if ((rc = dq.reserve((size_t)d * esz)) != SQ_OK) return done(rc);
+    if ((rc = dr.reserve((size_t)n * d * esz)) != SQ_OK) return done(rc);
     if ((rc = dout.reserve((size_t)n * osz)) != SQ_OK) return done(rc);
-    if (hipMemcpyAsync(dq.p, query, (size_t)d * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(dr.p, rows, (size_t)n * d * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+    if (hipMemcpyAsync(dq.p, query, (size_t)d * esz, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(dr.p, rows, (size_t)n * d * esz, hipMemcpyHostToDevice, st) != hipSuccess)
         return done(fail(SQ_ERR_HIP, "sq_dense_distances: H2D copy failed"));
-    hipLaunchKernelGGL(dense_distances_kernel, dim3(gx), dim3(256), 0, st, dr.as<float>(), (long long)n, d,
-                       dq.as<float>(), metric, dout.as<float>(), dout.as<double>());
+    if (dtype == SQ_DTYPE_F32)
+        distances_launch<float>(dr.p, n, d, dq.p, metric, dout.p, st);
+    else
+        distances_launch<double>(dr.p, n, d, dq.p, metric, dout.p, st);
     if (hipMemcpyAsync(out, dout.p, (size_t)n * osz, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         return done(fail(SQ_ERR_HIP, "sq_dense_distances: kernel or D2H copy failed: %s",

@@ -299,12 +299,12 @@ static void hist_dispatch(const HammingHandle* h, const u64* qs, int nq, int bit
     }
 }
 
-static constexpr int kSelectLdsKeys64 = 16384;  // 128 KiB of LDS for the sort buffer
+static constexpr int kSelectLdsKeys64 = 16384;  // 128 KiB of LDS for the candidate keys
 
 static int select_launch(const u64* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, u64* out,
                          hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = (size_t)kSelectLdsKeys64 * sizeof(u64);
+    const size_t lds = (size_t)(kSelectLdsKeys64 + SELECT_SORT_MAX) * sizeof(u64);
     if (!attr_set) {
         SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<u64>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

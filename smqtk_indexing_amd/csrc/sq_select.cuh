@@ -49,6 +49,15 @@ struct KeyOps<u64> {
     __device__ static __forceinline__ bool prefix_eq(u64 a, u64 p, int nb) {
         return nb == 0 || (a >> (8 * (8 - nb))) == (p >> (8 * (8 - nb)));
     }
+    // first nb bytes (1..8) of a <= those of p
+    __device__ static __forceinline__ bool prefix_le(u64 a, u64 p, int nb) {
+        return (a >> (8 * (8 - nb))) <= (p >> (8 * (8 - nb)));
+    }
+    // number of leading bytes shared by all keys in [lo, hi]
+    __device__ static __forceinline__ int common_bytes(u64 lo, u64 hi) {
+        const u64 x = lo ^ hi;
+        return x == 0 ? 8 : (__clzll((long long)x) >> 3);
+    }
 };
 template <>
 struct KeyOps<K128> {
@@ -74,6 +83,12 @@ struct KeyOps<K128> {
         if (a.hi != p.hi) return false;
         int r = nb - 8;  // 1..4 bytes of the low word's 32-bit id
         return ((a.lo & 0xffffffffull) >> (8 * (4 - r))) == ((p.lo & 0xffffffffull) >> (8 * (4 - r)));
+    }
+    __device__ static __forceinline__ bool prefix_le(K128 a, K128 p, int nb) {
+        if (nb <= 8) return (a.hi >> (8 * (8 - nb))) <= (p.hi >> (8 * (8 - nb)));
+        if (a.hi != p.hi) return a.hi < p.hi;
+        int r = nb - 8;
+        return ((a.lo & 0xffffffffull) >> (8 * (4 - r))) <= ((p.lo & 0xffffffffull) >> (8 * (4 - r)));
     }
 };
 
@@ -110,11 +125,18 @@ __device__ __forceinline__ int pow2_ceil(int v) {
 // One workgroup per query.  keys: [nq][stride] candidate keys, cnt[q] of them
 // valid (clamped to cap).  Writes the min(k, M) smallest keys ascending to
 // out[q][0..k) and pads the rest with the max key.
-//   M <= LDS_KEYS : everything is sorted in LDS.
-//   M  > LDS_KEYS : MSB-first radix select (8-bit digits, LDS histogram) finds
-//                   the k-th smallest key reading global memory, the keys
-//                   <= it are gathered (exactly k: keys are unique) and sorted.
-// Requires k <= LDS_KEYS.  Dynamic LDS: LDS_KEYS * sizeof(K).
+//
+//   * the keys are copied to LDS when they fit (M <= lds_keys);
+//   * an MSB-first radix select (8-bit digits, LDS histogram) finds the k-th
+//     smallest key; leading bytes shared by every key are skipped (u64 keys)
+//     and the walk stops early once a digit bin holds exactly the keys still
+//     needed;
+//   * the selected keys (exactly k: keys are unique) are gathered and
+//     bitonic-sorted in LDS.
+//   Small inputs (M <= 512) or k beyond the sort buffer are bitonic-sorted whole.
+// Requires k <= lds_keys.  Dynamic LDS: (lds_keys + SELECT_SORT_MAX) * sizeof(K).
+static constexpr int SELECT_SORT_MAX = 2048;
+
 template <class K>
 __global__ __launch_bounds__(1024) void select_topk_kernel(const K* __restrict__ keys,
                                                             const u32* __restrict__ cnt, u32 cap,
@@ -122,8 +144,10 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const K* __restrict__
                                                             K* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     K* sk = reinterpret_cast<K*>(smem_raw);
+    K* so = sk + lds_keys;
     __shared__ u32 hist[256];
-    __shared__ u32 sh_sel, sh_rem, sh_n;
+    __shared__ u32 sh_sel, sh_rem, sh_n, sh_stop;
+    __shared__ u64 sh_red[32];
     const int q = blockIdx.x;
     const int T = blockDim.x;
     const u32 craw = cnt[q];
@@ -131,18 +155,61 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const K* __restrict__
     const K* src = keys + (long long)q * stride;
     K* dst = out + (long long)q * k;
     const int kk = k < M ? k : M;
-    int nsort;
-    if (M <= lds_keys) {
+    const bool in_lds = M <= lds_keys;
+    if (in_lds)
         for (int i = threadIdx.x; i < M; i += T) sk[i] = src[i];
-        nsort = M;
-    } else {
+    __syncthreads();
+    K* sorted = sk;
+    int nsort = M;
+    const bool whole = in_lds && (M <= 512 || kk > SELECT_SORT_MAX || kk == M);
+    if (!whole) {
+        const K* rd = in_lds ? sk : src;
+        K* gather = in_lds ? so : sk;
+        const int gcap = in_lds ? SELECT_SORT_MAX : lds_keys;
+        int b0 = 0;
+        if constexpr (sizeof(K) == 8) {
+            // leading bytes common to every key need no pass
+            u64 lo = ~0ull, hi = 0ull;
+            for (int i = threadIdx.x; i < M; i += T) {
+                const u64 v = rd[i];
+                lo = v < lo ? v : lo;
+                hi = v > hi ? v : hi;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const u64 l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+                lo = l2 < lo ? l2 : lo;
+                hi = h2 > hi ? h2 : hi;
+            }
+            const int wv = threadIdx.x >> 6, nw = T >> 6;
+            if ((threadIdx.x & 63) == 0) {
+                sh_red[wv] = lo;
+                sh_red[16 + wv] = hi;
+            }
+            __syncthreads();
+            lo = ~0ull;
+            hi = 0ull;
+            for (int w = 0; w < nw; ++w) {
+                lo = sh_red[w] < lo ? sh_red[w] : lo;
+                hi = sh_red[16 + w] > hi ? sh_red[16 + w] : hi;
+            }
+            b0 = KeyOps<K>::common_bytes(lo, hi);
+            if (b0 > 7) b0 = 7;
+            __syncthreads();
+        }
         K prefix = KeyOps<K>::zero();
-        if (threadIdx.x == 0) sh_rem = (u32)kk;
-        for (int b = 0; b < KeyOps<K>::NBYTES; ++b) {
+        if constexpr (sizeof(K) == 8) {
+            if (b0 > 0) prefix = rd[0] & ~((~0ull) >> (8 * b0));
+        }
+        if (threadIdx.x == 0) {
+            sh_rem = (u32)kk;
+            sh_stop = 0;
+        }
+        int nb_done = b0;
+        for (int b = b0; b < KeyOps<K>::NBYTES; ++b) {
             for (int i = threadIdx.x; i < 256; i += T) hist[i] = 0;
             __syncthreads();
             for (int i = threadIdx.x; i < M; i += T) {
-                K key = src[i];
+                const K key = rd[i];
                 if (KeyOps<K>::prefix_eq(key, prefix, b)) atomicAdd(&hist[KeyOps<K>::byte(key, b)], 1u);
             }
             __syncthreads();
@@ -154,33 +221,37 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const K* __restrict__
                 }
                 sh_sel = v;
                 sh_rem = need - c;
+                sh_stop = (hist[v] == need - c) ? 1u : 0u;  // the whole bin is wanted: no finer digit needed
             }
             __syncthreads();
             KeyOps<K>::set_byte(prefix, b, sh_sel);
+            nb_done = b + 1;
+            const bool stop = sh_stop != 0;
             __syncthreads();
+            if (stop) break;
         }
-        // prefix is now the kk-th smallest key
+        // keys whose first nb_done bytes are <= the prefix's are exactly the kk smallest
         if (threadIdx.x == 0) sh_n = 0;
         __syncthreads();
         for (int i = threadIdx.x; i < M; i += T) {
-            K key = src[i];
-            if (!KeyOps<K>::less(prefix, key)) {
-                u32 pos = atomicAdd(&sh_n, 1u);
-                if ((int)pos < lds_keys) sk[pos] = key;
+            const K key = rd[i];
+            if (KeyOps<K>::prefix_le(key, prefix, nb_done)) {
+                const u32 pos = atomicAdd(&sh_n, 1u);
+                if ((int)pos < gcap) gather[pos] = key;
             }
         }
         __syncthreads();
-        nsort = (int)sh_n < lds_keys ? (int)sh_n : lds_keys;
+        nsort = (int)sh_n < gcap ? (int)sh_n : gcap;
+        sorted = gather;
     }
-    __syncthreads();
     if (nsort > 1) {
         const int P = pow2_ceil(nsort);
-        for (int i = nsort + threadIdx.x; i < P; i += T) sk[i] = KeyOps<K>::maxv();
-        bitonic_sort_lds<K>(sk, P);
+        for (int i = nsort + threadIdx.x; i < P; i += T) sorted[i] = KeyOps<K>::maxv();
+        bitonic_sort_lds<K>(sorted, P);
     } else {
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < k; i += T) dst[i] = (i < kk && i < nsort) ? sk[i] : KeyOps<K>::maxv();
+    for (int i = threadIdx.x; i < k; i += T) dst[i] = (i < kk && i < nsort) ? sorted[i] : KeyOps<K>::maxv();
 }
 
 // ------------------------------------------------------------ block helpers

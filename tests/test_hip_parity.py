@@ -207,6 +207,14 @@ def test_dense_distances_bit_exact(d):
     got = _lib.dense_distances(q, rows, _lib.SQ_METRIC_COSINE)
     ref = np.array([O.cosine_distance(q, r) for r in rows])
     np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-15)
+    # float64 descriptors (SMQTK's default dtype): float64 arithmetic, bit identical
+    rows64, q64 = rng.standard_normal((65, d)), rng.standard_normal(d)
+    got = _lib.dense_distances(q64, rows64, _lib.SQ_METRIC_L2)
+    assert got.dtype == np.float64
+    np.testing.assert_array_equal(got.view(np.uint64), O.euclidean_distance(rows64, q64).view(np.uint64))
+    got = _lib.dense_distances(q64, rows64, _lib.SQ_METRIC_COSINE)
+    ref = np.array([O.cosine_distance(q64, r) for r in rows64])
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-15)
 
 
 def test_dense_known_answers():
