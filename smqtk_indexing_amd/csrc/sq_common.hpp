@@ -50,6 +50,8 @@ struct Options {
     int force_fallback = 0;
     int dense_stages = 0;    // 0 = auto (LDS ring depth of the dense scan)
     int dense_blocks = 0;    // 0 = auto (row blocks of the dense scan grid)
+    int dense_debug = 0;     // measurement only (see DenseScanArgs::debug)
+    int dense_waves = 0;     // 0 = auto, 4 or 8 waves per scan workgroup
 };
 extern Options g_opt;
 

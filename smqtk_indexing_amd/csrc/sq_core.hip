@@ -75,6 +75,8 @@ extern "C" int sq_set_option(const char* name, int64_t value) {
     else if (n == "force_fallback") g_opt.force_fallback = (int)value;
     else if (n == "dense_stages") g_opt.dense_stages = (int)value;
     else if (n == "dense_blocks") g_opt.dense_blocks = (int)value;
+    else if (n == "dense_debug") g_opt.dense_debug = (int)value;
+    else if (n == "dense_waves") g_opt.dense_waves = (int)value;
     else return fail(SQ_ERR_INVALID, "sq_set_option: unknown option '%s'", name);
     return SQ_OK;
 }

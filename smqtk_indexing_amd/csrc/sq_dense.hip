@@ -38,9 +38,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static constexpr int KT = 64;                 // floats per k-unit (one 256-byte LDS bank row per matrix row)
 static constexpr int TILE_ROWS = 32;          // rows per MFMA tile / per wave unit
 static constexpr int UNIT_BYTES = TILE_ROWS * KT * 4;  // 8 KiB
-static constexpr int SCAN_WAVES = 4;
-static constexpr int EBUF_ENTRIES = 256;      // per-wave emission buffer (row, query) pairs
-static constexpr int EBUF_FLUSH = 128;        // flush the buffer to the global candidate lists at this fill
+static constexpr int EBUF_BYTES = 8192;       // emission buffers of a workgroup: (row, query) pairs, split over its waves
 static constexpr int MAX_DPAD = 512;
 
 struct DenseHandle : HandleBase {
@@ -200,6 +198,8 @@ struct DenseScanArgs {
     int nrb;                // row blocks (multiple of 8 when nqt > 1)
     int mode;               // 0 EMIT, 1 SAMPLE
     int add_norm;           // 1: L2 (add |x|^2 through one extra MFMA), 0: cosine
+    int waves;              // waves per workgroup of the launch (set by scan_launch)
+    int debug;              // measurement only: 1 = skip LDS reads + MFMA, 2 = skip the LDS-DMA (results invalid)
 };
 
 // LDS-DMA: 64 lanes x 16 bytes land at lds_dst + lane*16 (wave-uniform base in
@@ -261,15 +261,22 @@ __device__ __forceinline__ void wait_units_in_flight(int units) {
 
 typedef __attribute__((address_space(3))) u32 lds_u32;
 
-// NSTAGE: ring depth per wave; KU = d_pad / 64 k-units per row tile.
-template <int NSTAGE, int KU>
-__global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseScanArgs a) {
+// WAVES: waves per workgroup (one workgroup per CU: 4 = one wave per SIMD, 8 = two, which lets one
+// wave's DMA issue / epilogue run under the other's MFMAs); NSTAGE: ring depth per wave;
+// KU = d_pad / 64 k-units per row tile.
+template <int WAVES, int NSTAGE, int KU>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(DenseScanArgs a) {
     constexpr bool QREG = KU <= 2;  // query fragments live in registers for d_pad <= 128
+    constexpr int SCAN_WAVES = WAVES;
+    constexpr int EBUF_ENTRIES = EBUF_BYTES / 8 / WAVES;
+    constexpr int EBUF_FLUSH = EBUF_ENTRIES / 2;
     constexpr int DPAD = KU * KT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr u32 q_bytes = (u32)TILE_ROWS * DPAD * 4;
+    // the query tile keeps its own LDS region only when it is re-read per unit; when it lives in
+    // registers it is staged through the (not yet used) ring area
+    constexpr u32 q_bytes = QREG ? 0u : (u32)TILE_ROWS * DPAD * 4;
     // LDS map: [query tile][ring wave0..3][emission buffers][emission counters]
     const u32 lds_base = (u32)(uintptr_t)smem;  // low 32 bits of a flat LDS address = LDS offset
     const u32 ring_base = lds_base + q_bytes + (u32)wave * (NSTAGE * UNIT_BYTES);
@@ -331,6 +338,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseSca
             for (int g = 0; g < 8; ++g)
                 bq[kc][g] = *reinterpret_cast<const f32x4*>(smem + (u32)r31 * DPAD * 4 + kc * 256 +
                                                              ((2 * g + h) ^ (r31 & 15)) * 16);
+        __syncthreads();  // every wave holds its fragments before the DMA ring overwrites the staging area
     }
 
     // per-lane byte offsets of the 8 DMA instructions of a unit (row 4j + lane/16, swizzled 16-byte chunk)
@@ -383,11 +391,39 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseSca
         if (++iss_slot == NSTAGE) iss_slot = 0;
     };
 
-    for (int p = 0; p < NSTAGE - 1; ++p)
-        if (issued < total_units) issue_unit();
+    // Software pipeline over units (u = 0, 1, ...; slot of unit u = u % NSTAGE):
+    //   registers hold the A fragments of unit u (av_cur) while its 32 MFMAs run;
+    //   the fragments of unit u+1 are read from LDS (av_nxt) under those MFMAs;
+    //   the slot of unit u is refilled by the DMA of unit u+NSTAGE as soon as
+    //   av_cur is complete.  So NSTAGE-1 units stay in flight behind the one
+    //   being waited for, and no LDS latency sits between MFMA groups.
+    const bool do_dma = !(a.debug & 2), do_math = !(a.debug & 1);
+    auto issue_next = [&]() {
+        if (issued < total_units) {
+            if (do_dma || issued < NSTAGE)  // ablation: the ring is filled once, then reused
+                issue_unit();
+            else
+                ++issued;
+        }
+    };
+    auto read_frags = [&](int slot_idx, f32x4 (&dst)[8]) {
+        const unsigned char* arow = ring_ptr + slot_idx * UNIT_BYTES + r31 * 256;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) dst[g] = *reinterpret_cast<const f32x4*>(arow + ((2 * g + h) ^ (r31 & 15)) * 16);
+    };
+    for (int p = 0; p < NSTAGE; ++p) issue_next();
 
-    long long consumed = 0;
-    int con_slot = 0;
+    f32x4 av_cur[8], av_nxt[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) av_nxt[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    long long loaded = 0;  // units whose fragments have been requested from LDS
+    int rd_slot = 0;
+    if (total_units > 0) {
+        wait_units_in_flight<NSTAGE>((int)(issued - 1));
+        if (do_math) read_frags(0, av_nxt);
+        loaded = 1;
+        rd_slot = NSTAGE > 1 ? 1 : 0;
+    }
     for (long long tile = gw; tile < a.n_tiles; tile += nwaves) {
         f32x16 acc;
 #pragma unroll
@@ -395,30 +431,35 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 1) void dense_scan_kernel(DenseSca
         float nrm = 0.f;
 #pragma unroll
         for (int kc = 0; kc < KU; ++kc) {
-            if (issued < total_units) issue_unit();
-            wait_units_in_flight<NSTAGE>((int)(issued - consumed - 1));  // younger units may stay in flight
-            const unsigned char* arow = ring_ptr + con_slot * UNIT_BYTES + r31 * 256;
-            f32x4 av[8], bv[8];
+            // fragments of this unit are complete once copied (hipcc waits lgkmcnt here); its slot is free
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int sw = ((2 * g + h) ^ (r31 & 15)) * 16;
-                av[g] = *reinterpret_cast<const f32x4*>(arow + sw);
-                if constexpr (QREG)
-                    bv[g] = bq[kc][g];
-                else
-                    bv[g] = *reinterpret_cast<const f32x4*>(smem + (u32)r31 * DPAD * 4 + kc * 256 + sw);
+            for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];
+            asm volatile("" ::: "memory");
+            issue_next();
+            if (loaded < total_units) {
+                wait_units_in_flight<NSTAGE>((int)(issued - loaded - 1));  // younger units may stay in flight
+                if (do_math) read_frags(rd_slot, av_nxt);
+                ++loaded;
+                if (++rd_slot == NSTAGE) rd_slot = 0;
             }
+            if (do_math) {
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
+                for (int g = 0; g < 8; ++g) {
+                    f32x4 bvg;
+                    if constexpr (QREG)
+                        bvg = bq[kc][g];
+                    else
+                        bvg = *reinterpret_cast<const f32x4*>(smem + (u32)r31 * DPAD * 4 + kc * 256 +
+                                                              ((2 * g + h) ^ (r31 & 15)) * 16);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][j], bv[g][j], acc, 0, 0, 0);
-                    nrm = __builtin_fmaf(av[g][j], av[g][j], nrm);
+                    for (int j = 0; j < 4; ++j) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_cur[g][j], bvg[j], acc, 0, 0, 0);
+                        nrm = __builtin_fmaf(av_cur[g][j], av_cur[g][j], nrm);
+                    }
                 }
             }
-            ++consumed;
-            if (++con_slot == NSTAGE) con_slot = 0;
         }
+        if (!do_math) continue;
         // ---- tile complete: scores for 32 rows x 32 queries (lane = query, regs = rows)
         if (a.add_norm) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(nrm, 1.0f, acc, 0, 0, 0);
         const long long row0 = (a.tile_first + tile * a.tile_step) * TILE_ROWS;
@@ -748,52 +789,70 @@ static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long str
     return SQ_OK;
 }
 
-template <int NSTAGE, int KU>
+template <int WAVES, int NSTAGE, int KU>
 static int scan_launch_t(const DenseScanArgs& a, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<NSTAGE, KU>),
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<WAVES, NSTAGE, KU>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dense_scan_kernel<NSTAGE, KU>), dim3((unsigned)(a.nrb * a.nqt)), dim3(SCAN_WAVES * 64),
+    hipLaunchKernelGGL((dense_scan_kernel<WAVES, NSTAGE, KU>), dim3((unsigned)(a.nrb * a.nqt)), dim3(WAVES * 64),
                        lds, st, a);
     return SQ_OK;
 }
 
-static constexpr int SCAN_LDS_TAIL = SCAN_WAVES * EBUF_ENTRIES * 8 + SCAN_WAVES * 16;  // emission buffers + counters
+static constexpr int SCAN_LDS_TAIL = EBUF_BYTES + 8 * 16;  // emission buffers + per-wave counters
 
-static int scan_stages_for(int d_pad) {
-    // LDS: query tile + 4 waves * NSTAGE * 8 KiB + emission buffers <= 160 KiB
-    const int fixed = TILE_ROWS * d_pad * 4 + SCAN_LDS_TAIL;
-    int ns = (160 * 1024 - fixed) / (SCAN_WAVES * UNIT_BYTES);
-    if (ns > 4) ns = 4;
+// Launch geometry of the scan for a padded dimension: waves per workgroup and ring depth.
+struct ScanGeom {
+    int waves, stages;
+    size_t lds;
+};
+static ScanGeom scan_geometry(int d_pad) {
+    const int ku = d_pad / KT;
+    const bool qreg = ku <= 2;
+    const int qb = qreg ? 0 : TILE_ROWS * d_pad * 4;
+    ScanGeom g{};
+    g.waves = qreg ? 8 : 4;
+    if (g_opt.dense_waves == 4 || g_opt.dense_waves == 8) g.waves = g_opt.dense_waves;
+    if (!qreg) g.waves = 4;
+    int ns = (160 * 1024 - qb - SCAN_LDS_TAIL) / (g.waves * UNIT_BYTES);
+    const int ns_max = g.waves == 8 ? 2 : 4;
+    if (ns > ns_max) ns = ns_max;
     if (g_opt.dense_stages >= 2 && g_opt.dense_stages <= ns) ns = g_opt.dense_stages;
-    return ns;
+    g.stages = ns;
+    g.lds = (size_t)qb + (size_t)g.waves * ns * UNIT_BYTES + SCAN_LDS_TAIL;
+    // staging the query tile through the ring needs the ring to be at least as large
+    if (qreg && (size_t)TILE_ROWS * d_pad * 4 > (size_t)g.waves * ns * UNIT_BYTES) g.stages = 0;
+    return g;
 }
 
 template <int KU>
-static int scan_launch_ku(const DenseScanArgs& a, int ns, size_t lds, hipStream_t st) {
-    switch (ns) {
-        case 4: return scan_launch_t<4, KU>(a, lds, st);
-        case 3: return scan_launch_t<3, KU>(a, lds, st);
-        default: return scan_launch_t<2, KU>(a, lds, st);
+static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, hipStream_t st) {
+    if constexpr (KU <= 2) {
+        if (g.waves == 8) return scan_launch_t<8, 2, KU>(a, g.lds, st);
+    }
+    switch (g.stages) {
+        case 4: return scan_launch_t<4, 4, KU>(a, g.lds, st);
+        case 3: return scan_launch_t<4, 3, KU>(a, g.lds, st);
+        default: return scan_launch_t<4, 2, KU>(a, g.lds, st);
     }
 }
 
 static int scan_launch(DenseScanArgs a, hipStream_t st) {
-    const int ns = scan_stages_for(a.d_pad);
-    if (ns < 2) return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d leaves no room for the LDS ring", a.d_pad);
-    const size_t lds = (size_t)TILE_ROWS * a.d_pad * 4 + (size_t)SCAN_WAVES * ns * UNIT_BYTES + SCAN_LDS_TAIL;
+    const ScanGeom g = scan_geometry(a.d_pad);
+    if (g.stages < 2) return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d leaves no room for the LDS ring", a.d_pad);
+    a.waves = g.waves;
     switch (a.d_pad / KT) {
-        case 1: return scan_launch_ku<1>(a, ns, lds, st);
-        case 2: return scan_launch_ku<2>(a, ns, lds, st);
-        case 3: return scan_launch_ku<3>(a, ns, lds, st);
-        case 4: return scan_launch_ku<4>(a, ns, lds, st);
-        case 5: return scan_launch_ku<5>(a, ns, lds, st);
-        case 6: return scan_launch_ku<6>(a, ns, lds, st);
-        case 7: return scan_launch_ku<7>(a, ns, lds, st);
-        case 8: return scan_launch_ku<8>(a, ns, lds, st);
+        case 1: return scan_launch_ku<1>(a, g, st);
+        case 2: return scan_launch_ku<2>(a, g, st);
+        case 3: return scan_launch_ku<3>(a, g, st);
+        case 4: return scan_launch_ku<4>(a, g, st);
+        case 5: return scan_launch_ku<5>(a, g, st);
+        case 6: return scan_launch_ku<6>(a, g, st);
+        case 7: return scan_launch_ku<7>(a, g, st);
+        case 8: return scan_launch_ku<8>(a, g, st);
         default: return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d", a.d_pad);
     }
 }
@@ -898,13 +957,17 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         a.ns = ns;
         a.nqt = nqt;
         a.add_norm = cosine ? 0 : 1;
+        a.debug = g_opt.dense_debug;
         // sample pass
         a.mode = 1;
         a.tile_first = 0;
         a.tile_step = stride;
         a.n_tiles = ns_tiles;
         a.nrb = nrb;
-        if (ns_tiles < (long long)nrb * SCAN_WAVES) a.nrb = (int)(((ns_tiles + SCAN_WAVES - 1) / SCAN_WAVES + 7) / 8 * 8);
+        {
+            const int wv = scan_geometry(d_pad).waves;
+            if (ns_tiles < (long long)nrb * wv) a.nrb = (int)(((ns_tiles + wv - 1) / wv + 7) / 8 * 8);
+        }
         SQ_TRY(scan_launch(a, st));
         hipLaunchKernelGGL(fill_f32_kernel, dim3((nq_pad + 255) / 256), dim3(256), 0, st, thr, (long long)nq_pad,
                            -__builtin_inff());
