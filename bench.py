@@ -193,6 +193,12 @@ def main() -> None:
         value = nq * args.steps / elapsed
         mean_scan_ms = float(np.mean(scan_ms)) if scan_ms else 0.0
         alg_bytes = float(n_local) * d * 4           # N*d*4 bytes per pass per GPU
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
+        if os.path.isfile(tpath) and n_local == 10_000_000 and d == 128:
+            # HBM bytes of one full-pass launch from the PMC passes of the last committed profile
+            # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes)
+            traffic = json.load(open(tpath)).get("dense_scan_full_pass_hbm_bytes")
         achieved = alg_bytes / (mean_scan_ms * 1e-3) / 1e9 if mean_scan_ms > 0 else 0.0
         line = {
             "metric": "queries/sec, exact brute-force L2 kNN k=100 over 10Mx128 float32 (recall@100 = 1.0 by construction); scan HBM GB/s vs 8 TB/s peak",
@@ -218,7 +224,7 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "dense_scan_kernel (full pass)", "kernel_ms": mean_scan_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "mfma_TFLOPs": 2.0 * n_local * d * (-(-nq // 32) * 32) / (mean_scan_ms * 1e-3) / 1e12 if mean_scan_ms > 0 else None,
