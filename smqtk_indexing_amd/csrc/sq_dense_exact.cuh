@@ -1,0 +1,345 @@
+// Exact (reference-arithmetic) distance kernels, threshold slack and result
+// finalisation/certification of the dense path.  See sq_dense.hip for the
+// overall structure and DESIGN.md section 4.2.
+#pragma once
+#include "sq_pairwise.cuh"
+#include "sq_select.cuh"
+
+namespace sq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------- reference arithmetic
+// sum_{i<d} (x[i]-q[i])^2 exactly as numpy evaluates np.square(i - j).sum()
+// (metrics.py:86): float32 subtract, float32 square, pairwise add-reduce.
+__device__ __forceinline__ float np_sqdist_f32(const float* __restrict__ x, const float* __restrict__ q, int d, int j8) {
+    auto term = [x, q](int i) {
+        const float t = __fsub_rn(x[i], q[i]);
+        return __fmul_rn(t, t);
+    };
+    return np_pairwise_sum<float>(term, d, j8);
+}
+
+__device__ __forceinline__ float sqrt_rn_f32(float v) {
+    // correctly rounded: double sqrt is correctly rounded and 53 >= 2*24+2
+    return (float)sqrt((double)v);
+}
+
+// cosine_distance(q, x) of metrics.py:120-137 in float64, following the order
+// of scipy's C kernel behind cdist(..., 'cosine') (scipy/spatial/src/
+// distance_impl.h, scipy 1.15.3 as pinned here): sequential dot products,
+// c = u.v / (|u| |v|) clipped to [-1,1], cdist value 1 - c; the reference then
+// forms sim = 1 - cdist, clips again and returns (1+1) * arccos(sim) / pi.
+__device__ __forceinline__ double cosine_dist_f64(double dot, double nx2, double nq2) {
+    double c = __ddiv_rn(dot, __dmul_rn(sqrt(nq2), sqrt(nx2)));
+    if (fabs(c) > 1.0) c = copysign(1.0, c);
+    double dm = 1.0 - c;
+    double sim = 1.0 - dm;
+    sim = fmax(fmin(sim, 1.0), -1.0);
+    return 2.0 * acos(sim) / 3.141592653589793;
+}
+
+// One lane per row.  The dot products follow the order of the scipy 1.15.3
+// build pinned in this image (two interleaved accumulators over even / odd
+// elements, summed, then the odd tail; established against cdist itself, see
+// tests/test_oracle_golden.py::test_scipy_cosine_order).  Inputs are float32
+// values, so every product is exact in float64 and FMA contraction is moot.
+__device__ __forceinline__ double cosine_row_f64(const float* __restrict__ x, const float* __restrict__ q, int d) {
+    double dot0 = 0.0, dot1 = 0.0, nx0 = 0.0, nx1 = 0.0, nq0 = 0.0, nq1 = 0.0;
+    const int m = d - (d & 1);
+    for (int i = 0; i < m; i += 2) {
+        const double x0 = (double)x[i], x1 = (double)x[i + 1], q0 = (double)q[i], q1 = (double)q[i + 1];
+        dot0 = __dadd_rn(dot0, __dmul_rn(q0, x0));
+        dot1 = __dadd_rn(dot1, __dmul_rn(q1, x1));
+        nx0 = __dadd_rn(nx0, __dmul_rn(x0, x0));
+        nx1 = __dadd_rn(nx1, __dmul_rn(x1, x1));
+        nq0 = __dadd_rn(nq0, __dmul_rn(q0, q0));
+        nq1 = __dadd_rn(nq1, __dmul_rn(q1, q1));
+    }
+    double dot = __dadd_rn(dot0, dot1), nx = __dadd_rn(nx0, nx1), nq = __dadd_rn(nq0, nq1);
+    if (d & 1) {
+        const double xv = (double)x[m], qq = (double)q[m];
+        dot = __dadd_rn(dot, __dmul_rn(qq, xv));
+        nx = __dadd_rn(nx, __dmul_rn(xv, xv));
+        nq = __dadd_rn(nq, __dmul_rn(qq, qq));
+    }
+    return cosine_dist_f64(dot, nx, nq);
+}
+
+// ------------------------------------------------------ exact distance keys
+// One lane per row: numpy's eight interleaved accumulators are eight registers,
+// fed by two 16-byte row loads and two 16-byte LDS (query) reads per 8 elements.
+// Requires 16-byte aligned rows (row stride and base a multiple of 16 bytes).
+struct SqLeafLane {
+    const float* x;
+    const float* q;  // LDS copy of the query
+    __device__ __forceinline__ float term(int i) const {
+        const float t = __fsub_rn(x[i], q[i]);
+        return __fmul_rn(t, t);
+    }
+    __device__ __forceinline__ float leaf(int off, int n) const {
+        if (n < 8) {
+            float r = 0.f;
+            for (int i = 0; i < n; ++i) r = __fadd_rn(r, term(off + i));
+            return r;
+        }
+        float r[8];
+        {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + off), x1 = *reinterpret_cast<const f32x4*>(x + off + 4);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(q + off), q1 = *reinterpret_cast<const f32x4*>(q + off + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t0 = __fsub_rn(x0[j], q0[j]), t1 = __fsub_rn(x1[j], q1[j]);
+                r[j] = __fmul_rn(t0, t0);
+                r[4 + j] = __fmul_rn(t1, t1);
+            }
+        }
+        const int nfull = n - (n % 8);
+        for (int i = 8; i < nfull; i += 8) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + off + i), x1 = *reinterpret_cast<const f32x4*>(x + off + i + 4);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(q + off + i), q1 = *reinterpret_cast<const f32x4*>(q + off + i + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t0 = __fsub_rn(x0[j], q0[j]), t1 = __fsub_rn(x1[j], q1[j]);
+                r[j] = __fadd_rn(r[j], __fmul_rn(t0, t0));
+                r[4 + j] = __fadd_rn(r[4 + j], __fmul_rn(t1, t1));
+            }
+        }
+        float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                              __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+        for (int i = nfull; i < n; ++i) res = __fadd_rn(res, term(off + i));
+        return res;
+    }
+    // numpy pairwise recursion (split at n/2 rounded down to a multiple of 8), explicit stack
+    __device__ float sum(int d) const {
+        if (d <= 128) return leaf(0, d);
+        int s_off[24], s_n[24], s_state[24];
+        float s_left[24];
+        int sp = 1;
+        s_off[0] = 0;
+        s_n[0] = d;
+        s_state[0] = 0;
+        float ret = 0.f;
+        while (sp > 0) {
+            const int top = sp - 1;
+            const int off = s_off[top], m = s_n[top];
+            if (m <= 128) {
+                ret = leaf(off, m);
+                --sp;
+                continue;
+            }
+            int m2 = m / 2;
+            m2 -= m2 % 8;
+            if (s_state[top] == 0) {
+                s_state[top] = 1;
+                s_off[sp] = off;
+                s_n[sp] = m2;
+                s_state[sp] = 0;
+                ++sp;
+            } else if (s_state[top] == 1) {
+                s_left[top] = ret;
+                s_state[top] = 2;
+                s_off[sp] = off + m2;
+                s_n[sp] = m - m2;
+                s_state[sp] = 0;
+                ++sp;
+            } else {
+                ret = __fadd_rn(s_left[top], ret);
+                --sp;
+            }
+        }
+        return ret;
+    }
+};
+
+// Candidate j of query q (row = cand[q][j], or row_offset + j when cand == nullptr)
+// -> key (ordered float32 euclidean distance, row).  Dynamic LDS: round_up(d,4)*4 bytes.
+static __global__ __launch_bounds__(256) void dense_exact_l2_kernel(const float* __restrict__ db, long long ld, int d,
+                                                              const float* __restrict__ q_orig,
+                                                              const u32* __restrict__ cand, const u32* __restrict__ cnt,
+                                                              u32 cap, long long implicit_n, long long row_offset,
+                                                              u64* __restrict__ keys, long long key_stride) {
+    extern __shared__ __attribute__((aligned(16))) float s_q[];
+    const int q = blockIdx.y;
+    const long long M = cand ? (long long)(cnt[q] < cap ? cnt[q] : cap) : implicit_n;
+    if ((long long)blockIdx.x * 256 >= M) return;
+    for (int i = threadIdx.x; i < d; i += 256) s_q[i] = q_orig[(long long)q * d + i];
+    __syncthreads();
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < M; j += (long long)gridDim.x * 256) {
+        const long long row = cand ? (long long)cand[(long long)q * cap + j] : row_offset + j;
+        const SqLeafLane w{db + row * ld, s_q};
+        const float dist = sqrt_rn_f32(w.sum(d));
+        keys[(long long)q * key_stride + j] = ((u64)ordered_f32(dist) << 32) | (u64)(u32)row;
+    }
+}
+
+static __global__ __launch_bounds__(256) void dense_exact_cos_kernel(const float* __restrict__ db, long long ld, int d,
+                                                               const float* __restrict__ q_orig,
+                                                               const u32* __restrict__ cand, const u32* __restrict__ cnt,
+                                                               u32 cap, long long implicit_n, long long row_offset,
+                                                               K128* __restrict__ keys, long long key_stride) {
+    const int q = blockIdx.y;
+    const long long M = cand ? (long long)(cnt[q] < cap ? cnt[q] : cap) : implicit_n;
+    const float* qv = q_orig + (long long)q * d;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < M; j += (long long)gridDim.x * 256) {
+        const long long row = cand ? (long long)cand[(long long)q * cap + j] : row_offset + j;
+        const double dist = cosine_row_f64(db + row * ld, qv, d);
+        keys[(long long)q * key_stride + j] = K128{ordered_f64(dist), (u64)(u32)row};
+    }
+}
+
+// Plain distance vectors for sq_dense_distances (one query, n gathered rows),
+// in the rows' own dtype like metrics.euclidean_distance (float32 in -> float32
+// out, float64 in -> float64 out); cosine is always float64 (scipy cdist).
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(a, b); }
+__device__ __forceinline__ float mul_rn_t(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn_t(double a, double b) { return __dmul_rn(a, b); }
+
+template <class T>
+__device__ __forceinline__ double cosine_row_t(const T* __restrict__ x, const T* __restrict__ q, int d) {
+    double dot0 = 0.0, dot1 = 0.0, nx0 = 0.0, nx1 = 0.0, nq0 = 0.0, nq1 = 0.0;
+    const int m = d - (d & 1);
+    for (int i = 0; i < m; i += 2) {
+        const double x0 = (double)x[i], x1 = (double)x[i + 1], q0 = (double)q[i], q1 = (double)q[i + 1];
+        dot0 = __dadd_rn(dot0, __dmul_rn(q0, x0));
+        dot1 = __dadd_rn(dot1, __dmul_rn(q1, x1));
+        nx0 = __dadd_rn(nx0, __dmul_rn(x0, x0));
+        nx1 = __dadd_rn(nx1, __dmul_rn(x1, x1));
+        nq0 = __dadd_rn(nq0, __dmul_rn(q0, q0));
+        nq1 = __dadd_rn(nq1, __dmul_rn(q1, q1));
+    }
+    double dot = __dadd_rn(dot0, dot1), nx = __dadd_rn(nx0, nx1), nq = __dadd_rn(nq0, nq1);
+    if (d & 1) {
+        const double xv = (double)x[m], qq = (double)q[m];
+        dot = __dadd_rn(dot, __dmul_rn(qq, xv));
+        nx = __dadd_rn(nx, __dmul_rn(xv, xv));
+        nq = __dadd_rn(nq, __dmul_rn(qq, qq));
+    }
+    return cosine_dist_f64(dot, nx, nq);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void dense_distances_kernel(const T* __restrict__ rows, long long n, int d,
+                                                               const T* __restrict__ q, int metric,
+                                                               T* __restrict__ out_t, double* __restrict__ out64) {
+    const int j8 = threadIdx.x & 7;
+    const long long j = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const long long jc = j < n ? j : n - 1;
+    const T* x = rows + jc * d;
+    if (metric == SQ_METRIC_L2) {
+        auto term = [x, q](int i) {
+            const T t = sub_rn(x[i], q[i]);
+            return mul_rn_t(t, t);
+        };
+        const T s = np_pairwise_sum<T>(term, d, j8);
+        if (j8 == 0 && j < n) {
+            if constexpr (sizeof(T) == 4)
+                out_t[j] = sqrt_rn_f32(s);
+            else
+                out_t[j] = sqrt(s);
+        }
+    } else {
+        if (j8 == 0 && j < n) out64[j] = cosine_row_t<T>(x, q, d);
+    }
+}
+
+// The sampled threshold T is the score of an actual row.  The scan emits with
+// T + slack so that a query whose k-th neighbour IS that row still certifies:
+// slack covers twice the filter's error bound plus the relative rounding of
+// the exact distance (DESIGN.md "certification").
+// Error bound of the filter score (bf16x3 MFMA):
+//   L2:     eps = eps_a * X*|q| + eps_b * (X^2 + 2 X |q|)      (X^2 = max squared row norm)
+//   cosine: eps = eps_a + eps_b                                  (unit vectors)
+__device__ __forceinline__ double filter_eps(int cosine, double xn2_max, double qn2, double eps_a, double eps_b) {
+    if (cosine) return eps_a + eps_b;
+    const double xq = sqrt(xn2_max * qn2);
+    return eps_a * xq + eps_b * (xn2_max + 2.0 * xq);
+}
+
+static __global__ void dense_inflate_thr_kernel(float* __restrict__ thr, const double* __restrict__ qn2, int nq, int cosine,
+                                         double xn2_max, double eps_a, double eps_b) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const float t = thr[q];
+    if (!(t < __builtin_inff())) return;
+    double slack;
+    const double eps = filter_eps(cosine, xn2_max, qn2[q], eps_a, eps_b);
+    if (cosine)
+        slack = 2.0 * eps + 1e-8;
+    else
+        slack = 2.0 * eps + 4e-6 * fabs((double)t + qn2[q]);
+    // round up so the float threshold is never below T + slack
+    float r = (float)((double)t + slack);
+    if ((double)r < (double)t + slack) r = __uint_as_float(__float_as_uint(r) + (r >= 0.f ? 1 : -1));
+    thr[q] = r;
+}
+
+// --------------------------------------------------------------- finalize
+// status bits: 1 candidate overflow, 2 certification failed, 4 fewer than kk candidates
+static __global__ void dense_finalize_l2_kernel(const u64* __restrict__ sorted, const u32* __restrict__ cnt, u32 cap, int k,
+                                         int kk, long long id_base, const float* __restrict__ thr,
+                                         const double* __restrict__ qn2, double xn2_max, double eps_a, double eps_b,
+                                         int certify, float* __restrict__ out_dist, long long* __restrict__ out_idx,
+                                         u32* __restrict__ status) {
+    const int q = blockIdx.x;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const u64 key = sorted[(long long)q * k + j];
+        const bool pad = key == ~0ull;
+        out_dist[(long long)q * k + j] = pad ? __builtin_inff() : unordered_f32((u32)(key >> 32));
+        out_idx[(long long)q * k + j] = pad ? -1ll : id_base + (long long)(key & 0xffffffffull);
+    }
+    if (threadIdx.x == 0) {
+        u32 st = 0;
+        if (certify) {
+            const u32 c = cnt[q];
+            if (c > cap) st |= 1u;
+            if (c < (u32)kk) st |= 4u;
+            if (st == 0) {
+                const u64 key = sorted[(long long)q * k + (kk - 1)];
+                const double dk = (double)unordered_f32((u32)(key >> 32));
+                const double t = (double)thr[q];
+                const double eps = filter_eps(0, xn2_max, qn2[q], eps_a, eps_b);
+                const double lo2 = t + qn2[q] - eps;  // smallest squared distance a non-candidate can have
+                const double bound = lo2 > 0.0 ? sqrt(lo2) * (1.0 - 1e-6) : 0.0;
+                if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
+            }
+        }
+        status[q] = st;
+    }
+}
+
+static __global__ void dense_finalize_cos_kernel(const K128* __restrict__ sorted, const u32* __restrict__ cnt, u32 cap,
+                                          int k, int kk, long long id_base, const float* __restrict__ thr,
+                                          double eps, int certify, double* __restrict__ out_dist,
+                                          long long* __restrict__ out_idx, u32* __restrict__ status) {
+    const int q = blockIdx.x;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const K128 key = sorted[(long long)q * k + j];
+        const bool pad = key.hi == ~0ull && key.lo == ~0ull;
+        out_dist[(long long)q * k + j] = pad ? (double)__builtin_inff() : unordered_f64(key.hi);
+        out_idx[(long long)q * k + j] = pad ? -1ll : id_base + (long long)(key.lo & 0xffffffffull);
+    }
+    if (threadIdx.x == 0) {
+        u32 st = 0;
+        if (certify) {
+            const u32 c = cnt[q];
+            if (c > cap) st |= 1u;
+            if (c < (u32)kk) st |= 4u;
+            if (st == 0) {
+                const double dk = unordered_f64(sorted[(long long)q * k + (kk - 1)].hi);
+                const double t = (double)thr[q];  // threshold on -sim~
+                // non-candidates: -sim~ > t  =>  sim < -t + eps  =>  dist > 2 acos(min(1,-t+eps))/pi
+                double smax = -t + eps;
+                smax = smax > 1.0 ? 1.0 : (smax < -1.0 ? -1.0 : smax);
+                const double bound = 2.0 * acos(smax) / 3.141592653589793 - 1e-9;
+                if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
+            }
+        }
+        status[q] = st;
+    }
+}
+
+
+}  // namespace sq

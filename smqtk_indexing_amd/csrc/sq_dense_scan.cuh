@@ -1,0 +1,482 @@
+// The streaming filter of the dense path: one pass over a bf16 hi/lo "scan
+// copy" of the descriptor matrix on the bf16 matrix cores (gfx950).
+//
+// Why a scan copy.  The filter only has to be right within a known error
+// bound (every survivor is re-ranked in the reference's float32/float64
+// arithmetic), but it has to stream N*d*4 bytes at the HBM rate
+// for many queries at once.  float32 MFMA (v_mfma_f32_32x32x2_f32) runs at the
+// VALU rate, 1/16 of bf16, and made the scan compute bound beyond ~24 queries.
+// Splitting every float32 x into two bfloat16 x = hi + lo (|x - hi - lo| <=
+// 2^-16 |x|) and evaluating hi*hi' + hi*lo' + lo*hi' on
+// v_mfma_f32_32x32x16_bf16 keeps ~2^-14 relative accuracy per product at 3/16
+// of the float32 MFMA cycles, with no conversion work in the loop: the split
+// is done once at index build time and stored in exactly the order the MFMA
+// fragments are read (same bytes per row as float32, so the algorithmic HBM
+// traffic of a pass is unchanged).
+//
+// Scan-copy layout: row-major, row stride d_pad*4 bytes; a row is KU = d_pad/64
+// units of 256 bytes; a unit is 16 chunks of 16 bytes; chunk c = 4*s + 2*h + p
+// holds 8 bfloat16 = elements k = 64*unit + 16*s + 8*h + j (j = 0..7) of the
+// hi (p = 0) or lo (p = 1) part.  That is the A (and B) operand of MFMA k-step
+// s for lane half h (cdna_hip_programming.md section 3, bf16 operand maps).
+#pragma once
+#include "sq_common.hpp"
+
+namespace sq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int KT = 64;                          // floats per k-unit
+static constexpr int TILE_ROWS = 32;                   // rows per MFMA tile
+static constexpr int UNIT_BYTES = TILE_ROWS * KT * 4;  // 8 KiB: 32 rows x 256 bytes
+static constexpr int NORM_BYTES = 256;                 // per ring slot: |x|^2 of the tile's 32 rows (64 lanes x 4 B)
+static constexpr int SLOT_BYTES = UNIT_BYTES + NORM_BYTES;
+static constexpr int EBUF_BYTES = 8192;                // emission buffers of a workgroup: (row, query) pairs
+static constexpr int MAX_DPAD = 512;
+
+// --------------------------------------------------------------- bf16 split
+__device__ __forceinline__ u32 bf16_bits_rn(float x) {
+    u32 u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
+    return u >> 16;
+}
+__device__ __forceinline__ void bf16_split(float x, u32& hi, u32& lo) {
+    hi = bf16_bits_rn(x);
+    const float r = __fsub_rn(x, __uint_as_float(hi << 16));  // exact
+    lo = bf16_bits_rn(r);
+}
+
+// One thread per 16-byte chunk of the scan copy.  `row_scale` (cosine): 1/|x|.
+static __global__ __launch_bounds__(256) void dense_build_scan_kernel(const float* __restrict__ db, long long n,
+                                                                       long long ld, int d, int d_pad,
+                                                                       long long n_pad,
+                                                                       const float* __restrict__ row_scale,
+                                                                       uint4* __restrict__ scan) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = d_pad / 4;  // chunks per row
+    if (idx >= n_pad * cpr) return;
+    const long long row = idx / cpr;
+    const int cc = (int)(idx - row * cpr);
+    const int unit = cc >> 4, c = cc & 15, s = c >> 2, h = (c >> 1) & 1, p = c & 1;
+    const int k0 = unit * KT + 16 * s + 8 * h;
+    u32 w[4];
+    const float sc = (row < n && row_scale) ? row_scale[row] : 1.f;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        u32 half[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = k0 + j + e;
+            float x = 0.f;
+            if (row < n && k < d) x = row_scale ? __fmul_rn(db[row * ld + k], sc) : db[row * ld + k];
+            u32 hi, lo;
+            bf16_split(x, hi, lo);
+            half[e] = p ? lo : hi;
+        }
+        w[j >> 1] = half[0] | (half[1] << 16);
+    }
+    scan[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Per-row squared norms (float32, from a float64 sum), their maximum (for the
+// error bound) and, for cosine, 1/|x|.  8 lanes per row.
+static __global__ __launch_bounds__(256) void dense_rowstats_kernel(const float* __restrict__ db, long long n,
+                                                                     long long ld, int d, long long n_pad,
+                                                                     u32* __restrict__ max_bits,
+                                                                     float* __restrict__ norms,
+                                                                     float* __restrict__ inv_norm) {
+    const int lane8 = threadIdx.x & 7;
+    const long long row = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const long long r = row < n ? row : n - 1;
+    const float* x = db + r * ld;
+    double acc = 0.0;
+    for (int i = lane8; i < d; i += 8) acc += (double)x[i] * (double)x[i];
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    if (lane8 == 0 && row < n_pad) {
+        if (row < n) {
+            atomicMax(max_bits, __float_as_uint((float)(acc * (1.0 + 1e-6))));
+            norms[row] = (float)acc;
+            if (inv_norm) inv_norm[row] = acc > 0.0 ? (float)(1.0 / sqrt(acc)) : 0.f;
+        } else {
+            norms[row] = 0.f;
+        }
+    }
+}
+
+// Query prep: |q|^2 (f64) and the scaled query (L2: -2q, cosine: -q/|q|) split
+// and stored in the scan-copy chunk layout, [nq_pad][d_pad/4] chunks.
+static __global__ __launch_bounds__(256) void dense_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
+                                                                         int d_pad, int metric,
+                                                                         uint4* __restrict__ qs,
+                                                                         double* __restrict__ qn2) {
+    const int qi = blockIdx.x;
+    __shared__ double red[4];
+    double acc = 0.0;
+    if (qi < nq)
+        for (int i = threadIdx.x; i < d; i += 256) acc += (double)q[(long long)qi * d + i] * (double)q[(long long)qi * d + i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const double tot = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) qn2[qi] = qi < nq ? tot : 0.0;
+    double scale = -2.0;
+    if (metric == SQ_METRIC_COSINE) scale = tot > 0.0 ? -1.0 / sqrt(tot) : 0.0;
+    const int cpr = d_pad / 4;
+    for (int cc = threadIdx.x; cc < cpr; cc += 256) {
+        const int unit = cc >> 4, c = cc & 15, s = c >> 2, h = (c >> 1) & 1, p = c & 1;
+        const int k0 = unit * KT + 16 * s + 8 * h;
+        u32 w[4];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            u32 half[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = k0 + j + e;
+                float x = 0.f;
+                if (qi < nq && k < d) x = (float)((double)q[(long long)qi * d + k] * scale);
+                u32 hi, lo;
+                bf16_split(x, hi, lo);
+                half[e] = p ? lo : hi;
+            }
+            w[j >> 1] = half[0] | (half[1] << 16);
+        }
+        qs[(long long)qi * cpr + cc] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ------------------------------------------------------------- the scan kernel
+struct DenseScanArgs {
+    const uint4* scan;      // scan copy [n_pad][d_pad/4] chunks
+    const float* norms;     // |x|^2 per row [n_pad] (L2) or nullptr (cosine)
+    long long n;            // real rows (rows >= n are padding and never emitted)
+    long long n_tiles;      // ceil(n / 32)
+    const uint4* qs;        // [nqt*32][d_pad/4] prepared queries
+    const float* thr;       // [nqt*32] score thresholds (EMIT)
+    u32* cand;              // [nqt*32][cap] candidate row ids
+    u32* cnt;               // [nqt*32]
+    u32 cap;
+    float* sample_out;      // [nqt*32][ns] (SAMPLE)
+    long long ns;
+    long long tile_step;    // SAMPLE: every tile_step-th tile; EMIT: 1
+    long long n_sel;        // number of tiles this launch visits
+    int nqt;                // query tiles
+    int nrb;                // row blocks (multiple of 8 when nqt > 1)
+    int debug;              // measurement only: 1 = skip LDS reads + MFMA, 2 = stop the DMA after the first ring fill
+};
+
+// LDS-DMA: 64 lanes x 16 bytes land at lds_dst + lane*16 (wave-uniform base in
+// M0); the global source is a wave-uniform 64-bit base (SGPR pair) plus a
+// per-lane 32-bit byte offset.  Issued from inline asm so that hipcc does not
+// fence every later ds_read with vmcnt(0); completion is tracked by the counted
+// waits below (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16(const void* gbase_uniform, u32 voff, u32 lds_dst) {
+    u32 keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(gbase_uniform), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gbase_uniform, u32 voff, u32 lds_dst) {
+    u32 keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(gbase_uniform), "s"(lds_dst)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Allow `units` younger units (8 DMA instructions each, +1 for a tile's norms:
+// counting 8 is then merely conservative) to stay outstanding.
+template <int NSTAGE>
+__device__ __forceinline__ void wait_units_in_flight(int units) {
+    if constexpr (NSTAGE >= 4) {
+        if (units >= 3) {
+            wait_vmcnt<24>();
+            return;
+        }
+    }
+    if constexpr (NSTAGE >= 3) {
+        if (units == 2) {
+            wait_vmcnt<16>();
+            return;
+        }
+    }
+    if (units == 1)
+        wait_vmcnt<8>();
+    else
+        wait_vmcnt<0>();
+}
+
+typedef __attribute__((address_space(3))) u32 lds_u32;
+
+// WAVES: waves per workgroup (one workgroup per CU; 8 = two waves per SIMD, so
+// one wave's DMA issue / epilogue runs under the other's MFMAs); NSTAGE: ring
+// depth per wave; KU = d_pad/64 units per row tile; SAMPLE: write per-lane
+// minima of every visited tile instead of emitting candidates.
+template <int WAVES, int NSTAGE, int KU, bool SAMPLE>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(DenseScanArgs a) {
+    constexpr bool QREG = KU <= 2;  // query fragments live in registers for d_pad <= 128
+    constexpr int DPAD = KU * KT;
+    constexpr int EBUF_ENTRIES = EBUF_BYTES / 8 / WAVES;
+    constexpr int EBUF_FLUSH = EBUF_ENTRIES / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // LDS map: [query tile (only when re-read per unit)][rings][emission buffers][emission counters].
+    // With QREG the query tile is staged through the not yet used ring area.
+    constexpr u32 q_bytes = QREG ? 0u : (u32)TILE_ROWS * DPAD * 4;
+    const u32 lds_base = (u32)(uintptr_t)smem;  // low 32 bits of a flat LDS address = LDS offset
+    const u32 ring_base = lds_base + q_bytes + (u32)wave * (NSTAGE * SLOT_BYTES);
+    unsigned char* ring_ptr = smem + q_bytes + wave * (NSTAGE * SLOT_BYTES);
+    unsigned char* etop = smem + q_bytes + WAVES * NSTAGE * SLOT_BYTES;
+    uint2* ebuf = reinterpret_cast<uint2*>(etop) + wave * EBUF_ENTRIES;
+    lds_u32* ecnt_ptr = (lds_u32*)(etop + EBUF_BYTES + wave * 16);
+    const bool add_norm = a.norms != nullptr;
+
+    // block -> (row block, query tile); blocks that share an XCD (same id mod 8)
+    // walk the query tiles of the same rows so the matrix is re-read from L2.
+    const int L = blockIdx.x;
+    int qt, rb;
+    if (a.nqt > 1) {
+        const int xcd = L & 7, j = L >> 3;
+        qt = j % a.nqt;
+        rb = (j / a.nqt) * 8 + xcd;
+    } else {
+        qt = 0;
+        rb = L;
+    }
+
+    // stage the query tile: [32][DPAD*4 bytes], 16-byte chunks XOR-swizzled inside each
+    // 256-byte unit by (row & 15) -- the image the row units get from the DMA
+    {
+        const uint4* qsrc = a.qs + (long long)qt * TILE_ROWS * (DPAD / 4);
+        constexpr int cpr = DPAD / 4;
+        for (int c = threadIdx.x; c < TILE_ROWS * cpr; c += WAVES * 64) {
+            const int r = c / cpr, ch = c - r * cpr;
+            const uint4 v = qsrc[c];
+            const int sw = (ch & ~15) | ((ch & 15) ^ (r & 15));
+            *reinterpret_cast<uint4*>(smem + (u32)r * DPAD * 4 + sw * 16) = v;
+        }
+        if (lane == 0) *ecnt_ptr = 0u;
+    }
+    __syncthreads();
+
+    // Tiles are dealt round-robin over all waves of the launch: at any moment the
+    // grid reads one compact window of the matrix.
+    const long long gw = (long long)rb * WAVES + wave;
+    const long long nwaves = (long long)a.nrb * WAVES;
+    const long long my_tiles = gw < a.n_sel ? (a.n_sel - gw + nwaves - 1) / nwaves : 0;
+    const long long total_units = my_tiles * KU;
+
+    const int r31 = lane & 31, h = lane >> 5;
+    const int qglob = qt * TILE_ROWS + r31;
+    float thr_l = SAMPLE ? 0.f : a.thr[qglob];
+    // Force hipcc's wait for this load HERE.  Left to its first use inside the
+    // loop the compiler emits s_waitcnt vmcnt(0) there (it cannot see the asm
+    // LDS-DMAs), draining the whole ring once per tile.
+    asm volatile("" : "+v"(thr_l));
+
+    // B fragments of k-step s: chunk 4s+2h (hi) and 4s+2h+1 (lo) of the lane's query row
+    f32x4 bq[QREG ? KU : 1][8];
+    if constexpr (QREG) {
+#pragma unroll
+        for (int kc = 0; kc < KU; ++kc)
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                bq[kc][g] = *reinterpret_cast<const f32x4*>(smem + (u32)r31 * DPAD * 4 + kc * 256 +
+                                                             (((g >> 1) * 4 + 2 * h + (g & 1)) ^ (r31 & 15)) * 16);
+        __syncthreads();  // every wave holds its fragments before the DMA ring overwrites the staging area
+    }
+
+    // per-lane byte offsets of the 8 DMA instructions of a unit (row 4j + lane/16, swizzled chunk)
+    u32 voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 4 * j + (lane >> 4);
+        voff[j] = (u32)(r * (DPAD * 4) + (((lane & 15) ^ (r & 15)) * 16));
+    }
+    const u32 voff_norm = (u32)((lane & 31) * 4);
+
+    auto emit_global = [&](u32 row, u32 q) {
+        u32 pos = atomicAdd(&a.cnt[q], 1u);
+        if (pos < a.cap) a.cand[(long long)q * a.cap + pos] = row;
+    };
+    auto flush = [&](u32 c) {
+        const u32 n = c < (u32)EBUF_ENTRIES ? c : (u32)EBUF_ENTRIES;
+        for (u32 e = lane; e < n; e += 64) {
+            uint2 ent = ebuf[e];
+            emit_global(ent.x, ent.y);
+        }
+        if (lane == 0) *ecnt_ptr = 0u;
+    };
+
+    // issue cursor: unit u of this wave = (tile gw + (u / KU) * nwaves, k-unit u % KU), slot u % NSTAGE
+    long long iss_sel = gw;
+    int iss_kc = 0, iss_slot = 0;
+    long long issued = 0;
+    auto issue_unit = [&]() {
+        const long long row0 = iss_sel * a.tile_step * TILE_ROWS;
+        const u32 dst = ring_base + (u32)iss_slot * SLOT_BYTES;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan) + row0 * (DPAD * 4) + iss_kc * 256;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) glds16(base, voff[j], dst + (u32)j * 1024);
+        if (add_norm && iss_kc == 0) glds4(a.norms + row0, voff_norm, dst + UNIT_BYTES);
+        ++issued;
+        if (++iss_kc == KU) {
+            iss_kc = 0;
+            iss_sel += nwaves;
+        }
+        if (++iss_slot == NSTAGE) iss_slot = 0;
+    };
+
+    // Software pipeline over units (u = 0, 1, ...; slot of unit u = u % NSTAGE):
+    //   registers hold the A fragments of unit u (av_cur) while its 12 MFMAs run;
+    //   the fragments of unit u+1 are read from LDS (av_nxt) under those MFMAs;
+    //   the slot of unit u is refilled by the DMA of unit u+NSTAGE as soon as
+    //   av_cur is complete.
+    const bool do_dma = !(a.debug & 2), do_math = !(a.debug & 1);
+    auto issue_next = [&]() {
+        if (issued < total_units) {
+            if (do_dma || issued < NSTAGE)  // ablation: the ring is filled once, then reused
+                issue_unit();
+            else
+                ++issued;
+        }
+    };
+    f32x4 av_cur[8], av_nxt[8], nrm_cur[4], nrm_nxt[4];
+    auto read_frags = [&](int slot_idx, bool first_of_tile) {
+        const unsigned char* sl = ring_ptr + slot_idx * SLOT_BYTES;
+        const unsigned char* arow = sl + r31 * 256;
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            av_nxt[g] = *reinterpret_cast<const f32x4*>(arow + (((g >> 1) * 4 + 2 * h + (g & 1)) ^ (r31 & 15)) * 16);
+        if (first_of_tile && add_norm) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) nrm_nxt[c] = *reinterpret_cast<const f32x4*>(sl + UNIT_BYTES + (8 * c + 4 * h) * 4);
+        }
+    };
+    for (int p = 0; p < NSTAGE; ++p) issue_next();
+
+#pragma unroll
+    for (int g = 0; g < 8; ++g) av_nxt[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) nrm_nxt[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    long long loaded = 0;  // units whose fragments have been requested from LDS
+    int rd_slot = 0, rd_kc = 0;
+    if (total_units > 0) {
+        wait_units_in_flight<NSTAGE>((int)(issued - 1));
+        if (do_math) read_frags(0, true);
+        loaded = 1;
+        rd_slot = NSTAGE > 1 ? 1 : 0;
+        rd_kc = KU > 1 ? 1 : 0;
+    }
+    for (long long sel = gw; sel < a.n_sel; sel += nwaves) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KU; ++kc) {
+            // fragments of this unit are complete once copied (hipcc waits lgkmcnt here); its slot is free
+#pragma unroll
+            for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];
+            if (kc == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) nrm_cur[c] = nrm_nxt[c];
+            }
+            asm volatile("" ::: "memory");
+            issue_next();
+            if (loaded < total_units) {
+                wait_units_in_flight<NSTAGE>((int)(issued - loaded - 1));  // younger units may stay in flight
+                if (do_math) read_frags(rd_slot, rd_kc == 0);
+                ++loaded;
+                if (++rd_slot == NSTAGE) rd_slot = 0;
+                if (++rd_kc == KU) rd_kc = 0;
+            }
+            if (do_math) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    f32x4 bh, bl;
+                    if constexpr (QREG) {
+                        bh = bq[kc][2 * s];
+                        bl = bq[kc][2 * s + 1];
+                    } else {
+                        const unsigned char* brow = smem + (u32)r31 * DPAD * 4 + kc * 256;
+                        bh = *reinterpret_cast<const f32x4*>(brow + ((4 * s + 2 * h) ^ (r31 & 15)) * 16);
+                        bl = *reinterpret_cast<const f32x4*>(brow + ((4 * s + 2 * h + 1) ^ (r31 & 15)) * 16);
+                    }
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, av_cur[2 * s]);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, av_cur[2 * s + 1]);
+                    const bf16x8 bhv = __builtin_bit_cast(bf16x8, bh);
+                    const bf16x8 blv = __builtin_bit_cast(bf16x8, bl);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhv, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blv, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhv, acc, 0, 0, 0);
+                }
+            }
+        }
+        if (!do_math) continue;
+        // ---- tile complete: scores for 32 rows x 32 queries (lane = query, register i = row (i&3)+8(i>>2)+4h)
+        if (add_norm) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += nrm_cur[i >> 2][i & 3];
+        }
+        const long long row0 = sel * a.tile_step * TILE_ROWS;
+        if constexpr (!SAMPLE) {
+            float m = acc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) m = fminf(m, acc[i]);
+            if (__any(m <= thr_l)) {
+                if (m <= thr_l) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (acc[i] <= thr_l && row < a.n) {
+                            const u32 pos = __hip_atomic_fetch_add(ecnt_ptr, 1u, __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (pos < (u32)EBUF_ENTRIES)
+                                ebuf[pos] = make_uint2((u32)row, (u32)qglob);
+                            else
+                                emit_global((u32)row, (u32)qglob);  // buffer full (degenerate thresholds only)
+                        }
+                    }
+                }
+                const u32 c = __builtin_amdgcn_readfirstlane(*ecnt_ptr);
+                if (c >= (u32)EBUF_FLUSH) flush(c);
+            }
+        } else {
+            // the minimum score of this lane's 16 rows: the score of one actual row, hence a valid
+            // sample for an upper bound of the k-th smallest score (kth_threshold_f32_kernel)
+            float ml = __builtin_inff();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ro = (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (row0 + ro < a.n) ml = fminf(ml, acc[i]);
+            }
+            a.sample_out[(long long)qglob * a.ns + sel * 2 + h] = ml;
+        }
+    }
+    if constexpr (!SAMPLE) {
+        const u32 c = __builtin_amdgcn_readfirstlane(*ecnt_ptr);
+        if (c > 0) flush(c);
+    }
+}
+
+}  // namespace sq
