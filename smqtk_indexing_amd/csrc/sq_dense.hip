@@ -38,12 +38,12 @@ struct DenseHandle : HandleBase {
     long long id_base = 0;
     double xn2_max = 0.0;       // max squared row norm (error bound of the L2 filter)
     // workspace
-    DevBuf q_dev, q_scaled, qn2, thr, cand, cnt, keys, sample, out_keys, status, out_dist_dev, out_idx_dev, big_keys,
-        scratch;
+    DevBuf q_dev, q_scaled, q_al, qn2, thr, wave_out, wave_cnt, cnt, keys, sample, out_keys, status, out_dist_dev,
+        out_idx_dev, big_keys, scratch;
     HostPinned status_host;
     ~DenseHandle() override {
-        for (DevBuf* b : {&owned, &scan, &norms, &q_dev, &q_scaled, &qn2, &thr, &cand, &cnt, &keys, &sample, &out_keys,
-                          &status, &out_dist_dev, &out_idx_dev, &big_keys, &scratch})
+        for (DevBuf* b : {&owned, &scan, &norms, &q_dev, &q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt,
+                          &keys, &sample, &out_keys, &status, &out_dist_dev, &out_idx_dev, &big_keys, &scratch})
             b->release();
         status_host.release();
     }
@@ -82,7 +82,7 @@ static int scan_launch_t(const DenseScanArgs& a, size_t lds, hipStream_t st) {
     return SQ_OK;
 }
 
-static constexpr int SCAN_LDS_TAIL = EBUF_BYTES + 8 * 16;  // emission buffers + per-wave counters
+static constexpr int SCAN_LDS_TAIL = 8 * 16;  // per-wave survivor counters
 
 // Launch geometry of the scan for a padded dimension: waves per workgroup and ring depth.
 struct ScanGeom {
@@ -199,11 +199,11 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         if (cosine) {
             SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, (u32)n, key_stride, k, nq, h->out_keys.as<K128>(), st));
             hipLaunchKernelGGL(dense_finalize_cos_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<K128>(), cnt,
-                               (u32)n, k, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx, status);
+                               (u32)n, k, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx, status, nullptr);
         } else {
             SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, (u32)n, key_stride, k, nq, h->out_keys.as<u64>(), st));
             hipLaunchKernelGGL(dense_finalize_l2_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<u64>(), cnt, (u32)n,
-                               k, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 0, (float*)out_dist, out_idx, status);
+                               k, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 0, (float*)out_dist, out_idx, status, nullptr);
         }
     } else if (scan_ok) {
         hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, q, nq, d, d_pad, h->metric, qs,
@@ -216,13 +216,21 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         const long long ns_tiles = (n_tiles + stride - 1) / stride;
         const long long ns = ns_tiles * 2;  // one sample (a 16-row group minimum) per lane half per tile
         SQ_TRY(h->sample.reserve((size_t)nq_pad * ns * 4));
-        SQ_TRY(h->cand.reserve((size_t)nq_pad * cap * 4));
         SQ_TRY(h->keys.reserve((size_t)nq * key_stride * key_bytes));
-        u32* cand = h->cand.as<u32>();
         const int cus = cu_count(h->device);
         int nrb = g_opt.dense_blocks > 0 ? g_opt.dense_blocks : cus;
         nrb = (nrb + 7) / 8 * 8;
         const int wv = scan_geometry(d_pad).waves;
+        // survivors leave the scan as per-wave segments; the re-rank kernel turns them into per-query key lists
+        const long long n_waves = (long long)nrb * nqt * wv;
+        const u32 wave_cap = 2048;
+        const int ldq = (d + 3) / 4 * 4;
+        SQ_TRY(h->wave_out.reserve((size_t)n_waves * wave_cap * 8));
+        SQ_TRY(h->wave_cnt.reserve((size_t)n_waves * 4));
+        SQ_TRY(h->q_al.reserve((size_t)nq * ldq * 4));
+        u32* oflag = h->scratch.as<u32>() + 16;
+        hipLaunchKernelGGL(dense_align_queries_kernel, dim3((unsigned)(((long long)nq * ldq + 255) / 256)), dim3(256), 0,
+                           st, q, nq, d, ldq, h->q_al.as<float>());
         DenseScanArgs a{};
         a.scan = h->scan.as<uint4>();
         a.norms = cosine ? nullptr : h->norms.as<float>();
@@ -230,9 +238,9 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         a.n_tiles = n_tiles;
         a.qs = qs;
         a.thr = thr;
-        a.cand = cand;
-        a.cnt = cnt;
-        a.cap = cap;
+        a.wave_out = h->wave_out.as<uint2>();
+        a.wave_cnt = h->wave_cnt.as<u32>();
+        a.wave_cap = wave_cap;
         a.sample_out = h->sample.as<float>();
         a.ns = ns;
         a.nqt = nqt;
@@ -249,6 +257,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         hipLaunchKernelGGL(dense_inflate_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, thr, qn2, nq, cosine ? 1 : 0,
                            h->xn2_max, eps_a, eps_b);
         SQ_HIP(hipMemsetAsync(cnt, 0, (size_t)nq_pad * 4, st));
+        SQ_HIP(hipMemsetAsync(oflag, 0, 4, st));
         // full pass
         a.tile_step = 1;
         a.n_sel = n_tiles;
@@ -258,20 +267,25 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
         h->stats.scan_launches = 2;
         h->stats.bytes_scanned = n * (long long)d * 4;
-        // exact re-rank of the candidates, select, certify
-        const unsigned gx = 64;
+        // exact re-rank of the survivors (wave segments -> per-query keys), select, certify
+        const int wpb = 2;  // survivor segments per re-rank block (both from one scan workgroup: wv is even)
+        const size_t rr_lds = (size_t)32 * (ldq + 4) * 4;
+        const unsigned gxr = (unsigned)((n_waves + wpb - 1) / wpb);
         if (cosine) {
-            hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, nq), dim3(256), 0, st, h->db, h->ld, d, q, cand, cnt, cap,
-                               0ll, 0ll, h->keys.as<K128>(), key_stride);
+            hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3(gxr), dim3(256), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
+                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, h->keys.as<K128>(), cnt, cap,
+                               oflag);
             SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, cap, key_stride, k, nq, h->out_keys.as<K128>(), st));
             hipLaunchKernelGGL(dense_finalize_cos_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<K128>(), cnt, cap, k,
-                               kk, h->id_base, thr, eps_a + eps_b, 1, (double*)out_dist, out_idx, status);
+                               kk, h->id_base, thr, eps_a + eps_b, 1, (double*)out_dist, out_idx, status, oflag);
         } else {
-            hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, nq), dim3(256), l2_lds, st, h->db, h->ld, d, q, cand, cnt,
-                               cap, 0ll, 0ll, h->keys.as<u64>(), key_stride);
+            hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3(gxr), dim3(256), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
+                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, h->keys.as<u64>(), cnt, cap,
+                               oflag);
             SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, cap, key_stride, k, nq, h->out_keys.as<u64>(), st));
             hipLaunchKernelGGL(dense_finalize_l2_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<u64>(), cnt, cap, k,
-                               kk, h->id_base, thr, qn2, h->xn2_max, eps_a, eps_b, 1, (float*)out_dist, out_idx, status);
+                               kk, h->id_base, thr, qn2, h->xn2_max, eps_a, eps_b, 1, (float*)out_dist, out_idx, status,
+                               oflag);
         }
     } else {
         all_fallback = true;  // rows wider than the MFMA scan covers: exact path for every query
@@ -307,7 +321,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
                                          h->out_keys.as<K128>() + (long long)qi * k, st));
             hipLaunchKernelGGL(dense_finalize_cos_kernel, dim3(1), dim3(256), 0, st,
                                h->out_keys.as<K128>() + (long long)qi * k, cnt + qi, (u32)n, k, kk, h->id_base, thr, 0.0,
-                               0, (double*)out_dist + (long long)qi * k, out_idx + (long long)qi * k, status + qi);
+                               0, (double*)out_dist + (long long)qi * k, out_idx + (long long)qi * k, status + qi, nullptr);
         } else {
             hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, 1), dim3(256), l2_lds, st, h->db, h->ld, d,
                                q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<u64>(), n);
@@ -316,7 +330,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
             hipLaunchKernelGGL(dense_finalize_l2_kernel, dim3(1), dim3(256), 0, st,
                                h->out_keys.as<u64>() + (long long)qi * k, cnt + qi, (u32)n, k, kk, h->id_base, thr, qn2,
                                0.0, 0.0, 0.0, 0, (float*)out_dist + (long long)qi * k, out_idx + (long long)qi * k,
-                               status + qi);
+                               status + qi, nullptr);
         }
         h->stats.scan_launches++;
     }

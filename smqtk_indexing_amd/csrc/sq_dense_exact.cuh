@@ -189,6 +189,203 @@ static __global__ __launch_bounds__(256) void dense_exact_cos_kernel(const float
     }
 }
 
+// Two lanes per row (lane c of the pair owns numpy's accumulators 4c..4c+3):
+// 16-byte row loads, 16-byte LDS query reads, halves the serial chain of the
+// one-lane form and doubles the rows in flight.  Both lanes return the sum.
+struct SqLeafPair {
+    const float* x;  // 16-byte aligned row
+    const float* q;  // LDS copy of the query (16-byte aligned)
+    int c;           // 0 / 1: which half of the eight accumulators
+    __device__ __forceinline__ float term(int i) const {
+        const float t = __fsub_rn(x[i], q[i]);
+        return __fmul_rn(t, t);
+    }
+    __device__ __forceinline__ float leaf(int off, int n) const {
+        if (n < 8) {
+            float r = 0.f;
+            for (int i = 0; i < n; ++i) r = __fadd_rn(r, term(off + i));
+            return r;
+        }
+        float r[4];
+        {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off + 4 * c);
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(q + off + 4 * c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = __fsub_rn(xv[j], qv[j]);
+                r[j] = __fmul_rn(t, t);
+            }
+        }
+        const int nfull = n - (n % 8);
+#pragma unroll 4
+        for (int i = 8; i < nfull; i += 8) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off + i + 4 * c);
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(q + off + i + 4 * c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = __fsub_rn(xv[j], qv[j]);
+                r[j] = __fadd_rn(r[j], __fmul_rn(t, t));
+            }
+        }
+        const float part = __fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3]));
+        float res = __fadd_rn(part, __shfl_xor(part, 1));  // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+        for (int i = nfull; i < n; ++i) res = __fadd_rn(res, term(off + i));
+        return res;
+    }
+    __device__ float sum(int d) const {
+        if (d <= 128) return leaf(0, d);
+        int s_off[24], s_n[24], s_state[24];
+        float s_left[24];
+        int sp = 1;
+        s_off[0] = 0;
+        s_n[0] = d;
+        s_state[0] = 0;
+        float ret = 0.f;
+        while (sp > 0) {
+            const int top = sp - 1;
+            const int off = s_off[top], m = s_n[top];
+            if (m <= 128) {
+                ret = leaf(off, m);
+                --sp;
+                continue;
+            }
+            int m2 = m / 2;
+            m2 -= m2 % 8;
+            if (s_state[top] == 0) {
+                s_state[top] = 1;
+                s_off[sp] = off;
+                s_n[sp] = m2;
+                s_state[sp] = 0;
+                ++sp;
+            } else if (s_state[top] == 1) {
+                s_left[top] = ret;
+                s_state[top] = 2;
+                s_off[sp] = off + m2;
+                s_n[sp] = m - m2;
+                s_state[sp] = 0;
+                ++sp;
+            } else {
+                ret = __fadd_rn(s_left[top], ret);
+                --sp;
+            }
+        }
+        return ret;
+    }
+};
+
+// Per block (= `waves_per_block` survivor segments of ONE scan workgroup, hence one
+// 32-query tile): (1) count the survivors per query in LDS and stage the tile's 32
+// query vectors in LDS, (2) reserve a range in every touched query's key list with
+// ONE global atomic per (block, query), (3) exact distance per survivor (L2: two
+// lanes per row; cosine: one lane per row), key stored at its reserved slot.
+// Dynamic LDS: 32 * (ldq + 4) floats.
+template <class K, bool COSINE>
+__device__ __forceinline__ void rerank_block(const float* __restrict__ db, long long ld, int d,
+                                             const float* __restrict__ q_al, int ldq, int nq,
+                                             const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt,
+                                             u32 wave_cap, long long n_waves, int waves_per_block,
+                                             K* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
+                                             u32* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) float s_qrows[];
+    __shared__ u32 s_hist[32], s_base[32], s_fill[32], s_qt;
+    const int ldl = ldq + 4;  // LDS row stride: +16 bytes so that different query rows hit different banks
+    const long long w0 = (long long)blockIdx.x * waves_per_block;
+    if (threadIdx.x < 32) {
+        s_hist[threadIdx.x] = 0;
+        s_fill[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) s_qt = 0xffffffffu;
+    __syncthreads();
+    for (int wi = 0; wi < waves_per_block; ++wi) {
+        const long long w = w0 + wi;
+        if (w >= n_waves) break;
+        u32 c = wave_cnt[w];
+        if (c > wave_cap) {
+            if (threadIdx.x == 0) atomicOr(overflow, 1u);
+            c = wave_cap;
+        }
+        for (u32 e = threadIdx.x; e < c; e += blockDim.x) {
+            const u32 qy = wave_out[w * wave_cap + e].y;
+            atomicAdd(&s_hist[qy & 31u], 1u);
+            s_qt = qy >> 5;
+        }
+    }
+    __syncthreads();
+    const u32 qt = s_qt;
+    if (qt == 0xffffffffu) return;
+    if (threadIdx.x < 32) {
+        const u32 hcount = s_hist[threadIdx.x];
+        s_base[threadIdx.x] = hcount ? atomicAdd(&cnt[qt * 32 + threadIdx.x], hcount) : 0u;
+    }
+    for (int i = threadIdx.x; i < 32 * ldq; i += blockDim.x) {
+        const int r = i / ldq, cc = i - r * ldq;
+        const long long qg = (long long)qt * 32 + r;
+        s_qrows[r * ldl + cc] = qg < nq ? q_al[qg * ldq + cc] : 0.f;
+    }
+    __syncthreads();
+    constexpr int LPR = COSINE ? 1 : 2;  // lanes per row
+    const int sub = threadIdx.x % LPR;
+    for (int wi = 0; wi < waves_per_block; ++wi) {
+        const long long w = w0 + wi;
+        if (w >= n_waves) break;
+        u32 c = wave_cnt[w];
+        c = c > wave_cap ? wave_cap : c;
+        const u32 c_round = (c + 63u) & ~63u;  // keep lane pairs converged for the shuffle
+        for (u32 e = threadIdx.x / LPR; e < c_round; e += blockDim.x / LPR) {
+            const bool live = e < c;
+            const uint2 ent = wave_out[w * wave_cap + (live ? e : 0u)];
+            const u32 ql = ent.y & 31u;
+            if constexpr (COSINE) {
+                if (live) {
+                    const double dist = cosine_row_f64(db + (long long)ent.x * ld, s_qrows + ql * ldl, d);
+                    const u32 pos = s_base[ql] + atomicAdd(&s_fill[ql], 1u);
+                    if (pos < cap) keys[(long long)ent.y * cap + pos] = K128{ordered_f64(dist), (u64)ent.x};
+                }
+            } else {
+                const SqLeafPair pr{db + (long long)ent.x * ld, s_qrows + ql * ldl, sub};
+                const float dist = sqrt_rn_f32(pr.sum(d));
+                if (live && sub == 0) {
+                    const u32 pos = s_base[ql] + atomicAdd(&s_fill[ql], 1u);
+                    if (pos < cap) keys[(long long)ent.y * cap + pos] = ((u64)ordered_f32(dist) << 32) | (u64)ent.x;
+                }
+            }
+        }
+    }
+}
+
+// Survivors of the scan arrive as per-wave segments of (row, query) pairs
+// (dense_scan_kernel writes them with plain stores); the returning atomics on
+// the per-query counters live here, outside the streaming kernel.  A wave that
+// overflowed its segment raises `overflow` (every query of the call then takes
+// the exact path; only degenerate thresholds get there).
+// q_al: queries copied to [nq][ldq] floats, ldq % 4 == 0, 16-byte aligned.
+static __global__ __launch_bounds__(256) void dense_rerank_l2_kernel(
+    const float* __restrict__ db, long long ld, int d, const float* __restrict__ q_al, int ldq,
+    const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt, u32 wave_cap, long long n_waves,
+    int waves_per_block, int nq, u64* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
+    u32* __restrict__ overflow) {
+    rerank_block<u64, false>(db, ld, d, q_al, ldq, nq, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block, keys,
+                             cnt, cap, overflow);
+}
+
+static __global__ __launch_bounds__(256) void dense_rerank_cos_kernel(
+    const float* __restrict__ db, long long ld, int d, const float* __restrict__ q_al, int ldq,
+    const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt, u32 wave_cap, long long n_waves,
+    int waves_per_block, int nq, K128* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
+    u32* __restrict__ overflow) {
+    rerank_block<K128, true>(db, ld, d, q_al, ldq, nq, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block, keys,
+                             cnt, cap, overflow);
+}
+
+// Copy queries into the aligned, padded layout the lane-per-row kernels read.
+static __global__ void dense_align_queries_kernel(const float* __restrict__ q, int nq, int d, int ldq,
+                                                  float* __restrict__ q_al) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nq * ldq) return;
+    const int r = (int)(i / ldq), c = (int)(i - (long long)r * ldq);
+    q_al[i] = c < d ? q[(long long)r * d + c] : 0.f;
+}
+
 // Plain distance vectors for sq_dense_distances (one query, n gathered rows),
 // in the rows' own dtype like metrics.euclidean_distance (float32 in -> float32
 // out, float64 in -> float64 out); cosine is always float64 (scipy cdist).
@@ -282,7 +479,7 @@ static __global__ void dense_finalize_l2_kernel(const u64* __restrict__ sorted, 
                                          int kk, long long id_base, const float* __restrict__ thr,
                                          const double* __restrict__ qn2, double xn2_max, double eps_a, double eps_b,
                                          int certify, float* __restrict__ out_dist, long long* __restrict__ out_idx,
-                                         u32* __restrict__ status) {
+                                         u32* __restrict__ status, const u32* __restrict__ overflow) {
     const int q = blockIdx.x;
     for (int j = threadIdx.x; j < k; j += blockDim.x) {
         const u64 key = sorted[(long long)q * k + j];
@@ -294,7 +491,7 @@ static __global__ void dense_finalize_l2_kernel(const u64* __restrict__ sorted, 
         u32 st = 0;
         if (certify) {
             const u32 c = cnt[q];
-            if (c > cap) st |= 1u;
+            if (c > cap || (overflow && *overflow)) st |= 1u;
             if (c < (u32)kk) st |= 4u;
             if (st == 0) {
                 const u64 key = sorted[(long long)q * k + (kk - 1)];
@@ -313,7 +510,8 @@ static __global__ void dense_finalize_l2_kernel(const u64* __restrict__ sorted, 
 static __global__ void dense_finalize_cos_kernel(const K128* __restrict__ sorted, const u32* __restrict__ cnt, u32 cap,
                                           int k, int kk, long long id_base, const float* __restrict__ thr,
                                           double eps, int certify, double* __restrict__ out_dist,
-                                          long long* __restrict__ out_idx, u32* __restrict__ status) {
+                                          long long* __restrict__ out_idx, u32* __restrict__ status,
+                                          const u32* __restrict__ overflow) {
     const int q = blockIdx.x;
     for (int j = threadIdx.x; j < k; j += blockDim.x) {
         const K128 key = sorted[(long long)q * k + j];
@@ -325,7 +523,7 @@ static __global__ void dense_finalize_cos_kernel(const K128* __restrict__ sorted
         u32 st = 0;
         if (certify) {
             const u32 c = cnt[q];
-            if (c > cap) st |= 1u;
+            if (c > cap || (overflow && *overflow)) st |= 1u;
             if (c < (u32)kk) st |= 4u;
             if (st == 0) {
                 const double dk = unordered_f64(sorted[(long long)q * k + (kk - 1)].hi);

@@ -33,7 +33,6 @@ static constexpr int TILE_ROWS = 32;                   // rows per MFMA tile
 static constexpr int UNIT_BYTES = TILE_ROWS * KT * 4;  // 8 KiB: 32 rows x 256 bytes
 static constexpr int NORM_BYTES = 256;                 // per ring slot: |x|^2 of the tile's 32 rows (64 lanes x 4 B)
 static constexpr int SLOT_BYTES = UNIT_BYTES + NORM_BYTES;
-static constexpr int EBUF_BYTES = 8192;                // emission buffers of a workgroup: (row, query) pairs
 static constexpr int MAX_DPAD = 512;
 
 // --------------------------------------------------------------- bf16 split
@@ -156,9 +155,9 @@ struct DenseScanArgs {
     long long n_tiles;      // ceil(n / 32)
     const uint4* qs;        // [nqt*32][d_pad/4] prepared queries
     const float* thr;       // [nqt*32] score thresholds (EMIT)
-    u32* cand;              // [nqt*32][cap] candidate row ids
-    u32* cnt;               // [nqt*32]
-    u32 cap;
+    uint2* wave_out;        // [waves of the launch][wave_cap] survivors (row, query), one segment per wave
+    u32* wave_cnt;          // [waves of the launch] survivors each wave found (may exceed wave_cap: overflow)
+    u32 wave_cap;
     float* sample_out;      // [nqt*32][ns] (SAMPLE)
     long long ns;
     long long tile_step;    // SAMPLE: every tile_step-th tile; EMIT: 1
@@ -235,20 +234,19 @@ template <int WAVES, int NSTAGE, int KU, bool SAMPLE>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(DenseScanArgs a) {
     constexpr bool QREG = KU <= 2;  // query fragments live in registers for d_pad <= 128
     constexpr int DPAD = KU * KT;
-    constexpr int EBUF_ENTRIES = EBUF_BYTES / 8 / WAVES;
-    constexpr int EBUF_FLUSH = EBUF_ENTRIES / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // LDS map: [query tile (only when re-read per unit)][rings][emission buffers][emission counters].
+    // LDS map: [query tile (only when re-read per unit)][rings][per-wave survivor counters].
     // With QREG the query tile is staged through the not yet used ring area.
     constexpr u32 q_bytes = QREG ? 0u : (u32)TILE_ROWS * DPAD * 4;
     const u32 lds_base = (u32)(uintptr_t)smem;  // low 32 bits of a flat LDS address = LDS offset
     const u32 ring_base = lds_base + q_bytes + (u32)wave * (NSTAGE * SLOT_BYTES);
     unsigned char* ring_ptr = smem + q_bytes + wave * (NSTAGE * SLOT_BYTES);
     unsigned char* etop = smem + q_bytes + WAVES * NSTAGE * SLOT_BYTES;
-    uint2* ebuf = reinterpret_cast<uint2*>(etop) + wave * EBUF_ENTRIES;
-    lds_u32* ecnt_ptr = (lds_u32*)(etop + EBUF_BYTES + wave * 16);
+    lds_u32* ecnt_ptr = (lds_u32*)(etop + wave * 16);
+    const long long wave_id = (long long)blockIdx.x * WAVES + wave;  // unique per wave of the launch
+    uint2* wout = a.wave_out + wave_id * a.wave_cap;
     const bool add_norm = a.norms != nullptr;
 
     // block -> (row block, query tile); blocks that share an XCD (same id mod 8)
@@ -292,6 +290,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     // Force hipcc's wait for this load HERE.  Left to its first use inside the
     // loop the compiler emits s_waitcnt vmcnt(0) there (it cannot see the asm
     // LDS-DMAs), draining the whole ring once per tile.
+    if (a.debug & 4) thr_l = -__builtin_inff();  // ablation: nothing is emitted
     asm volatile("" : "+v"(thr_l));
 
     // B fragments of k-step s: chunk 4s+2h (hi) and 4s+2h+1 (lo) of the lane's query row
@@ -314,19 +313,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         voff[j] = (u32)(r * (DPAD * 4) + (((lane & 15) ^ (r & 15)) * 16));
     }
     const u32 voff_norm = (u32)((lane & 31) * 4);
-
-    auto emit_global = [&](u32 row, u32 q) {
-        u32 pos = atomicAdd(&a.cnt[q], 1u);
-        if (pos < a.cap) a.cand[(long long)q * a.cap + pos] = row;
-    };
-    auto flush = [&](u32 c) {
-        const u32 n = c < (u32)EBUF_ENTRIES ? c : (u32)EBUF_ENTRIES;
-        for (u32 e = lane; e < n; e += 64) {
-            uint2 ent = ebuf[e];
-            emit_global(ent.x, ent.y);
-        }
-        if (lane == 0) *ecnt_ptr = 0u;
-    };
 
     // issue cursor: unit u of this wave = (tile gw + (u / KU) * nwaves, k-unit u % KU), slot u % NSTAGE
     long long iss_sel = gw;
@@ -445,21 +431,30 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
             for (int i = 1; i < 16; ++i) m = fminf(m, acc[i]);
             if (__any(m <= thr_l)) {
                 if (m <= thr_l) {
+                    // branch-free survivor mask of this lane's 16 rows, one LDS atomic for all of them
+                    u32 mask = 0;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (acc[i] <= thr_l && row < a.n) {
-                            const u32 pos = __hip_atomic_fetch_add(ecnt_ptr, 1u, __ATOMIC_RELAXED,
-                                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (pos < (u32)EBUF_ENTRIES)
-                                ebuf[pos] = make_uint2((u32)row, (u32)qglob);
-                            else
-                                emit_global((u32)row, (u32)qglob);  // buffer full (degenerate thresholds only)
+                    for (int i = 0; i < 16; ++i) mask |= (acc[i] <= thr_l ? 1u : 0u) << i;
+                    if (row0 + TILE_ROWS > a.n) {  // the last, partial tile: drop padding rows
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (row0 + (i & 3) + 8 * (i >> 2) + 4 * h >= a.n) mask &= ~(1u << i);
+                    }
+                    if (a.debug & 16) mask = 0;  // ablation: survivors found but not recorded
+                    if (mask) {
+                        // survivors go to this wave's own segment with plain stores: nothing in the
+                        // streaming loop waits on a returning global atomic (that drained the DMA ring)
+                        u32 pos = __hip_atomic_fetch_add(ecnt_ptr, (u32)__popc(mask), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                        while (mask) {
+                            const int i = __ffs((int)mask) - 1;
+                            mask &= mask - 1;
+                            const u32 row = (u32)(row0 + (i & 3) + 8 * (i >> 2) + 4 * h);
+                            if (pos < a.wave_cap) wout[pos] = make_uint2(row, (u32)qglob);
+                            ++pos;
                         }
                     }
                 }
-                const u32 c = __builtin_amdgcn_readfirstlane(*ecnt_ptr);
-                if (c >= (u32)EBUF_FLUSH) flush(c);
             }
         } else {
             // the minimum score of this lane's 16 rows: the score of one actual row, hence a valid
@@ -475,7 +470,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     }
     if constexpr (!SAMPLE) {
         const u32 c = __builtin_amdgcn_readfirstlane(*ecnt_ptr);
-        if (c > 0) flush(c);
+        if (lane == 0) a.wave_cnt[wave_id] = c;
     }
 }
 

@@ -26,12 +26,9 @@ def main():
         for kk in opts: _lib.set_option(kk, 0)
         return float(np.median(ms[1:])), float(np.median(tot[1:])), s["fallback_queries"]
     rows = []
-    for nq in (1, 32):
-        for name, opts in [("default", {}), ("w4s4", {"dense_waves": 4}), ("w4s3", {"dense_waves": 4, "dense_stages": 3}),
-                           ("w4s2", {"dense_waves": 4, "dense_stages": 2}),
-                           ("w8 dma_only", {"dense_debug": 1}), ("w8 mfma_only", {"dense_debug": 2}),
-                           ("w4 dma_only", {"dense_waves": 4, "dense_debug": 1}),
-                           ("w4 mfma_only", {"dense_waves": 4, "dense_debug": 2})]:
+    for nq in (32,):
+        for name, opts in [("default", {}), ("no_emit", {"dense_debug": 4}), ("no_flush", {"dense_debug": 8}),
+                           ("no_record", {"dense_debug": 16}), ("w4", {"dense_waves": 4})]:
             sm, tm, fb = run(nq, **opts)
             rows.append((nq, name, sm, tm, n * d * 4 / sm / 1e6 if sm else 0))
             print(f"nq={nq:5d} {name:12s} scan_ms={sm:8.4f} total_ms={tm:8.4f} scan_GBps={rows[-1][4]:9.1f} fb={fb}", flush=True)
