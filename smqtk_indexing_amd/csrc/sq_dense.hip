@@ -159,19 +159,19 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         SQ_HIP(hipEventRecord(h->ev[1], st));
         SQ_HIP(hipEventRecord(h->ev[2], st));
     }
-    SQ_TRY(h->cnt.reserve((size_t)nq_pad * 4));
+    SQ_TRY(h->cnt.reserve((size_t)(nq_pad + nq) * 4));
     SQ_TRY(h->thr.reserve((size_t)nq_pad * 4));
     SQ_TRY(h->qn2.reserve((size_t)nq_pad * 8));
     SQ_TRY(h->q_scaled.reserve((size_t)nq_pad * d_pad * 4));
     SQ_TRY(h->out_keys.reserve((size_t)nq * k * key_bytes));
-    SQ_TRY(h->status.reserve((size_t)nq * 4));
-    SQ_TRY(h->status_host.reserve((size_t)nq * 8));
+    SQ_TRY(h->status_host.reserve((size_t)(nq_pad + nq) * 4));
     u32* cnt = h->cnt.as<u32>();
     float* thr = h->thr.as<float>();
     double* qn2 = h->qn2.as<double>();
     uint4* qs = h->q_scaled.as<uint4>();
-    u32* status = h->status.as<u32>();
-    u32* hs = reinterpret_cast<u32*>(h->status_host.p);
+    u32* status = cnt + nq_pad;
+    u32* hs_raw = reinterpret_cast<u32*>(h->status_host.p);  // [cnt (nq_pad) | status (nq)]
+    u32* hs = hs_raw + nq_pad;                               // status words
     // error bound of the bf16x3 filter score (sq_dense_exact.cuh filter_eps):
     //   products: |x q' - (xh qh + xh ql + xl qh)| <= 2^-14 |x||q'|, q' = -2q   ->  eps_a = 2^-13 (times X|q|)
     //   float32 accumulation of 3d+1 terms and the float32 norm                ->  eps_b = (3d+8) 2^-23
@@ -206,10 +206,11 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
                                k, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 0, (float*)out_dist, out_idx, status, nullptr);
         }
     } else if (scan_ok) {
-        hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, q, nq, d, d_pad, h->metric, qs,
-                           qn2);
         const long long n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+        // Sample every stride-th tile: the sample pass costs 1/stride of a pass, the re-rank + select work
+        // falls with the candidates (~stride*k per query); 16 balances them at k = 100.
         long long stride = g_opt.sample_stride > 0 ? g_opt.sample_stride : (long long)cap / (8ll * kk);
+        if (stride > 16 && g_opt.sample_stride <= 0) stride = 16;
         if (stride > 64) stride = 64;
         if (stride < 1) stride = 1;
         while (stride > 1 && (n_tiles / stride) * 2 < 8ll * kk) stride >>= 1;
@@ -229,8 +230,8 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         SQ_TRY(h->wave_cnt.reserve((size_t)n_waves * 4));
         SQ_TRY(h->q_al.reserve((size_t)nq * ldq * 4));
         u32* oflag = h->scratch.as<u32>() + 16;
-        hipLaunchKernelGGL(dense_align_queries_kernel, dim3((unsigned)(((long long)nq * ldq + 255) / 256)), dim3(256), 0,
-                           st, q, nq, d, ldq, h->q_al.as<float>());
+        hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, q, nq, d, d_pad, h->metric, qs,
+                           qn2, thr, cnt, oflag, h->q_al.as<float>(), ldq);
         DenseScanArgs a{};
         a.scan = h->scan.as<uint4>();
         a.norms = cosine ? nullptr : h->norms.as<float>();
@@ -251,13 +252,9 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         a.nrb = nrb;
         if (ns_tiles < (long long)nrb * wv) a.nrb = (int)(((ns_tiles + wv - 1) / wv + 7) / 8 * 8);
         SQ_TRY(scan_launch<true>(a, d_pad, st));
-        hipLaunchKernelGGL(fill_f32_kernel, dim3((nq_pad + 255) / 256), dim3(256), 0, st, thr, (long long)nq_pad,
-                           -__builtin_inff());
         hipLaunchKernelGGL(kth_threshold_f32_kernel, dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr);
         hipLaunchKernelGGL(dense_inflate_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, thr, qn2, nq, cosine ? 1 : 0,
                            h->xn2_max, eps_a, eps_b);
-        SQ_HIP(hipMemsetAsync(cnt, 0, (size_t)nq_pad * 4, st));
-        SQ_HIP(hipMemsetAsync(oflag, 0, 4, st));
         // full pass
         a.tile_step = 1;
         a.n_sel = n_tiles;
@@ -292,8 +289,8 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     }
     if (prof) SQ_HIP(hipEventRecord(h->ev[3], st));
     if (!all_fallback) {
-        SQ_HIP(hipMemcpyAsync(hs, status, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-        SQ_HIP(hipMemcpyAsync(hs + nq, cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        // status[nq] sits right behind cnt[nq_pad] in one buffer: one small D2H copy
+        SQ_HIP(hipMemcpyAsync(hs_raw, cnt, (size_t)(nq_pad + nq) * 4, hipMemcpyDeviceToHost, st));
         SQ_HIP(hipStreamSynchronize(st));
         SQ_HIP(hipGetLastError());
         if (prof) {
@@ -303,7 +300,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
             h->stats.scan_ms = t1;
             h->stats.total_ms = t2;
         }
-        for (int qi = 0; qi < nq; ++qi) h->stats.candidates += hs[nq + qi];
+        for (int qi = 0; qi < nq; ++qi) h->stats.candidates += hs_raw[qi];
     }
     // exact full-keys path, one query at a time: keys for all n rows -> radix select
     for (int qi = 0; qi < nq; ++qi) {

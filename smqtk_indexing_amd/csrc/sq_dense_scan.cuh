@@ -108,12 +108,25 @@ static __global__ __launch_bounds__(256) void dense_rowstats_kernel(const float*
 
 // Query prep: |q|^2 (f64) and the scaled query (L2: -2q, cosine: -q/|q|) split
 // and stored in the scan-copy chunk layout, [nq_pad][d_pad/4] chunks.
+// Also resets the per-call state of query qi (threshold = -inf, candidate count 0,
+// overflow flag) and writes the aligned float32 copy q_al[nq][ldq] the re-rank reads.
 static __global__ __launch_bounds__(256) void dense_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
                                                                          int d_pad, int metric,
                                                                          uint4* __restrict__ qs,
-                                                                         double* __restrict__ qn2) {
+                                                                         double* __restrict__ qn2,
+                                                                         float* __restrict__ thr,
+                                                                         u32* __restrict__ cnt,
+                                                                         u32* __restrict__ oflag,
+                                                                         float* __restrict__ q_al, int ldq) {
     const int qi = blockIdx.x;
     __shared__ double red[4];
+    if (threadIdx.x == 0) {
+        thr[qi] = -__builtin_inff();
+        cnt[qi] = 0u;
+        if (qi == 0) *oflag = 0u;
+    }
+    if (qi < nq)
+        for (int i = threadIdx.x; i < ldq; i += 256) q_al[(long long)qi * ldq + i] = i < d ? q[(long long)qi * d + i] : 0.f;
     double acc = 0.0;
     if (qi < nq)
         for (int i = threadIdx.x; i < d; i += 256) acc += (double)q[(long long)qi * d + i] * (double)q[(long long)qi * d + i];
