@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "sq_common.hpp"
@@ -94,30 +95,71 @@ extern "C" int sq_get_stats(sq_handle_t hid, sq_stats_t* out) {
 // Host-side k-way merge of per-shard sorted lists: concatenate the shard rows
 // of a query, order by (distance, id), keep k_out.  Shard lists are short
 // (k_in <= 16384) so a partial sort per query is ample.
+// Each shard list is already sorted by (distance, id) with its padding (id -1) at
+// the end, so a query's result is a k-way merge: k_out steps, each picking the
+// smallest head among the shards (nshards <= 8 on one node: a linear scan).
 template <class D>
-static void merge_impl(const D* dist, const int64_t* idx, int nshards, int nq, int k_in, int k_out, D* out_dist,
-                       int64_t* out_idx, D pad_value) {
-    std::vector<std::pair<D, int64_t>> buf;
-    buf.reserve((size_t)nshards * k_in);
-    for (int q = 0; q < nq; ++q) {
-        buf.clear();
-        for (int s = 0; s < nshards; ++s) {
-            const size_t base = ((size_t)s * nq + q) * k_in;
-            for (int j = 0; j < k_in; ++j)
-                if (idx[base + j] >= 0) buf.emplace_back(dist[base + j], idx[base + j]);
+static void merge_range(const D* dist, const int64_t* idx, int nshards, int nq, int k_in, int k_out, D* out_dist,
+                        int64_t* out_idx, D pad_value, int q0, int q1) {
+    constexpr int64_t kDone = std::numeric_limits<int64_t>::max();  // id of an exhausted list (sorts last)
+    std::vector<int> head((size_t)nshards);
+    std::vector<D> hd((size_t)nshards);
+    std::vector<int64_t> hi((size_t)nshards);
+    auto load = [&](int s, int q) {  // cache the head of shard s
+        const int hpos = head[(size_t)s];
+        if (hpos < k_in) {
+            const size_t at = ((size_t)s * nq + q) * k_in + hpos;
+            if (idx[at] >= 0) {
+                hd[(size_t)s] = dist[at];
+                hi[(size_t)s] = idx[at];
+                return;
+            }
         }
-        const size_t take = std::min<size_t>(buf.size(), (size_t)k_out);
-        std::partial_sort(buf.begin(), buf.begin() + take, buf.end());
+        hd[(size_t)s] = pad_value;  // exhausted, or the rest of the list is padding
+        hi[(size_t)s] = kDone;
+    };
+    for (int q = q0; q < q1; ++q) {
+        for (int s = 0; s < nshards; ++s) {
+            head[(size_t)s] = 0;
+            load(s, q);
+        }
         for (int j = 0; j < k_out; ++j) {
-            if ((size_t)j < take) {
-                out_dist[(size_t)q * k_out + j] = buf[j].first;
-                out_idx[(size_t)q * k_out + j] = buf[j].second;
+            int best = 0;
+            for (int s = 1; s < nshards; ++s)
+                if (hd[(size_t)s] < hd[(size_t)best] || (hd[(size_t)s] == hd[(size_t)best] && hi[(size_t)s] < hi[(size_t)best]))
+                    best = s;
+            if (hi[(size_t)best] != kDone) {
+                out_dist[(size_t)q * k_out + j] = hd[(size_t)best];
+                out_idx[(size_t)q * k_out + j] = hi[(size_t)best];
+                ++head[(size_t)best];
+                load(best, q);
             } else {
                 out_dist[(size_t)q * k_out + j] = pad_value;
                 out_idx[(size_t)q * k_out + j] = -1;
             }
         }
     }
+}
+
+template <class D>
+static void merge_impl(const D* dist, const int64_t* idx, int nshards, int nq, int k_in, int k_out, D* out_dist,
+                       int64_t* out_idx, D pad_value) {
+    // a few host threads when the batch is large (the merge is on the timed path of a multi-GPU step)
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+    if ((long long)nq * k_out * nshards < 200000) nt = 1;
+    nt = std::min(nt, nq);
+    if (nt <= 1) {
+        merge_range<D>(dist, idx, nshards, nq, k_in, k_out, out_dist, out_idx, pad_value, 0, nq);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)nt);
+    for (int t = 0; t < nt; ++t) {
+        const int q0 = (int)((long long)nq * t / nt), q1 = (int)((long long)nq * (t + 1) / nt);
+        pool.emplace_back(merge_range<D>, dist, idx, nshards, nq, k_in, k_out, out_dist, out_idx, pad_value, q0, q1);
+    }
+    for (auto& th : pool) th.join();
 }
 
 extern "C" int sq_merge_topk(const void* dist, const int64_t* idx, int dist_dtype, int nshards, int nq, int k_in,

