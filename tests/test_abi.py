@@ -43,7 +43,7 @@ def test_host_merge_orders_by_distance_then_id():
     np.testing.assert_array_equal(od[0], [1., 1., 2., 2., 3.])
     od, oi = _lib.merge_topk(d.astype(np.float64), i, 6)
     assert oi[0, 5] == -1 and np.isinf(od[0, 5])
-    od, oi = _lib.merge_topk(np.array([[[4, 1]], [[1, 9]]], dtype=np.int32), np.array([[[8, 2]], [[1, 0]]]), 3)
+    od, oi = _lib.merge_topk(np.array([[[1, 4]], [[1, 9]]], dtype=np.int32), np.array([[[2, 8]], [[1, 0]]]), 3)
     np.testing.assert_array_equal(oi[0], [1, 2, 8])
 
 
