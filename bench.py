@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--queries-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="testing: run the all-gather + merge path even with one rank (launch under torch.distributed.run)")
     ap.add_argument("--extra-batches", type=str, default="1,1024",
                     help="other batch sizes measured after the timed region (N=1 only); '' to skip")
     return ap.parse_args()
@@ -76,8 +78,12 @@ def main() -> None:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     n_total, d, k = args.rows, args.dim, args.k
@@ -106,7 +112,7 @@ def main() -> None:
                             id_base=r0, keepalive=db)
     out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    if world > 1:
+    if use_dist:
         all_d = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
         all_i = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -119,7 +125,7 @@ def main() -> None:
         scan_ms.append(st["scan_ms"])
         cands.append(st["candidates"])
         fallbacks.append(st["fallback_queries"])
-        if world > 1:
+        if use_dist:
             # per-shard top-k candidates over xGMI, then the host-side merge (north_star)
             dist.all_gather_into_tensor(all_d, out_d)
             dist.all_gather_into_tensor(all_i, out_i)
@@ -130,7 +136,7 @@ def main() -> None:
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -143,7 +149,7 @@ def main() -> None:
         result = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -218,7 +224,7 @@ def main() -> None:
                 "db_rows_total": n_total, "db_rows_per_gpu": n_local, "dim": d, "k": k,
                 "queries_per_step": nq, "queries_per_step_per_gpu": args.queries_per_gpu,
                 "sharding": "rows" if world > 1 else "none",
-                "collective": "all_gather(top-k dist,idx) + host merge" if world > 1 else "none",
+                "collective": "all_gather(top-k dist,idx) + host merge" if use_dist else "none",
                 "mean_candidates_per_query": float(np.mean(cands)) / nq if cands else None,
                 "fallback_queries": int(np.sum(fallbacks)) if fallbacks else 0,
             },
@@ -243,7 +249,7 @@ def main() -> None:
                           f"(host has {len(os.sched_getaffinity(0))} cores); scaled linearly in rows to {n_total}",
             }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     index.close()

@@ -237,3 +237,38 @@ def test_lsh_config_roundtrip_on_gpu():
     idx = _lsh(4, "euclidean")
     j = HipLSHNearestNeighborIndex.from_config(idx.get_config())
     assert isinstance(j.hash_index, HipLinearHashIndex) and j.lsh_functor.bit_length == 4
+
+
+def test_sharded_index_rccl_world1():
+    """The collective path on the real backend (RCCL) with one rank: shard with an
+    id offset, all-gather of the per-shard top-k, host merge."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from smqtk_indexing_amd.distributed import dense_shard, hamming_shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29517"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(21)
+        db = rng.standard_normal((90_000, 128)).astype(np.float32)
+        qs = rng.standard_normal((5, 128)).astype(np.float32)
+        shard = dense_shard(torch.from_numpy(db).to(dev), row0=1000)
+        d, i = shard.search(torch.from_numpy(qs).to(dev), 20)
+        for j in range(5):
+            rd, ri = O.dense_topk(db, qs[j], 20)
+            np.testing.assert_array_equal(i[j], ri + 1000)
+            np.testing.assert_array_equal(d[j].view(np.uint32), rd.view(np.uint32))
+        codes = np.unique(rng.integers(0, 2 ** 63, size=(80_000, 1), dtype=np.int64).astype(np.uint64), axis=0)
+        hs = hamming_shard(torch.from_numpy(codes.view(np.int64)).to(dev), row0=7)
+        qc = codes[:3]
+        d, i = hs.search(torch.from_numpy(qc.view(np.int64)).to(dev), 10)
+        for j in range(3):
+            rd, ri = O.hamming_topk(codes, qc[j], 10)
+            np.testing.assert_array_equal(i[j], ri + 7)
+            np.testing.assert_array_equal(d[j], rd)
+    finally:
+        dist.destroy_process_group()
