@@ -66,6 +66,11 @@ def cpu_baseline(dim: int, k: int, seed: int):
 
 def main() -> None:
     args = parse_args()
+    # Only the one JSON line may reach stdout: libraries (RCCL prints a version banner) write to
+    # fd 1 too, so fd 1 is pointed at stderr for the run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from smqtk_indexing_amd import _lib
@@ -113,8 +118,10 @@ def main() -> None:
     out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
     if use_dist:
-        all_d = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
-        all_i = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
+        # one collective per step: ids and the float32 distance bits travel in one int64 tensor
+        packed = torch.empty((nq, 2 * k), dtype=torch.int64, device=dev)
+        all_packed = torch.empty((world, nq, 2 * k), dtype=torch.int64, device=dev)
+        host_packed = torch.empty((world, nq, 2 * k), dtype=torch.int64, pin_memory=True)
     stream = torch.cuda.current_stream().cuda_stream
 
     scan_ms, cands, fallbacks = [], [], []
@@ -127,10 +134,16 @@ def main() -> None:
         fallbacks.append(st["fallback_queries"])
         if use_dist:
             # per-shard top-k candidates over xGMI, then the host-side merge (north_star)
-            dist.all_gather_into_tensor(all_d, out_d)
-            dist.all_gather_into_tensor(all_i, out_i)
+            packed[:, :k] = out_i
+            packed[:, k:] = out_d.view(torch.int32)
+            dist.all_gather_into_tensor(all_packed, packed)
             if rank == 0:
-                return _lib.merge_topk(all_d.cpu().numpy(), all_i.cpu().numpy(), k)
+                host_packed.copy_(all_packed, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                hp = host_packed.numpy()
+                gi = np.ascontiguousarray(hp[:, :, :k])
+                gd = np.ascontiguousarray(hp[:, :, k:].astype(np.int32)).view(np.float32)
+                return _lib.merge_topk(gd, gi, k)
             return None
         return out_d, out_i
 
@@ -248,7 +261,8 @@ def main() -> None:
                 "sample": f"oracle/cpu_ref.dense_topk: {cq} queries x {rows} rows x {d} f32 in {dt:.2f} s on 1 thread "
                           f"(host has {len(os.sched_getaffinity(0))} cores); scaled linearly in rows to {n_total}",
             }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
