@@ -84,11 +84,34 @@ def _declare(lib: ctypes.CDLL) -> None:
             getattr(lib, name).restype = c_int
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own
+    ``libamdhip64.so`` (SONAME ``libamdhip64.so.7``, the same as ROCm's).  If
+    this library pulls in ``/opt/rocm/lib/libamdhip64.so.7`` first and torch is
+    imported later, the process ends up with two runtimes and the second one
+    to initialise finds no GPU.  Loading torch's copy first (without importing
+    torch) makes both bind to the same runtime in either import order.  Set
+    ``SMQTK_HIP_RUNTIME=system`` to skip this."""
+    if os.environ.get("SMQTK_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.isfile(path):
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load() -> ctypes.CDLL:
     """Load the shared library (once).  Raises HipError when it is missing."""
     global _lib
     with _lock:
         if _lib is None:
+            _share_torch_hip_runtime()
             if not os.path.isfile(LIB_PATH):
                 raise HipError(
                     f"{LIB_NAME} not found at {LIB_PATH}; build it with "

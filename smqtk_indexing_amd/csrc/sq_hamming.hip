@@ -20,7 +20,7 @@ struct HammingHandle : HandleBase {
     int words = 0;
     long long id_base = 0;
     // workspace
-    DevBuf q_dev, keys, cnt, hist, thr, out_keys, status, out_dist_dev, out_idx_dev, big_keys;
+    DevBuf q_dev, keys, cnt, hist, thr, out_keys, status, out_dist_dev, out_idx_dev, big_keys, seg, bcnt;
     HostPinned status_host;
     ~HammingHandle() override {
         owned.release();
@@ -34,6 +34,8 @@ struct HammingHandle : HandleBase {
         out_dist_dev.release();
         out_idx_dev.release();
         big_keys.release();
+        seg.release();
+        bcnt.release();
         status_host.release();
     }
 };
@@ -133,6 +135,128 @@ __global__ __launch_bounds__(256) void hamming_scan_kernel(const u64* __restrict
             }
         }
     }
+}
+
+// ---- the streaming scan of large code arrays --------------------------------
+// Persistent workgroups (a few per CU) walk the 256*C-code chunks of the array
+// round-robin.  Queries and thresholds sit in LDS and are taken QG at a time
+// into registers, so the inner loop is pure VALU (xor + v_bcnt + compare, ~5 ops
+// per (code word, query)); a lane whose distance is within the threshold takes a
+// slot in the block's own (block, query) mini-list with an LDS atomic and stores
+// the key there -- no global atomic anywhere in the stream (per-survivor
+// returning atomics on 32 hot counters cost 10x at 32 queries).  Mini-lists:
+// seg[(block*nq + q)*S + slot]; their fills go to bcnt[block*nq + q].
+template <int W, int C>
+__global__ __launch_bounds__(256) void hamming_stream_kernel(const u64* __restrict__ codes, long long n,
+                                                              const u64* __restrict__ qs, int nq,
+                                                              const int* __restrict__ thr, u64* __restrict__ seg,
+                                                              u32* __restrict__ bcnt, u32 S) {
+    constexpr int QG = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    u64* lq = reinterpret_cast<u64*>(hsm);                       // [nq][W]
+    int* lthr = reinterpret_cast<int*>(lq + (size_t)nq * W);     // [nq]
+    u32* lcnt = reinterpret_cast<u32*>(lthr + nq);               // [nq]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nq * W; i += 256) lq[i] = qs[i];
+    for (int i = tid; i < nq; i += 256) {
+        lthr[i] = thr[i];
+        lcnt[i] = 0u;
+    }
+    __syncthreads();
+    const long long per_chunk = 256ll * C;
+    const long long nchunks = (n + per_chunk - 1) / per_chunk;
+    u64* myseg = seg + (long long)blockIdx.x * nq * S;
+    u64 cn[C][W];
+    bool validn[C];
+    if ((long long)blockIdx.x < nchunks) load_codes<W, C>(codes, n, (long long)blockIdx.x * per_chunk, tid, cn, validn);
+    for (long long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const long long bb = chunk * per_chunk;
+        u64 c[C][W];
+        bool valid[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            valid[i] = validn[i];
+#pragma unroll
+            for (int w = 0; w < W; ++w) c[i][w] = cn[i][w];
+        }
+        // the next chunk's codes travel while this one is compared with every query
+        if (chunk + gridDim.x < nchunks) load_codes<W, C>(codes, n, (chunk + gridDim.x) * per_chunk, tid, cn, validn);
+        for (int q0 = 0; q0 < nq; q0 += QG) {
+            u64 qw[QG][W];
+            int tq[QG];
+#pragma unroll
+            for (int j = 0; j < QG; ++j) {
+                const int q = (q0 + j) < nq ? (q0 + j) : (nq - 1);
+#pragma unroll
+                for (int w = 0; w < W; ++w) qw[j][w] = lq[(size_t)q * W + w];
+                tq[j] = (q0 + j) < nq ? lthr[q] : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < QG; ++j) {
+                int dist[C];
+                int m = 0x7fffffff;
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    int dsum = 0;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) dsum += __popcll(c[i][w] ^ qw[j][w]);
+                    dist[i] = dsum;
+                    m = dsum < m ? dsum : m;
+                }
+                if (m <= tq[j]) {  // one branch per (query, C codes); padding codes are screened inside
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        if (valid[i] && dist[i] <= tq[j]) {
+                            const int q = q0 + j;
+                            const u32 pos = atomicAdd(&lcnt[q], 1u);
+                            if (pos < S)
+                                myseg[(long long)q * S + pos] =
+                                    ((u64)(u32)dist[i] << 32) | (u64)(u32)code_row<W, C>(bb, tid, i);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nq; i += 256) bcnt[(long long)blockIdx.x * nq + i] = lcnt[i];
+}
+
+// One workgroup per query: concatenate the G blocks' mini-lists into keys[q][..]
+// (prefix sum over the fills, no atomics) and publish the total in cnt[q]; a
+// mini-list that overflowed its S slots marks the query (cnt = cap + 1) so that
+// it is recomputed on the exact path.
+__global__ __launch_bounds__(256) void hamming_compact_kernel(const u64* __restrict__ seg,
+                                                               const u32* __restrict__ bcnt, int G, int nq, u32 S,
+                                                               u64* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
+                                                               long long key_stride) {
+    __shared__ u32 s_off[2049];
+    __shared__ u32 s_over;
+    const int q = blockIdx.x;
+    if (threadIdx.x == 0) s_over = 0u;
+    __syncthreads();
+    // G <= 2048: thread t owns blocks t, t+256, ...
+    for (int g = threadIdx.x; g < G; g += 256) {
+        u32 c = bcnt[(long long)g * nq + q];
+        if (c > S) {
+            s_over = 1u;
+            c = S;
+        }
+        s_off[g + 1] = c;
+    }
+    if (threadIdx.x == 0) s_off[0] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int g = 1; g <= G; ++g) s_off[g] += s_off[g - 1];  // G <= 2048 serial adds: a few us, off the scan's path
+    __syncthreads();
+    const u32 total = s_off[G];
+    for (int g = threadIdx.x >> 3; g < G; g += 32) {  // 8 lanes per mini-list
+        const u32 b0 = s_off[g], c = s_off[g + 1] - b0;
+        const u64* src = seg + ((long long)g * nq + q) * S;
+        for (u32 e = threadIdx.x & 7; e < c; e += 8)
+            if (b0 + e < cap) keys[(long long)q * key_stride + b0 + e] = src[e];
+    }
+    if (threadIdx.x == 0) cnt[q] = s_over ? cap + 1u : total;
 }
 
 // Generic word count (W not specialised): one code per thread.
@@ -367,7 +491,44 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         hist_dispatch(h, qs, nq, bits, hist, step, st);
         hipLaunchKernelGGL(hamming_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, hist, nq, bits, kk, thr);
         if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
-        scan_dispatch(h, qs, nq, thr, keys, cnt, cap, key_stride, /*mode*/ 0, st);
+        if (W == 1 || W == 2 || W == 4) {
+            // streaming scan into per-(block, query) mini-lists, then a prefix-sum compaction: no global atomics
+            // 8 workgroups per CU (32 waves: the VALU-bound inner loop wants full occupancy); the LDS copy of
+            // the queries (nq * (8W+8) bytes) must fit 8 times, so wide codes take the queries in smaller batches
+            const int qbatch = W == 4 ? 384 : 1024;
+            int G = 8 * cu_count(h->device);
+            if (G > 2048) G = 2048;
+            {
+                const long long per_chunk = 256ll * (W == 1 ? 8 : W == 2 ? 4 : 2);
+                const long long nchunks = (n + per_chunk - 1) / per_chunk;
+                if ((long long)G > nchunks) G = (int)nchunks;  // short arrays: fewer, fuller mini-lists
+            }
+            long long want = 8ll * 128ll * kk / G;  // ~8x the expected fill of a mini-list
+            u32 S = 32;
+            while ((long long)S < want && S < 4096u) S <<= 1;
+            SQ_TRY(h->bcnt.reserve((size_t)G * nq * 4));
+            u32* bcnt = h->bcnt.as<u32>();
+            for (int q0 = 0; q0 < nq; q0 += qbatch) {
+                const int nqc = nq - q0 < qbatch ? nq - q0 : qbatch;
+                SQ_TRY(h->seg.reserve((size_t)G * nqc * S * 8));
+                u64* seg = h->seg.as<u64>();
+                const size_t lds = (size_t)nqc * (W * 8 + 8);
+                const u64* qc = qs + (long long)q0 * W;
+                if (W == 1)
+                    hipLaunchKernelGGL((hamming_stream_kernel<1, 8>), dim3(G), dim3(256), lds, st, h->codes, n, qc, nqc,
+                                       thr + q0, seg, bcnt, S);
+                else if (W == 2)
+                    hipLaunchKernelGGL((hamming_stream_kernel<2, 4>), dim3(G), dim3(256), lds, st, h->codes, n, qc, nqc,
+                                       thr + q0, seg, bcnt, S);
+                else
+                    hipLaunchKernelGGL((hamming_stream_kernel<4, 2>), dim3(G), dim3(256), lds, st, h->codes, n, qc, nqc,
+                                       thr + q0, seg, bcnt, S);
+                hipLaunchKernelGGL(hamming_compact_kernel, dim3(nqc), dim3(256), 0, st, seg, bcnt, G, nqc, S,
+                                   keys + (long long)q0 * key_stride, cnt + q0, cap, key_stride);
+            }
+        } else {
+            scan_dispatch(h, qs, nq, thr, keys, cnt, cap, key_stride, /*mode*/ 0, st);
+        }
         if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
         h->stats.scan_launches = 1;
         h->stats.bytes_scanned = n * W * 8;
