@@ -12,6 +12,8 @@
 // B = 4 k x 16 hash bits of R from LDS).  Sign bits leave the accumulators
 // through wave ballots and are packed so that hash bit 0 is the most
 // significant bit of the right-aligned uint64[W] code.
+#include <algorithm>
+
 #include "sq_common.hpp"
 #include "sq_pairwise.cuh"
 
@@ -33,6 +35,8 @@ struct ItqArgs {
     int dk;             // k rows of R staged per chunk (multiple of 16)
     int nchunks;
     int d16;            // d rounded up to 16
+    const void* nrm;    // [n] row L2 norms in x's dtype (normalize=2), from itq_norms_kernel
+    int vec4;           // rows are 4-element aligned (d % 4 == 0, base aligned): vector loads of x
 };
 
 template <class T>
@@ -53,10 +57,31 @@ __device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(
 __device__ __forceinline__ float sqrt_rn(float a) { return (float)sqrt((double)a); }
 __device__ __forceinline__ double sqrt_rn(double a) { return sqrt(a); }
 
+// Row L2 norms in numpy's arithmetic (itq.py:185: np.linalg.norm(v, 2, axis, keepdims)):
+// pairwise float sum of squares in x's dtype, correctly rounded sqrt, 0 -> 1.
+// 8 lanes per row.  Kept out of the MFMA kernel so that one stays within 256
+// VGPRs (two workgroups per CU) without spilling.
+template <class T>
+__global__ __launch_bounds__(256) void itq_norms_kernel(const T* __restrict__ X, long long n, int d, T* __restrict__ nrm) {
+    const int j8 = threadIdx.x & 7;
+    const long long stride = (long long)gridDim.x * 32;
+    for (long long row0 = (long long)blockIdx.x * 32; row0 < n; row0 += stride) {
+        long long row = row0 + (threadIdx.x >> 3);
+        const bool live = row < n;
+        row = live ? row : n - 1;
+        const T* xr = X + row * d;
+        auto term = [xr](int i) { return mul_rn(xr[i], xr[i]); };
+        T s = np_pairwise_sum<T>(term, d, j8);
+        T nv = sqrt_rn(s);
+        if (nv == (T)0) nv = (T)1;
+        if (live && j8 == 0) nrm[row] = nv;
+    }
+}
+
 // CT column tiles of 16 hash bits per pass (CT*16 padded columns), RT = 16/CT
 // row tiles of 16 rows per wave.  grid.y walks groups of CT*16 columns.
 template <class T, int CT>
-__global__ __launch_bounds__(256, 1) void itq_hash_kernel(ItqArgs a) {
+__global__ __launch_bounds__(256, 2) void itq_hash_kernel(ItqArgs a) {
     constexpr int RT = 16 / CT;
     constexpr int NCOL = CT * 16;
     constexpr int RSTRIDE = NCOL + 4;        // f64 per staged R row (+32 B: lanes l and l+16 hit different bank halves)
@@ -65,10 +90,8 @@ __global__ __launch_bounds__(256, 1) void itq_hash_kernel(ItqArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* s_mean = reinterpret_cast<double*>(smem);                 // [d16]
     double* s_rot = s_mean + a.d16;                                    // [dk][RSTRIDE]
-    double* s_nrm = s_rot + (size_t)a.dk * RSTRIDE;                    // [4][ROWS_PER_WAVE]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int j8 = lane & 7;
     const T* X = reinterpret_cast<const T*>(a.x);
     const int col0 = blockIdx.y * NCOL;      // first padded column of this group
 
@@ -91,20 +114,6 @@ __global__ __launch_bounds__(256, 1) void itq_hash_kernel(ItqArgs a) {
     const long long nblocks = (a.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const long long wrow0 = blk * ROWS_PER_BLOCK + (long long)wave * ROWS_PER_WAVE;
-        // ---- row norms in numpy's arithmetic (itq.py:185: np.linalg.norm(v, 2, axis, keepdims))
-        if (a.norm == SQ_NORM_L2) {
-            for (int rr = 0; rr < ROWS_PER_WAVE; rr += 8) {
-                const int rloc = rr + (lane >> 3);
-                long long row = wrow0 + rloc;
-                row = row < a.n ? row : a.n - 1;
-                const T* xr = X + row * a.d;
-                auto term = [xr](int i) { return mul_rn(xr[i], xr[i]); };
-                T s = np_pairwise_sum<T>(term, a.d, j8);
-                T nv = sqrt_rn(s);
-                if (nv == (T)0) nv = (T)1;
-                if (j8 == 0) s_nrm[wave * ROWS_PER_WAVE + rloc] = (double)nv;
-            }
-        }
         f64x4 acc[RT][CT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void itq_hash_kernel(ItqArgs a) {
             long long row = wrow0 + rt * 16 + l15;
             row = row < a.n ? row : a.n - 1;
             xrow[rt] = X + row * a.d;
-            nrm_l[rt] = a.norm == SQ_NORM_L2 ? (T)s_nrm[wave * ROWS_PER_WAVE + rt * 16 + l15] : (T)1;
+            nrm_l[rt] = a.norm == SQ_NORM_L2 ? reinterpret_cast<const T*>(a.nrm)[row] : (T)1;
         }
         for (int chunk = 0; chunk < a.nchunks; ++chunk) {
             if (a.nchunks > 1) {
@@ -132,12 +141,21 @@ __global__ __launch_bounds__(256, 1) void itq_hash_kernel(ItqArgs a) {
                 double av[RT][4];
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
+                    T xq[4];
+                    if (a.vec4 && kb < a.d) {  // d % 4 == 0 and 16-byte aligned rows: one vector load
+                        const typename Vec4<T>::type v4 = *reinterpret_cast<const typename Vec4<T>::type*>(xrow[rt] + kb);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xq[j] = v4[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xq[j] = (kb + j < a.d) ? xrow[rt][kb + j] : (T)0;
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int k = kb + j;
                         double v = 0.0;
                         if (k < a.d) {
-                            T xv = xrow[rt][k];
+                            T xv = xq[j];
                             if (a.norm == SQ_NORM_L2) xv = div_rn(xv, nrm_l[rt]);
                             v = __dsub_rn((double)xv, s_mean[k]);
                         }
@@ -202,8 +220,8 @@ template <class T, int CT>
 static int itq_launch_t(const ItqArgs& a0, hipStream_t st, int device) {
     ItqArgs a = a0;
     constexpr int NCOL = CT * 16, RSTRIDE = NCOL + 4, RT = 16 / CT;
-    const size_t fixed = (size_t)a.d16 * 8 + (size_t)4 * RT * 16 * 8;
-    const size_t budget = 150 * 1024;
+    const size_t fixed = (size_t)a.d16 * 8;
+    const size_t budget = 76 * 1024;  // two workgroups per CU: one hides the other's load + conversion phase
     if (fixed + (size_t)16 * RSTRIDE * 8 > budget)
         return fail(SQ_ERR_UNSUPPORTED, "sq_itq_hash: d=%d too large for the LDS mean vector", a.d);
     int dk = (int)((budget - fixed) / ((size_t)RSTRIDE * 8));
@@ -211,6 +229,7 @@ static int itq_launch_t(const ItqArgs& a0, hipStream_t st, int device) {
     if (dk > a.d16) dk = a.d16;
     a.dk = dk;
     a.nchunks = (a.d16 + dk - 1) / dk;
+    a.vec4 = (a.d % 4 == 0) && (reinterpret_cast<uintptr_t>(a.x) % (4 * sizeof(T)) == 0);
     const size_t lds = fixed + (size_t)dk * RSTRIDE * 8;
     static bool attr_set = false;
     if (!attr_set) {
@@ -220,7 +239,7 @@ static int itq_launch_t(const ItqArgs& a0, hipStream_t st, int device) {
     }
     const long long rows_per_block = 4ll * RT * 16;
     const long long nblocks = (a.n + rows_per_block - 1) / rows_per_block;
-    long long gx = cu_count(device);
+    long long gx = 2ll * cu_count(device);
     if (gx > nblocks) gx = nblocks;
     const int groups = (a.words * 64 + NCOL - 1) / NCOL;
     hipLaunchKernelGGL((itq_hash_kernel<T, CT>), dim3((unsigned)gx, (unsigned)groups), dim3(256), lds, st, a);
@@ -229,10 +248,22 @@ static int itq_launch_t(const ItqArgs& a0, hipStream_t st, int device) {
 }
 
 template <class T>
-static int itq_launch(const ItqArgs& a, hipStream_t st, int device) {
-    if (a.words == 1) return itq_launch_t<T, 4>(a, st, device);
-    if (a.words == 2) return itq_launch_t<T, 8>(a, st, device);
-    return itq_launch_t<T, 16>(a, st, device);
+static int itq_launch(const ItqArgs& a0, hipStream_t st, int device) {
+    ItqArgs a = a0;
+    void* nrm = nullptr;
+    if (a.norm == SQ_NORM_L2) {  // stream-ordered scratch: [n] norms in x's dtype
+        SQ_HIP(hipMallocAsync(&nrm, (size_t)a.n * sizeof(T), st));
+        long long gx = std::min<long long>((a.n + 31) / 32, 16ll * cu_count(device));
+        hipLaunchKernelGGL((itq_norms_kernel<T>), dim3((unsigned)gx), dim3(256), 0, st, reinterpret_cast<const T*>(a.x),
+                           a.n, a.d, reinterpret_cast<T*>(nrm));
+        a.nrm = nrm;
+    }
+    int rc;
+    if (a.words == 1) rc = itq_launch_t<T, 4>(a, st, device);
+    else if (a.words == 2) rc = itq_launch_t<T, 8>(a, st, device);
+    else rc = itq_launch_t<T, 16>(a, st, device);
+    if (nrm) (void)hipFreeAsync(nrm, st);
+    return rc;
 }
 
 }  // namespace sq
