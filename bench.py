@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
 
 
 def parse_args():
@@ -203,15 +203,22 @@ def main() -> None:
             s_ms = float(np.mean(sm))
             extra[f"batch_{b}"] = {
                 "queries_per_s": b / dt, "ms_per_call": dt * 1e3, "scan_kernel_ms": s_ms,
-                "scan_hbm_GBps": n_local * d * 4 / (s_ms * 1e-3) / 1e9 if s_ms > 0 else None,
-                "scan_TFLOPs": 2.0 * n_local * d * (-(-b // 32) * 32) / (s_ms * 1e-3) / 1e12 if s_ms > 0 else None,
+                "scan_GBps_per_query_tile": (-(-n_local // 32) * 32) * (-(-d // 128) * 256 + 4) * (-(-b // 32)) / (s_ms * 1e-3) / 1e9 if s_ms > 0 else None,
+                "scan_bf16_TFLOPs_executed": 2 * 2.0 * n_local * (-(-d // 128) * 128) * (-(-b // 32) * 32) / (s_ms * 1e-3) / 1e12 if s_ms > 0 else None,
             }
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = nq * args.steps / elapsed
         mean_scan_ms = float(np.mean(scan_ms)) if scan_ms else 0.0
-        alg_bytes = float(n_local) * d * 4           # N*d*4 bytes per pass per GPU
+        # Bytes one full-pass launch has to read: the bfloat16 scan copy (d_pad*2 bytes per row) plus the
+        # float32 |x|^2 per row.  SURVEY 8(d) prices a pass at N*d*4 bytes (the float32
+        # matrix); the scan copy halves that, so the float32-equivalent rate is reported beside it and
+        # `achieved`/`frac` use only the bytes the kernel really streams.
+        d_pad = -(-d // 128) * 128
+        n_pad = -(-n_local // 32) * 32
+        alg_bytes = float(n_pad) * (d_pad * 2 + 4)
+        f32_bytes = float(n_local) * d * 4
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         if os.path.isfile(tpath) and n_local == 10_000_000 and d == 128:
@@ -246,8 +253,10 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "dense_scan_kernel (full pass)", "kernel_ms": mean_scan_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "mfma_TFLOPs": 2.0 * n_local * d * (-(-nq // 32) * 32) / (mean_scan_ms * 1e-3) / 1e12 if mean_scan_ms > 0 else None,
-                "mfma_peak_TFLOPs": MFMA_F32_PEAK_TF,
+                "bytes_per_row": d_pad * 2 + 4,
+                "f32_matrix_equivalent_GBps": f32_bytes / (mean_scan_ms * 1e-3) / 1e9 if mean_scan_ms > 0 else None,
+                "mfma_TFLOPs_executed": 2 * 2.0 * n_pad * d_pad * (-(-nq // 32) * 32) / (mean_scan_ms * 1e-3) / 1e12 if mean_scan_ms > 0 else None,
+                "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TF,
             },
         }
         if parity is not None:

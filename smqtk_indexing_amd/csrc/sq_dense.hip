@@ -8,9 +8,9 @@
 // (utils/metrics.py:73-86, 89-137) for every row and keep the n smallest.
 //
 // Structure:
-//   1. dense_scan_kernel (sq_dense_scan.cuh) streams a bf16 hi/lo copy of the
+//   1. dense_scan_kernel (sq_dense_scan.cuh) streams a bfloat16 copy of the
 //      matrix once per 32-query tile: LDS-DMA ring per wave, bf16 MFMA
-//      (hi*hi + hi*lo + lo*hi), scores s = |x|^2 - 2 x.q (cosine: -x^.q^)
+//      (x_hi*q_hi + x_hi*q_lo), scores s = |x|^2 - 2 x.q (cosine: -x^.q^)
 //      compared with a per-query threshold; survivors go to candidate lists.
 //      The threshold comes from the same kernel in SAMPLE mode over every S-th
 //      tile + kth_threshold_f32_kernel.
@@ -29,7 +29,7 @@ namespace sq {
 struct DenseHandle : HandleBase {
     const float* db = nullptr;  // device [n][ld], the caller's float32 rows (borrowed or owned)
     DevBuf owned;
-    DevBuf scan;                // bf16 hi/lo scan copy [n_pad][d_pad*4 bytes]
+    DevBuf scan;                // bfloat16 scan copy [n_pad][d_pad*2 bytes]
     DevBuf norms;               // float32 |x|^2 [n_pad]
     long long n = 0, n_pad = 0;
     int d = 0, d_pad = 0;
@@ -91,7 +91,7 @@ struct ScanGeom {
 };
 static ScanGeom scan_geometry(int d_pad) {
     const int ku = d_pad / KT;
-    const bool qreg = ku <= 2;
+    const bool qreg = ku <= 1;
     const int qb = qreg ? 0 : TILE_ROWS * d_pad * 4;
     ScanGeom g{};
     g.waves = qreg ? 8 : 4;
@@ -109,7 +109,7 @@ static ScanGeom scan_geometry(int d_pad) {
 
 template <int KU, bool SAMPLE>
 static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, hipStream_t st) {
-    if constexpr (KU <= 2) {
+    if constexpr (KU <= 1) {
         if (g.waves == 8) return scan_launch_t<8, 2, KU, SAMPLE>(a, g.lds, st);
     }
     switch (g.stages) {
@@ -128,10 +128,6 @@ static int scan_launch(const DenseScanArgs& a, int d_pad, hipStream_t st) {
         case 2: return scan_launch_ku<2, SAMPLE>(a, g, st);
         case 3: return scan_launch_ku<3, SAMPLE>(a, g, st);
         case 4: return scan_launch_ku<4, SAMPLE>(a, g, st);
-        case 5: return scan_launch_ku<5, SAMPLE>(a, g, st);
-        case 6: return scan_launch_ku<6, SAMPLE>(a, g, st);
-        case 7: return scan_launch_ku<7, SAMPLE>(a, g, st);
-        case 8: return scan_launch_ku<8, SAMPLE>(a, g, st);
         default: return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d", d_pad);
     }
 }
@@ -172,10 +168,11 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     u32* status = cnt + nq_pad;
     u32* hs_raw = reinterpret_cast<u32*>(h->status_host.p);  // [cnt (nq_pad) | status (nq)]
     u32* hs = hs_raw + nq_pad;                               // status words
-    // error bound of the bf16x3 filter score (sq_dense_exact.cuh filter_eps):
-    //   products: |x q' - (xh qh + xh ql + xl qh)| <= 2^-14 |x||q'|, q' = -2q   ->  eps_a = 2^-13 (times X|q|)
-    //   float32 accumulation of 3d+1 terms and the float32 norm                ->  eps_b = (3d+8) 2^-23
-    const double eps_a = 1.220703125e-4;
+    // error bound of the bf16 filter score (sq_dense_exact.cuh filter_eps):
+    //   products: |x q' - x_hi (q'_hi + q'_lo)| <= (2^-8 + 2^-15) |x||q'|, q' = -2q  ->  eps_a = 2^-7 + 2^-14 (times X|q|)
+    //             (cosine: unit vectors, q' = -q^: half of that; eps_a is kept as the common, looser constant)
+    //   float32 accumulation of 2d+1 terms and the float32 norm                     ->  eps_b = (3d+8) 2^-23
+    const double eps_a = 0.0078125 + 6.103515625e-05;
     const double eps_b = (3.0 * d_pad + 8.0) * 1.1920928955078125e-07;
     const size_t l2_lds = (size_t)((d + 3) / 4 * 4) * 4;
 
@@ -263,7 +260,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         SQ_TRY(scan_launch<false>(a, d_pad, st));
         if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
         h->stats.scan_launches = 2;
-        h->stats.bytes_scanned = n * (long long)d * 4;
+        h->stats.bytes_scanned = h->n_pad * ((long long)d_pad * 2 + (cosine ? 0 : 4));
         // exact re-rank of the survivors (wave segments -> per-query keys), select, certify
         const int wpb = 2;  // survivor segments per re-rank block (both from one scan workgroup: wv is even)
         const size_t rr_lds = (size_t)32 * (ldq + 4) * 4;
@@ -390,7 +387,7 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
         h->db = h->owned.as<float>();
         h->ld = ldo;
     }
-    // row statistics, then the bf16 hi/lo scan copy (skipped for rows wider than the scan kernel covers)
+    // row statistics, then the bfloat16 scan copy (skipped for rows wider than the scan kernel covers)
     {
         int rc = h->scratch.reserve(256);
         if (rc != SQ_OK) return bail(rc);
@@ -407,12 +404,12 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
         hipLaunchKernelGGL(dense_rowstats_kernel, dim3((unsigned)(h->n_pad / 32)), dim3(256), 0, 0, h->db, (long long)n,
                            h->ld, d, h->n_pad, h->scratch.as<u32>(), h->norms.as<float>(), invp);
         if (d_pad <= MAX_DPAD) {
-            rc = h->scan.reserve((size_t)h->n_pad * d_pad * 4);
+            rc = h->scan.reserve((size_t)h->n_pad * d_pad * 2);
             if (rc != SQ_OK) {
                 inv.release();
                 return bail(rc);
             }
-            const long long chunks = h->n_pad * (long long)(d_pad / 4);
+            const long long chunks = h->n_pad * (long long)(d_pad / 8);
             hipLaunchKernelGGL(dense_build_scan_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, 0, h->db,
                                (long long)n, h->ld, d, d_pad, h->n_pad, invp, h->scan.as<uint4>());
         }

@@ -1,24 +1,27 @@
-// The streaming filter of the dense path: one pass over a bf16 hi/lo "scan
-// copy" of the descriptor matrix on the bf16 matrix cores (gfx950).
+// The streaming filter of the dense path: one pass over a bfloat16 "scan copy"
+// of the descriptor matrix on the bf16 matrix cores (gfx950).
 //
 // Why a scan copy.  The filter only has to be right within a known error
 // bound (every survivor is re-ranked in the reference's float32/float64
-// arithmetic), but it has to stream N*d*4 bytes at the HBM rate
-// for many queries at once.  float32 MFMA (v_mfma_f32_32x32x2_f32) runs at the
-// VALU rate, 1/16 of bf16, and made the scan compute bound beyond ~24 queries.
-// Splitting every float32 x into two bfloat16 x = hi + lo (|x - hi - lo| <=
-// 2^-16 |x|) and evaluating hi*hi' + hi*lo' + lo*hi' on
-// v_mfma_f32_32x32x16_bf16 keeps ~2^-14 relative accuracy per product at 3/16
-// of the float32 MFMA cycles, with no conversion work in the loop: the split
-// is done once at index build time and stored in exactly the order the MFMA
-// fragments are read (same bytes per row as float32, so the algorithmic HBM
-// traffic of a pass is unchanged).
+// arithmetic from the original rows), but it has to stream the
+// whole matrix at the HBM rate for many queries at once.  float32 MFMA
+// (v_mfma_f32_32x32x2_f32) runs at the VALU rate, 1/16 of bf16, and made the
+// scan compute bound beyond ~24 queries.  The rows are therefore rounded once,
+// at index build time, to bfloat16 (|x - x_hi| <= 2^-8 |x| per element) and
+// stored in exactly the order the MFMA fragments are read: HALF the bytes of
+// the float32 matrix, so a pass moves N*d*2 (+ N*4 of norms) bytes.  The
+// queries keep two bfloat16 planes (q = q_hi + q_lo, residual <= 2^-16 |q|):
+// a tile costs two MFMAs per k-step, x_hi*q_hi + x_hi*q_lo, and the score
+// error is bounded by (2^-8 + 2^-15) |x||q'| (Cauchy-Schwarz over the
+// element-wise bounds) plus float32 accumulation: the bound the threshold
+// slack and the certification use (sq_dense.hip).
 //
-// Scan-copy layout: row-major, row stride d_pad*4 bytes; a row is KU = d_pad/64
-// units of 256 bytes; a unit is 16 chunks of 16 bytes; chunk c = 4*s + 2*h + p
-// holds 8 bfloat16 = elements k = 64*unit + 16*s + 8*h + j (j = 0..7) of the
-// hi (p = 0) or lo (p = 1) part.  That is the A (and B) operand of MFMA k-step
-// s for lane half h (cdna_hip_programming.md section 3, bf16 operand maps).
+// Scan-copy layout: row-major, row stride d_pad*2 bytes; a row is KU = d_pad/128
+// units of 256 bytes; a unit is 16 chunks of 16 bytes; chunk c = 2*s + h holds
+// 8 bfloat16 = elements k = 128*unit + 16*s + 8*h + j (j = 0..7).  That is the
+// A operand of MFMA k-step s (0..7) for lane half h (cdna_hip_programming.md
+// section 3, bf16 operand maps).  A prepared query row is KU units of 512
+// bytes: the 16 chunks of the hi plane, then the 16 chunks of the lo plane.
 #pragma once
 #include "sq_common.hpp"
 
@@ -28,9 +31,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-static constexpr int KT = 64;                          // floats per k-unit
+static constexpr int KT = 128;                         // elements per k-unit (256 bytes of bfloat16)
 static constexpr int TILE_ROWS = 32;                   // rows per MFMA tile
-static constexpr int UNIT_BYTES = TILE_ROWS * KT * 4;  // 8 KiB: 32 rows x 256 bytes
+static constexpr int UNIT_BYTES = TILE_ROWS * KT * 2;  // 8 KiB: 32 rows x 256 bytes
 static constexpr int NORM_BYTES = 256;                 // per ring slot: |x|^2 of the tile's 32 rows (64 lanes x 4 B)
 static constexpr int SLOT_BYTES = UNIT_BYTES + NORM_BYTES;
 static constexpr int MAX_DPAD = 512;
@@ -54,11 +57,11 @@ static __global__ __launch_bounds__(256) void dense_build_scan_kernel(const floa
                                                                        const float* __restrict__ row_scale,
                                                                        uint4* __restrict__ scan) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int cpr = d_pad / 4;  // chunks per row
+    const int cpr = d_pad / 8;  // chunks per row
     if (idx >= n_pad * cpr) return;
     const long long row = idx / cpr;
     const int cc = (int)(idx - row * cpr);
-    const int unit = cc >> 4, c = cc & 15, s = c >> 2, h = (c >> 1) & 1, p = c & 1;
+    const int unit = cc >> 4, c = cc & 15, s = c >> 1, h = c & 1;
     const int k0 = unit * KT + 16 * s + 8 * h;
     u32 w[4];
     const float sc = (row < n && row_scale) ? row_scale[row] : 1.f;
@@ -70,9 +73,7 @@ static __global__ __launch_bounds__(256) void dense_build_scan_kernel(const floa
             const int k = k0 + j + e;
             float x = 0.f;
             if (row < n && k < d) x = row_scale ? __fmul_rn(db[row * ld + k], sc) : db[row * ld + k];
-            u32 hi, lo;
-            bf16_split(x, hi, lo);
-            half[e] = p ? lo : hi;
+            half[e] = bf16_bits_rn(x);
         }
         w[j >> 1] = half[0] | (half[1] << 16);
     }
@@ -106,8 +107,8 @@ static __global__ __launch_bounds__(256) void dense_rowstats_kernel(const float*
     }
 }
 
-// Query prep: |q|^2 (f64) and the scaled query (L2: -2q, cosine: -q/|q|) split
-// and stored in the scan-copy chunk layout, [nq_pad][d_pad/4] chunks.
+// Query prep: |q|^2 (f64) and the scaled query (L2: -2q, cosine: -q/|q|) split into
+// bfloat16 hi + lo planes in the fragment order, [nq_pad][d_pad/4] chunks.
 // Also resets the per-call state of query qi (threshold = -inf, candidate count 0,
 // overflow flag) and writes the aligned float32 copy q_al[nq][ldq] the re-rank reads.
 static __global__ __launch_bounds__(256) void dense_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
@@ -139,7 +140,7 @@ static __global__ __launch_bounds__(256) void dense_prep_queries_kernel(const fl
     if (metric == SQ_METRIC_COSINE) scale = tot > 0.0 ? -1.0 / sqrt(tot) : 0.0;
     const int cpr = d_pad / 4;
     for (int cc = threadIdx.x; cc < cpr; cc += 256) {
-        const int unit = cc >> 4, c = cc & 15, s = c >> 2, h = (c >> 1) & 1, p = c & 1;
+        const int unit = cc >> 5, p = (cc >> 4) & 1, c = cc & 15, s = c >> 1, h = c & 1;
         const int k0 = unit * KT + 16 * s + 8 * h;
         u32 w[4];
 #pragma unroll
@@ -162,7 +163,7 @@ static __global__ __launch_bounds__(256) void dense_prep_queries_kernel(const fl
 
 // ------------------------------------------------------------- the scan kernel
 struct DenseScanArgs {
-    const uint4* scan;      // scan copy [n_pad][d_pad/4] chunks
+    const uint4* scan;      // scan copy [n_pad][d_pad/8] chunks
     const float* norms;     // |x|^2 per row [n_pad] (L2) or nullptr (cosine)
     long long n;            // real rows (rows >= n are padding and never emitted)
     long long n_tiles;      // ceil(n / 32)
@@ -215,24 +216,26 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Allow `units` younger units (8 DMA instructions each, +1 for a tile's norms:
-// counting 8 is then merely conservative) to stay outstanding.
-template <int NSTAGE>
+// Allow `units` younger units to stay outstanding.  PER = DMA instructions per
+// unit: 8, or 9 when every unit also carries its tile's norms (KU == 1, L2).
+// With KU > 1 only a tile's first unit has the norm load: counting 8 is then
+// merely conservative.
+template <int NSTAGE, int PER>
 __device__ __forceinline__ void wait_units_in_flight(int units) {
     if constexpr (NSTAGE >= 4) {
         if (units >= 3) {
-            wait_vmcnt<24>();
+            wait_vmcnt<3 * PER>();
             return;
         }
     }
     if constexpr (NSTAGE >= 3) {
         if (units == 2) {
-            wait_vmcnt<16>();
+            wait_vmcnt<2 * PER>();
             return;
         }
     }
     if (units == 1)
-        wait_vmcnt<8>();
+        wait_vmcnt<PER>();
     else
         wait_vmcnt<0>();
 }
@@ -241,11 +244,11 @@ typedef __attribute__((address_space(3))) u32 lds_u32;
 
 // WAVES: waves per workgroup (one workgroup per CU; 8 = two waves per SIMD, so
 // one wave's DMA issue / epilogue runs under the other's MFMAs); NSTAGE: ring
-// depth per wave; KU = d_pad/64 units per row tile; SAMPLE: write per-lane
+// depth per wave; KU = d_pad/128 units per row tile; SAMPLE: write per-lane
 // minima of every visited tile instead of emitting candidates.
 template <int WAVES, int NSTAGE, int KU, bool SAMPLE>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(DenseScanArgs a) {
-    constexpr bool QREG = KU <= 2;  // query fragments live in registers for d_pad <= 128
+    constexpr bool QREG = KU <= 1;  // query fragments live in registers for d_pad <= 128
     constexpr int DPAD = KU * KT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     const long long wave_id = (long long)blockIdx.x * WAVES + wave;  // unique per wave of the launch
     uint2* wout = a.wave_out + wave_id * a.wave_cap;
     const bool add_norm = a.norms != nullptr;
+    const bool nine = add_norm && KU == 1;  // DMA instructions per unit: 9 when each unit carries its norms
 
     // block -> (row block, query tile); blocks that share an XCD (same id mod 8)
     // walk the query tiles of the same rows so the matrix is re-read from L2.
@@ -275,8 +279,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         rb = L;
     }
 
-    // stage the query tile: [32][DPAD*4 bytes], 16-byte chunks XOR-swizzled inside each
-    // 256-byte unit by (row & 15) -- the image the row units get from the DMA
+    // stage the query tile: [32][DPAD*4 bytes] (per k-unit a hi and a lo plane of 256 bytes), 16-byte
+    // chunks XOR-swizzled inside each 256-byte plane by (row & 15) -- the image the row units get from the DMA
     {
         const uint4* qsrc = a.qs + (long long)qt * TILE_ROWS * (DPAD / 4);
         constexpr int cpr = DPAD / 4;
@@ -306,15 +310,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     if (a.debug & 4) thr_l = -__builtin_inff();  // ablation: nothing is emitted
     asm volatile("" : "+v"(thr_l));
 
-    // B fragments of k-step s: chunk 4s+2h (hi) and 4s+2h+1 (lo) of the lane's query row
-    f32x4 bq[QREG ? KU : 1][8];
+    // B fragments of k-step s: chunk 2s+h of the hi plane (bq[.][2s]) and of the lo plane (bq[.][2s+1])
+    f32x4 bq[QREG ? KU : 1][16];
     if constexpr (QREG) {
 #pragma unroll
         for (int kc = 0; kc < KU; ++kc)
 #pragma unroll
-            for (int g = 0; g < 8; ++g)
-                bq[kc][g] = *reinterpret_cast<const f32x4*>(smem + (u32)r31 * DPAD * 4 + kc * 256 +
-                                                             (((g >> 1) * 4 + 2 * h + (g & 1)) ^ (r31 & 15)) * 16);
+            for (int g = 0; g < 16; ++g)
+                bq[kc][g] = *reinterpret_cast<const f32x4*>(smem + (u32)r31 * DPAD * 4 + kc * 512 + (g & 1) * 256 +
+                                                             ((2 * (g >> 1) + h) ^ (r31 & 15)) * 16);
         __syncthreads();  // every wave holds its fragments before the DMA ring overwrites the staging area
     }
 
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int r = 4 * j + (lane >> 4);
-        voff[j] = (u32)(r * (DPAD * 4) + (((lane & 15) ^ (r & 15)) * 16));
+        voff[j] = (u32)(r * (DPAD * 2) + (((lane & 15) ^ (r & 15)) * 16));
     }
     const u32 voff_norm = (u32)((lane & 31) * 4);
 
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     auto issue_unit = [&]() {
         const long long row0 = iss_sel * a.tile_step * TILE_ROWS;
         const u32 dst = ring_base + (u32)iss_slot * SLOT_BYTES;
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan) + row0 * (DPAD * 4) + iss_kc * 256;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan) + row0 * (DPAD * 2) + iss_kc * 256;
 #pragma unroll
         for (int j = 0; j < 8; ++j) glds16(base, voff[j], dst + (u32)j * 1024);
         if (add_norm && iss_kc == 0) glds4(a.norms + row0, voff_norm, dst + UNIT_BYTES);
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     };
 
     // Software pipeline over units (u = 0, 1, ...; slot of unit u = u % NSTAGE):
-    //   registers hold the A fragments of unit u (av_cur) while its 12 MFMAs run;
+    //   registers hold the A fragments of unit u (av_cur) while its 16 MFMAs run;
     //   the fragments of unit u+1 are read from LDS (av_nxt) under those MFMAs;
     //   the slot of unit u is refilled by the DMA of unit u+NSTAGE as soon as
     //   av_cur is complete.
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         const unsigned char* arow = sl + r31 * 256;
 #pragma unroll
         for (int g = 0; g < 8; ++g)
-            av_nxt[g] = *reinterpret_cast<const f32x4*>(arow + (((g >> 1) * 4 + 2 * h + (g & 1)) ^ (r31 & 15)) * 16);
+            av_nxt[g] = *reinterpret_cast<const f32x4*>(arow + ((2 * g + h) ^ (r31 & 15)) * 16);
         if (first_of_tile && add_norm) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) nrm_nxt[c] = *reinterpret_cast<const f32x4*>(sl + UNIT_BYTES + (8 * c + 4 * h) * 4);
@@ -381,7 +385,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     long long loaded = 0;  // units whose fragments have been requested from LDS
     int rd_slot = 0, rd_kc = 0;
     if (total_units > 0) {
-        wait_units_in_flight<NSTAGE>((int)(issued - 1));
+        if (nine)
+            wait_units_in_flight<NSTAGE, 9>((int)(issued - 1));
+        else
+            wait_units_in_flight<NSTAGE, 8>((int)(issued - 1));
         if (do_math) read_frags(0, true);
         loaded = 1;
         rd_slot = NSTAGE > 1 ? 1 : 0;
@@ -403,7 +410,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
             asm volatile("" ::: "memory");
             issue_next();
             if (loaded < total_units) {
-                wait_units_in_flight<NSTAGE>((int)(issued - loaded - 1));  // younger units may stay in flight
+                if (nine)  // younger units may stay in flight
+                    wait_units_in_flight<NSTAGE, 9>((int)(issued - loaded - 1));
+                else
+                    wait_units_in_flight<NSTAGE, 8>((int)(issued - loaded - 1));
                 if (do_math) read_frags(rd_slot, rd_kc == 0);
                 ++loaded;
                 if (++rd_slot == NSTAGE) rd_slot = 0;
@@ -411,23 +421,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
             }
             if (do_math) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
+                for (int s = 0; s < 8; ++s) {
                     f32x4 bh, bl;
                     if constexpr (QREG) {
                         bh = bq[kc][2 * s];
                         bl = bq[kc][2 * s + 1];
                     } else {
-                        const unsigned char* brow = smem + (u32)r31 * DPAD * 4 + kc * 256;
-                        bh = *reinterpret_cast<const f32x4*>(brow + ((4 * s + 2 * h) ^ (r31 & 15)) * 16);
-                        bl = *reinterpret_cast<const f32x4*>(brow + ((4 * s + 2 * h + 1) ^ (r31 & 15)) * 16);
+                        const unsigned char* brow = smem + (u32)r31 * DPAD * 4 + kc * 512 + ((2 * s + h) ^ (r31 & 15)) * 16;
+                        bh = *reinterpret_cast<const f32x4*>(brow);
+                        bl = *reinterpret_cast<const f32x4*>(brow + 256);
                     }
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, av_cur[2 * s]);
-                    const bf16x8 al = __builtin_bit_cast(bf16x8, av_cur[2 * s + 1]);
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, av_cur[s]);
                     const bf16x8 bhv = __builtin_bit_cast(bf16x8, bh);
                     const bf16x8 blv = __builtin_bit_cast(bf16x8, bl);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhv, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blv, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhv, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhv, acc, 0, 0, 0);
                 }
             }
         }
