@@ -111,45 +111,9 @@ struct SqLeafLane {
         for (int i = nfull; i < n; ++i) res = __fadd_rn(res, term(off + i));
         return res;
     }
-    // numpy pairwise recursion (split at n/2 rounded down to a multiple of 8), explicit stack
-    __device__ float sum(int d) const {
-        if (d <= 128) return leaf(0, d);
-        int s_off[24], s_n[24], s_state[24];
-        float s_left[24];
-        int sp = 1;
-        s_off[0] = 0;
-        s_n[0] = d;
-        s_state[0] = 0;
-        float ret = 0.f;
-        while (sp > 0) {
-            const int top = sp - 1;
-            const int off = s_off[top], m = s_n[top];
-            if (m <= 128) {
-                ret = leaf(off, m);
-                --sp;
-                continue;
-            }
-            int m2 = m / 2;
-            m2 -= m2 % 8;
-            if (s_state[top] == 0) {
-                s_state[top] = 1;
-                s_off[sp] = off;
-                s_n[sp] = m2;
-                s_state[sp] = 0;
-                ++sp;
-            } else if (s_state[top] == 1) {
-                s_left[top] = ret;
-                s_state[top] = 2;
-                s_off[sp] = off + m2;
-                s_n[sp] = m - m2;
-                s_state[sp] = 0;
-                ++sp;
-            } else {
-                ret = __fadd_rn(s_left[top], ret);
-                --sp;
-            }
-        }
-        return ret;
+    // numpy pairwise recursion (split at n/2 rounded down to a multiple of 8)
+    __device__ __forceinline__ float sum(int d) const {
+        return pw_tree<float>([this](int off, int n) { return leaf(off, n); }, d);
     }
 };
 
@@ -232,44 +196,8 @@ struct SqLeafPair {
         for (int i = nfull; i < n; ++i) res = __fadd_rn(res, term(off + i));
         return res;
     }
-    __device__ float sum(int d) const {
-        if (d <= 128) return leaf(0, d);
-        int s_off[24], s_n[24], s_state[24];
-        float s_left[24];
-        int sp = 1;
-        s_off[0] = 0;
-        s_n[0] = d;
-        s_state[0] = 0;
-        float ret = 0.f;
-        while (sp > 0) {
-            const int top = sp - 1;
-            const int off = s_off[top], m = s_n[top];
-            if (m <= 128) {
-                ret = leaf(off, m);
-                --sp;
-                continue;
-            }
-            int m2 = m / 2;
-            m2 -= m2 % 8;
-            if (s_state[top] == 0) {
-                s_state[top] = 1;
-                s_off[sp] = off;
-                s_n[sp] = m2;
-                s_state[sp] = 0;
-                ++sp;
-            } else if (s_state[top] == 1) {
-                s_left[top] = ret;
-                s_state[top] = 2;
-                s_off[sp] = off + m2;
-                s_n[sp] = m - m2;
-                s_state[sp] = 0;
-                ++sp;
-            } else {
-                ret = __fadd_rn(s_left[top], ret);
-                --sp;
-            }
-        }
-        return ret;
+    __device__ __forceinline__ float sum(int d) const {
+        return pw_tree<float>([this](int off, int n) { return leaf(off, n); }, d);
     }
 };
 

@@ -39,46 +39,70 @@ __device__ __forceinline__ T pw_leaf(F& term, int off, int n, int j8) {
     return r;
 }
 
-template <class T, class F>
-__device__ T np_pairwise_sum(F term, int n, int j8) {
-    if (n <= 128) return pw_leaf<T>(term, 0, n, j8);
-    // explicit-stack post-order walk of the recursion (depth <= log2(n/64))
-    int s_off[24], s_n[24], s_state[24];
-    T s_left[24];
-    int sp = 1;
-    s_off[0] = 0;
-    s_n[0] = n;
-    s_state[0] = 0;
-    T ret = (T)0;
-    while (sp > 0) {
-        const int top = sp - 1;
-        const int off = s_off[top], m = s_n[top];
-        if (m <= 128) {
-            ret = pw_leaf<T>(term, off, m, j8);
-            --sp;
-            continue;
+// numpy's recursion over the leaves without a per-thread stack array.
+// `leaf(off, n)` returns the leaf sum of elements [off, off+n), n <= 128.  The
+// walk is post-order; the position in the tree is the bit string `path` (bit i
+// = went right at depth i) and a node's range is re-derived from the root when
+// the walk moves to a right sibling (a few integer operations per 128-element
+// leaf).  Pending left sums sit in a 12-deep shift register of scalars with
+// static indices, so everything stays in a handful of VGPRs (an indexed stack
+// of (offset, size, state, sum) cost ~100 registers or scratch and held the
+// kernels that use this at one wave per SIMD).  Depth 12: n <= 128 * 2^12.
+static constexpr int PW_MAX_DEPTH = 12;
+static constexpr int PW_MAX_N = 128 << PW_MAX_DEPTH;
+
+__device__ __forceinline__ int pw_split(int m) {
+    int m2 = m / 2;
+    return m2 - (m2 % 8);
+}
+
+template <class T, class L>
+__device__ __forceinline__ T pw_tree(L&& leaf, int n) {
+    if (n <= 128) return leaf(0, n);
+    T st[PW_MAX_DEPTH];
+#pragma unroll
+    for (int i = 0; i < PW_MAX_DEPTH; ++i) st[i] = (T)0;
+    unsigned path = 0;
+    int depth = 0, off = 0, m = n;
+    for (;;) {
+        while (m > 128) {  // descend to the leftmost leaf of this subtree
+            m = pw_split(m);
+            path &= ~(1u << depth);
+            ++depth;
         }
-        int m2 = m / 2;
-        m2 -= m2 % 8;
-        if (s_state[top] == 0) {
-            s_state[top] = 1;
-            s_off[sp] = off;
-            s_n[sp] = m2;
-            s_state[sp] = 0;
-            ++sp;
-        } else if (s_state[top] == 1) {
-            s_left[top] = ret;
-            s_state[top] = 2;
-            s_off[sp] = off + m2;
-            s_n[sp] = m - m2;
-            s_state[sp] = 0;
-            ++sp;
-        } else {
-            ret = add_rn(s_left[top], ret);
-            --sp;
+        T v = leaf(off, m);
+        while (depth > 0 && ((path >> (depth - 1)) & 1u)) {  // a right child: combine with the pending left sum
+            v = add_rn(st[0], v);
+#pragma unroll
+            for (int i = 0; i + 1 < PW_MAX_DEPTH; ++i) st[i] = st[i + 1];
+            --depth;
         }
+        if (depth == 0) return v;
+#pragma unroll
+        for (int i = PW_MAX_DEPTH - 1; i > 0; --i) st[i] = st[i - 1];
+        st[0] = v;
+        path |= 1u << (depth - 1);
+        // the right sibling: the parent's range from the root, then its right part
+        off = 0;
+        m = n;
+        for (int i = 0; i + 1 < depth; ++i) {
+            const int m2 = pw_split(m);
+            if ((path >> i) & 1u) {
+                off += m2;
+                m -= m2;
+            } else {
+                m = m2;
+            }
+        }
+        const int m2 = pw_split(m);
+        off += m2;
+        m -= m2;
     }
-    return ret;
+}
+
+template <class T, class F>
+__device__ __forceinline__ T np_pairwise_sum(F term, int n, int j8) {
+    return pw_tree<T>([&](int off, int m) { return pw_leaf<T>(term, off, m, j8); }, n);
 }
 
 }  // namespace sq

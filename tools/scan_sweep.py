@@ -25,16 +25,18 @@ def main():
             s = idx.stats(); ms.append(s["scan_ms"]); tot.append(s["total_ms"])
         for kk in opts: _lib.set_option(kk, 0)
         return float(np.median(ms[1:])), float(np.median(tot[1:])), s["fallback_queries"]
-    rows = []
+    bpr = (-(-d // 128) * 256 + 4)
     for nq in (32,):
-        for name, opts in [("default", {}), ("no_emit", {"dense_debug": 4}), ("no_flush", {"dense_debug": 8}),
-                           ("no_record", {"dense_debug": 16}), ("w4", {"dense_waves": 4})]:
+        for name, opts in [("default", {}), ("dma_only", {"dense_debug": 1}), ("no_emit", {"dense_debug": 4}),
+                           ("w4", {"dense_waves": 4}), ("w4_s4", {"dense_waves": 4, "dense_stages": 4}),
+                           ("stride8", {"sample_stride": 8}), ("stride32", {"sample_stride": 32}),
+                           ("stride64", {"sample_stride": 64}), ("blocks512", {"dense_blocks": 512})]:
             sm, tm, fb = run(nq, **opts)
-            rows.append((nq, name, sm, tm, n * d * 4 / sm / 1e6 if sm else 0))
-            print(f"nq={nq:5d} {name:12s} scan_ms={sm:8.4f} total_ms={tm:8.4f} scan_GBps={rows[-1][4]:9.1f} fb={fb}", flush=True)
-    for nq in (256, 1024):
+            c = idx.stats()["candidates"] / nq
+            print(f"nq={nq:5d} {name:12s} scan_ms={sm:8.4f} total_ms={tm:8.4f} scan_GBps={n * bpr / sm / 1e6 if sm else 0:9.1f} cand/q={c:8.0f} fb={fb}", flush=True)
+    for nq in (1, 64, 128, 256, 1024):
         sm, tm, fb = run(nq, reps=3)
-        print(f"nq={nq:5d} default      scan_ms={sm:8.4f} total_ms={tm:8.4f} TF={2*n*d*nq/sm/1e9:8.2f} fb={fb}", flush=True)
+        print(f"nq={nq:5d} default      scan_ms={sm:8.4f} total_ms={tm:8.4f} fb={fb}", flush=True)
 
 if __name__ == "__main__":
     main()
