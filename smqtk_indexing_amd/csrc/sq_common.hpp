@@ -52,6 +52,7 @@ struct Options {
     int dense_blocks = 0;    // 0 = auto (row blocks of the dense scan grid)
     int dense_debug = 0;     // measurement only (see DenseScanArgs::debug)
     int dense_waves = 0;     // 0 = auto, 4 or 8 waves per scan workgroup
+    int dense_qt = 0;        // 0 = auto, 1 / 2 / 4 query tiles per scan wave
 };
 extern Options g_opt;
 

@@ -69,67 +69,79 @@ static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long str
     return SQ_OK;
 }
 
-template <int WAVES, int NSTAGE, int KU, bool SAMPLE>
+template <int WAVES, int NSTAGE, int KU, int QT, bool SAMPLE>
 static int scan_launch_t(const DenseScanArgs& a, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<WAVES, NSTAGE, KU, SAMPLE>),
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<WAVES, NSTAGE, KU, QT, SAMPLE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dense_scan_kernel<WAVES, NSTAGE, KU, SAMPLE>), dim3((unsigned)(a.nrb * a.nqt)),
+    hipLaunchKernelGGL((dense_scan_kernel<WAVES, NSTAGE, KU, QT, SAMPLE>), dim3((unsigned)(a.nrb * a.nqt)),
                        dim3(WAVES * 64), lds, st, a);
     return SQ_OK;
 }
 
 static constexpr int SCAN_LDS_TAIL = 8 * 16;  // per-wave survivor counters
 
-// Launch geometry of the scan for a padded dimension: waves per workgroup and ring depth.
+// Launch geometry of the scan for a padded dimension and `qt` query tiles per wave:
+// waves per workgroup and ring depth.
 struct ScanGeom {
     int waves, stages;
     size_t lds;
 };
-static ScanGeom scan_geometry(int d_pad) {
+static ScanGeom scan_geometry(int d_pad, int qt) {
     const int ku = d_pad / KT;
     const bool qreg = ku <= 1;
     const int qb = qreg ? 0 : TILE_ROWS * d_pad * 4;
     ScanGeom g{};
-    g.waves = qreg ? 8 : 4;
+    g.waves = (qreg && qt == 1) ? 8 : 4;
     if (qreg && g_opt.dense_waves == 4) g.waves = 4;
     int ns = (160 * 1024 - qb - SCAN_LDS_TAIL) / (g.waves * SLOT_BYTES);
     const int ns_max = g.waves == 8 ? 2 : 4;
     if (ns > ns_max) ns = ns_max;
-    if (g_opt.dense_stages >= 2 && g_opt.dense_stages <= ns) ns = g_opt.dense_stages;
+    if (qt == 1 && g_opt.dense_stages >= 2 && g_opt.dense_stages <= ns) ns = g_opt.dense_stages;
     g.stages = ns;
     g.lds = (size_t)qb + (size_t)g.waves * ns * SLOT_BYTES + SCAN_LDS_TAIL;
-    // staging the query tile through the ring needs the ring to be at least as large
-    if (qreg && (size_t)TILE_ROWS * d_pad * 4 > (size_t)g.waves * ns * SLOT_BYTES) g.stages = 0;
+    // staging the query tiles through the ring needs the ring to be at least as large
+    if (qreg && (size_t)qt * TILE_ROWS * d_pad * 4 > (size_t)g.waves * ns * SLOT_BYTES) g.stages = 0;
     return g;
 }
 
 template <int KU, bool SAMPLE>
-static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, hipStream_t st) {
+static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, int qt, hipStream_t st) {
     if constexpr (KU <= 1) {
-        if (g.waves == 8) return scan_launch_t<8, 2, KU, SAMPLE>(a, g.lds, st);
+        if (qt == 4) return scan_launch_t<4, 4, KU, 4, SAMPLE>(a, g.lds, st);
+        if (qt == 2) return scan_launch_t<4, 4, KU, 2, SAMPLE>(a, g.lds, st);
+        if (g.waves == 8) return scan_launch_t<8, 2, KU, 1, SAMPLE>(a, g.lds, st);
     }
     switch (g.stages) {
-        case 4: return scan_launch_t<4, 4, KU, SAMPLE>(a, g.lds, st);
-        case 3: return scan_launch_t<4, 3, KU, SAMPLE>(a, g.lds, st);
-        default: return scan_launch_t<4, 2, KU, SAMPLE>(a, g.lds, st);
+        case 4: return scan_launch_t<4, 4, KU, 1, SAMPLE>(a, g.lds, st);
+        case 3: return scan_launch_t<4, 3, KU, 1, SAMPLE>(a, g.lds, st);
+        default: return scan_launch_t<4, 2, KU, 1, SAMPLE>(a, g.lds, st);
     }
 }
 
 template <bool SAMPLE>
-static int scan_launch(const DenseScanArgs& a, int d_pad, hipStream_t st) {
-    const ScanGeom g = scan_geometry(d_pad);
-    if (g.stages < 2) return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d leaves no room for the LDS ring", d_pad);
+static int scan_launch(const DenseScanArgs& a, int d_pad, int qt, hipStream_t st) {
+    const ScanGeom g = scan_geometry(d_pad, qt);
+    if (g.stages < 2 || (qt > 1 && (d_pad != KT || g.stages != 4)))
+        return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d qt=%d leaves no room for the LDS ring", d_pad, qt);
     switch (d_pad / KT) {
-        case 1: return scan_launch_ku<1, SAMPLE>(a, g, st);
-        case 2: return scan_launch_ku<2, SAMPLE>(a, g, st);
-        case 3: return scan_launch_ku<3, SAMPLE>(a, g, st);
-        case 4: return scan_launch_ku<4, SAMPLE>(a, g, st);
+        case 1: return scan_launch_ku<1, SAMPLE>(a, g, qt, st);
+        case 2: return scan_launch_ku<2, SAMPLE>(a, g, qt, st);
+        case 3: return scan_launch_ku<3, SAMPLE>(a, g, qt, st);
+        case 4: return scan_launch_ku<4, SAMPLE>(a, g, qt, st);
         default: return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d", d_pad);
     }
+}
+
+// Query tiles per wave for a batch of `nqt` 32-query tiles (sq_dense_scan.cuh): one tile keeps the
+// eight-wave HBM-bound configuration; larger batches reuse each streamed row tile for 2 or 4 query tiles.
+static int scan_query_tiles(int d_pad, int nqt) {
+    if (d_pad != KT) return 1;
+    if (g_opt.dense_qt == 1 || g_opt.dense_qt == 2 || g_opt.dense_qt == 4) return g_opt.dense_qt;
+    return nqt >= 3 ? 4 : (nqt == 2 ? 2 : 1);
 }
 
 static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, void* out_dist, long long* out_idx,
@@ -145,8 +157,10 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     const bool force_fb = g_opt.force_fallback != 0;
     const bool small = n <= (long long)cap;
     const bool scan_ok = h->scan.p != nullptr && !small;
-    const int nqt = (nq + TILE_ROWS - 1) / TILE_ROWS;
-    const int nq_pad = nqt * TILE_ROWS;
+    const int qt = scan_query_tiles(d_pad, (nq + TILE_ROWS - 1) / TILE_ROWS);  // query tiles per wave
+    const int group_q = qt * TILE_ROWS;                                           // queries per scan workgroup
+    const int nqt = (nq + group_q - 1) / group_q;                                 // groups of qt query tiles
+    const int nq_pad = nqt * group_q;
     h->stats = sq_stats_t{};
     if (prof) {
         for (auto& e : h->ev)
@@ -218,13 +232,13 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         const int cus = cu_count(h->device);
         int nrb = g_opt.dense_blocks > 0 ? g_opt.dense_blocks : cus;
         nrb = (nrb + 7) / 8 * 8;
-        const int wv = scan_geometry(d_pad).waves;
+        const int wv = scan_geometry(d_pad, qt).waves;
         // survivors leave the scan as per-wave segments; the re-rank kernel turns them into per-query key lists
         const long long n_waves = (long long)nrb * nqt * wv;
         const u32 wave_cap = 2048;
         const int ldq = (d + 3) / 4 * 4;
         SQ_TRY(h->wave_out.reserve((size_t)n_waves * wave_cap * 8));
-        SQ_TRY(h->wave_cnt.reserve((size_t)n_waves * 4));
+        SQ_TRY(h->wave_cnt.reserve((size_t)n_waves * 8));
         SQ_TRY(h->q_al.reserve((size_t)nq * ldq * 4));
         u32* oflag = h->scratch.as<u32>() + 16;
         hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, q, nq, d, d_pad, h->metric, qs,
@@ -248,7 +262,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         a.n_sel = ns_tiles;
         a.nrb = nrb;
         if (ns_tiles < (long long)nrb * wv) a.nrb = (int)(((ns_tiles + wv - 1) / wv + 7) / 8 * 8);
-        SQ_TRY(scan_launch<true>(a, d_pad, st));
+        SQ_TRY(scan_launch<true>(a, d_pad, qt, st));
         hipLaunchKernelGGL(kth_threshold_f32_kernel, dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr);
         hipLaunchKernelGGL(dense_inflate_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, thr, qn2, nq, cosine ? 1 : 0,
                            h->xn2_max, eps_a, eps_b);
@@ -257,25 +271,25 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         a.n_sel = n_tiles;
         a.nrb = nrb;
         if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
-        SQ_TRY(scan_launch<false>(a, d_pad, st));
+        SQ_TRY(scan_launch<false>(a, d_pad, qt, st));
         if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
         h->stats.scan_launches = 2;
         h->stats.bytes_scanned = h->n_pad * ((long long)d_pad * 2 + (cosine ? 0 : 4));
         // exact re-rank of the survivors (wave segments -> per-query keys), select, certify
         const int wpb = 2;  // survivor segments per re-rank block (both from one scan workgroup: wv is even)
-        const size_t rr_lds = (size_t)32 * (ldq + 4) * 4;
+        const size_t rr_lds = qt == 1 ? (size_t)32 * (ldq + 4) * 4 : 0;  // the query tile in LDS (one-tile groups)
         const unsigned gxr = (unsigned)((n_waves + wpb - 1) / wpb);
         if (cosine) {
             hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3(gxr), dim3(256), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
-                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, h->keys.as<K128>(), cnt, cap,
-                               oflag);
+                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, h->keys.as<K128>(), cnt,
+                               cap, oflag);
             SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, cap, key_stride, k, nq, h->out_keys.as<K128>(), st));
             hipLaunchKernelGGL(dense_finalize_cos_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<K128>(), cnt, cap, k,
                                kk, h->id_base, thr, eps_a + eps_b, 1, (double*)out_dist, out_idx, status, oflag);
         } else {
             hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3(gxr), dim3(256), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
-                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, h->keys.as<u64>(), cnt, cap,
-                               oflag);
+                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, h->keys.as<u64>(), cnt,
+                               cap, oflag);
             SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, cap, key_stride, k, nq, h->out_keys.as<u64>(), st));
             hipLaunchKernelGGL(dense_finalize_l2_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<u64>(), cnt, cap, k,
                                kk, h->id_base, thr, qn2, h->xn2_max, eps_a, eps_b, 1, (float*)out_dist, out_idx, status,

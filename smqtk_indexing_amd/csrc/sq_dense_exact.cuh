@@ -202,79 +202,96 @@ struct SqLeafPair {
 };
 
 // Per block (= `waves_per_block` survivor segments of ONE scan workgroup, hence one
-// 32-query tile): (1) count the survivors per query in LDS and stage the tile's 32
-// query vectors in LDS, (2) reserve a range in every touched query's key list with
-// ONE global atomic per (block, query), (3) exact distance per survivor (L2: two
-// lanes per row; cosine: one lane per row), key stored at its reserved slot.
-// Dynamic LDS: 32 * (ldq + 4) floats.
+// group of `group_q` = 32, 64 or 128 queries).  A segment entry is (first row,
+// mask << 16 | query within the group): bit i of the mask is row first +
+// (i&3) + 8(i>>2) (the MFMA accumulator layout of one lane).  (1) count the
+// survivors per query in LDS, (2) reserve a range in every touched query's key
+// list with ONE global atomic per (block, query), (3) exact distance per
+// survivor (L2: two lanes per entry; cosine: one lane per entry; a lane walks
+// the bits of its entry), key stored at its reserved slot.  A one-tile group
+// stages its 32 query vectors in LDS (dynamic LDS: 32 * (ldq + 4) floats); larger
+// groups read the query rows through the cache.
+static constexpr int RERANK_MAX_GROUP = 128;
+
 template <class K, bool COSINE>
 __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long long ld, int d,
-                                             const float* __restrict__ q_al, int ldq, int nq,
+                                             const float* __restrict__ q_al, int ldq, int nq, int group_q,
                                              const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt,
                                              u32 wave_cap, long long n_waves, int waves_per_block,
                                              K* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
                                              u32* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) float s_qrows[];
-    __shared__ u32 s_hist[32], s_base[32], s_fill[32], s_qt;
+    __shared__ u32 s_hist[RERANK_MAX_GROUP], s_base[RERANK_MAX_GROUP], s_fill[RERANK_MAX_GROUP];
     const int ldl = ldq + 4;  // LDS row stride: +16 bytes so that different query rows hit different banks
+    const bool q_in_lds = group_q == 32;
     const long long w0 = (long long)blockIdx.x * waves_per_block;
-    if (threadIdx.x < 32) {
+    if (w0 >= n_waves) return;
+    const u32 q0 = wave_cnt[2 * w0 + 1] * 32u;  // first query of the group (the same for all segments of the block)
+    if (threadIdx.x < RERANK_MAX_GROUP) {
         s_hist[threadIdx.x] = 0;
         s_fill[threadIdx.x] = 0;
     }
-    if (threadIdx.x == 0) s_qt = 0xffffffffu;
     __syncthreads();
+    u32 total = 0;
     for (int wi = 0; wi < waves_per_block; ++wi) {
         const long long w = w0 + wi;
         if (w >= n_waves) break;
-        u32 c = wave_cnt[w];
+        u32 c = wave_cnt[2 * w];
         if (c > wave_cap) {
             if (threadIdx.x == 0) atomicOr(overflow, 1u);
             c = wave_cap;
         }
+        total += c;
         for (u32 e = threadIdx.x; e < c; e += blockDim.x) {
-            const u32 qy = wave_out[w * wave_cap + e].y;
-            atomicAdd(&s_hist[qy & 31u], 1u);
-            s_qt = qy >> 5;
+            const u32 ey = wave_out[w * wave_cap + e].y;
+            atomicAdd(&s_hist[ey & 0xffffu], (u32)__popc(ey >> 16));
+        }
+    }
+    if (total == 0) return;  // uniform: every thread read the same counts
+    __syncthreads();
+    if (threadIdx.x < group_q) {
+        const u32 hcount = s_hist[threadIdx.x];
+        s_base[threadIdx.x] = hcount ? atomicAdd(&cnt[q0 + threadIdx.x], hcount) : 0u;
+    }
+    if (q_in_lds) {
+        const int vpr = ldq / 4;  // 16-byte vectors per query row (ldq % 4 == 0, rows 16-byte aligned)
+        for (int i = threadIdx.x; i < 32 * vpr; i += blockDim.x) {
+            const int r = i / vpr, cc = i - r * vpr;
+            const long long qg = (long long)q0 + r;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (qg < nq) v = *reinterpret_cast<const f32x4*>(q_al + qg * ldq + 4 * cc);
+            *reinterpret_cast<f32x4*>(s_qrows + r * ldl + 4 * cc) = v;
         }
     }
     __syncthreads();
-    const u32 qt = s_qt;
-    if (qt == 0xffffffffu) return;
-    if (threadIdx.x < 32) {
-        const u32 hcount = s_hist[threadIdx.x];
-        s_base[threadIdx.x] = hcount ? atomicAdd(&cnt[qt * 32 + threadIdx.x], hcount) : 0u;
-    }
-    for (int i = threadIdx.x; i < 32 * ldq; i += blockDim.x) {
-        const int r = i / ldq, cc = i - r * ldq;
-        const long long qg = (long long)qt * 32 + r;
-        s_qrows[r * ldl + cc] = qg < nq ? q_al[qg * ldq + cc] : 0.f;
-    }
-    __syncthreads();
-    constexpr int LPR = COSINE ? 1 : 2;  // lanes per row
+    constexpr int LPR = COSINE ? 1 : 2;  // lanes per entry
     const int sub = threadIdx.x % LPR;
     for (int wi = 0; wi < waves_per_block; ++wi) {
         const long long w = w0 + wi;
         if (w >= n_waves) break;
-        u32 c = wave_cnt[w];
+        u32 c = wave_cnt[2 * w];
         c = c > wave_cap ? wave_cap : c;
-        const u32 c_round = (c + 63u) & ~63u;  // keep lane pairs converged for the shuffle
-        for (u32 e = threadIdx.x / LPR; e < c_round; e += blockDim.x / LPR) {
-            const bool live = e < c;
-            const uint2 ent = wave_out[w * wave_cap + (live ? e : 0u)];
-            const u32 ql = ent.y & 31u;
-            if constexpr (COSINE) {
-                if (live) {
-                    const double dist = cosine_row_f64(db + (long long)ent.x * ld, s_qrows + ql * ldl, d);
+        for (u32 e = threadIdx.x / LPR; e < c; e += blockDim.x / LPR) {
+            const uint2 ent = wave_out[w * wave_cap + e];
+            const u32 ql = ent.y & 0xffffu;
+            const u32 qg = q0 + ql;
+            const float* qrow = q_in_lds ? s_qrows + ql * ldl : q_al + (long long)qg * ldq;
+            u32 mask = ent.y >> 16;  // both lanes of a pair hold the same entry: they stay converged
+            while (mask) {
+                const int i = __ffs((int)mask) - 1;
+                mask &= mask - 1;
+                const u32 row = ent.x + (u32)((i & 3) + 8 * (i >> 2));
+                if constexpr (COSINE) {
+                    const double dist = cosine_row_f64(db + (long long)row * ld, qrow, d);
                     const u32 pos = s_base[ql] + atomicAdd(&s_fill[ql], 1u);
-                    if (pos < cap) keys[(long long)ent.y * cap + pos] = K128{ordered_f64(dist), (u64)ent.x};
-                }
-            } else {
-                const SqLeafPair pr{db + (long long)ent.x * ld, s_qrows + ql * ldl, sub};
-                const float dist = sqrt_rn_f32(pr.sum(d));
-                if (live && sub == 0) {
-                    const u32 pos = s_base[ql] + atomicAdd(&s_fill[ql], 1u);
-                    if (pos < cap) keys[(long long)ent.y * cap + pos] = ((u64)ordered_f32(dist) << 32) | (u64)ent.x;
+                    if (pos < cap) keys[(long long)qg * cap + pos] = K128{ordered_f64(dist), (u64)row};
+                } else {
+                    const SqLeafPair pr{db + (long long)row * ld, qrow, sub};
+                    const float dist = sqrt_rn_f32(pr.sum(d));
+                    if (sub == 0) {
+                        const u32 pos = s_base[ql] + atomicAdd(&s_fill[ql], 1u);
+                        if (pos < cap) keys[(long long)qg * cap + pos] = ((u64)ordered_f32(dist) << 32) | (u64)row;
+                    }
                 }
             }
         }
@@ -286,23 +303,23 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
 // the per-query counters live here, outside the streaming kernel.  A wave that
 // overflowed its segment raises `overflow` (every query of the call then takes
 // the exact path; only degenerate thresholds get there).
-// q_al: queries copied to [nq][ldq] floats, ldq % 4 == 0, 16-byte aligned.
+// q_al: queries copied to [nq_pad][ldq] floats, ldq % 4 == 0, 16-byte aligned.
 static __global__ __launch_bounds__(256) void dense_rerank_l2_kernel(
     const float* __restrict__ db, long long ld, int d, const float* __restrict__ q_al, int ldq,
     const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt, u32 wave_cap, long long n_waves,
-    int waves_per_block, int nq, u64* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
+    int waves_per_block, int nq, int group_q, u64* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
     u32* __restrict__ overflow) {
-    rerank_block<u64, false>(db, ld, d, q_al, ldq, nq, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block, keys,
-                             cnt, cap, overflow);
+    rerank_block<u64, false>(db, ld, d, q_al, ldq, nq, group_q, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block,
+                             keys, cnt, cap, overflow);
 }
 
 static __global__ __launch_bounds__(256) void dense_rerank_cos_kernel(
     const float* __restrict__ db, long long ld, int d, const float* __restrict__ q_al, int ldq,
     const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt, u32 wave_cap, long long n_waves,
-    int waves_per_block, int nq, K128* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
+    int waves_per_block, int nq, int group_q, K128* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
     u32* __restrict__ overflow) {
-    rerank_block<K128, true>(db, ld, d, q_al, ldq, nq, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block, keys,
-                             cnt, cap, overflow);
+    rerank_block<K128, true>(db, ld, d, q_al, ldq, nq, group_q, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block,
+                             keys, cnt, cap, overflow);
 }
 
 // Copy queries into the aligned, padded layout the lane-per-row kernels read.

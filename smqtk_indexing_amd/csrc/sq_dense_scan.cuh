@@ -169,14 +169,14 @@ struct DenseScanArgs {
     long long n_tiles;      // ceil(n / 32)
     const uint4* qs;        // [nqt*32][d_pad/4] prepared queries
     const float* thr;       // [nqt*32] score thresholds (EMIT)
-    uint2* wave_out;        // [waves of the launch][wave_cap] survivors (row, query), one segment per wave
-    u32* wave_cnt;          // [waves of the launch] survivors each wave found (may exceed wave_cap: overflow)
+    uint2* wave_out;        // [waves of the launch][wave_cap] survivor entries (first row, mask<<16 | query), one segment per wave
+    u32* wave_cnt;          // [waves of the launch][2] entries each wave wrote (may exceed wave_cap: overflow), first query tile
     u32 wave_cap;
     float* sample_out;      // [nqt*32][ns] (SAMPLE)
     long long ns;
     long long tile_step;    // SAMPLE: every tile_step-th tile; EMIT: 1
     long long n_sel;        // number of tiles this launch visits
-    int nqt;                // query tiles
+    int nqt;                // groups of QT query tiles (QT = template parameter of the launch)
     int nrb;                // row blocks (multiple of 8 when nqt > 1)
     int debug;              // measurement only: 1 = skip LDS reads + MFMA, 2 = stop the DMA after the first ring fill
 };
@@ -242,13 +242,80 @@ __device__ __forceinline__ void wait_units_in_flight(int units) {
 
 typedef __attribute__((address_space(3))) u32 lds_u32;
 
+// ---- hand-placed MFMA for the multi-tile (QT > 1) configuration.
+// With QT*64 registers of query fragments a wave needs more than the 256
+// architectural VGPRs; hipcc then parks the fragments in AGPRs and copies each one
+// back (4 v_accvgpr_read + s_nop per MFMA, ~60% of the loop's issue slots).  The
+// matrix core reads its B operand from an AGPR directly, so the QT > 1 path loads
+// the fragments into AGPRs itself (ds_read_b128 with an AGPR destination) and
+// issues the MFMAs from inline asm with the B operand constrained to "a".
+// hipcc does not pad hazards of instructions inside asm strings
+// (cdna_hip_programming.md 5.7 item 2); the pads are explicit:
+//   mfma_fence_in : VALU write of A / C registers -> MFMA read (2 states)
+//   mfma_fence_out: MFMA result -> any non-MFMA reader, and A registers ->
+//                   overwritten (8-pass MFMA: 12 states; 16 given)
+__device__ __forceinline__ void mfma_bf16_agpr_b(f32x16& acc, const f32x4& a_v, const f32x4& b_a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_v), "a"(b_a));
+}
+// first MFMA of a chain: D = A*B + C with C a different register block (the tile's norms)
+__device__ __forceinline__ void mfma_bf16_agpr_b_first(f32x16& acc, const f32x4& a_v, const f32x4& b_a, const f32x16& c_v) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a_v), "a"(b_a), "v"(c_v));
+}
+template <int QT>
+__device__ __forceinline__ void mfma_fence_in(f32x16 (&acc)[QT], f32x4 (&av)[8]) {
+    // every A / C register is written before this point and the pad follows the last write
+    if constexpr (QT == 4)
+        asm volatile("s_nop 1"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(av[0]), "+v"(av[1]), "+v"(av[2]),
+                       "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]));
+    else if constexpr (QT == 2)
+        asm volatile("s_nop 1"
+                     : "+v"(acc[0]), "+v"(acc[1]), "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]),
+                       "+v"(av[5]), "+v"(av[6]), "+v"(av[7]));
+}
+// the same pad for the norm block (C of every chain's first MFMA) and the A fragments
+__device__ __forceinline__ void mfma_fence_in_c(f32x16& c, f32x4 (&av)[8]) {
+    asm volatile("s_nop 1"
+                 : "+v"(c), "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]),
+                   "+v"(av[7]));
+}
+template <int QT>
+__device__ __forceinline__ void mfma_fence_out(f32x16 (&acc)[QT]) {
+    if constexpr (QT == 4)
+        asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    else if constexpr (QT == 2)
+        asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+}
+// eight 16-byte LDS reads straight into AGPRs, complete on return
+__device__ __forceinline__ void lds_read8_agpr(f32x4 (&dst)[16], int g0, const u32 (&ad)[8]) {
+    asm volatile(
+        "ds_read_b128 %0, %8\n\t"
+        "ds_read_b128 %1, %9\n\t"
+        "ds_read_b128 %2, %10\n\t"
+        "ds_read_b128 %3, %11\n\t"
+        "ds_read_b128 %4, %12\n\t"
+        "ds_read_b128 %5, %13\n\t"
+        "ds_read_b128 %6, %14\n\t"
+        "ds_read_b128 %7, %15\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&a"(dst[g0 + 0]), "=&a"(dst[g0 + 1]), "=&a"(dst[g0 + 2]), "=&a"(dst[g0 + 3]), "=&a"(dst[g0 + 4]),
+          "=&a"(dst[g0 + 5]), "=&a"(dst[g0 + 6]), "=&a"(dst[g0 + 7])
+        : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
+        : "memory");
+}
+
 // WAVES: waves per workgroup (one workgroup per CU; 8 = two waves per SIMD, so
 // one wave's DMA issue / epilogue runs under the other's MFMAs); NSTAGE: ring
-// depth per wave; KU = d_pad/128 units per row tile; SAMPLE: write per-lane
-// minima of every visited tile instead of emitting candidates.
-template <int WAVES, int NSTAGE, int KU, bool SAMPLE>
+// depth per wave; KU = d_pad/128 units per row tile; QT: 32-query tiles a wave
+// scores against every row tile it streams (the A fragments are read from LDS
+// once and reused QT times, so a large batch re-reads the matrix from L2 QT
+// times less often; QT > 1 keeps QT*64 registers of query fragments and runs
+// four waves per CU); SAMPLE: write per-lane minima of every visited tile
+// instead of emitting candidates.
+template <int WAVES, int NSTAGE, int KU, int QT, bool SAMPLE>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(DenseScanArgs a) {
     constexpr bool QREG = KU <= 1;  // query fragments live in registers for d_pad <= 128
+    static_assert(QT == 1 || QREG, "several query tiles per wave need the register-resident query fragments");
     constexpr int DPAD = KU * KT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -259,20 +326,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     const u32 lds_base = (u32)(uintptr_t)smem;  // low 32 bits of a flat LDS address = LDS offset
     const u32 ring_base = lds_base + q_bytes + (u32)wave * (NSTAGE * SLOT_BYTES);
     unsigned char* ring_ptr = smem + q_bytes + wave * (NSTAGE * SLOT_BYTES);
-    unsigned char* etop = smem + q_bytes + WAVES * NSTAGE * SLOT_BYTES;
-    lds_u32* ecnt_ptr = (lds_u32*)(etop + wave * 16);
     const long long wave_id = (long long)blockIdx.x * WAVES + wave;  // unique per wave of the launch
     uint2* wout = a.wave_out + wave_id * a.wave_cap;
     const bool add_norm = a.norms != nullptr;
     const bool nine = add_norm && KU == 1;  // DMA instructions per unit: 9 when each unit carries its norms
 
-    // block -> (row block, query tile); blocks that share an XCD (same id mod 8)
-    // walk the query tiles of the same rows so the matrix is re-read from L2.
+    // block -> (row block, group of QT query tiles); blocks that share an XCD (same id mod 8)
+    // walk the query groups of the same rows so the matrix is re-read from L2.
     const int L = blockIdx.x;
-    int qt, rb;
+    int qt, rb;  // qt: first query tile of this block's group
     if (a.nqt > 1) {
         const int xcd = L & 7, j = L >> 3;
-        qt = j % a.nqt;
+        qt = (j % a.nqt) * QT;
         rb = (j / a.nqt) * 8 + xcd;
     } else {
         qt = 0;
@@ -284,13 +349,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     {
         const uint4* qsrc = a.qs + (long long)qt * TILE_ROWS * (DPAD / 4);
         constexpr int cpr = DPAD / 4;
-        for (int c = threadIdx.x; c < TILE_ROWS * cpr; c += WAVES * 64) {
+        for (int c = threadIdx.x; c < QT * TILE_ROWS * cpr; c += WAVES * 64) {
             const int r = c / cpr, ch = c - r * cpr;
             const uint4 v = qsrc[c];
             const int sw = (ch & ~15) | ((ch & 15) ^ (r & 15));
             *reinterpret_cast<uint4*>(smem + (u32)r * DPAD * 4 + sw * 16) = v;
         }
-        if (lane == 0) *ecnt_ptr = 0u;
     }
     __syncthreads();
 
@@ -302,24 +366,53 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     const long long total_units = my_tiles * KU;
 
     const int r31 = lane & 31, h = lane >> 5;
-    const int qglob = qt * TILE_ROWS + r31;
-    float thr_l = SAMPLE ? 0.f : a.thr[qglob];
-    // Force hipcc's wait for this load HERE.  Left to its first use inside the
-    // loop the compiler emits s_waitcnt vmcnt(0) there (it cannot see the asm
-    // LDS-DMAs), draining the whole ring once per tile.
-    if (a.debug & 4) thr_l = -__builtin_inff();  // ablation: nothing is emitted
-    asm volatile("" : "+v"(thr_l));
+    const int qglob0 = qt * TILE_ROWS + r31;  // this lane's query in tile t of the group: qglob0 + 32 t
+    float thr_l[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        thr_l[t] = SAMPLE ? 0.f : a.thr[qglob0 + t * TILE_ROWS];
+        // Force hipcc's wait for this load HERE.  Left to its first use inside the
+        // loop the compiler emits s_waitcnt vmcnt(0) there (it cannot see the asm
+        // LDS-DMAs), draining the whole ring once per tile.
+        if (a.debug & 4) thr_l[t] = -__builtin_inff();  // ablation: nothing is emitted
+        asm volatile("" : "+v"(thr_l[t]));
+    }
 
-    // B fragments of k-step s: chunk 2s+h of the hi plane (bq[.][2s]) and of the lo plane (bq[.][2s+1])
-    f32x4 bq[QREG ? KU : 1][16];
+    // B fragments of k-step s: chunk 2s+h of the hi plane (bq[.][2s]) and of the lo plane (bq[.][2s+1]);
+    // with QREG (KU == 1) one set per query tile of the group
+    f32x4 bq[QT][16];
     if constexpr (QREG) {
 #pragma unroll
-        for (int kc = 0; kc < KU; ++kc)
+        for (int t = 0; t < QT; ++t) {
+            const u32 rowb = (u32)(t * TILE_ROWS + r31) * DPAD * 4;
+            if constexpr (QT > 1) {  // into AGPRs (see mfma_bf16_agpr_b)
 #pragma unroll
-            for (int g = 0; g < 16; ++g)
-                bq[kc][g] = *reinterpret_cast<const f32x4*>(smem + (u32)r31 * DPAD * 4 + kc * 512 + (g & 1) * 256 +
-                                                             ((2 * (g >> 1) + h) ^ (r31 & 15)) * 16);
+                for (int g0 = 0; g0 < 16; g0 += 8) {
+                    u32 ad[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int g = g0 + j;
+                        ad[j] = lds_base + rowb + (g & 1) * 256 + ((2 * (g >> 1) + h) ^ (r31 & 15)) * 16;
+                    }
+                    lds_read8_agpr(bq[t], g0, ad);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    bq[t][g] = *reinterpret_cast<const f32x4*>(smem + rowb + (g & 1) * 256 +
+                                                                ((2 * (g >> 1) + h) ^ (r31 & 15)) * 16);
+            }
+        }
         __syncthreads();  // every wave holds its fragments before the DMA ring overwrites the staging area
+    }
+
+    u32 wcount = 0;  // survivor entries of this wave so far (wave-uniform)
+    // rows of the last, partial tile that exist (bit i <-> accumulator register i of this lane)
+    u32 tail_mask = 0;
+    {
+        const int nvalid = (int)(a.n - (a.n_tiles - 1) * TILE_ROWS);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tail_mask |= ((i & 3) + 8 * (i >> 2) + 4 * h < nvalid ? 1u : 0u) << i;
     }
 
     // per-lane byte offsets of the 8 DMA instructions of a unit (row 4j + lane/16, swizzled chunk)
@@ -364,7 +457,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 ++issued;
         }
     };
-    f32x4 av_cur[8], av_nxt[8], nrm_cur[4], nrm_nxt[4];
+    f32x4 av_cur[8], av_nxt[8], nrm_nxt[4];
     auto read_frags = [&](int slot_idx, bool first_of_tile) {
         const unsigned char* sl = ring_ptr + slot_idx * SLOT_BYTES;
         const unsigned char* arow = sl + r31 * 256;
@@ -395,103 +488,156 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         rd_kc = KU > 1 ? 1 : 0;
     }
     for (long long sel = gw; sel < a.n_sel; sel += nwaves) {
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int kc = 0; kc < KU; ++kc) {
-            // fragments of this unit are complete once copied (hipcc waits lgkmcnt here); its slot is free
+        f32x16 acc[QT];
+        if constexpr (QT > 1) {
+            // ---- KU == 1: one unit per tile.  One wave per SIMD: nothing else hides this wave's side
+            // work, so it is placed by hand into the issue gaps of the 16*QT MFMAs (an MFMA holds the
+            // vector issue for 8 of its 32 cycles): LDS reads of the next unit after k-step 0, the nine
+            // DMA instructions that refill this unit's slot after k-steps 1..7.
 #pragma unroll
             for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];
-            if (kc == 0) {
+            f32x16 nrm_c;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) nrm_cur[c] = nrm_nxt[c];
-            }
+            for (int i = 0; i < 16; ++i) nrm_c[i] = add_norm ? nrm_nxt[i >> 2][i & 3] : 0.f;
             asm volatile("" ::: "memory");
-            issue_next();
-            if (loaded < total_units) {
-                if (nine)  // younger units may stay in flight
-                    wait_units_in_flight<NSTAGE, 9>((int)(issued - loaded - 1));
-                else
-                    wait_units_in_flight<NSTAGE, 8>((int)(issued - loaded - 1));
-                if (do_math) read_frags(rd_slot, rd_kc == 0);
-                ++loaded;
-                if (++rd_slot == NSTAGE) rd_slot = 0;
-                if (++rd_kc == KU) rd_kc = 0;
-            }
-            if (do_math) {
+            const bool rd = loaded < total_units;
+            const bool iss_any = issued < total_units;
+            const bool iss = iss_any && (do_dma || issued < NSTAGE);  // ablation: the ring is filled once, then reused
+            const int units_behind = (int)(issued - loaded - 1);      // younger units that may stay in flight
+            const long long irow0 = iss_sel * a.tile_step * TILE_ROWS;
+            const u32 idst = ring_base + (u32)iss_slot * SLOT_BYTES;
+            const unsigned char* ibase = reinterpret_cast<const unsigned char*>(a.scan) + irow0 * (DPAD * 2);
+            if (do_math) mfma_fence_in_c(nrm_c, av_cur);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    f32x4 bh, bl;
-                    if constexpr (QREG) {
-                        bh = bq[kc][2 * s];
-                        bl = bq[kc][2 * s + 1];
+            for (int s = 0; s < 8; ++s) {
+                if (do_math) {
+                    if (s == 0) {
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) mfma_bf16_agpr_b_first(acc[t], av_cur[0], bq[t][1], nrm_c);
                     } else {
-                        const unsigned char* brow = smem + (u32)r31 * DPAD * 4 + kc * 512 + ((2 * s + h) ^ (r31 & 15)) * 16;
-                        bh = *reinterpret_cast<const f32x4*>(brow);
-                        bl = *reinterpret_cast<const f32x4*>(brow + 256);
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) mfma_bf16_agpr_b(acc[t], av_cur[s], bq[t][2 * s + 1]);
                     }
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, av_cur[s]);
-                    const bf16x8 bhv = __builtin_bit_cast(bf16x8, bh);
-                    const bf16x8 blv = __builtin_bit_cast(bf16x8, bl);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blv, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhv, acc, 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) mfma_bf16_agpr_b(acc[t], av_cur[s], bq[t][2 * s]);
+                }
+                if (s == 0) {
+                    if (rd) {
+                        if (nine)
+                            wait_units_in_flight<NSTAGE, 9>(units_behind);
+                        else
+                            wait_units_in_flight<NSTAGE, 8>(units_behind);
+                        if (do_math) read_frags(rd_slot, true);
+                        ++loaded;
+                        if (++rd_slot == NSTAGE) rd_slot = 0;
+                    }
+                } else if (iss) {
+                    glds16(ibase, voff[s - 1], idst + (u32)(s - 1) * 1024);
+                    if (s == 7) {
+                        glds16(ibase, voff[7], idst + 7u * 1024);
+                        if (add_norm) glds4(a.norms + irow0, voff_norm, idst + UNIT_BYTES);
+                    }
+                }
+            }
+            if (iss_any) {
+                ++issued;
+                iss_sel += nwaves;
+                if (++iss_slot == NSTAGE) iss_slot = 0;
+            }
+            if (do_math) mfma_fence_out<QT>(acc);
+        } else {
+#pragma unroll
+            for (int kc = 0; kc < KU; ++kc) {
+                // fragments of this unit are complete once copied (hipcc waits lgkmcnt here); its slot is free
+#pragma unroll
+                for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];
+                if (kc == 0) {
+                    // the accumulator starts from |x|^2 of the tile's rows (0 for cosine): score = |x|^2 + x.q'
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[0][i] = add_norm ? nrm_nxt[i >> 2][i & 3] : 0.f;
+                }
+                asm volatile("" ::: "memory");
+                issue_next();
+                if (loaded < total_units) {
+                    if (nine)  // younger units may stay in flight
+                        wait_units_in_flight<NSTAGE, 9>((int)(issued - loaded - 1));
+                    else
+                        wait_units_in_flight<NSTAGE, 8>((int)(issued - loaded - 1));
+                    if (do_math) read_frags(rd_slot, rd_kc == 0);
+                    ++loaded;
+                    if (++rd_slot == NSTAGE) rd_slot = 0;
+                    if (++rd_kc == KU) rd_kc = 0;
+                }
+                if (do_math) {
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, av_cur[s]);
+                        f32x4 bh, bl;
+                        if constexpr (QREG) {
+                            bh = bq[0][2 * s];
+                            bl = bq[0][2 * s + 1];
+                        } else {
+                            const unsigned char* brow = smem + (u32)r31 * DPAD * 4 + kc * 512 + ((2 * s + h) ^ (r31 & 15)) * 16;
+                            bh = *reinterpret_cast<const f32x4*>(brow);
+                            bl = *reinterpret_cast<const f32x4*>(brow + 256);
+                        }
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bl), acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bh), acc[0], 0, 0, 0);
+                    }
                 }
             }
         }
         if (!do_math) continue;
-        // ---- tile complete: scores for 32 rows x 32 queries (lane = query, register i = row (i&3)+8(i>>2)+4h)
-        if (add_norm) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] += nrm_cur[i >> 2][i & 3];
-        }
+        // ---- tile complete: scores for 32 rows x QT*32 queries (lane = query, register i = row (i&3)+8(i>>2)+4h)
         const long long row0 = sel * a.tile_step * TILE_ROWS;
-        if constexpr (!SAMPLE) {
-            float m = acc[0];
+        const bool is_tail = row0 + TILE_ROWS > a.n;  // wave-uniform: the last, partial tile
 #pragma unroll
-            for (int i = 1; i < 16; ++i) m = fminf(m, acc[i]);
-            if (__any(m <= thr_l)) {
-                if (m <= thr_l) {
-                    // branch-free survivor mask of this lane's 16 rows, one LDS atomic for all of them
+        for (int t = 0; t < QT; ++t) {
+            const int qglob = qglob0 + t * TILE_ROWS;
+            if constexpr (!SAMPLE) {
+                float m = acc[t][0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) m = fminf(m, acc[t][i]);
+                if (__any(m <= thr_l[t])) {
+                    // survivor mask of this lane's 16 rows (bit i <-> row row0 + (i&3) + 8(i>>2) + 4h)
                     u32 mask = 0;
+                    if (m <= thr_l[t]) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) mask |= (acc[i] <= thr_l ? 1u : 0u) << i;
-                    if (row0 + TILE_ROWS > a.n) {  // the last, partial tile: drop padding rows
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            if (row0 + (i & 3) + 8 * (i >> 2) + 4 * h >= a.n) mask &= ~(1u << i);
+                        for (int i = 0; i < 16; ++i) mask |= (acc[t][i] <= thr_l[t] ? 1u : 0u) << i;
+                        if (is_tail) mask &= tail_mask;  // drop padding rows
+                        if (a.debug & 16) mask = 0;      // ablation: survivors found but not recorded
                     }
-                    if (a.debug & 16) mask = 0;  // ablation: survivors found but not recorded
+                    // One entry per lane that has survivors: (row0 + 4h, mask << 16 | query within the group),
+                    // appended to this wave's own segment with a plain store.  The position comes from a
+                    // ballot (no atomic, nothing the streaming loop waits for); the re-rank expands the masks.
+                    const u64 bal = __ballot(mask != 0);
                     if (mask) {
-                        // survivors go to this wave's own segment with plain stores: nothing in the
-                        // streaming loop waits on a returning global atomic (that drained the DMA ring)
-                        u32 pos = __hip_atomic_fetch_add(ecnt_ptr, (u32)__popc(mask), __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
-                        while (mask) {
-                            const int i = __ffs((int)mask) - 1;
-                            mask &= mask - 1;
-                            const u32 row = (u32)(row0 + (i & 3) + 8 * (i >> 2) + 4 * h);
-                            if (pos < a.wave_cap) wout[pos] = make_uint2(row, (u32)qglob);
-                            ++pos;
-                        }
+                        const u32 pos = wcount + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                        if (pos < a.wave_cap) wout[pos] = make_uint2((u32)(row0 + 4 * h), (mask << 16) | (u32)(t * TILE_ROWS + r31));
                     }
+                    wcount += (u32)__popcll(bal);
                 }
-            }
-        } else {
-            // the minimum score of this lane's 16 rows: the score of one actual row, hence a valid
-            // sample for an upper bound of the k-th smallest score (kth_threshold_f32_kernel)
-            float ml = __builtin_inff();
+            } else {
+                // the minimum score of this lane's 16 rows: the score of one actual row, hence a valid
+                // sample for an upper bound of the k-th smallest score (kth_threshold_f32_kernel)
+                float ml = __builtin_inff();
+                if (is_tail) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int ro = (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (row0 + ro < a.n) ml = fminf(ml, acc[i]);
+                    for (int i = 0; i < 16; ++i)
+                        if ((tail_mask >> i) & 1u) ml = fminf(ml, acc[t][i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) ml = fminf(ml, acc[t][i]);
+                }
+                a.sample_out[(long long)qglob * a.ns + sel * 2 + h] = ml;
             }
-            a.sample_out[(long long)qglob * a.ns + sel * 2 + h] = ml;
         }
     }
     if constexpr (!SAMPLE) {
-        const u32 c = __builtin_amdgcn_readfirstlane(*ecnt_ptr);
-        if (lane == 0) a.wave_cnt[wave_id] = c;
+        if (lane == 0) {
+            a.wave_cnt[2 * wave_id] = wcount;        // entries written (beyond wave_cap: overflow)
+            a.wave_cnt[2 * wave_id + 1] = (u32)qt;   // first query tile of this wave's group
+        }
     }
 }
 

@@ -161,6 +161,25 @@ def test_dense_scan_path_l2(n, d, nq, k, stages):
     assert st["candidates"] >= nq * k
 
 
+@pytest.mark.parametrize("metric,nq,qt", [("euclidean", 130, 0), ("euclidean", 97, 2), ("euclidean", 65, 1),
+                                          ("cosine", 70, 0), ("cosine", 33, 4)])
+def test_dense_scan_query_tiles_per_wave(metric, nq, qt):
+    """Batches of several 32-query tiles: 2 or 4 query tiles per scan wave (padded
+    groups, survivors of several tiles in one segment, group-wide re-rank)."""
+    rng = np.random.default_rng(1000 + nq)
+    db = rng.standard_normal((150_000, 128)).astype(np.float32)
+    qs = rng.standard_normal((nq, 128)).astype(np.float32)
+    qs[nq - 1] = db[4242]
+    _lib.set_option("dense_qt", qt)
+    try:
+        idx = _dense_check(db, qs, 20, metric)
+    finally:
+        _lib.set_option("dense_qt", 0)
+    st = idx.stats()
+    assert st["fallback_queries"] == 0, st
+    assert st["candidates"] >= nq * 20
+
+
 def test_dense_scan_path_cosine():
     rng = np.random.default_rng(99)
     db = rng.random((150_000, 128)).astype(np.float32)

@@ -25,18 +25,13 @@ def main():
             s = idx.stats(); ms.append(s["scan_ms"]); tot.append(s["total_ms"])
         for kk in opts: _lib.set_option(kk, 0)
         return float(np.median(ms[1:])), float(np.median(tot[1:])), s["fallback_queries"]
-    bpr = (-(-d // 128) * 256 + 4)
-    for nq in (32,):
-        for name, opts in [("default", {}), ("dma_only", {"dense_debug": 1}), ("no_emit", {"dense_debug": 4}),
-                           ("w4", {"dense_waves": 4}), ("w4_s4", {"dense_waves": 4, "dense_stages": 4}),
-                           ("stride8", {"sample_stride": 8}), ("stride32", {"sample_stride": 32}),
-                           ("stride64", {"sample_stride": 64}), ("blocks512", {"dense_blocks": 512})]:
-            sm, tm, fb = run(nq, **opts)
-            c = idx.stats()["candidates"] / nq
-            print(f"nq={nq:5d} {name:12s} scan_ms={sm:8.4f} total_ms={tm:8.4f} scan_GBps={n * bpr / sm / 1e6 if sm else 0:9.1f} cand/q={c:8.0f} fb={fb}", flush=True)
-    for nq in (1, 64, 128, 256, 1024):
-        sm, tm, fb = run(nq, reps=3)
-        print(f"nq={nq:5d} default      scan_ms={sm:8.4f} total_ms={tm:8.4f} fb={fb}", flush=True)
+    for qt in (4,):
+        for name, dbg in (("full", 0), ("dma_only", 1), ("no_dma", 2), ("no_emit", 4)):
+            sm, tm, fb = run(256, reps=3, dense_qt=qt, dense_debug=dbg)
+            print(f"nq=  256 qt={qt} {name:9s} scan_ms={sm:8.4f} total_ms={tm:8.4f} fb={fb}", flush=True)
+
+def qt_sweep():
+    pass
 
 if __name__ == "__main__":
     main()
