@@ -23,6 +23,8 @@
 // section 3, bf16 operand maps).  A prepared query row is KU units of 512
 // bytes: the 16 chunks of the hi plane, then the 16 chunks of the lo plane.
 #pragma once
+#include <type_traits>
+
 #include "sq_common.hpp"
 
 namespace sq {
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     //   the fragments of unit u+1 are read from LDS (av_nxt) under those MFMAs;
     //   the slot of unit u is refilled by the DMA of unit u+NSTAGE as soon as
     //   av_cur is complete.
-    const bool do_dma = !(a.debug & 2), do_math = !(a.debug & 1);
+    const bool do_dma = QT > 1 || !(a.debug & 2), do_math = QT > 1 || !(a.debug & 1);
     auto issue_next = [&]() {
         if (issued < total_units) {
             if (do_dma || issued < NSTAGE)  // ablation: the ring is filled once, then reused
@@ -491,60 +493,74 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         f32x16 acc[QT];
         if constexpr (QT > 1) {
             // ---- KU == 1: one unit per tile.  One wave per SIMD: nothing else hides this wave's side
-            // work, so it is placed by hand into the issue gaps of the 16*QT MFMAs (an MFMA holds the
-            // vector issue for 8 of its 32 cycles): LDS reads of the next unit after k-step 0, the nine
-            // DMA instructions that refill this unit's slot after k-steps 1..7.
+            // work, so it sits in the issue shadow of the 16*QT MFMAs (an MFMA holds the vector issue for
+            // 8 of its 32 cycles): the LDS reads of the next unit's fragments behind the first MFMAs, one
+            // of the nine DMA instructions that refill this unit's slot behind every few MFMAs after
+            // that.  The body is specialised on (refill?, read ahead?) so the block is free of branches;
+            // the measurement-only ablations (debug 1 / 2) are not available in this configuration.
+            auto unit = [&](auto iss_c, auto rd_c) {
+                constexpr bool ISS = decltype(iss_c)::value, RD = decltype(rd_c)::value;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];
-            f32x16 nrm_c;
+                for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];
+                f32x16 nrm_c;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) nrm_c[i] = add_norm ? nrm_nxt[i >> 2][i & 3] : 0.f;
-            asm volatile("" ::: "memory");
-            const bool rd = loaded < total_units;
-            const bool iss_any = issued < total_units;
-            const bool iss = iss_any && (do_dma || issued < NSTAGE);  // ablation: the ring is filled once, then reused
-            const int units_behind = (int)(issued - loaded - 1);      // younger units that may stay in flight
-            const long long irow0 = iss_sel * a.tile_step * TILE_ROWS;
-            const u32 idst = ring_base + (u32)iss_slot * SLOT_BYTES;
-            const unsigned char* ibase = reinterpret_cast<const unsigned char*>(a.scan) + irow0 * (DPAD * 2);
-            if (do_math) mfma_fence_in_c(nrm_c, av_cur);
+                for (int i = 0; i < 16; ++i) nrm_c[i] = add_norm ? nrm_nxt[i >> 2][i & 3] : 0.f;
+                asm volatile("" ::: "memory");
+                const int units_behind = (int)(issued - loaded - 1);  // younger units that may stay in flight
+                const long long irow0 = iss_sel * a.tile_step * TILE_ROWS;
+                const u32 idst = ring_base + (u32)iss_slot * SLOT_BYTES;
+                const unsigned char* ibase = reinterpret_cast<const unsigned char*>(a.scan) + irow0 * (DPAD * 2);
+                mfma_fence_in_c(nrm_c, av_cur);
+                constexpr int NSLOT = 16 * QT;                 // one slot behind every MFMA
+                constexpr int DMA0 = 6, DSTEP = (NSLOT - DMA0 - 1) / 9;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (do_math) {
-                    if (s == 0) {
+                for (int s = 0; s < 8; ++s) {
 #pragma unroll
-                        for (int t = 0; t < QT; ++t) mfma_bf16_agpr_b_first(acc[t], av_cur[0], bq[t][1], nrm_c);
-                    } else {
+                    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                        for (int t = 0; t < QT; ++t) mfma_bf16_agpr_b(acc[t], av_cur[s], bq[t][2 * s + 1]);
+                        for (int t = 0; t < QT; ++t) {
+                            if (s == 0 && half == 0)
+                                mfma_bf16_agpr_b_first(acc[t], av_cur[0], bq[t][1], nrm_c);
+                            else
+                                mfma_bf16_agpr_b(acc[t], av_cur[s], bq[t][2 * s + 1 - half]);
+                            const int slot = (s * 2 + half) * QT + t;
+                            if constexpr (RD) {
+                                if (slot == 1) {
+                                    if (nine)
+                                        wait_units_in_flight<NSTAGE, 9>(units_behind);
+                                    else
+                                        wait_units_in_flight<NSTAGE, 8>(units_behind);
+                                    read_frags(rd_slot, true);
+                                }
+                            }
+                            if constexpr (ISS) {
+                                if (slot >= DMA0 && (slot - DMA0) % DSTEP == 0) {
+                                    const int j = (slot - DMA0) / DSTEP;
+                                    if (j < 8) glds16(ibase, voff[j], idst + (u32)j * 1024);
+                                    if (j == 8 && add_norm) glds4(a.norms + irow0, voff_norm, idst + UNIT_BYTES);
+                                }
+                            }
+                        }
                     }
-#pragma unroll
-                    for (int t = 0; t < QT; ++t) mfma_bf16_agpr_b(acc[t], av_cur[s], bq[t][2 * s]);
                 }
-                if (s == 0) {
-                    if (rd) {
-                        if (nine)
-                            wait_units_in_flight<NSTAGE, 9>(units_behind);
-                        else
-                            wait_units_in_flight<NSTAGE, 8>(units_behind);
-                        if (do_math) read_frags(rd_slot, true);
-                        ++loaded;
-                        if (++rd_slot == NSTAGE) rd_slot = 0;
-                    }
-                } else if (iss) {
-                    glds16(ibase, voff[s - 1], idst + (u32)(s - 1) * 1024);
-                    if (s == 7) {
-                        glds16(ibase, voff[7], idst + 7u * 1024);
-                        if (add_norm) glds4(a.norms + irow0, voff_norm, idst + UNIT_BYTES);
-                    }
+                if constexpr (RD) {
+                    ++loaded;
+                    if (++rd_slot == NSTAGE) rd_slot = 0;
                 }
-            }
-            if (iss_any) {
-                ++issued;
-                iss_sel += nwaves;
-                if (++iss_slot == NSTAGE) iss_slot = 0;
-            }
-            if (do_math) mfma_fence_out<QT>(acc);
+                if constexpr (ISS) {
+                    ++issued;
+                    iss_sel += nwaves;
+                    if (++iss_slot == NSTAGE) iss_slot = 0;
+                }
+                mfma_fence_out<QT>(acc);
+            };
+            const bool rd = loaded < total_units, iss = issued < total_units;  // iss implies rd
+            if (iss)
+                unit(std::true_type{}, std::true_type{});
+            else if (rd)
+                unit(std::false_type{}, std::true_type{});
+            else
+                unit(std::false_type{}, std::false_type{});
         } else {
 #pragma unroll
             for (int kc = 0; kc < KU; ++kc) {
