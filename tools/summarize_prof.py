@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 outputs under gpurun_out/ into the small files kept in profiles/.
-usage: tools/summarize_prof.py <round-tag> <kernel_stats.csv> [<pmc counter_collection.csv> ...]"""
+usage: tools/summarize_prof.py <round-tag>[:suffix] <kernel_stats.csv> [<pmc counter_collection.csv> ...]
+(a tag like r01:default_cmd writes r01_kernel_stats_default_cmd.csv and touches nothing else)"""
 import collections, csv, json, os, sys
 
 def main():
     tag, stats = sys.argv[1], sys.argv[2]
+    suffix = ""
+    if ":" in tag:
+        tag, suffix = tag.split(":", 1)
+        suffix = "_" + suffix
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     os.makedirs(out_dir, exist_ok=True)
     rows = list(csv.DictReader(open(stats)))
-    with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats{suffix}.csv"), "w") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows:
