@@ -263,9 +263,8 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         a.nrb = nrb;
         if (ns_tiles < (long long)nrb * wv) a.nrb = (int)(((ns_tiles + wv - 1) / wv + 7) / 8 * 8);
         SQ_TRY(scan_launch<true>(a, d_pad, qt, st));
-        hipLaunchKernelGGL(kth_threshold_f32_kernel, dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr);
-        hipLaunchKernelGGL(dense_inflate_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, thr, qn2, nq, cosine ? 1 : 0,
-                           h->xn2_max, eps_a, eps_b);
+        hipLaunchKernelGGL((kth_threshold_f32_kernel<DenseThrPost>), dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr,
+                           DenseThrPost{qn2, cosine ? 1 : 0, h->xn2_max, eps_a, eps_b});
         // full pass
         a.tile_step = 1;
         a.n_sel = n_tiles;

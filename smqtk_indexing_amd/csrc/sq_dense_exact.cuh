@@ -400,23 +400,25 @@ __device__ __forceinline__ double filter_eps(int cosine, double xn2_max, double 
     return eps_a * xq + eps_b * (xn2_max + 2.0 * xq);
 }
 
-static __global__ void dense_inflate_thr_kernel(float* __restrict__ thr, const double* __restrict__ qn2, int nq, int cosine,
-                                         double xn2_max, double eps_a, double eps_b) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    const float t = thr[q];
-    if (!(t < __builtin_inff())) return;
-    double slack;
-    const double eps = filter_eps(cosine, xn2_max, qn2[q], eps_a, eps_b);
-    if (cosine)
-        slack = 2.0 * eps + 1e-8;
-    else
-        slack = 2.0 * eps + 4e-6 * fabs((double)t + qn2[q]);
-    // round up so the float threshold is never below T + slack
-    float r = (float)((double)t + slack);
-    if ((double)r < (double)t + slack) r = __uint_as_float(__float_as_uint(r) + (r >= 0.f ? 1 : -1));
-    thr[q] = r;
-}
+// T -> T' = T + slack, rounded up (applied by kth_threshold_f32_kernel as it stores the threshold).
+struct DenseThrPost {
+    const double* qn2;
+    int cosine;
+    double xn2_max, eps_a, eps_b;
+    __device__ __forceinline__ float operator()(int q, float t) const {
+        if (!(t < __builtin_inff())) return t;
+        double slack;
+        const double eps = filter_eps(cosine, xn2_max, qn2[q], eps_a, eps_b);
+        if (cosine)
+            slack = 2.0 * eps + 1e-8;
+        else
+            slack = 2.0 * eps + 4e-6 * fabs((double)t + qn2[q]);
+        // round up so the float threshold is never below T + slack
+        float r = (float)((double)t + slack);
+        if ((double)r < (double)t + slack) r = __uint_as_float(__float_as_uint(r) + (r >= 0.f ? 1 : -1));
+        return r;
+    }
+};
 
 // --------------------------------------------------------------- finalize
 // status bits: 1 candidate overflow, 2 certification failed, 4 fewer than kk candidates

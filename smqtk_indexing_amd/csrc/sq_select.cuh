@@ -278,19 +278,154 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
 // Method: iterated linear bucketing (2048 buckets over [lo,hi]); bucket index
 // is a monotone function of the score, so everything in lower buckets is
 // strictly smaller than everything in the selected bucket.
+// Fast path (k <= 1024): the k-th smallest of the 1024 per-thread minima is an
+// upper bound T0 of the k-th smallest sample (each minimum is a sample); the
+// samples <= T0 (about k of them) are collected in LDS and sorted, and T is the
+// exact k-th smallest sample: two read passes and two small bitonic sorts.
+// `post(q, T)` maps the result before it is stored (the dense path adds its
+// slack there, sq_dense_exact.cuh: DenseThrPost).
+struct KthIdentity {
+    __device__ __forceinline__ float operator()(int, float t) const { return t; }
+};
+
+__device__ __forceinline__ void bitonic_sort_f32_lds(float* sk, int P) {
+    const int T = blockDim.x;
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < (P >> 1); i += T) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool asc = (lo & size) == 0;
+                const float a = sk[lo], b = sk[hi];
+                if ((b < a) == asc) {
+                    sk[lo] = b;
+                    sk[hi] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <class Post>
 static __global__ __launch_bounds__(1024) void kth_threshold_f32_kernel(const float* __restrict__ scores,
                                                                   long long ns, int k,
-                                                                  float* __restrict__ thr) {
+                                                                  float* __restrict__ thr, Post post) {
     constexpr int NB = 2048;
+    constexpr int LCAP = 4096;
     __shared__ u32 hist[NB];
+    __shared__ float flist[LCAP];
     __shared__ float red_a[16], red_b[16];
     __shared__ u32 red_c[16];
-    __shared__ u32 sh_b, sh_below, sh_cin;
+    __shared__ u32 sh_b, sh_below, sh_cin, sh_cnt;
+    __shared__ float sh_t0;
     const int q = blockIdx.x;
     const int T = blockDim.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = T >> 6;
     const float* s = scores + (long long)q * ns;
     const float INF = __builtin_inff();
+
+    if (k <= T && T <= LCAP) {
+        constexpr int U = 8;      // loads in flight per thread when streaming
+        constexpr int VMAX = 40;  // samples per thread kept in registers (ns <= 40960: one load latency, no re-read)
+        const bool in_regs = ns <= (long long)VMAX * T;
+        float vr[VMAX];
+        float mymin = INF;
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < VMAX; ++u) {
+                const long long i = (long long)u * T + threadIdx.x;
+                vr[u] = i < ns ? s[i] : INF;
+            }
+#pragma unroll
+            for (int u = 0; u < VMAX; ++u) mymin = fminf(mymin, vr[u]);
+        } else {
+            for (long long base = threadIdx.x; base < ns; base += (long long)T * U) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const long long i = base + (long long)u * T;
+                    v[u] = i < ns ? s[i] : INF;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) mymin = fminf(mymin, v[u]);
+            }
+        }
+        // An upper bound t0 of the k-th smallest sample from the T thread minima: every wave sorts
+        // its 64 minima in registers (shuffle network, no barrier); with p = ceil(k / waves), each
+        // wave has p minima <= its p-th smallest, so at least k samples are <= the largest of the
+        // waves' p-th smallest minima.
+        {
+            float v = mymin;
+            for (int kk2 = 2; kk2 <= 64; kk2 <<= 1)
+                for (int j = kk2 >> 1; j > 0; j >>= 1) {
+                    const float o = __shfl_xor(v, j);
+                    const bool up = (lane & kk2) == 0, lower = (lane & j) == 0;
+                    v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
+                }
+            const int p = (k + nw - 1) / nw;  // <= 64 because k <= T = 64 nw
+            if (lane == p - 1) red_a[wv] = v;
+            if (threadIdx.x == 0) sh_cnt = 0;
+            __syncthreads();
+            float m = -INF;
+            for (int w = 0; w < nw; ++w) m = fmaxf(m, red_a[w]);
+            if (threadIdx.x == 0) sh_t0 = m;
+            __syncthreads();
+        }
+        const float t0 = sh_t0;
+        __syncthreads();
+        if (t0 < INF) {
+            if (in_regs) {
+#pragma unroll
+                for (int u = 0; u < VMAX; ++u) {
+                    if (vr[u] <= t0) {
+                        const u32 pos = atomicAdd(&sh_cnt, 1u);
+                        if (pos < (u32)LCAP) flist[pos] = vr[u];
+                    }
+                }
+            } else {
+                for (long long base = threadIdx.x; base < ns; base += (long long)T * U) {
+                    float v[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const long long i = base + (long long)u * T;
+                        v[u] = i < ns ? s[i] : INF;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (v[u] <= t0) {
+                            const u32 pos = atomicAdd(&sh_cnt, 1u);
+                            if (pos < (u32)LCAP) flist[pos] = v[u];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const u32 c = sh_cnt;  // >= k: at least k thread minima are <= t0
+            if (c <= (u32)T) {
+                // rank by counting (about k elements; the reads are LDS broadcasts)
+                if (threadIdx.x < c) {
+                    const float v = flist[threadIdx.x];
+                    u32 rank = 0;
+                    for (u32 j = 0; j < c; ++j) {
+                        const float e = flist[j];
+                        rank += (e < v || (e == v && j < threadIdx.x)) ? 1u : 0u;
+                    }
+                    if (rank == (u32)(k - 1)) thr[q] = post(q, v);
+                }
+                return;
+            }
+            if (c <= (u32)LCAP) {
+                const int P = pow2_ceil((int)c);
+                for (int i = (int)c + threadIdx.x; i < P; i += T) flist[i] = INF;
+                bitonic_sort_f32_lds(flist, P);
+                if (threadIdx.x == 0) thr[q] = post(q, flist[k - 1]);
+                return;
+            }
+            __syncthreads();  // mass duplicates at t0: the general method below
+        }
+    }
 
     // pass 0: min / max / count of finite scores
     float vmin = INF, vmax = -INF;
@@ -322,7 +457,7 @@ static __global__ __launch_bounds__(1024) void kth_threshold_f32_kernel(const fl
     }
     __syncthreads();
     if (nfin < (u32)k) {
-        if (threadIdx.x == 0) thr[q] = INF;
+        if (threadIdx.x == 0) thr[q] = post(q, INF);
         return;
     }
     float lo = vmin, hi = vmax, result = vmax;
@@ -407,7 +542,7 @@ static __global__ __launch_bounds__(1024) void kth_threshold_f32_kernel(const fl
         lo = bmin;
         hi = bmax;
     }
-    if (threadIdx.x == 0) thr[q] = result;
+    if (threadIdx.x == 0) thr[q] = post(q, result);
 }
 
 // ------------------------------------------------------------------ fills
