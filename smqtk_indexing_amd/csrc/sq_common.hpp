@@ -53,6 +53,7 @@ struct Options {
     int dense_debug = 0;     // measurement only (see DenseScanArgs::debug)
     int dense_waves = 0;     // 0 = auto, 4 or 8 waves per scan workgroup
     int dense_qt = 0;        // 0 = auto, 1 / 2 / 4 query tiles per scan wave
+    int itq_exact = 0;       // 1 = every row through the float64 ITQ kernel (no bf16 filter)
 };
 extern Options g_opt;
 

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "sq_common.hpp"
+#include "sq_dma.cuh"
 
 namespace sq {
 
@@ -182,65 +183,6 @@ struct DenseScanArgs {
     int nrb;                // row blocks (multiple of 8 when nqt > 1)
     int debug;              // measurement only: 1 = skip LDS reads + MFMA, 2 = stop the DMA after the first ring fill
 };
-
-// LDS-DMA: 64 lanes x 16 bytes land at lds_dst + lane*16 (wave-uniform base in
-// M0); the global source is a wave-uniform 64-bit base (SGPR pair) plus a
-// per-lane 32-bit byte offset.  Issued from inline asm so that hipcc does not
-// fence every later ds_read with vmcnt(0); completion is tracked by the counted
-// waits below (cdna_hip_programming.md section 5.7).
-__device__ __forceinline__ void glds16(const void* gbase_uniform, u32 voff, u32 lds_dst) {
-    u32 keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(gbase_uniform), "s"(lds_dst)
-        : "memory");
-}
-__device__ __forceinline__ void glds4(const void* gbase_uniform, u32 voff, u32 lds_dst) {
-    u32 keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dword %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(gbase_uniform), "s"(lds_dst)
-        : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// Allow `units` younger units to stay outstanding.  PER = DMA instructions per
-// unit: 8, or 9 when every unit also carries its tile's norms (KU == 1, L2).
-// With KU > 1 only a tile's first unit has the norm load: counting 8 is then
-// merely conservative.
-template <int NSTAGE, int PER>
-__device__ __forceinline__ void wait_units_in_flight(int units) {
-    if constexpr (NSTAGE >= 4) {
-        if (units >= 3) {
-            wait_vmcnt<3 * PER>();
-            return;
-        }
-    }
-    if constexpr (NSTAGE >= 3) {
-        if (units == 2) {
-            wait_vmcnt<2 * PER>();
-            return;
-        }
-    }
-    if (units == 1)
-        wait_vmcnt<PER>();
-    else
-        wait_vmcnt<0>();
-}
 
 typedef __attribute__((address_space(3))) u32 lds_u32;
 

@@ -16,6 +16,7 @@
 
 #include "sq_common.hpp"
 #include "sq_pairwise.cuh"
+#include "sq_itq_fast.cuh"
 
 namespace sq {
 
@@ -37,6 +38,8 @@ struct ItqArgs {
     int d16;            // d rounded up to 16
     const void* nrm;    // [n] row L2 norms in x's dtype (normalize=2), from itq_norms_kernel
     int vec4;           // rows are 4-element aligned (d % 4 == 0, base aligned): vector loads of x
+    const u32* list;        // optional: only these rows (the filter's uncertain rows, sq_itq_fast.cuh)
+    const u32* list_total;  // device count of `list`
 };
 
 template <class T>
@@ -62,13 +65,16 @@ __device__ __forceinline__ double sqrt_rn(double a) { return sqrt(a); }
 // 8 lanes per row.  Kept out of the MFMA kernel so that one stays within 256
 // VGPRs (two workgroups per CU) without spilling.
 template <class T>
-__global__ __launch_bounds__(256) void itq_norms_kernel(const T* __restrict__ X, long long n, int d, T* __restrict__ nrm) {
+__global__ __launch_bounds__(256) void itq_norms_kernel(const T* __restrict__ X, long long n_all, int d, T* __restrict__ nrm,
+                                                        const u32* __restrict__ list, const u32* __restrict__ list_total) {
     const int j8 = threadIdx.x & 7;
     const long long stride = (long long)gridDim.x * 32;
+    const long long n = list ? (long long)*list_total : n_all;  // listed rows only (sq_itq_fast.cuh), or all
     for (long long row0 = (long long)blockIdx.x * 32; row0 < n; row0 += stride) {
         long long row = row0 + (threadIdx.x >> 3);
         const bool live = row < n;
         row = live ? row : n - 1;
+        if (list) row = (long long)list[row];
         const T* xr = X + row * d;
         auto term = [xr](int i) { return mul_rn(xr[i], xr[i]); };
         T s = np_pairwise_sum<T>(term, d, j8);
@@ -111,7 +117,9 @@ __global__ __launch_bounds__(256, 2) void itq_hash_kernel(ItqArgs a) {
     if (a.nchunks == 1) stage_rot(0);
     __syncthreads();
 
-    const long long nblocks = (a.n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    // rows to do: all n, or the listed ones (virtual row v -> list[v])
+    const long long nrows = a.list ? (long long)*a.list_total : a.n;
+    const long long nblocks = (nrows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const long long wrow0 = blk * ROWS_PER_BLOCK + (long long)wave * ROWS_PER_WAVE;
         f64x4 acc[RT][CT];
@@ -124,7 +132,8 @@ __global__ __launch_bounds__(256, 2) void itq_hash_kernel(ItqArgs a) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             long long row = wrow0 + rt * 16 + l15;
-            row = row < a.n ? row : a.n - 1;
+            row = row < nrows ? row : nrows - 1;
+            if (a.list) row = (long long)a.list[row];
             xrow[rt] = X + row * a.d;
             nrm_l[rt] = a.norm == SQ_NORM_L2 ? reinterpret_cast<const T*>(a.nrm)[row] : (T)1;
         }
@@ -198,8 +207,9 @@ __global__ __launch_bounds__(256, 2) void itq_hash_kernel(ItqArgs a) {
             if (l15 == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const long long row = wrow0 + rt * 16 + g + 4 * r;
-                    if (row < a.n) {
+                    long long row = wrow0 + rt * 16 + g + 4 * r;
+                    if (row < nrows) {
+                        if (a.list) row = (long long)a.list[row];
 #pragma unroll
                         for (int w = 0; w < WPG; ++w) {
                             const int gw = blockIdx.y * (NCOL / 64) + w;
@@ -247,15 +257,174 @@ static int itq_launch_t(const ItqArgs& a0, hipStream_t st, int device) {
     return SQ_OK;
 }
 
+// ---- the certified bf16x3 filter in front of the float64 kernel (sq_itq_fast.cuh)
+template <int WAVES, int NSTAGE, int KU, int CT, bool NORMED, bool BREG>
+static int itq_fast_launch_t(const ItqFastArgs& fa, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&itq_fast_kernel<WAVES, NSTAGE, KU, CT, NORMED, BREG>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((itq_fast_kernel<WAVES, NSTAGE, KU, CT, NORMED, BREG>), dim3((unsigned)fa.nrb), dim3(WAVES * 64), lds,
+                       st, fa);
+    SQ_HIP(hipGetLastError());
+    return SQ_OK;
+}
+
+// Geometry of the filter for (d, words); stages == 0: the filter does not apply.
+struct ItqFastGeom {
+    int ku, ct, stages, waves;
+    bool breg;
+    size_t lds;
+};
+static ItqFastGeom itq_fast_geometry(int d, int words) {
+    ItqFastGeom g{};
+    if (d % 64 != 0 || d > 256 || words > 2) return g;
+    g.ku = d / 64;
+    g.ct = words * 2;
+    g.breg = g.ku * g.ct <= 4;  // R fragments fit in registers: eight waves, LDS is all rings
+    g.waves = g.breg ? ITQF_WAVES_BREG : ITQF_WAVES_LDSB;
+    const int dp = (d + 127) / 128 * 128;
+    const size_t fixed = g.breg ? 0 : (size_t)g.ct * 32 * dp * 4;
+    for (int ns = g.breg ? 2 : 4; ns >= 2; --ns) {
+        const size_t lds = fixed + (size_t)g.waves * ns * ITQF_UNIT_BYTES;
+        if (lds <= 160 * 1024) {
+            g.stages = ns;
+            g.lds = lds;
+            break;
+        }
+    }
+    return g;
+}
+
+template <bool NORMED>
+static int itq_fast_dispatch(const ItqFastArgs& fa, const ItqFastGeom& g, hipStream_t st) {
+    if (g.breg) {
+        switch (g.ku * 10 + g.ct) {
+            case 12: return itq_fast_launch_t<8, 2, 1, 2, NORMED, true>(fa, g.lds, st);
+            case 14: return itq_fast_launch_t<8, 2, 1, 4, NORMED, true>(fa, g.lds, st);
+            default: return itq_fast_launch_t<8, 2, 2, 2, NORMED, true>(fa, g.lds, st);  // 22
+        }
+    }
+#define SQ_ITQF_CASE(KUv, CTv)                                                                                 \
+    case KUv * 10 + CTv:                                                                                       \
+        if (g.stages == 4) return itq_fast_launch_t<4, 4, KUv, CTv, NORMED, false>(fa, g.lds, st);             \
+        if (g.stages == 3) return itq_fast_launch_t<4, 3, KUv, CTv, NORMED, false>(fa, g.lds, st);             \
+        return itq_fast_launch_t<4, 2, KUv, CTv, NORMED, false>(fa, g.lds, st);
+    switch (g.ku * 10 + g.ct) {
+        SQ_ITQF_CASE(2, 4)
+        SQ_ITQF_CASE(3, 2)
+        SQ_ITQF_CASE(3, 4)
+        SQ_ITQF_CASE(4, 2)
+        SQ_ITQF_CASE(4, 4)
+        default: return fail(SQ_ERR_UNSUPPORTED, "itq filter: no kernel for d=%d words=%d", g.ku * 64, g.ct / 2);
+    }
+#undef SQ_ITQF_CASE
+}
+
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+// float32 rows through the filter; the rows it cannot decide through the float64 kernel.
+static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st, int device) {
+    const int pc = a.words * 64;
+    const long long n_tiles = (a.n + 31) / 32;
+    const int nrb = cu_count(device);
+    const long long nwaves = (long long)nrb * g.waves;
+    const long long seg_cap = ((n_tiles + nwaves - 1) / nwaves) * 32;
+    // one stream-ordered scratch block: colnorm | c_b | c_b error | R image | norms | segments | counts | list | total
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += align256(bytes);
+        return at;
+    };
+    const size_t o_cn = take((size_t)pc * 4), o_cb = take((size_t)pc * 4), o_cbe = take((size_t)pc * 4);
+    const size_t o_img = take((size_t)pc * ((a.d + 127) / 128 * 128) * 4);
+    const bool l2 = a.norm == SQ_NORM_L2;
+    const size_t o_nrm = take(l2 ? (size_t)a.n * 4 : 0);
+    const size_t o_seg = take((size_t)nwaves * seg_cap * 4), o_cnt = take((size_t)nwaves * 4);
+    const size_t o_list = take((size_t)a.n * 4), o_tot = take(4);
+    {
+        // keep the stream-ordered pool's memory across calls: by default it is handed back at every
+        // synchronisation and each call would pay for ~100 MB of fresh allocation
+        static std::mutex mu;
+        static bool kept[64] = {};
+        std::lock_guard<std::mutex> l(mu);
+        if (device >= 0 && device < 64 && !kept[device]) {
+            hipMemPool_t pool;
+            if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+                uint64_t keep = ~0ull;
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            }
+            kept[device] = true;
+        }
+    }
+    unsigned char* base = nullptr;
+    SQ_HIP(hipMallocAsync(reinterpret_cast<void**>(&base), off, st));
+    auto done = [&](int rc) {
+        (void)hipFreeAsync(base, st);
+        return rc;
+    };
+    hipLaunchKernelGGL(itq_fast_prep_kernel, dim3((unsigned)pc), dim3(256), 0, st, a.mean, a.rot, a.d, a.bits, a.pad,
+                       reinterpret_cast<unsigned short*>(base + o_img), reinterpret_cast<float*>(base + o_cn),
+                       reinterpret_cast<float*>(base + o_cb), reinterpret_cast<float*>(base + o_cbe));
+    ItqFastArgs fa{};
+    fa.x = reinterpret_cast<const float*>(a.x);
+    fa.n = a.n;
+    fa.d = a.d;
+    fa.rimage = reinterpret_cast<const uint4*>(base + o_img);
+    fa.colnorm = reinterpret_cast<const float*>(base + o_cn);
+    fa.cb32 = reinterpret_cast<const float*>(base + o_cb);
+    fa.cberr = reinterpret_cast<const float*>(base + o_cbe);
+    // 3 * 2^-16 (the dropped pieces of the bf16 splits) + 3d * 2^-24 (float32 accumulation) + 2^-20 (the float32
+    // scale / subtract, the reference's float32 x/|x|) [+ 2^-18: float32 |x|^2, normalize=2]; sq_itq_fast.cuh
+    fa.eps_rel = (float)((3.0 * 1.52587890625e-05 * 1.001 + 3.0 * a.d * 5.9604644775390625e-08 + 9.5367431640625e-07 +
+                          (l2 ? 3.814697265625e-06 : 0.0)) * 1.001);
+    fa.out = a.out;
+    fa.words = a.words;
+    fa.pad = a.pad;
+    fa.bits = a.bits;
+    fa.seg = reinterpret_cast<u32*>(base + o_seg);
+    fa.seg_cnt = reinterpret_cast<u32*>(base + o_cnt);
+    fa.seg_cap = seg_cap;
+    fa.n_tiles = n_tiles;
+    fa.nrb = nrb;
+    fa.nstage = g.stages;
+    int rc = l2 ? itq_fast_dispatch<true>(fa, g, st) : itq_fast_dispatch<false>(fa, g, st);
+    if (rc != SQ_OK) return done(rc);
+    hipLaunchKernelGGL(itq_fast_compact_kernel, dim3((unsigned)nwaves), dim3(256), 0, st, fa.seg, fa.seg_cnt, seg_cap,
+                       (int)nwaves, reinterpret_cast<u32*>(base + o_list), reinterpret_cast<u32*>(base + o_tot));
+    ItqArgs ex = a;  // the float64 kernel's view of the same job, restricted to the listed rows
+    if (l2) {
+        // numpy-order norms (the exact kernel divides by them element-wise) of the listed rows only
+        hipLaunchKernelGGL((itq_norms_kernel<float>), dim3((unsigned)(4 * cu_count(device))), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(a.x), a.n, a.d, reinterpret_cast<float*>(base + o_nrm),
+                           reinterpret_cast<const u32*>(base + o_list), reinterpret_cast<const u32*>(base + o_tot));
+        ex.nrm = base + o_nrm;
+    }
+    ex.list = reinterpret_cast<const u32*>(base + o_list);
+    ex.list_total = reinterpret_cast<const u32*>(base + o_tot);
+    if (ex.words == 1) rc = itq_launch_t<float, 4>(ex, st, device);
+    else rc = itq_launch_t<float, 8>(ex, st, device);
+    return done(rc);
+}
+
 template <class T>
 static int itq_launch(const ItqArgs& a0, hipStream_t st, int device) {
     ItqArgs a = a0;
+    if constexpr (sizeof(T) == 4) {
+        const ItqFastGeom g = itq_fast_geometry(a.d, a.words);
+        if (g.stages >= 2 && a.n >= 32 && a.n < (1ll << 32) && (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 &&
+            !g_opt.itq_exact)
+            return itq_fast_path(a, g, st, device);
+    }
     void* nrm = nullptr;
     if (a.norm == SQ_NORM_L2) {  // stream-ordered scratch: [n] norms in x's dtype
         SQ_HIP(hipMallocAsync(&nrm, (size_t)a.n * sizeof(T), st));
         long long gx = std::min<long long>((a.n + 31) / 32, 16ll * cu_count(device));
         hipLaunchKernelGGL((itq_norms_kernel<T>), dim3((unsigned)gx), dim3(256), 0, st, reinterpret_cast<const T*>(a.x),
-                           a.n, a.d, reinterpret_cast<T*>(nrm));
+                           a.n, a.d, reinterpret_cast<T*>(nrm), (const u32*)nullptr, (const u32*)nullptr);
         a.nrm = nrm;
     }
     int rc;

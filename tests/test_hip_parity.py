@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _reset_options():
     yield
-    for name in ("candidate_cap", "sample_stride", "force_fallback", "profile", "dense_stages", "dense_blocks"):
+    for name in ("candidate_cap", "sample_stride", "force_fallback", "profile", "dense_stages", "dense_blocks", "dense_qt",
+                 "itq_exact"):
         _lib.set_option(name, 0)
 
 
@@ -295,3 +296,33 @@ def test_itq_hash_bulk(n, d, bits):
         if bad.any():
             assert np.abs(z[bad]).min(axis=1).max() < 1e-10
         assert bad.mean() < 1e-3
+
+
+@pytest.mark.parametrize("n,d,bits", [(100_003, 128, 64), (40_000, 64, 33), (30_001, 256, 128), (20_000, 192, 100),
+                                      (33, 128, 64)])
+def test_itq_filter_matches_float64_kernel(n, d, bits):
+    """The bf16x3 filter + float64 recompute of the undecided rows returns exactly the codes of
+    the all-float64 kernel (option itq_exact), and both agree with the oracle."""
+    rng = np.random.default_rng(n + d + bits)
+    x = (rng.standard_normal((n, d)) * rng.uniform(0.1, 30.0, (n, 1))).astype(np.float32)
+    mean = x[:2000].mean(axis=0).astype(np.float64)
+    x[5] = mean.astype(np.float32)          # z ~ 0 in every bit: the whole row is undecided
+    x[7] = 0.0                              # zero row (norm 0 -> 1 with normalize=2)
+    x[n - 1] = x[0]
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    rot = np.ascontiguousarray(q[:, :bits])
+    rot[:, 3] = 0.0                         # a degenerate hash bit: z == -mean.R == 0 -> True everywhere
+    for norm, ordv in ((None, _lib.SQ_NORM_NONE), (2, _lib.SQ_NORM_L2)):
+        got = _lib.itq_hash(x, mean, rot, ordv)
+        _lib.set_option("itq_exact", 1)
+        try:
+            exact = _lib.itq_hash(x, mean, rot, ordv)
+        finally:
+            _lib.set_option("itq_exact", 0)
+        np.testing.assert_array_equal(got, exact)
+        z = O.itq_z(x, mean, rot, norm)
+        ref = O.pack_bits_msb(z >= 0)
+        bad = (got != ref).any(axis=1)
+        if bad.any():
+            assert np.abs(z[bad]).min(axis=1).max() < 1e-9
+        assert bad.mean() < 1e-2
