@@ -138,6 +138,26 @@ int sq_dense_destroy(sq_handle_t h);
 int sq_dense_distances(const void* query, const void* rows, int dtype, int64_t n, int d,
                        int metric, void* out, int mem, void* stream);
 
+/* ------------------------------------------------------- LSH re-rank stage
+ * Replaces the tail of LSHNearestNeighborIndex._nn (impls/nn_index/lsh.py:
+ * 499-519): fetch every candidate descriptor, one distance call per row
+ * (lsh.py:511), stable sort by distance, first n (lsh.py:513-518).
+ * sq_rows_create keeps the descriptor matrix ([n][d] float32 or float64,
+ * row order chosen by the caller) on the device.  sq_rows_rerank takes, for
+ * nq queries (same dtype as the rows, host memory), the concatenated candidate
+ * row ids of all queries and their offsets [nq+1] (host memory), computes each
+ * candidate's distance in the reference arithmetic (as sq_dense_distances) and
+ * returns per query the k smallest in (distance, position in that query's
+ * candidate list) order -- the order of the reference's stable sort.
+ * out_dist: float32[nq][k] for float32 rows with SQ_METRIC_L2, float64[nq][k]
+ * otherwise (+inf padding); out_pos: int64[nq][k] positions into the query's
+ * candidate list (-1 padding). */
+int sq_rows_create(const void* rows, int dtype, int64_t n, int d, int mem, sq_handle_t* out);
+int sq_rows_rerank(sq_handle_t h, const void* queries, int nq, int metric,
+                   const int64_t* cand_rows, const int64_t* cand_offsets, int k,
+                   void* out_dist, int64_t* out_pos, void* stream);
+int sq_rows_destroy(sq_handle_t h);
+
 /* ----------------------------------------------------------------- merge
  * Host-side k-way merge of per-shard top-k lists after the RCCL all-gather
  * (BASELINE.json north_star; no reference counterpart: the reference is

@@ -38,6 +38,7 @@ EXPORTS = (
     "sq_hamming_create", "sq_hamming_search", "sq_hamming_destroy",
     "sq_dense_create", "sq_dense_search", "sq_dense_destroy",
     "sq_dense_distances", "sq_merge_topk",
+    "sq_rows_create", "sq_rows_rerank", "sq_rows_destroy",
 )
 
 
@@ -79,6 +80,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_dense_destroy.argtypes = [c_i64]
     lib.sq_dense_distances.argtypes = [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_int, c_vp]
     lib.sq_merge_topk.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]
+    lib.sq_rows_create.argtypes = [c_vp, c_int, c_i64, c_int, c_int, ctypes.POINTER(c_i64)]
+    lib.sq_rows_rerank.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]
+    lib.sq_rows_destroy.argtypes = [c_i64]
     for name in EXPORTS:
         if name not in ("sq_last_error",):
             getattr(lib, name).restype = c_int
@@ -362,3 +366,56 @@ def merge_topk(dist: np.ndarray, idx: np.ndarray, k_out: int) -> Tuple[np.ndarra
     _check(load().sq_merge_topk(_ptr(dist), _ptr(idx), dt, ns, nq, k_in, int(k_out), _ptr(od), _ptr(oi)),
            "sq_merge_topk")
     return od, oi
+
+
+class RowMatrix:
+    """Descriptor rows resident on the device for the LSH re-rank stage
+    (``sq_rows_*``; lsh.py:499-519).  ``rows``: ``[n, d]`` float32 or float64."""
+
+    def __init__(self, rows: np.ndarray):
+        rows = np.asarray(rows)
+        if rows.ndim != 2 or rows.dtype not in (np.float32, np.float64):
+            raise ValueError("rows must be a [n, d] float32 or float64 matrix")
+        rows = np.ascontiguousarray(rows)
+        self.dtype = rows.dtype
+        self.n, self.d = int(rows.shape[0]), int(rows.shape[1])
+        h = ctypes.c_int64(0)
+        _check(load().sq_rows_create(_ptr(rows), SQ_DTYPE_F32 if rows.dtype == np.float32 else SQ_DTYPE_F64,
+                                     self.n, self.d, SQ_MEM_HOST, ctypes.byref(h)), "sq_rows_create")
+        self._h: Optional[int] = h.value
+
+    def rerank(self, queries: np.ndarray, metric: int, cand_rows: np.ndarray, cand_offsets: np.ndarray,
+               k: int) -> Tuple[np.ndarray, np.ndarray]:
+        """Per query the ``k`` smallest distances among its candidate rows, in
+        (distance, position in the candidate list) order.  Returns
+        (dist ``[nq, k]`` -- float32 for float32 rows with L2, else float64; +inf
+        padding, pos ``[nq, k]`` int64 positions into the query's candidate list; -1 padding)."""
+        if self._h is None:
+            raise HipError("RowMatrix is closed")
+        q = _host(np.asarray(queries), self.dtype)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError("queries must be [nq, d]")
+        cand = _host(np.asarray(cand_rows), np.int64).reshape(-1)
+        off = _host(np.asarray(cand_offsets), np.int64).reshape(-1)
+        nq = q.shape[0]
+        if off.shape[0] != nq + 1 or off[0] != 0 or off[-1] != cand.shape[0]:
+            raise ValueError("cand_offsets must be [nq + 1], start at 0 and end at len(cand_rows)")
+        k64 = self.dtype == np.float32 and metric == SQ_METRIC_L2
+        dist = np.empty((nq, k), dtype=np.float32 if k64 else np.float64)
+        pos = np.empty((nq, k), dtype=np.int64)
+        if cand.shape[0] == 0:
+            cand = np.zeros(1, dtype=np.int64)
+        _check(load().sq_rows_rerank(self._h, _ptr(q), nq, int(metric), _ptr(cand), _ptr(off), int(k), _ptr(dist),
+                                     _ptr(pos), None), "sq_rows_rerank")
+        return dist, pos
+
+    def close(self) -> None:
+        if self._h is not None and _lib is not None:
+            _lib.sq_rows_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

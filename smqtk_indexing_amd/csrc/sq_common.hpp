@@ -110,7 +110,7 @@ struct HostPinned {
 };
 
 // ------------------------------------------------------------------ handles
-enum HandleKind { H_HAMMING = 1, H_DENSE = 2 };
+enum HandleKind { H_HAMMING = 1, H_DENSE = 2, H_ROWS = 3 };
 
 struct HandleBase {
     int kind = 0;

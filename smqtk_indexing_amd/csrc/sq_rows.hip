@@ -1,0 +1,213 @@
+// Device-resident descriptor rows for the LSH re-rank stage (gfx950).
+//
+// Replaces the tail of LSHNearestNeighborIndex._nn
+// (smqtk_indexing/impls/nn_index/lsh.py:499-519): after the nearest hash codes
+// are expanded to candidate descriptors, the reference fetches every candidate
+// vector, calls the distance function per row (lsh.py:511) and stable-sorts
+// the candidates by distance (lsh.py:513).  Here the descriptor matrix stays on
+// the device; a call gathers each query's candidate rows, computes their
+// distances in the reference's arithmetic (the code of sq_dense_distances) and
+// returns the k smallest in (distance, position in the candidate list) order,
+// which is exactly the order a stable sort over the candidate list produces.
+#include <vector>
+
+#include "sq_dense_exact.cuh"
+
+namespace sq {
+
+struct RowsHandle : HandleBase {
+    const void* rows = nullptr;  // device [n][d] of float32 / float64
+    DevBuf owned;
+    int dtype = SQ_DTYPE_F32;
+    long long n = 0;
+    int d = 0;
+    DevBuf q_dev, cand_dev, off_dev, cnt_dev, keys, out_keys, out_dist, out_pos;
+    ~RowsHandle() override {
+        for (DevBuf* b : {&owned, &q_dev, &cand_dev, &off_dev, &cnt_dev, &keys, &out_keys, &out_dist, &out_pos}) b->release();
+    }
+};
+
+// Candidate p of query q (row cand[off[q] + p]) -> key (ordered distance, p).  Eight lanes per
+// candidate; float32 rows with L2 give float32 distances in 64-bit keys, everything else float64
+// distances in 128-bit keys.  grid = (ceil(maxc / 32), nq).
+template <class T, class K>
+__global__ __launch_bounds__(256) void rows_rerank_keys_kernel(const T* __restrict__ rows, long long n, int d,
+                                                                const T* __restrict__ queries, int metric,
+                                                                const long long* __restrict__ cand,
+                                                                const long long* __restrict__ off,
+                                                                long long maxc, K* __restrict__ keys,
+                                                                u32* __restrict__ cnt) {
+    const int qi = blockIdx.y;
+    const long long c0 = off[qi], c = off[qi + 1] - c0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[qi] = (u32)c;
+    const int j8 = threadIdx.x & 7;
+    const long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if ((long long)blockIdx.x * 32 >= c) return;
+    const long long pc = p < c ? p : c - 1;  // keep the eight-lane groups converged
+    long long row = cand[c0 + pc];
+    row = row < 0 ? 0 : (row >= n ? n - 1 : row);
+    const T* x = rows + row * d;
+    const T* q = queries + (long long)qi * d;
+    if (metric == SQ_METRIC_L2) {
+        auto term = [x, q](int i) {
+            const T t = sub_rn(x[i], q[i]);
+            return mul_rn_t(t, t);
+        };
+        const T s = np_pairwise_sum<T>(term, d, j8);
+        if (j8 == 0 && p < c) {
+            if constexpr (sizeof(K) == 8)
+                keys[(long long)qi * maxc + p] = ((u64)ordered_f32(sqrt_rn_f32((float)s)) << 32) | (u64)(u32)p;
+            else
+                keys[(long long)qi * maxc + p] = K128{ordered_f64(sqrt((double)s)), (u64)p};
+        }
+    } else {
+        if (j8 == 0 && p < c) {
+            const double dist = cosine_row_t<T>(x, q, d);
+            if constexpr (sizeof(K) == 16) keys[(long long)qi * maxc + p] = K128{ordered_f64(dist), (u64)p};
+        }
+    }
+}
+
+template <class K>
+__global__ void rows_finalize_kernel(const K* __restrict__ sorted, const u32* __restrict__ cnt, int k,
+                                     void* __restrict__ out_dist, long long* __restrict__ out_pos) {
+    const int q = blockIdx.x;
+    const u32 c = cnt[q];
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const bool ok = (u32)i < c;
+        const K key = sorted[(long long)q * k + i];
+        if constexpr (sizeof(K) == 8) {
+            reinterpret_cast<float*>(out_dist)[(long long)q * k + i] = ok ? unordered_f32((u32)(key >> 32)) : __builtin_inff();
+            out_pos[(long long)q * k + i] = ok ? (long long)(key & 0xffffffffull) : -1ll;
+        } else {
+            reinterpret_cast<double*>(out_dist)[(long long)q * k + i] = ok ? unordered_f64(key.hi) : (double)__builtin_inff();
+            out_pos[(long long)q * k + i] = ok ? (long long)key.lo : -1ll;
+        }
+    }
+}
+
+template <class K>
+static int rows_select(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out, hipStream_t st) {
+    static bool attr_set = false;
+    const int lds_keys = sizeof(K) == 8 ? 16384 : 7168;
+    const size_t lds = (size_t)(lds_keys + SELECT_SORT_MAX) * sizeof(K);
+    if (!attr_set) {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<K>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((select_topk_kernel<K>), dim3(nq), dim3(1024), lds, st, keys, cnt, cap, stride, k, lds_keys, out);
+    return SQ_OK;
+}
+
+template <class T, class K>
+static int rows_rerank_t(RowsHandle* h, int nq, int metric, long long maxc, int k, hipStream_t st) {
+    SQ_TRY(h->keys.reserve((size_t)nq * maxc * sizeof(K)));
+    SQ_TRY(h->out_keys.reserve((size_t)nq * k * sizeof(K)));
+    const unsigned gx = (unsigned)((maxc + 31) / 32);
+    hipLaunchKernelGGL((rows_rerank_keys_kernel<T, K>), dim3(gx, nq), dim3(256), 0, st,
+                       reinterpret_cast<const T*>(h->rows), h->n, h->d, h->q_dev.as<T>(), metric,
+                       h->cand_dev.as<long long>(), h->off_dev.as<long long>(), maxc, h->keys.as<K>(), h->cnt_dev.as<u32>());
+    SQ_TRY(rows_select<K>(h->keys.as<K>(), h->cnt_dev.as<u32>(), (u32)maxc, maxc, k, nq, h->out_keys.as<K>(), st));
+    hipLaunchKernelGGL((rows_finalize_kernel<K>), dim3(nq), dim3(256), 0, st, h->out_keys.as<K>(), h->cnt_dev.as<u32>(), k,
+                       h->out_dist.p, h->out_pos.as<long long>());
+    SQ_HIP(hipGetLastError());
+    return SQ_OK;
+}
+
+}  // namespace sq
+
+using namespace sq;
+
+extern "C" int sq_rows_create(const void* rows, int dtype, int64_t n, int d, int mem, sq_handle_t* out) {
+    if (!rows || !out || n <= 0 || d <= 0) return fail(SQ_ERR_INVALID, "sq_rows_create: bad argument");
+    if (dtype != SQ_DTYPE_F32 && dtype != SQ_DTYPE_F64) return fail(SQ_ERR_INVALID, "sq_rows_create: unknown dtype %d", dtype);
+    auto* h = new RowsHandle();
+    h->kind = H_ROWS;
+    h->dtype = dtype;
+    h->n = n;
+    h->d = d;
+    if (hipGetDevice(&h->device) != hipSuccess) {
+        delete h;
+        return fail(SQ_ERR_HIP, "sq_rows_create: no HIP device");
+    }
+    if (mem == SQ_MEM_DEVICE) {
+        h->rows = rows;
+    } else {
+        const size_t bytes = (size_t)n * d * (dtype == SQ_DTYPE_F32 ? 4 : 8);
+        int rc = h->owned.reserve(bytes);
+        if (rc != SQ_OK) {
+            delete h;
+            return rc;
+        }
+        if (hipMemcpy(h->owned.p, rows, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            delete h;
+            return fail(SQ_ERR_HIP, "sq_rows_create: H2D copy failed");
+        }
+        h->rows = h->owned.p;
+    }
+    *out = register_handle(h);
+    return SQ_OK;
+}
+
+extern "C" int sq_rows_rerank(sq_handle_t hid, const void* queries, int nq, int metric, const int64_t* cand_rows,
+                              const int64_t* cand_offsets, int k, void* out_dist, int64_t* out_pos, void* stream) {
+    auto* h = static_cast<RowsHandle*>(lookup_handle(hid, H_ROWS));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_rows_rerank: unknown handle");
+    if (!queries || !cand_rows || !cand_offsets || !out_dist || !out_pos || nq <= 0 || k <= 0)
+        return fail(SQ_ERR_INVALID, "sq_rows_rerank: bad argument");
+    if (metric != SQ_METRIC_L2 && metric != SQ_METRIC_COSINE) return fail(SQ_ERR_INVALID, "sq_rows_rerank: unknown metric");
+    if (k > SQ_MAX_K) return fail(SQ_ERR_UNSUPPORTED, "sq_rows_rerank: k=%d exceeds SQ_MAX_K=%d", k, SQ_MAX_K);
+    const bool f32 = h->dtype == SQ_DTYPE_F32;
+    const bool k64 = f32 && metric == SQ_METRIC_L2;  // float32 distances, 64-bit keys
+    if (!k64 && k > 7168) return fail(SQ_ERR_UNSUPPORTED, "sq_rows_rerank: k=%d exceeds 7168 for float64 distances", k);
+    long long maxc = 0;
+    const long long total = cand_offsets[nq];
+    for (int q = 0; q < nq; ++q) {
+        const long long c = cand_offsets[q + 1] - cand_offsets[q];
+        if (c < 0) return fail(SQ_ERR_INVALID, "sq_rows_rerank: offsets must not decrease");
+        if (c > maxc) maxc = c;
+    }
+    if (maxc >= (1ll << 32)) return fail(SQ_ERR_UNSUPPORTED, "sq_rows_rerank: more than 2^32-1 candidates for one query");
+    std::lock_guard<std::mutex> lock(h->mu);
+    SQ_HIP(hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t esz = f32 ? 4 : 8, dsz = k64 ? 4 : 8;
+    if (maxc == 0) {  // nothing to rank: padding only
+        for (long long i = 0; i < (long long)nq * k; ++i) {
+            if (k64) reinterpret_cast<float*>(out_dist)[i] = __builtin_inff();
+            else reinterpret_cast<double*>(out_dist)[i] = (double)__builtin_inff();
+            out_pos[i] = -1;
+        }
+        return SQ_OK;
+    }
+    SQ_TRY(h->q_dev.reserve((size_t)nq * h->d * esz));
+    SQ_TRY(h->cand_dev.reserve((size_t)(total > 0 ? total : 1) * 8));
+    SQ_TRY(h->off_dev.reserve((size_t)(nq + 1) * 8));
+    SQ_TRY(h->cnt_dev.reserve((size_t)nq * 4));
+    SQ_TRY(h->out_dist.reserve((size_t)nq * k * dsz));
+    SQ_TRY(h->out_pos.reserve((size_t)nq * k * 8));
+    SQ_HIP(hipMemcpyAsync(h->q_dev.p, queries, (size_t)nq * h->d * esz, hipMemcpyHostToDevice, st));
+    SQ_HIP(hipMemcpyAsync(h->cand_dev.p, cand_rows, (size_t)total * 8, hipMemcpyHostToDevice, st));
+    SQ_HIP(hipMemcpyAsync(h->off_dev.p, cand_offsets, (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, st));
+    int rc;
+    if (k64)
+        rc = rows_rerank_t<float, u64>(h, nq, metric, maxc, k, st);
+    else if (f32)
+        rc = rows_rerank_t<float, K128>(h, nq, metric, maxc, k, st);
+    else
+        rc = rows_rerank_t<double, K128>(h, nq, metric, maxc, k, st);
+    if (rc != SQ_OK) return rc;
+    SQ_HIP(hipMemcpyAsync(out_dist, h->out_dist.p, (size_t)nq * k * dsz, hipMemcpyDeviceToHost, st));
+    SQ_HIP(hipMemcpyAsync(out_pos, h->out_pos.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+    SQ_HIP(hipStreamSynchronize(st));
+    return SQ_OK;
+}
+
+extern "C" int sq_rows_destroy(sq_handle_t hid) {
+    auto* h = remove_handle(hid, H_ROWS);
+    if (!h) return fail(SQ_ERR_INVALID, "sq_rows_destroy: unknown handle");
+    (void)hipSetDevice(h->device);
+    delete h;
+    return SQ_OK;
+}

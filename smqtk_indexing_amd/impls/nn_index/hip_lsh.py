@@ -19,8 +19,15 @@ What moved to the GPU:
     per query when ``hash_index`` is None;
   * the per-candidate distance calls (lsh.py:511) -> one ``sq_dense_distances``
     call in the reference's arithmetic.
-Bucket expansion and the final stable sort + slice (lsh.py:489-519) stay on the
-host: they are dictionary lookups over at most a few thousand candidates.
+With ``device_rerank`` (default) the index also keeps a device mirror of the
+descriptor matrix (``sq_rows_*``) and a CSR map code -> rows, so a query's
+bucket expansion is a vectorised gather of row ids and the re-rank (gather of
+candidate rows, distances, stable top-n: lsh.py:499-519) is one device call that
+returns only the n winners; ``nn_many`` answers a
+batch of queries with one hash, one Hamming and one re-rank call.  The mirror is
+rebuilt lazily after ``update_index`` / ``remove_from_index``.  Without a mirror
+(mixed dtypes, ragged vectors, a foreign ``hash_index``) the host path below is
+used: dictionary lookups + one ``sq_dense_distances`` call per query.
 """
 import collections
 import itertools
@@ -42,6 +49,45 @@ from ...utils.bits import (ints_to_packed, pack_bits_msb, packed_to_ints,
 from ..hash_index.hip_linear import HipLinearHashIndex
 
 T = TypeVar("T", bound="HipLSHNearestNeighborIndex")
+
+
+class _DeviceMirror:
+    """Row-ordered device copy of the descriptors + CSR map from code id to rows."""
+
+    def __init__(self, uuids: List[Hashable], matrix: np.ndarray, packed: np.ndarray):
+        self.uuids = uuids
+        self.dtype = matrix.dtype
+        self.rows = _lib.RowMatrix(matrix)
+        codes, inverse = np.unique(packed, axis=0, return_inverse=True)
+        inverse = np.asarray(inverse).reshape(-1)
+        self.codes = np.ascontiguousarray(codes)                 # [C, W] ascending (= HipLinearHashIndex order)
+        order = np.argsort(inverse, kind="stable")               # rows grouped by code id, row order inside a bucket
+        self.csr_rows = order.astype(np.int64)
+        self.csr_off = np.searchsorted(inverse[order], np.arange(codes.shape[0] + 1)).astype(np.int64)
+        self.own_index: Optional[HipLinearHashIndex] = None      # for hash_index=None
+        self.checked_codes: Optional[np.ndarray] = None          # hash_index code array last compared with self.codes
+        self.checked_ok = False
+
+    def expand(self, code_ids: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """code ids ``[nq, m]`` (-1 = none) -> (candidate rows concatenated, offsets ``[nq+1]``),
+        buckets in the given order, rows of a bucket in row order."""
+        ids = np.asarray(code_ids, dtype=np.int64)
+        valid = ids >= 0
+        safe = np.where(valid, ids, 0)
+        lens = np.where(valid, self.csr_off[safe + 1] - self.csr_off[safe], 0)
+        starts = self.csr_off[safe]
+        flat_len, flat_start = lens.reshape(-1), starts.reshape(-1)
+        total = int(flat_len.sum())
+        seg_end = np.cumsum(flat_len)
+        # position inside its bucket for every candidate, then the CSR entry
+        within = np.arange(total, dtype=np.int64) - np.repeat(seg_end - flat_len, flat_len)
+        cand = self.csr_rows[np.repeat(flat_start, flat_len) + within]
+        off = np.zeros(ids.shape[0] + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens.sum(axis=1))
+        return cand, off
+
+    def close(self) -> None:
+        self.rows.close()
 
 _METRICS = {"euclidean": _lib.SQ_METRIC_L2, "cosine": _lib.SQ_METRIC_COSINE}
 
@@ -79,8 +125,12 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
 
     def __init__(self, lsh_functor: LshFunctor, descriptor_set: DescriptorSet,
                  hash2uuids_kvstore: KeyValueStore, hash_index: Optional[HashIndex] = None,
-                 distance_method: str = "cosine", read_only: bool = False):
+                 distance_method: str = "cosine", read_only: bool = False, device_rerank: bool = True):
         super().__init__()
+        self.device_rerank = bool(device_rerank)
+        self._mirror: Optional[_DeviceMirror] = None
+        self._mirror_tried = False
+        self._count_cache: Optional[Tuple[int, int]] = None
         self.lsh_functor = lsh_functor
         self.descriptor_set = descriptor_set
         self.hash_index = hash_index
@@ -102,6 +152,7 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
             "hash2uuids_kvstore": to_config_dict(self.hash2uuids_kvstore),
             "distance_method": self.distance_method,
             "read_only": self.read_only,
+            "device_rerank": self.device_rerank,
         }
 
     # ---------------------------------------------------------------- helpers
@@ -117,6 +168,102 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
         hv = np.vstack([np.asarray(self.lsh_functor.get_hash(v)).astype(bool) for v in vectors])
         return hv, packed_to_ints(pack_bits_msb(hv))
 
+    # ---------------------------------------------------------- device mirror
+    def _drop_mirror(self) -> None:
+        if self._mirror is not None:
+            self._mirror.close()
+        self._mirror = None
+        self._mirror_tried = False
+
+    def _set_mirror(self, elems: List[DescriptorElement], vectors: List[np.ndarray], hv: np.ndarray) -> None:
+        """(Re)build the device mirror from descriptors in row order, their vectors and bool codes."""
+        self._drop_mirror()
+        self._mirror_tried = True
+        if not self.device_rerank or not elems:
+            return
+        try:
+            mat = np.asarray(vectors)
+        except ValueError:
+            return
+        if mat.ndim != 2 or mat.dtype not in (np.float32, np.float64):
+            return
+        self._mirror = _DeviceMirror([d.uuid() for d in elems], mat, pack_bits_msb(np.asarray(hv).astype(bool)))
+
+    def _ensure_mirror(self) -> Optional[_DeviceMirror]:
+        if self._mirror is None and not self._mirror_tried and self.device_rerank:
+            elems = list(self.descriptor_set)
+            if elems:
+                vectors = [d.vector() for d in elems]
+                hv, _ = self._hash_many(vectors)
+                self._set_mirror(elems, vectors, hv)
+            self._mirror_tried = True
+        return self._mirror
+
+    def _mirror_hash_index(self, m: _DeviceMirror) -> Optional[HipLinearHashIndex]:
+        """The index whose row ids are the mirror's code ids, or None (host path)."""
+        hi = self.hash_index
+        if hi is None:
+            if m.own_index is None:
+                m.own_index = HipLinearHashIndex()
+                m.own_index.set_codes_packed(m.codes)
+            return m.own_index
+        if isinstance(hi, HipLinearHashIndex):
+            cp = hi.codes_packed()
+            if m.checked_codes is cp:                      # the same array object as last time: already compared
+                return hi if m.checked_ok else None
+            m.checked_codes = cp
+            m.checked_ok = bool(cp.shape == m.codes.shape and np.array_equal(cp, m.codes))
+            return hi if m.checked_ok else None
+        return None
+
+    def _nn_device(self, vectors: np.ndarray, n: int
+                   ) -> Optional[List[Tuple[Tuple[DescriptorElement, ...], Tuple[float, ...]]]]:
+        """Batched query through the device mirror; None when the host path has to answer."""
+        m = self._ensure_mirror()
+        if m is None or vectors.dtype != m.dtype or vectors.ndim != 2 or vectors.shape[1] != m.rows.d:
+            return None
+        hi = self._mirror_hash_index(m)
+        if hi is None:
+            return None
+        hv, _ = self._hash_many(list(vectors))
+        qp = pack_bits_msb(np.asarray(hv).astype(bool))
+        w = m.codes.shape[1]
+        if qp.shape[1] < w:
+            qp = np.pad(qp, ((0, 0), (w - qp.shape[1], 0)))
+        _, code_ids = hi.nn_packed(np.ascontiguousarray(qp), n)
+        cand, off = m.expand(code_ids)
+        k = int(min(n, max(1, int((off[1:] - off[:-1]).max()))))
+        dist, pos = m.rows.rerank(vectors, self._metric, cand, off, k)
+        out = []
+        for qi in range(vectors.shape[0]):
+            good = pos[qi] >= 0
+            rows = cand[off[qi] + pos[qi][good]]
+            uuids = [m.uuids[int(r)] for r in rows]
+            descrs = tuple(self.descriptor_set.get_many_descriptors(uuids))
+            out.append((descrs, tuple(float(x) for x in dist[qi][good])))
+        return out
+
+    def nn_many(self, descriptors: Iterable[DescriptorElement], n: int = 1
+                ) -> List[Tuple[Tuple[DescriptorElement, ...], Tuple[float, ...]]]:
+        """``nn`` for a batch of query descriptors: one hashing, one Hamming and one
+        re-rank call for all of them (device mirror), else a loop over ``nn``."""
+        descriptors = list(descriptors)
+        vecs = [d.vector() for d in descriptors]
+        if any(v is None for v in vecs):
+            raise ValueError("Query descriptor did not have a vector set!")
+        with self._model_lock:
+            if not self.count():
+                raise ValueError("No index currently set to query from!")
+            try:
+                mat = np.asarray(vecs)
+            except ValueError:
+                mat = None
+            if mat is not None and mat.ndim == 2:
+                res = self._nn_device(mat, n)
+                if res is not None and all(len(r[0]) for r in res):
+                    return res
+        return [self.nn(d, n) for d in descriptors]
+
     def _guard(self) -> None:
         if self.read_only:
             raise ReadOnlyError("Cannot modify container attributes due "
@@ -124,8 +271,14 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
 
     # -------------------------------------------------------------- interface
     def count(self) -> int:
+        # sum of bucket sizes (lsh.py:271-281).  The reference walks every bucket on each call, and
+        # NearestNeighborsIndex.nn calls count() per query; here the sum is cached and recomputed only
+        # after this index mutated the store or the store's key count changed underneath it.
         with self._model_lock:
-            return sum(len(s) for s in self.hash2uuids_kvstore.values())
+            nkeys = len(self.hash2uuids_kvstore)
+            if self._count_cache is None or self._count_cache[0] != nkeys:
+                self._count_cache = (nkeys, sum(len(s) for s in self.hash2uuids_kvstore.values()))
+            return self._count_cache[1]
 
     def _build_index(self, descriptors: Iterable[DescriptorElement]) -> None:
         with self._model_lock:
@@ -134,13 +287,16 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
             self.descriptor_set.add_many_descriptors(descriptors)
             self.hash2uuids_kvstore.clear()
             elems = list(self.descriptor_set)
-            hv, keys = self._hash_many([d.vector() for d in elems])
+            vectors = [d.vector() for d in elems]
+            hv, keys = self._hash_many(vectors)
             update: Dict[Hashable, Set[Hashable]] = collections.defaultdict(set)
             for d, key in zip(elems, keys):
                 update[key].add(d.uuid())
             self.hash2uuids_kvstore.add_many(update)
+            self._count_cache = None
             if self.hash_index is not None:
                 self.hash_index.build_index(hv)
+            self._set_mirror(elems, vectors, hv)
 
     def _update_index(self, descriptors: Iterable[DescriptorElement]) -> None:
         with self._model_lock:
@@ -155,8 +311,10 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
                     update[key] = self.hash2uuids_kvstore.get(key, set())
                 update[key] |= {d.uuid()}
             self.hash2uuids_kvstore.add_many(update)
+            self._count_cache = None
             if self.hash_index is not None:
                 self.hash_index.update_index(hv)
+            self._drop_mirror()  # rebuilt from the descriptor set at the next query
 
     def _remove_from_index(self, uids: Iterable[Hashable]) -> None:
         with self._model_lock:
@@ -178,13 +336,20 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
                     gone.append(h)
             self.hash2uuids_kvstore.add_many(update)
             self.hash2uuids_kvstore.remove_many(remove_keys)
+            self._count_cache = None
             if self.hash_index and gone:
                 self.hash_index.remove_from_index(gone)
             self.descriptor_set.remove_many_descriptors(uids)
+            self._drop_mirror()
 
     def _nn(self, d: DescriptorElement, n: int = 1
             ) -> Tuple[Tuple[DescriptorElement, ...], Tuple[float, ...]]:
         d_v = np.asarray(d.vector())
+        with self._model_lock:
+            if d_v.ndim == 1:
+                res = self._nn_device(d_v.reshape(1, -1), n)
+                if res is not None and len(res[0][0]):
+                    return res[0]
         hv, _ = self._hash_many([d_v])
         d_h = hv[0]
         with self._model_lock:

@@ -233,6 +233,79 @@ def test_lsh_matches_reference_golden(golden):
             assert len(r) >= 1 and dists[0] >= 0
 
 
+def test_row_matrix_rerank_matches_oracle():
+    """sq_rows_rerank: gathered candidates, reference-arithmetic distances, stable top-k."""
+    rng = np.random.default_rng(5)
+    for dt in (np.float32, np.float64):
+        rows = rng.standard_normal((5000, 96)).astype(dt)
+        rows[100] = rows[7]                                        # a distance tie inside a candidate list
+        qs = rng.standard_normal((4, 96)).astype(dt)
+        m = _lib.RowMatrix(rows)
+        cands = [np.array([7, 3, 100, 4999, 12, 7]), rng.permutation(5000)[:700], np.zeros(0, dtype=np.int64),
+                 np.arange(64)[::-1].copy()]
+        off = np.zeros(5, dtype=np.int64)
+        off[1:] = np.cumsum([len(c) for c in cands])
+        flat = np.concatenate(cands).astype(np.int64)
+        for metric, name in ((_lib.SQ_METRIC_L2, "euclidean"), (_lib.SQ_METRIC_COSINE, "cosine")):
+            dist, pos = m.rerank(qs, metric, flat, off, 50)
+            for qi, c in enumerate(cands):
+                full = O.dense_distances(rows[c], qs[qi], name) if len(c) else np.zeros(0)
+                order = np.argsort(full, kind="stable")[:50]
+                kk = len(order)
+                np.testing.assert_array_equal(pos[qi, :kk], order)
+                assert (pos[qi, kk:] == -1).all()
+                if name == "euclidean":
+                    np.testing.assert_array_equal(dist[qi, :kk], full[order])
+                else:
+                    np.testing.assert_allclose(dist[qi, :kk], full[order], rtol=1e-12, atol=1e-15)
+        m.close()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("hash_index", [True, False])
+def test_lsh_device_rerank_equals_host_path(metric, dt, hash_index):
+    """The device mirror (CSR bucket expansion + sq_rows_rerank) returns what the host path
+    (dictionary lookups + sq_dense_distances + stable sort) returns, single and batched,
+    also after update_index / remove_from_index."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((3000, 64)).astype(dt)
+    f = HipItqFunctor(bit_length=12, itq_iterations=5, random_seed=3)
+    f.fit([DescriptorMemoryElement(i).set_vector(v) for i, v in enumerate(x[:500])])
+
+    def make(device):
+        idx = HipLSHNearestNeighborIndex(f, MemoryDescriptorSet(), MemoryKeyValueStore(),
+                                         HipLinearHashIndex() if hash_index else None, distance_method=metric,
+                                         device_rerank=device)
+        idx.build_index(_elems(x[:2500]))
+        return idx
+
+    dev, host = make(True), make(False)
+    assert dev._mirror is not None and host._mirror is None
+    qs = [DescriptorMemoryElement(f"q{i}").set_vector(v) for i, v in enumerate(rng.standard_normal((6, 64)).astype(dt))]
+
+    def same(a, b):
+        (ra, da), (rb, db) = a, b
+        np.testing.assert_allclose(da, db, rtol=1e-12, atol=0)
+        da = np.asarray(da)
+        if len(da) > 1 and (da[1:] != da[:-1]).all():
+            assert [e.uuid() for e in ra] == [e.uuid() for e in rb]
+        assert len(ra) == len(rb)
+
+    for n in (1, 7, 40):
+        batch = dev.nn_many(qs, n)
+        for q, b in zip(qs, batch):
+            same(dev.nn(q, n), host.nn(q, n))
+            same(b, host.nn(q, n))
+    for idx in (dev, host):
+        idx.update_index(_elems(x[2500:], base=2500))
+        idx.remove_from_index(list(range(0, 300)))
+    assert dev._mirror is None
+    for q in qs:
+        same(dev.nn(q, 25), host.nn(q, 25))
+    assert dev._mirror is not None and len(dev._mirror.uuids) == 2700
+
+
 def test_lsh_config_roundtrip_on_gpu():
     idx = _lsh(4, "euclidean")
     j = HipLSHNearestNeighborIndex.from_config(idx.get_config())
