@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--queries-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--no-other-paths", action="store_true",
+                    help="skip the ITQ / Hamming timings reported beside the headline metric")
     ap.add_argument("--force-collective", action="store_true",
                     help="testing: run the all-gather + merge path even with one rank (launch under torch.distributed.run)")
     ap.add_argument("--extra-batches", type=str, default="1,1024",
@@ -207,6 +209,46 @@ def main() -> None:
                 "scan_bf16_TFLOPs_executed": 2 * 2.0 * n_local * (-(-d // 128) * 128) * (-(-b // 32) * 32) / (s_ms * 1e-3) / 1e12 if s_ms > 0 else None,
             }
 
+    # ---- the other two kernels of the hot path on the same resident matrix (BASELINE config C3):
+    # ITQ codes of all rows, then Hamming top-k over the unique codes.  Outside the timed region.
+    other_paths = None
+    if world == 1 and not args.no_other_paths and d % 4 == 0:
+        def timed(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            return float(np.median(ts))
+
+        bits = 64
+        rot_np, _ = np.linalg.qr(np.random.default_rng(5).standard_normal((d, d)))
+        rot = torch.from_numpy(np.ascontiguousarray(rot_np[:, :bits])).to(dev)
+        mean = db[:100_000].to(torch.float64).mean(dim=0).contiguous()
+        codes = torch.empty((n_local, 1), dtype=torch.int64, device=dev)
+        other_paths = {}
+        for norm, tag in ((_lib.SQ_NORM_NONE, "itq_hash"), (_lib.SQ_NORM_L2, "itq_hash_normalize2")):
+            dt = timed(lambda: _lib.itq_hash_device(db.data_ptr(), 0, n_local, d, mean.data_ptr(), rot.data_ptr(), bits,
+                                                    norm, codes.data_ptr(), stream))
+            other_paths[tag] = {"rows": n_local, "dim": d, "bits": bits, "ms": dt * 1e3,
+                                "GBps_of_algorithmic_bytes": (n_local * d * 4 + n_local * 8) / dt / 1e9,
+                                "frac_of_hbm_peak": (n_local * d * 4 + n_local * 8) / dt / 1e9 / HBM_PEAK_GBS}
+        ucodes = torch.unique(codes.view(-1), sorted=True).contiguous()   # int64 order != uint64 order: timing only
+        hidx = _lib.HammingIndex(ucodes.data_ptr(), n=int(ucodes.numel()), words=1, device_ptr=True, keepalive=ucodes)
+        for hq in (32, 1024):
+            qc = ucodes[torch.randint(0, ucodes.numel(), (hq,), device=dev, generator=gq)].contiguous()
+            hd = torch.empty((hq, k), dtype=torch.int32, device=dev)
+            hi_ = torch.empty((hq, k), dtype=torch.int64, device=dev)
+            dt = timed(lambda: hidx.search_device(qc.data_ptr(), hq, k, hd.data_ptr(), hi_.data_ptr(), stream))
+            other_paths[f"hamming_top{k}_batch_{hq}"] = {"codes": int(ucodes.numel()), "bits": bits, "ms_per_call": dt * 1e3,
+                                                        "queries_per_s": hq / dt,
+                                                        "fallback_queries": hidx.stats()["fallback_queries"]}
+        hidx.close()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = nq * args.steps / elapsed
@@ -263,6 +305,8 @@ def main() -> None:
             line["parity_check"] = parity
         if extra:
             line["other_batches"] = extra
+        if other_paths:
+            line["other_paths"] = other_paths
         if not args.no_cpu_baseline and world == 1:
             rows, cq, dt = cpu_baseline(d, k, 7)
             line["cpu_baseline"] = {

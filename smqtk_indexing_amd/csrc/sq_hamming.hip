@@ -19,6 +19,7 @@ struct HammingHandle : HandleBase {
     long long n = 0;
     int words = 0;
     long long id_base = 0;
+    u64 pmul = 1;  // physical row p holds caller row (p * pmul) mod n
     // workspace
     DevBuf q_dev, keys, cnt, hist, thr, out_keys, status, out_dist_dev, out_idx_dev, big_keys, seg, bcnt;
     HostPinned status_host;
@@ -41,6 +42,26 @@ struct HammingHandle : HandleBase {
 };
 
 // ------------------------------------------------------------------ kernels
+// The host index keeps its codes SORTED (row id = rank of the code, which is what makes
+// (distance, row) the canonical (distance, code value) order).  In sorted order the codes near a
+// query sit in a few narrow ranges, so a block sample of the array says little about the distance
+// distribution and the survivors pile up in a handful of workgroups' lists (every second query of a
+// 10 M-code index overflowed to the exact path).  The device copy is therefore stored in a
+// low-discrepancy permutation: physical row p holds sorted row (p * pmul) mod n with pmul ~ 0.618 n
+// coprime to n, so any run of consecutive physical rows is spread evenly over the sorted array;
+// keys carry the sorted row, recomputed only for survivors.
+__device__ __forceinline__ u32 orig_row(long long row, u64 pmul, long long n) {
+    return pmul == 1ull ? (u32)row : (u32)(((u64)row * pmul) % (u64)n);
+}
+
+static __global__ void hamming_permute_kernel(const u64* __restrict__ src, long long n, int W, u64 pmul,
+                                              u64* __restrict__ dst) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const long long r = (long long)(((u64)p * pmul) % (u64)n);
+    for (int w = 0; w < W; ++w) dst[p * W + w] = src[r * W + w];
+}
+
 // Row handled by register slot i of thread t in the block that starts at code bb.
 // W <= 2: every 16-byte vector load is fully coalesced across the wave (lane t
 // takes vector j*256+t of the block); wider codes stay contiguous per thread.
@@ -102,7 +123,7 @@ __device__ __forceinline__ void load_codes(const u64* __restrict__ codes, long l
 // mode 0: emit keys with dist <= thr[q] through per-query atomic counters.
 // mode 1: write the key of EVERY code at its own position (keys[q][row]).
 template <int W, int C>
-__global__ __launch_bounds__(256) void hamming_scan_kernel(const u64* __restrict__ codes, long long n,
+__global__ __launch_bounds__(256) void hamming_scan_kernel(const u64* __restrict__ codes, long long n, u64 pmul,
                                                             const u64* __restrict__ qs, int nq,
                                                             const int* __restrict__ thr,
                                                             u64* __restrict__ keys, u32* __restrict__ cnt,
@@ -125,7 +146,7 @@ __global__ __launch_bounds__(256) void hamming_scan_kernel(const u64* __restrict
             for (int w = 0; w < W; ++w) dist += __popcll(c[i][w] ^ qw[w]);
             if (valid[i] && dist <= t) {
                 const long long row = code_row<W, C>(bb, tid, i);
-                const u64 key = ((u64)(u32)dist << 32) | (u64)(u32)row;
+                const u64 key = ((u64)(u32)dist << 32) | (u64)orig_row(row, pmul, n);
                 if (mode == 0) {
                     u32 pos = atomicAdd(&cnt[q], 1u);
                     if (pos < cap) keys[(long long)q * key_stride + pos] = key;
@@ -147,7 +168,7 @@ __global__ __launch_bounds__(256) void hamming_scan_kernel(const u64* __restrict
 // returning atomics on 32 hot counters cost 10x at 32 queries).  Mini-lists:
 // seg[(block*nq + q)*S + slot]; their fills go to bcnt[block*nq + q].
 template <int W, int C>
-__global__ __launch_bounds__(256) void hamming_stream_kernel(const u64* __restrict__ codes, long long n,
+__global__ __launch_bounds__(256) void hamming_stream_kernel(const u64* __restrict__ codes, long long n, u64 pmul,
                                                               const u64* __restrict__ qs, int nq,
                                                               const int* __restrict__ thr, u64* __restrict__ seg,
                                                               u32* __restrict__ bcnt, u32 S) {
@@ -211,7 +232,7 @@ __global__ __launch_bounds__(256) void hamming_stream_kernel(const u64* __restri
                             const u32 pos = atomicAdd(&lcnt[q], 1u);
                             if (pos < S)
                                 myseg[(long long)q * S + pos] =
-                                    ((u64)(u32)dist[i] << 32) | (u64)(u32)code_row<W, C>(bb, tid, i);
+                                    ((u64)(u32)dist[i] << 32) | (u64)orig_row(code_row<W, C>(bb, tid, i), pmul, n);
                         }
                     }
                 }
@@ -260,7 +281,7 @@ __global__ __launch_bounds__(256) void hamming_compact_kernel(const u64* __restr
 }
 
 // Generic word count (W not specialised): one code per thread.
-__global__ __launch_bounds__(256) void hamming_scan_generic_kernel(const u64* __restrict__ codes, long long n,
+__global__ __launch_bounds__(256) void hamming_scan_generic_kernel(const u64* __restrict__ codes, long long n, u64 pmul,
                                                                     int W, const u64* __restrict__ qs, int nq,
                                                                     const int* __restrict__ thr,
                                                                     u64* __restrict__ keys, u32* __restrict__ cnt,
@@ -274,7 +295,7 @@ __global__ __launch_bounds__(256) void hamming_scan_generic_kernel(const u64* __
         for (int w = 0; w < W; ++w) dist += __popcll(cp[w] ^ qp[w]);
         const int t = mode == 0 ? thr[q] : 0x7fffffff;
         if (dist <= t) {
-            const u64 key = ((u64)(u32)dist << 32) | (u64)(u32)row;
+            const u64 key = ((u64)(u32)dist << 32) | (u64)orig_row(row, pmul, n);
             if (mode == 0) {
                 u32 pos = atomicAdd(&cnt[q], 1u);
                 if (pos < cap) keys[(long long)q * key_stride + pos] = key;
@@ -375,7 +396,7 @@ static void launch_scan(const HammingHandle* h, const u64* qs, int nq, const int
                         long long key_stride, int mode, hipStream_t st) {
     long long per_block = 256ll * C;
     unsigned blocks = (unsigned)((h->n + per_block - 1) / per_block);
-    hipLaunchKernelGGL((hamming_scan_kernel<W, C>), dim3(blocks), dim3(256), 0, st, h->codes, h->n, qs, nq, thr, keys,
+    hipLaunchKernelGGL((hamming_scan_kernel<W, C>), dim3(blocks), dim3(256), 0, st, h->codes, h->n, h->pmul, qs, nq, thr, keys,
                        cnt, cap, key_stride, mode);
 }
 
@@ -387,7 +408,7 @@ static void scan_dispatch(const HammingHandle* h, const u64* qs, int nq, const i
         case 4: launch_scan<4, 1>(h, qs, nq, thr, keys, cnt, cap, key_stride, mode, st); break;
         default: {
             unsigned blocks = (unsigned)((h->n + 255) / 256);
-            hipLaunchKernelGGL(hamming_scan_generic_kernel, dim3(blocks), dim3(256), 0, st, h->codes, h->n, h->words,
+            hipLaunchKernelGGL(hamming_scan_generic_kernel, dim3(blocks), dim3(256), 0, st, h->codes, h->n, h->pmul, h->words,
                                qs, nq, thr, keys, cnt, cap, key_stride, mode);
         }
     }
@@ -515,13 +536,13 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
                 const size_t lds = (size_t)nqc * (W * 8 + 8);
                 const u64* qc = qs + (long long)q0 * W;
                 if (W == 1)
-                    hipLaunchKernelGGL((hamming_stream_kernel<1, 8>), dim3(G), dim3(256), lds, st, h->codes, n, qc, nqc,
+                    hipLaunchKernelGGL((hamming_stream_kernel<1, 8>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
                                        thr + q0, seg, bcnt, S);
                 else if (W == 2)
-                    hipLaunchKernelGGL((hamming_stream_kernel<2, 4>), dim3(G), dim3(256), lds, st, h->codes, n, qc, nqc,
+                    hipLaunchKernelGGL((hamming_stream_kernel<2, 4>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
                                        thr + q0, seg, bcnt, S);
                 else
-                    hipLaunchKernelGGL((hamming_stream_kernel<4, 2>), dim3(G), dim3(256), lds, st, h->codes, n, qc, nqc,
+                    hipLaunchKernelGGL((hamming_stream_kernel<4, 2>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
                                        thr + q0, seg, bcnt, S);
                 hipLaunchKernelGGL(hamming_compact_kernel, dim3(nqc), dim3(256), 0, st, seg, bcnt, G, nqc, S,
                                    keys + (long long)q0 * key_stride, cnt + q0, cap, key_stride);
@@ -591,21 +612,51 @@ extern "C" int sq_hamming_create(const uint64_t* codes, int64_t n, int words, in
         delete h;
         return fail(SQ_ERR_HIP, "sq_hamming_create: no HIP device");
     }
-    if (mem == SQ_MEM_DEVICE) {
-        h->codes = reinterpret_cast<const u64*>(codes);
-    } else {
-        size_t bytes = (size_t)n * words * 8;
-        int rc = h->owned.reserve(bytes);
-        if (rc != SQ_OK) {
+    {
+        // stride ~ n / golden ratio, coprime to n (permutation of Z_n); tiny arrays stay in caller order
+        u64 mul = 1;
+        if (n >= 4096 && !g_opt.hamming_no_permute) {
+            mul = (u64)((double)n * 0.6180339887498949);
+            auto gcd = [](u64 a, u64 b) {
+                while (b) {
+                    const u64 t = a % b;
+                    a = b;
+                    b = t;
+                }
+                return a;
+            };
+            while (mul < 2 || gcd(mul, (u64)n) != 1) ++mul;
+        }
+        h->pmul = mul;
+        const size_t bytes = (size_t)n * words * 8;
+        const u64* src = reinterpret_cast<const u64*>(codes);
+        DevBuf staged;
+        auto bail = [&](int rc) {
+            staged.release();
             delete h;
             return rc;
+        };
+        if (mem != SQ_MEM_DEVICE) {
+            // host codes: straight into the owned buffer when no permutation is needed, else through a staging copy
+            DevBuf& first = mul == 1 ? h->owned : staged;
+            int rc = first.reserve(bytes);
+            if (rc != SQ_OK) return bail(rc);
+            hipError_t e = hipMemcpy(first.p, codes, bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return bail(fail(SQ_ERR_HIP, "sq_hamming_create: H2D copy failed: %s", hipGetErrorString(e)));
+            src = first.as<u64>();
         }
-        hipError_t e = hipMemcpy(h->owned.p, codes, bytes, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            delete h;
-            return fail(SQ_ERR_HIP, "sq_hamming_create: H2D copy failed: %s", hipGetErrorString(e));
+        if (mul == 1) {
+            h->codes = src;  // caller order: the borrowed device array or the owned upload
+        } else {
+            int rc = h->owned.reserve(bytes);
+            if (rc != SQ_OK) return bail(rc);
+            hipLaunchKernelGGL(hamming_permute_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, src, (long long)n,
+                               words, mul, h->owned.as<u64>());
+            hipError_t e = hipDeviceSynchronize();
+            if (e != hipSuccess) return bail(fail(SQ_ERR_HIP, "sq_hamming_create: permutation failed: %s", hipGetErrorString(e)));
+            h->codes = h->owned.as<u64>();
         }
-        h->codes = h->owned.as<u64>();
+        staged.release();
     }
     *out = register_handle(h);
     return SQ_OK;

@@ -178,6 +178,8 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
     def _set_mirror(self, elems: List[DescriptorElement], vectors: List[np.ndarray], hv: np.ndarray) -> None:
         """(Re)build the device mirror from descriptors in row order, their vectors and bool codes."""
         self._drop_mirror()
+        if not _lib.usable():
+            return  # no device here: the containers are still maintained; a query will fail loudly in the kernels
         self._mirror_tried = True
         if not self.device_rerank or not elems:
             return

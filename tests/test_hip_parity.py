@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def _reset_options():
     yield
     for name in ("candidate_cap", "sample_stride", "force_fallback", "profile", "dense_stages", "dense_blocks", "dense_qt",
-                 "itq_exact"):
+                 "itq_exact", "hamming_no_permute"):
         _lib.set_option(name, 0)
 
 
@@ -68,6 +68,25 @@ def test_hamming_scan_path(bits, n, nq, k):
     st = idx.stats()
     assert st["fallback_queries"] == 0
     assert st["candidates"] >= nq * k
+
+
+def test_hamming_sorted_codes_large_index_no_fallback():
+    """The host index keeps its codes sorted; near codes then sit in a few narrow row ranges.  The
+    device copy is stored in a low-discrepancy permutation so that the block sample and the
+    per-workgroup survivor lists still see an even spread (no query may fall to the exact path),
+    while row ids and tie order stay those of the sorted array."""
+    rng = np.random.default_rng(123)
+    codes = np.unique(rng.integers(0, 2 ** 64, size=(3_000_000, 1), dtype=np.uint64), axis=0)
+    queries = np.concatenate([codes[rng.integers(0, codes.shape[0], 20)],
+                              rng.integers(0, 2 ** 64, size=(12, 1), dtype=np.uint64)])
+    idx = _hamming_check(codes, queries, 100)
+    st = idx.stats()
+    assert st["fallback_queries"] == 0, st
+    _lib.set_option("hamming_no_permute", 1)
+    try:
+        _hamming_check(codes[:500_000], queries[:4], 10)      # caller-order layout still answers identically
+    finally:
+        _lib.set_option("hamming_no_permute", 0)
 
 
 def test_hamming_low_entropy_overflow_and_fallback():

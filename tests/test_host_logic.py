@@ -284,6 +284,30 @@ def test_lsh_state_machine():
         HipLSHNearestNeighborIndex(_BitsOfSum(), ds, kv, None, "hik")
 
 
+def test_lsh_device_mirror_bucket_expansion():
+    """CSR expansion of nearest-code ids into candidate rows (host side of the device re-rank)."""
+    from smqtk_indexing_amd.impls.nn_index.hip_lsh import _DeviceMirror
+    m = object.__new__(_DeviceMirror)
+    # 4 codes; rows grouped by code: code0 -> rows [2, 5], code1 -> [], code2 -> [0], code3 -> [1, 3, 4]
+    m.csr_rows = np.array([2, 5, 0, 1, 3, 4], dtype=np.int64)
+    m.csr_off = np.array([0, 2, 2, 3, 6], dtype=np.int64)
+    cand, off = m.expand(np.array([[3, 0], [1, -1], [2, 2]]))
+    assert off.tolist() == [0, 5, 5, 7]
+    assert cand.tolist() == [1, 3, 4, 2, 5, 0, 0]            # buckets in the given order, rows in row order
+    cand, off = m.expand(np.zeros((2, 0), dtype=np.int64))
+    assert cand.shape == (0,) and off.tolist() == [0, 0, 0]
+
+
+def test_lsh_float_vectors_build_without_gpu_keeps_containers():
+    """Without a device the mirror is skipped at build time; the reference containers are maintained."""
+    if not NO_GPU:
+        pytest.skip("needs a machine without a GPU")
+    ds, kv = MemoryDescriptorSet(), MemoryKeyValueStore()
+    idx = HipLSHNearestNeighborIndex(_BitsOfSum(), ds, kv, HipLinearHashIndex(), distance_method="euclidean")
+    idx.build_index(_elems([[0.0], [1.0], [2.0]]))
+    assert idx.count() == 3 and idx._mirror is None
+
+
 def test_lsh_config_roundtrip():
     idx = HipLSHNearestNeighborIndex(HipItqFunctor(bit_length=4), MemoryDescriptorSet(), MemoryKeyValueStore(),
                                      HipLinearHashIndex(), "euclidean")
