@@ -30,7 +30,8 @@ struct DenseHandle : HandleBase {
     const float* db = nullptr;  // device [n][ld], the caller's float32 rows (borrowed or owned)
     DevBuf owned;
     DevBuf scan;                // bfloat16 scan copy [n_pad][d_pad*2 bytes]
-    DevBuf norms;               // float32 |x|^2 [n_pad]
+    DevBuf norms;               // float32 |x - c|^2 [n_pad] (cosine: of the rows themselves)
+    DevBuf center;              // float32 c [d_pad]: column means (L2), the filter's origin
     long long n = 0, n_pad = 0;
     int d = 0, d_pad = 0;
     long long ld = 0;
@@ -42,7 +43,7 @@ struct DenseHandle : HandleBase {
         out_idx_dev, big_keys, scratch;
     HostPinned status_host;
     ~DenseHandle() override {
-        for (DevBuf* b : {&owned, &scan, &norms, &q_dev, &q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt,
+        for (DevBuf* b : {&owned, &scan, &norms, &center, &q_dev, &q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt,
                           &keys, &sample, &out_keys, &status, &out_dist_dev, &out_idx_dev, &big_keys, &scratch})
             b->release();
         status_host.release();
@@ -242,7 +243,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         SQ_TRY(h->q_al.reserve((size_t)nq * ldq * 4));
         u32* oflag = h->scratch.as<u32>() + 16;
         hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, q, nq, d, d_pad, h->metric, qs,
-                           qn2, thr, cnt, oflag, h->q_al.as<float>(), ldq);
+                           qn2, thr, cnt, oflag, h->q_al.as<float>(), ldq, h->center.p ? h->center.as<float>() : nullptr);
         DenseScanArgs a{};
         a.scan = h->scan.as<uint4>();
         a.norms = cosine ? nullptr : h->norms.as<float>();
@@ -414,8 +415,32 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
             if (rc != SQ_OK) return bail(rc);
             invp = inv.as<float>();
         }
+        float* centerp = nullptr;
+        if (metric == SQ_METRIC_L2 && d_pad <= MAX_DPAD && !g_opt.dense_no_center) {
+            // the filter's origin: the column means (float64 sums over row blocks)
+            rc = h->center.reserve((size_t)d_pad * 4);
+            if (rc != SQ_OK) return bail(rc);
+            DevBuf colsum;
+            rc = colsum.reserve((size_t)d * 8);
+            if (rc != SQ_OK) return bail(rc);
+            if (hipMemset(colsum.p, 0, (size_t)d * 8) != hipSuccess) {
+                colsum.release();
+                return bail(fail(SQ_ERR_HIP, "memset failed"));
+            }
+            const long long rpb = 512;
+            hipLaunchKernelGGL(dense_colsum_kernel, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, 0, h->db,
+                               (long long)n, h->ld, d, rpb, colsum.as<double>());
+            hipLaunchKernelGGL(dense_center_kernel, dim3((d_pad + 255) / 256), dim3(256), 0, 0, colsum.as<double>(),
+                               (long long)n, d, d_pad, h->center.as<float>());
+            if (hipDeviceSynchronize() != hipSuccess) {
+                colsum.release();
+                return bail(fail(SQ_ERR_HIP, "sq_dense_create: column means failed"));
+            }
+            colsum.release();
+            centerp = h->center.as<float>();
+        }
         hipLaunchKernelGGL(dense_rowstats_kernel, dim3((unsigned)(h->n_pad / 32)), dim3(256), 0, 0, h->db, (long long)n,
-                           h->ld, d, h->n_pad, h->scratch.as<u32>(), h->norms.as<float>(), invp);
+                           h->ld, d, h->n_pad, h->scratch.as<u32>(), h->norms.as<float>(), invp, centerp);
         if (d_pad <= MAX_DPAD) {
             rc = h->scan.reserve((size_t)h->n_pad * d_pad * 2);
             if (rc != SQ_OK) {
@@ -424,7 +449,7 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
             }
             const long long chunks = h->n_pad * (long long)(d_pad / 8);
             hipLaunchKernelGGL(dense_build_scan_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, 0, h->db,
-                               (long long)n, h->ld, d, d_pad, h->n_pad, invp, h->scan.as<uint4>());
+                               (long long)n, h->ld, d, d_pad, h->n_pad, invp, centerp, h->scan.as<uint4>());
         }
         u32 bits = 0;
         hipError_t e = hipMemcpy(&bits, h->scratch.p, 4, hipMemcpyDeviceToHost);

@@ -53,11 +53,34 @@ __device__ __forceinline__ void bf16_split(float x, u32& hi, u32& lo) {
     lo = bf16_bits_rn(r);
 }
 
-// One thread per 16-byte chunk of the scan copy.  `row_scale` (cosine): 1/|x|.
+// Column means of the matrix, float64 sums -> float32 centre c (L2 only).  Euclidean distance is
+// translation invariant, so the FILTER scores x - c against q - c: its error bound scales with
+// |x - c||q - c| instead of |x||q|, which is what keeps the candidate lists short when the data
+// sits far from the origin (all-positive features, un-centred embeddings: with |x| = 20 and a
+// spread of 0.5 the un-centred bound covered every row).  The exact re-rank uses the original rows.
+static __global__ __launch_bounds__(256) void dense_colsum_kernel(const float* __restrict__ db, long long n, long long ld,
+                                                                   int d, long long rows_per_block,
+                                                                   double* __restrict__ colsum) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    for (int k = threadIdx.x; k < d; k += 256) {
+        double acc = 0.0;
+        for (long long r = r0; r < r1; ++r) acc += (double)db[r * ld + k];
+        atomicAdd(&colsum[k], acc);
+    }
+}
+static __global__ void dense_center_kernel(const double* __restrict__ colsum, long long n, int d, int d_pad,
+                                           float* __restrict__ center) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < d_pad) center[k] = k < d ? (float)(colsum[k] / (double)n) : 0.f;
+}
+
+// One thread per 16-byte chunk of the scan copy.  `row_scale` (cosine): 1/|x|; `center` (L2): c.
 static __global__ __launch_bounds__(256) void dense_build_scan_kernel(const float* __restrict__ db, long long n,
                                                                        long long ld, int d, int d_pad,
                                                                        long long n_pad,
                                                                        const float* __restrict__ row_scale,
+                                                                       const float* __restrict__ center,
                                                                        uint4* __restrict__ scan) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int cpr = d_pad / 8;  // chunks per row
@@ -75,7 +98,10 @@ static __global__ __launch_bounds__(256) void dense_build_scan_kernel(const floa
         for (int e = 0; e < 2; ++e) {
             const int k = k0 + j + e;
             float x = 0.f;
-            if (row < n && k < d) x = row_scale ? __fmul_rn(db[row * ld + k], sc) : db[row * ld + k];
+            if (row < n && k < d) {
+                x = row_scale ? __fmul_rn(db[row * ld + k], sc) : db[row * ld + k];
+                if (center) x = __fsub_rn(x, center[k]);  // L2: the filter works on x - c (see dense_colmean_kernel)
+            }
             half[e] = bf16_bits_rn(x);
         }
         w[j >> 1] = half[0] | (half[1] << 16);
@@ -89,7 +115,8 @@ static __global__ __launch_bounds__(256) void dense_rowstats_kernel(const float*
                                                                      long long ld, int d, long long n_pad,
                                                                      u32* __restrict__ max_bits,
                                                                      float* __restrict__ norms,
-                                                                     float* __restrict__ inv_norm) {
+                                                                     float* __restrict__ inv_norm,
+                                                                     const float* __restrict__ center) {
     const int lane8 = threadIdx.x & 7;
     const long long row = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
     const long long r = row < n ? row : n - 1;
@@ -99,12 +126,19 @@ static __global__ __launch_bounds__(256) void dense_rowstats_kernel(const float*
     // contiguous bytes per step
     const int d4 = d & ~3;
     for (int i = 4 * lane8; i < d4; i += 32) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        if (center) {  // the float32 difference the scan copy is built from
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = __fsub_rn(v[j], center[i + j]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc += (double)v[j] * (double)v[j];
     }
     if (lane8 == 0)
-        for (int i = d4; i < d; ++i) acc += (double)x[i] * (double)x[i];
+        for (int i = d4; i < d; ++i) {
+            const float v = center ? __fsub_rn(x[i], center[i]) : x[i];
+            acc += (double)v * (double)v;
+        }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     acc += __shfl_xor(acc, 4);
@@ -138,7 +172,8 @@ static __global__ __launch_bounds__(256) void dense_prep_queries_kernel(const fl
                                                                          float* __restrict__ thr,
                                                                          u32* __restrict__ cnt,
                                                                          u32* __restrict__ oflag,
-                                                                         float* __restrict__ q_al, int ldq) {
+                                                                         float* __restrict__ q_al, int ldq,
+                                                                         const float* __restrict__ center) {
     const int qi = blockIdx.x;
     __shared__ double red[4];
     if (threadIdx.x == 0) {
@@ -148,9 +183,14 @@ static __global__ __launch_bounds__(256) void dense_prep_queries_kernel(const fl
     }
     if (qi < nq)
         for (int i = threadIdx.x; i < ldq; i += 256) q_al[(long long)qi * ldq + i] = i < d ? q[(long long)qi * d + i] : 0.f;
+    // L2 with a centre: everything the filter uses (|q'|^2, the split planes) is q' = q - c in float32
+    auto qv = [&](int i) {
+        const float v = q[(long long)qi * d + i];
+        return center ? __fsub_rn(v, center[i]) : v;
+    };
     double acc = 0.0;
     if (qi < nq)
-        for (int i = threadIdx.x; i < d; i += 256) acc += (double)q[(long long)qi * d + i] * (double)q[(long long)qi * d + i];
+        for (int i = threadIdx.x; i < d; i += 256) acc += (double)qv(i) * (double)qv(i);
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -170,7 +210,7 @@ static __global__ __launch_bounds__(256) void dense_prep_queries_kernel(const fl
             for (int e = 0; e < 2; ++e) {
                 const int k = k0 + j + e;
                 float x = 0.f;
-                if (qi < nq && k < d) x = (float)((double)q[(long long)qi * d + k] * scale);
+                if (qi < nq && k < d) x = (float)((double)qv(k) * scale);
                 u32 hi, lo;
                 bf16_split(x, hi, lo);
                 half[e] = p ? lo : hi;

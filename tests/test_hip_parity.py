@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def _reset_options():
     yield
     for name in ("candidate_cap", "sample_stride", "force_fallback", "profile", "dense_stages", "dense_blocks", "dense_qt",
-                 "itq_exact", "hamming_no_permute"):
+                 "itq_exact", "hamming_no_permute", "dense_no_center"):
         _lib.set_option(name, 0)
 
 
@@ -198,6 +198,26 @@ def test_dense_scan_query_tiles_per_wave(metric, nq, qt):
     st = idx.stats()
     assert st["fallback_queries"] == 0, st
     assert st["candidates"] >= nq * 20
+
+
+def test_dense_offset_data_is_filtered_around_its_mean():
+    """Rows far from the origin (|x| >> spread): the L2 filter scores x - c against q - c (c = column
+    means), so its error bound does not swallow the distance differences; no query may need the exact
+    path and the candidate lists stay short.  With the centre switched off the same data overflows."""
+    rng = np.random.default_rng(77)
+    db = (20.0 + 0.5 * rng.standard_normal((200_000, 128))).astype(np.float32)
+    qs = (20.0 + 0.5 * rng.standard_normal((5, 128))).astype(np.float32)
+    qs[0] = db[31337]
+    idx = _dense_check(db, qs, 50, "euclidean")
+    st = idx.stats()
+    assert st["fallback_queries"] == 0, st
+    assert st["candidates"] < 5 * 20_000, st
+    _lib.set_option("dense_no_center", 1)
+    try:
+        idx2 = _dense_check(db, qs, 50, "euclidean")            # still exact, through the fallback
+        assert idx2.stats()["fallback_queries"] == 5
+    finally:
+        _lib.set_option("dense_no_center", 0)
 
 
 def test_dense_scan_path_cosine():
