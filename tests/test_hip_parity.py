@@ -220,6 +220,30 @@ def test_dense_offset_data_is_filtered_around_its_mean():
         _lib.set_option("dense_no_center", 0)
 
 
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_dense_clustered_rows_in_cluster_order(metric):
+    """A mixture of tight clusters stored cluster after cluster (the order an ingest pipeline
+    produces), queries inside clusters, k larger than a cluster: the sampled threshold and the
+    per-wave survivor segments must cope without the exact path."""
+    rng = np.random.default_rng(404)
+    centers = rng.standard_normal((400, 128)).astype(np.float32) * 4.0
+    sizes = rng.integers(50, 1500, size=400)
+    db = np.concatenate([c + 0.3 * rng.standard_normal((m, 128)).astype(np.float32) for c, m in zip(centers, sizes)])
+    qs = np.stack([db[10], db[len(db) // 2] + 0.01, centers[7], centers[399] + 0.2,
+                   rng.standard_normal(128).astype(np.float32)]).astype(np.float32)
+    idx = _dense_check(db, qs, 300, metric)
+    st = idx.stats()
+    assert st["fallback_queries"] == 0, st
+
+
+def test_dense_large_k_scan_path():
+    rng = np.random.default_rng(9)
+    db = rng.standard_normal((250_000, 64)).astype(np.float32)
+    qs = rng.standard_normal((3, 64)).astype(np.float32)
+    idx = _dense_check(db, qs, 3000, "euclidean")
+    assert idx.stats()["fallback_queries"] == 0
+
+
 def test_dense_scan_path_cosine():
     rng = np.random.default_rng(99)
     db = rng.random((150_000, 128)).astype(np.float32)
