@@ -54,6 +54,7 @@ struct Options {
     int dense_waves = 0;     // 0 = auto, 4 or 8 waves per scan workgroup
     int dense_qt = 0;        // 0 = auto, 1 / 2 / 4 query tiles per scan wave
     int itq_exact = 0;       // 1 = every row through the float64 ITQ kernel (no bf16 filter)
+    int dense_qplanes = 0;       // 0 = auto, 2 = keep q_hi + q_lo also in the multi-tile scan
     int dense_no_center = 0;     // 1 = the dense L2 filter scores the rows as given (no column-mean origin; measurement)
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
 };

@@ -70,15 +70,15 @@ static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long str
     return SQ_OK;
 }
 
-template <int WAVES, int NSTAGE, int KU, int QT, bool SAMPLE>
+template <int WAVES, int NSTAGE, int KU, int QT, int QP, bool SAMPLE>
 static int scan_launch_t(const DenseScanArgs& a, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<WAVES, NSTAGE, KU, QT, SAMPLE>),
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, SAMPLE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dense_scan_kernel<WAVES, NSTAGE, KU, QT, SAMPLE>), dim3((unsigned)(a.nrb * a.nqt)),
+    hipLaunchKernelGGL((dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, SAMPLE>), dim3((unsigned)(a.nrb * a.nqt)),
                        dim3(WAVES * 64), lds, st, a);
     return SQ_OK;
 }
@@ -110,29 +110,29 @@ static ScanGeom scan_geometry(int d_pad, int qt) {
 }
 
 template <int KU, bool SAMPLE>
-static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, int qt, hipStream_t st) {
+static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, int qt, int qp, hipStream_t st) {
     if constexpr (KU <= 1) {
-        if (qt == 4) return scan_launch_t<4, 4, KU, 4, SAMPLE>(a, g.lds, st);
-        if (qt == 2) return scan_launch_t<4, 4, KU, 2, SAMPLE>(a, g.lds, st);
-        if (g.waves == 8) return scan_launch_t<8, 2, KU, 1, SAMPLE>(a, g.lds, st);
+        if (qt == 4) return qp == 1 ? scan_launch_t<4, 4, KU, 4, 1, SAMPLE>(a, g.lds, st) : scan_launch_t<4, 4, KU, 4, 2, SAMPLE>(a, g.lds, st);
+        if (qt == 2) return qp == 1 ? scan_launch_t<4, 4, KU, 2, 1, SAMPLE>(a, g.lds, st) : scan_launch_t<4, 4, KU, 2, 2, SAMPLE>(a, g.lds, st);
+        if (g.waves == 8) return scan_launch_t<8, 2, KU, 1, 2, SAMPLE>(a, g.lds, st);
     }
     switch (g.stages) {
-        case 4: return scan_launch_t<4, 4, KU, 1, SAMPLE>(a, g.lds, st);
-        case 3: return scan_launch_t<4, 3, KU, 1, SAMPLE>(a, g.lds, st);
-        default: return scan_launch_t<4, 2, KU, 1, SAMPLE>(a, g.lds, st);
+        case 4: return scan_launch_t<4, 4, KU, 1, 2, SAMPLE>(a, g.lds, st);
+        case 3: return scan_launch_t<4, 3, KU, 1, 2, SAMPLE>(a, g.lds, st);
+        default: return scan_launch_t<4, 2, KU, 1, 2, SAMPLE>(a, g.lds, st);
     }
 }
 
 template <bool SAMPLE>
-static int scan_launch(const DenseScanArgs& a, int d_pad, int qt, hipStream_t st) {
+static int scan_launch(const DenseScanArgs& a, int d_pad, int qt, int qp, hipStream_t st) {
     const ScanGeom g = scan_geometry(d_pad, qt);
     if (g.stages < 2 || (qt > 1 && (d_pad != KT || g.stages != 4)))
         return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d qt=%d leaves no room for the LDS ring", d_pad, qt);
     switch (d_pad / KT) {
-        case 1: return scan_launch_ku<1, SAMPLE>(a, g, qt, st);
-        case 2: return scan_launch_ku<2, SAMPLE>(a, g, qt, st);
-        case 3: return scan_launch_ku<3, SAMPLE>(a, g, qt, st);
-        case 4: return scan_launch_ku<4, SAMPLE>(a, g, qt, st);
+        case 1: return scan_launch_ku<1, SAMPLE>(a, g, qt, qp, st);
+        case 2: return scan_launch_ku<2, SAMPLE>(a, g, qt, qp, st);
+        case 3: return scan_launch_ku<3, SAMPLE>(a, g, qt, qp, st);
+        case 4: return scan_launch_ku<4, SAMPLE>(a, g, qt, qp, st);
         default: return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d", d_pad);
     }
 }
@@ -159,6 +159,9 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     const bool small = n <= (long long)cap;
     const bool scan_ok = h->scan.p != nullptr && !small;
     const int qt = scan_query_tiles(d_pad, (nq + TILE_ROWS - 1) / TILE_ROWS);  // query tiles per wave
+    // query planes: the multi-tile configuration is MFMA bound, so it drops q_lo (half the MFMAs, twice the
+    // product bound: ~1.4x more rows pass the filter) unless asked otherwise
+    const int qp = (qt > 1 && g_opt.dense_qplanes != 2) ? 1 : 2;
     const int group_q = qt * TILE_ROWS;                                           // queries per scan workgroup
     const int nqt = (nq + group_q - 1) / group_q;                                 // groups of qt query tiles
     const int nq_pad = nqt * group_q;
@@ -187,7 +190,8 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     //   products: |x q' - x_hi (q'_hi + q'_lo)| <= (2^-8 + 2^-15) |x||q'|, q' = -2q  ->  eps_a = 2^-7 + 2^-14 (times X|q|)
     //             (cosine: unit vectors, q' = -q^: half of that; eps_a is kept as the common, looser constant)
     //   float32 accumulation of 2d+1 terms and the float32 norm                     ->  eps_b = (3d+8) 2^-23
-    const double eps_a = 0.0078125 + 6.103515625e-05;
+    //   one query plane: |x q' - x_hi q'_hi| <= (2^-8 + 2^-8 + 2^-16) |x||q'|                 ->  eps_a = 2^-6 + 2^-13
+    const double eps_a = qp == 2 ? 0.0078125 + 6.103515625e-05 : 0.015625 + 1.220703125e-04;
     const double eps_b = (3.0 * d_pad + 8.0) * 1.1920928955078125e-07;
     const size_t l2_lds = (size_t)((d + 3) / 4 * 4) * 4;
 
@@ -263,7 +267,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         a.n_sel = ns_tiles;
         a.nrb = nrb;
         if (ns_tiles < (long long)nrb * wv) a.nrb = (int)(((ns_tiles + wv - 1) / wv + 7) / 8 * 8);
-        SQ_TRY(scan_launch<true>(a, d_pad, qt, st));
+        SQ_TRY(scan_launch<true>(a, d_pad, qt, qp, st));
         hipLaunchKernelGGL((kth_threshold_f32_kernel<DenseThrPost>), dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr,
                            DenseThrPost{qn2, cosine ? 1 : 0, h->xn2_max, eps_a, eps_b});
         // full pass
@@ -271,7 +275,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         a.n_sel = n_tiles;
         a.nrb = nrb;
         if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
-        SQ_TRY(scan_launch<false>(a, d_pad, qt, st));
+        SQ_TRY(scan_launch<false>(a, d_pad, qt, qp, st));
         if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
         h->stats.scan_launches = 2;
         h->stats.bytes_scanned = h->n_pad * ((long long)d_pad * 2 + (cosine ? 0 : 4));

@@ -311,10 +311,13 @@ __device__ __forceinline__ void lds_read8_agpr(f32x4 (&dst)[16], int g0, const u
 // scores against every row tile it streams (the A fragments are read from LDS
 // once and reused QT times, so a large batch re-reads the matrix from L2 QT
 // times less often; QT > 1 keeps QT*64 registers of query fragments and runs
-// four waves per CU); SAMPLE: write per-lane minima of every visited tile
-// instead of emitting candidates.
-template <int WAVES, int NSTAGE, int KU, int QT, bool SAMPLE>
+// four waves per CU); QP: query planes used (2 = q_hi + q_lo; 1 = q_hi only in the
+// multi-tile, MFMA-bound configuration: half the MFMAs for a bound of 2^-7 instead
+// of 2^-8 per product, sq_dense.hip); SAMPLE: write per-lane minima of every
+// visited tile instead of emitting candidates.
+template <int WAVES, int NSTAGE, int KU, int QT, int QP, bool SAMPLE>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(DenseScanArgs a) {
+    static_assert(QP == 2 || (QP == 1 && QT > 1), "one query plane only in the multi-tile configuration");
     constexpr bool QREG = KU <= 1;  // query fragments live in registers for d_pad <= 128
     static_assert(QT == 1 || QREG, "several query tiles per wave need the register-resident query fragments");
     constexpr int DPAD = KU * KT;
@@ -386,13 +389,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             const u32 rowb = (u32)(t * TILE_ROWS + r31) * DPAD * 4;
-            if constexpr (QT > 1) {  // into AGPRs (see mfma_bf16_agpr_b)
+            if constexpr (QT > 1) {  // into AGPRs (see mfma_bf16_agpr_b); QP == 1: bq[t][s] = hi fragment of k-step s
 #pragma unroll
-                for (int g0 = 0; g0 < 16; g0 += 8) {
+                for (int g0 = 0; g0 < 8 * QP; g0 += 8) {
                     u32 ad[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int g = g0 + j;
+                        const int g = QP == 2 ? g0 + j : 2 * j;  // (k-step, plane) = (g >> 1, g & 1)
                         ad[j] = lds_base + rowb + (g & 1) * 256 + ((2 * (g >> 1) + h) ^ (r31 & 15)) * 16;
                     }
                     lds_read8_agpr(bq[t], g0, ad);
@@ -510,19 +513,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 const u32 idst = ring_base + (u32)iss_slot * SLOT_BYTES;
                 const unsigned char* ibase = reinterpret_cast<const unsigned char*>(a.scan) + irow0 * (DPAD * 2);
                 mfma_fence_in_c(nrm_c, av_cur);
-                constexpr int NSLOT = 16 * QT;                 // one slot behind every MFMA
+                constexpr int NSLOT = 8 * QP * QT;             // one slot behind every MFMA
                 constexpr int DMA0 = 6, DSTEP = (NSLOT - DMA0 - 1) / 9;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
+                    for (int half = 0; half < QP; ++half) {  // two planes: lo first, then hi
 #pragma unroll
                         for (int t = 0; t < QT; ++t) {
+                            const int frag = QP == 2 ? 2 * s + 1 - half : s;
                             if (s == 0 && half == 0)
-                                mfma_bf16_agpr_b_first(acc[t], av_cur[0], bq[t][1], nrm_c);
+                                mfma_bf16_agpr_b_first(acc[t], av_cur[0], bq[t][frag], nrm_c);
                             else
-                                mfma_bf16_agpr_b(acc[t], av_cur[s], bq[t][2 * s + 1 - half]);
-                            const int slot = (s * 2 + half) * QT + t;
+                                mfma_bf16_agpr_b(acc[t], av_cur[s], bq[t][frag]);
+                            const int slot = (s * QP + half) * QT + t;
                             if constexpr (RD) {
                                 if (slot == 1) {
                                     if (nine)

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def _reset_options():
     yield
     for name in ("candidate_cap", "sample_stride", "force_fallback", "profile", "dense_stages", "dense_blocks", "dense_qt",
-                 "itq_exact", "hamming_no_permute", "dense_no_center"):
+                 "itq_exact", "hamming_no_permute", "dense_no_center", "dense_qplanes"):
         _lib.set_option(name, 0)
 
 
@@ -181,9 +181,10 @@ def test_dense_scan_path_l2(n, d, nq, k, stages):
     assert st["candidates"] >= nq * k
 
 
+@pytest.mark.parametrize("qplanes", [0, 2])
 @pytest.mark.parametrize("metric,nq,qt", [("euclidean", 130, 0), ("euclidean", 97, 2), ("euclidean", 65, 1),
                                           ("cosine", 70, 0), ("cosine", 33, 4)])
-def test_dense_scan_query_tiles_per_wave(metric, nq, qt):
+def test_dense_scan_query_tiles_per_wave(metric, nq, qt, qplanes):
     """Batches of several 32-query tiles: 2 or 4 query tiles per scan wave (padded
     groups, survivors of several tiles in one segment, group-wide re-rank)."""
     rng = np.random.default_rng(1000 + nq)
@@ -191,10 +192,12 @@ def test_dense_scan_query_tiles_per_wave(metric, nq, qt):
     qs = rng.standard_normal((nq, 128)).astype(np.float32)
     qs[nq - 1] = db[4242]
     _lib.set_option("dense_qt", qt)
+    _lib.set_option("dense_qplanes", qplanes)   # 0: q_hi only in the multi-tile scan; 2: q_hi + q_lo
     try:
         idx = _dense_check(db, qs, 20, metric)
     finally:
         _lib.set_option("dense_qt", 0)
+        _lib.set_option("dense_qplanes", 0)
     st = idx.stats()
     assert st["fallback_queries"] == 0, st
     assert st["candidates"] >= nq * 20
