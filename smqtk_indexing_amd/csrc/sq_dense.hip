@@ -91,12 +91,13 @@ struct ScanGeom {
     int waves, stages;
     size_t lds;
 };
-static ScanGeom scan_geometry(int d_pad, int qt) {
+static ScanGeom scan_geometry(int d_pad, int qt, int qp) {
     const int ku = d_pad / KT;
     const bool qreg = ku <= 1;
     const int qb = qreg ? 0 : TILE_ROWS * d_pad * 4;
     ScanGeom g{};
-    g.waves = (qreg && qt == 1) ? 8 : 4;
+    // eight waves (two per SIMD) whenever the query fragments leave room: one tile, or two tiles of one plane
+    g.waves = (qreg && (qt == 1 || (qt == 2 && qp == 1))) ? 8 : 4;
     if (qreg && g_opt.dense_waves == 4) g.waves = 4;
     int ns = (160 * 1024 - qb - SCAN_LDS_TAIL) / (g.waves * SLOT_BYTES);
     const int ns_max = g.waves == 8 ? 2 : 4;
@@ -113,6 +114,7 @@ template <int KU, bool SAMPLE>
 static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, int qt, int qp, hipStream_t st) {
     if constexpr (KU <= 1) {
         if (qt == 4) return qp == 1 ? scan_launch_t<4, 4, KU, 4, 1, SAMPLE>(a, g.lds, st) : scan_launch_t<4, 4, KU, 4, 2, SAMPLE>(a, g.lds, st);
+        if (qt == 2 && qp == 1 && g.waves == 8) return scan_launch_t<8, 2, KU, 2, 1, SAMPLE>(a, g.lds, st);
         if (qt == 2) return qp == 1 ? scan_launch_t<4, 4, KU, 2, 1, SAMPLE>(a, g.lds, st) : scan_launch_t<4, 4, KU, 2, 2, SAMPLE>(a, g.lds, st);
         if (g.waves == 8) return scan_launch_t<8, 2, KU, 1, 2, SAMPLE>(a, g.lds, st);
     }
@@ -125,8 +127,8 @@ static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, int qt, int
 
 template <bool SAMPLE>
 static int scan_launch(const DenseScanArgs& a, int d_pad, int qt, int qp, hipStream_t st) {
-    const ScanGeom g = scan_geometry(d_pad, qt);
-    if (g.stages < 2 || (qt > 1 && (d_pad != KT || g.stages != 4)))
+    const ScanGeom g = scan_geometry(d_pad, qt, qp);
+    if (g.stages < 2 || (qt > 1 && (d_pad != KT || (g.waves == 4 && g.stages != 4))))
         return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d qt=%d leaves no room for the LDS ring", d_pad, qt);
     switch (d_pad / KT) {
         case 1: return scan_launch_ku<1, SAMPLE>(a, g, qt, qp, st);
@@ -237,7 +239,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         const int cus = cu_count(h->device);
         int nrb = g_opt.dense_blocks > 0 ? g_opt.dense_blocks : cus;
         nrb = (nrb + 7) / 8 * 8;
-        const int wv = scan_geometry(d_pad, qt).waves;
+        const int wv = scan_geometry(d_pad, qt, qp).waves;
         // survivors leave the scan as per-wave segments; the re-rank kernel turns them into per-query key lists
         const long long n_waves = (long long)nrb * nqt * wv;
         const u32 wave_cap = 2048;
