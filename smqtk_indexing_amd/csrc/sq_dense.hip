@@ -21,6 +21,8 @@
 //   3. select_topk_kernel sorts the keys; dense_finalize_* converts and
 //      CERTIFIES each query against the filter's error bound.  Queries that fail
 //      (or overflow their list) are redone on the exact full-keys path.
+#include <cmath>
+
 #include "sq_dense_exact.cuh"
 #include "sq_dense_scan.cuh"
 
@@ -225,10 +227,17 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         }
     } else if (scan_ok) {
         const long long n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
-        // Sample every stride-th tile: the sample pass costs 1/stride of a pass, the re-rank + select work
-        // falls with the candidates (~stride*k per query); 16 balances them at k = 100.
-        long long stride = g_opt.sample_stride > 0 ? g_opt.sample_stride : (long long)cap / (8ll * kk);
-        if (stride > 16 && g_opt.sample_stride <= 0) stride = 16;
+        // Sample every stride-th tile.  The sample pass costs ~ n * groups / stride, the re-rank + select
+        // ~ nq * stride * k (candidates per query ~ stride * k * slack); with groups ~ nq / (32 qt) the
+        // balance is stride ~ sqrt(n / (qt k)), independent of the batch: 20 at 10 M rows, k = 100, one
+        // query tile per wave (measured optimum 16-24; 8-12 with four tiles; 4 on a 1.25 M-row shard).
+        long long stride = g_opt.sample_stride;
+        if (stride <= 0) {
+            stride = (long long)(20.0 * sqrt((double)n / 1e7 * 100.0 / (double)kk / (double)qt) + 0.5);
+            if (stride > 24) stride = 24;
+            if (stride < 2) stride = 2;
+            if (stride > (long long)cap / (8ll * kk)) stride = (long long)cap / (8ll * kk);  // room in the key lists
+        }
         if (stride > 64) stride = 64;
         if (stride < 1) stride = 1;
         while (stride > 1 && (n_tiles / stride) * 2 < 8ll * kk) stride >>= 1;
