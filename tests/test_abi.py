@@ -53,3 +53,30 @@ def test_bad_arguments_are_reported_not_crashed():
     if _lib.device_count() == 0:
         with pytest.raises(_lib.HipError):
             _lib.DenseIndex(np.zeros((4, 8), np.float32))
+
+
+def test_argument_validation_through_the_raw_abi():
+    """Status codes and sq_last_error for calls that must fail before touching a device."""
+    lib = _lib.load()
+    h = ctypes.c_int64(0)
+    null = None
+    assert lib.sq_dense_create(null, 10, 8, 0, 0, 0, ctypes.byref(h)) != 0
+    assert b"sq_dense_create" in lib.sq_last_error()
+    x = np.zeros((4, 8), np.float32)
+    assert lib.sq_dense_create(x.ctypes.data, 4, 8, 99, 0, 0, ctypes.byref(h)) != 0          # unknown metric
+    assert b"metric" in lib.sq_last_error()
+    assert lib.sq_hamming_create(x.ctypes.data, 0, 1, 0, 0, ctypes.byref(h)) != 0             # n <= 0
+    assert lib.sq_hamming_search(12345, x.ctypes.data, 1, 1, x.ctypes.data, x.ctypes.data, 0, null) != 0
+    assert b"unknown handle" in lib.sq_last_error()
+    assert lib.sq_dense_search(12345, x.ctypes.data, 1, 1, x.ctypes.data, x.ctypes.data, 0, null) != 0
+    assert lib.sq_rows_create(x.ctypes.data, 7, 4, 8, 0, ctypes.byref(h)) != 0                # unknown dtype
+    assert b"dtype" in lib.sq_last_error()
+    assert lib.sq_rows_rerank(12345, x.ctypes.data, 1, 0, x.ctypes.data, x.ctypes.data, 1, x.ctypes.data,
+                              x.ctypes.data, null) != 0
+    assert lib.sq_rows_destroy(12345) != 0 and lib.sq_dense_destroy(12345) != 0 and lib.sq_hamming_destroy(12345) != 0
+    m = np.zeros(8)
+    assert lib.sq_itq_hash(x.ctypes.data, 0, 4, 8, m.ctypes.data, m.ctypes.data, 0, -1, x.ctypes.data, 0, null) != 0  # bits <= 0
+    assert lib.sq_itq_hash(x.ctypes.data, 0, 4, 8, m.ctypes.data, m.ctypes.data, 4, 1, x.ctypes.data, 0, null) != 0   # normalize=1
+    assert b"normalize" in lib.sq_last_error()
+    st = _lib.SqStats()
+    assert lib.sq_get_stats(12345, ctypes.byref(st)) != 0
