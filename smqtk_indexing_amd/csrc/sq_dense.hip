@@ -18,7 +18,7 @@
 //      candidate from the ORIGINAL float32 rows in the REFERENCE arithmetic
 //      (float32 subtract, square, numpy pairwise order, correctly rounded sqrt;
 //      cosine in float64) and forms (distance, row) keys.
-//   3. select_topk_kernel sorts the keys; dense_finalize_* converts and
+//   3. select_topk_kernel sorts the keys; its post-op (DenseFinalize*) converts and
 //      CERTIFIES each query against the filter's error bound.  Queries that fail
 //      (or overflow their list) are redone on the exact full-keys path.
 #include <cmath>
@@ -56,19 +56,20 @@ struct DenseHandle : HandleBase {
 static constexpr int kSelectLdsKeys64 = 16384;
 static constexpr int kSelectLdsKeys128 = 7168;
 
-template <class K>
+// select + the finalisation post-op (keys -> distances / ids, certification, status) in one launch
+template <class K, class Post>
 static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out,
-                           hipStream_t st) {
+                           const Post& post, hipStream_t st) {
     static bool attr_set = false;
     const int lds_keys = sizeof(K) == 8 ? kSelectLdsKeys64 : kSelectLdsKeys128;
     const size_t lds = (size_t)(lds_keys + SELECT_SORT_MAX) * sizeof(K);
     if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<K>),
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<K, Post>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((select_topk_kernel<K>), dim3(nq), dim3(1024), lds, st, keys, cnt, cap, stride, k, lds_keys,
-                       out);
+    hipLaunchKernelGGL((select_topk_kernel<K, Post>), dim3(nq), dim3(1024), lds, st, keys, cnt, cap, stride, k, lds_keys,
+                       out, post);
     return SQ_OK;
 }
 
@@ -188,8 +189,14 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     double* qn2 = h->qn2.as<double>();
     uint4* qs = h->q_scaled.as<uint4>();
     u32* status = cnt + nq_pad;
-    u32* hs_raw = reinterpret_cast<u32*>(h->status_host.p);  // [cnt (nq_pad) | status (nq)]
-    u32* hs = hs_raw + nq_pad;                               // status words
+    // per-query candidate counts and status words land in pinned host memory straight from the
+    // finalisation (no copy launch): [cnt (nq_pad) | status (nq)]
+    u32* hs_raw = reinterpret_cast<u32*>(h->status_host.p);
+    u32* hs = hs_raw + nq_pad;
+    u32* hs_raw_dev = nullptr;
+    SQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs_raw_dev), hs_raw, 0));
+    u32* hs_dev = hs_raw_dev + nq_pad;
+    (void)status;
     // error bound of the bf16 filter score (sq_dense_exact.cuh filter_eps):
     //   products: |x q' - x_hi (q'_hi + q'_lo)| <= (2^-8 + 2^-15) |x||q'|, q' = -2q  ->  eps_a = 2^-7 + 2^-14 (times X|q|)
     //             (cosine: unit vectors, q' = -q^: half of that; eps_a is kept as the common, looser constant)
@@ -217,13 +224,15 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         h->stats.scan_launches = 1;
         h->stats.bytes_scanned = n * (long long)d * 4;
         if (cosine) {
-            SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, (u32)n, key_stride, k, nq, h->out_keys.as<K128>(), st));
-            hipLaunchKernelGGL(dense_finalize_cos_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<K128>(), cnt,
-                               (u32)n, k, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx, status, nullptr);
+            SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, (u32)n, key_stride, k, nq, h->out_keys.as<K128>(),
+                                         DenseFinalizeCos{cnt, (u32)n, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx,
+                                                          hs_dev, hs_raw_dev, nullptr, 0},
+                                         st));
         } else {
-            SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, (u32)n, key_stride, k, nq, h->out_keys.as<u64>(), st));
-            hipLaunchKernelGGL(dense_finalize_l2_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<u64>(), cnt, (u32)n,
-                               k, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 0, (float*)out_dist, out_idx, status, nullptr);
+            SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, (u32)n, key_stride, k, nq, h->out_keys.as<u64>(),
+                                        DenseFinalizeL2{cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 0,
+                                                        (float*)out_dist, out_idx, hs_dev, hs_raw_dev, nullptr, 0},
+                                        st));
         }
     } else if (scan_ok) {
         const long long n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
@@ -298,26 +307,25 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
             hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3(gxr), dim3(256), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
                                ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, h->keys.as<K128>(), cnt,
                                cap, oflag);
-            SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, cap, key_stride, k, nq, h->out_keys.as<K128>(), st));
-            hipLaunchKernelGGL(dense_finalize_cos_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<K128>(), cnt, cap, k,
-                               kk, h->id_base, thr, eps_a + eps_b, 1, (double*)out_dist, out_idx, status, oflag);
+            SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, cap, key_stride, k, nq, h->out_keys.as<K128>(),
+                                         DenseFinalizeCos{cnt, cap, kk, h->id_base, thr, eps_a + eps_b, 1, (double*)out_dist,
+                                                          out_idx, hs_dev, hs_raw_dev, oflag, 0},
+                                         st));
         } else {
             hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3(gxr), dim3(256), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
                                ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, h->keys.as<u64>(), cnt,
                                cap, oflag);
-            SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, cap, key_stride, k, nq, h->out_keys.as<u64>(), st));
-            hipLaunchKernelGGL(dense_finalize_l2_kernel, dim3(nq), dim3(256), 0, st, h->out_keys.as<u64>(), cnt, cap, k,
-                               kk, h->id_base, thr, qn2, h->xn2_max, eps_a, eps_b, 1, (float*)out_dist, out_idx, status,
-                               oflag);
+            SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, cap, key_stride, k, nq, h->out_keys.as<u64>(),
+                                        DenseFinalizeL2{cnt, cap, kk, h->id_base, thr, qn2, h->xn2_max, eps_a, eps_b, 1,
+                                                        (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0},
+                                        st));
         }
     } else {
         all_fallback = true;  // rows wider than the MFMA scan covers: exact path for every query
     }
     if (prof) SQ_HIP(hipEventRecord(h->ev[3], st));
     if (!all_fallback) {
-        // status[nq] sits right behind cnt[nq_pad] in one buffer: one small D2H copy
-        SQ_HIP(hipMemcpyAsync(hs_raw, cnt, (size_t)(nq_pad + nq) * 4, hipMemcpyDeviceToHost, st));
-        SQ_HIP(hipStreamSynchronize(st));
+        SQ_HIP(hipStreamSynchronize(st));  // counts and status words are in hs_raw / hs now
         SQ_HIP(hipGetLastError());
         if (prof) {
             float t1 = 0, t2 = 0;
@@ -341,19 +349,18 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
             hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, 1), dim3(256), 0, st, h->db, h->ld, d,
                                q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<K128>(), n);
             SQ_TRY(select_launch_t<K128>(h->big_keys.as<K128>(), cnt + qi, (u32)n, n, k, 1,
-                                         h->out_keys.as<K128>() + (long long)qi * k, st));
-            hipLaunchKernelGGL(dense_finalize_cos_kernel, dim3(1), dim3(256), 0, st,
-                               h->out_keys.as<K128>() + (long long)qi * k, cnt + qi, (u32)n, k, kk, h->id_base, thr, 0.0,
-                               0, (double*)out_dist + (long long)qi * k, out_idx + (long long)qi * k, status + qi, nullptr);
+                                         h->out_keys.as<K128>() + (long long)qi * k,
+                                         DenseFinalizeCos{cnt, (u32)n, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx,
+                                                          hs_dev, nullptr, nullptr, qi},
+                                         st));
         } else {
             hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, 1), dim3(256), l2_lds, st, h->db, h->ld, d,
                                q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<u64>(), n);
             SQ_TRY(select_launch_t<u64>(h->big_keys.as<u64>(), cnt + qi, (u32)n, n, k, 1,
-                                        h->out_keys.as<u64>() + (long long)qi * k, st));
-            hipLaunchKernelGGL(dense_finalize_l2_kernel, dim3(1), dim3(256), 0, st,
-                               h->out_keys.as<u64>() + (long long)qi * k, cnt + qi, (u32)n, k, kk, h->id_base, thr, qn2,
-                               0.0, 0.0, 0.0, 0, (float*)out_dist + (long long)qi * k, out_idx + (long long)qi * k,
-                               status + qi, nullptr);
+                                        h->out_keys.as<u64>() + (long long)qi * k,
+                                        DenseFinalizeL2{cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 0,
+                                                        (float*)out_dist, out_idx, hs_dev, nullptr, nullptr, qi},
+                                        st));
         }
         h->stats.scan_launches++;
     }

@@ -422,69 +422,96 @@ struct DenseThrPost {
 
 // --------------------------------------------------------------- finalize
 // status bits: 1 candidate overflow, 2 certification failed, 4 fewer than kk candidates
-static __global__ void dense_finalize_l2_kernel(const u64* __restrict__ sorted, const u32* __restrict__ cnt, u32 cap, int k,
-                                         int kk, long long id_base, const float* __restrict__ thr,
-                                         const double* __restrict__ qn2, double xn2_max, double eps_a, double eps_b,
-                                         int certify, float* __restrict__ out_dist, long long* __restrict__ out_idx,
-                                         u32* __restrict__ status, const u32* __restrict__ overflow) {
-    const int q = blockIdx.x;
-    for (int j = threadIdx.x; j < k; j += blockDim.x) {
-        const u64 key = sorted[(long long)q * k + j];
-        const bool pad = key == ~0ull;
-        out_dist[(long long)q * k + j] = pad ? __builtin_inff() : unordered_f32((u32)(key >> 32));
-        out_idx[(long long)q * k + j] = pad ? -1ll : id_base + (long long)(key & 0xffffffffull);
-    }
-    if (threadIdx.x == 0) {
-        u32 st = 0;
-        if (certify) {
-            const u32 c = cnt[q];
-            if (c > cap || (overflow && *overflow)) st |= 1u;
-            if (c < (u32)kk) st |= 4u;
-            if (st == 0) {
-                const u64 key = sorted[(long long)q * k + (kk - 1)];
-                const double dk = (double)unordered_f32((u32)(key >> 32));
-                const double t = (double)thr[q];
-                const double eps = filter_eps(0, xn2_max, qn2[q], eps_a, eps_b);
-                const double lo2 = t + qn2[q] - eps;  // smallest squared distance a non-candidate can have
-                const double bound = lo2 > 0.0 ? sqrt(lo2) * (1.0 - 1e-6) : 0.0;
-                if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
-            }
+// Post-ops of select_topk_kernel (one workgroup per query, all threads call): keys -> (distance, id),
+// certification, status word.  `status` and `cnt_out` may be host-mapped memory: the host then only
+// has to synchronise the stream.  q0: index of the launch's first query in the per-query arrays
+// (the exact path runs one query per launch).
+struct DenseFinalizeL2 {
+    const u32* cnt;
+    u32 cap;
+    int kk;
+    long long id_base;
+    const float* thr;
+    const double* qn2;
+    double xn2_max, eps_a, eps_b;
+    int certify;
+    float* out_dist;
+    long long* out_idx;
+    u32* status;
+    u32* cnt_out;
+    const u32* overflow;
+    int q0;
+    __device__ __forceinline__ void operator()(int ql, const u64* sorted, int k) const {
+        const int q = q0 + ql;
+        for (int j = threadIdx.x; j < k; j += blockDim.x) {
+            const u64 key = sorted[j];
+            const bool pad = key == ~0ull;
+            out_dist[(long long)q * k + j] = pad ? __builtin_inff() : unordered_f32((u32)(key >> 32));
+            out_idx[(long long)q * k + j] = pad ? -1ll : id_base + (long long)(key & 0xffffffffull);
         }
-        status[q] = st;
-    }
-}
-
-static __global__ void dense_finalize_cos_kernel(const K128* __restrict__ sorted, const u32* __restrict__ cnt, u32 cap,
-                                          int k, int kk, long long id_base, const float* __restrict__ thr,
-                                          double eps, int certify, double* __restrict__ out_dist,
-                                          long long* __restrict__ out_idx, u32* __restrict__ status,
-                                          const u32* __restrict__ overflow) {
-    const int q = blockIdx.x;
-    for (int j = threadIdx.x; j < k; j += blockDim.x) {
-        const K128 key = sorted[(long long)q * k + j];
-        const bool pad = key.hi == ~0ull && key.lo == ~0ull;
-        out_dist[(long long)q * k + j] = pad ? (double)__builtin_inff() : unordered_f64(key.hi);
-        out_idx[(long long)q * k + j] = pad ? -1ll : id_base + (long long)(key.lo & 0xffffffffull);
-    }
-    if (threadIdx.x == 0) {
-        u32 st = 0;
-        if (certify) {
+        if (threadIdx.x == 0) {
+            u32 st = 0;
             const u32 c = cnt[q];
-            if (c > cap || (overflow && *overflow)) st |= 1u;
-            if (c < (u32)kk) st |= 4u;
-            if (st == 0) {
-                const double dk = unordered_f64(sorted[(long long)q * k + (kk - 1)].hi);
-                const double t = (double)thr[q];  // threshold on -sim~
-                // non-candidates: -sim~ > t  =>  sim < -t + eps  =>  dist > 2 acos(min(1,-t+eps))/pi
-                double smax = -t + eps;
-                smax = smax > 1.0 ? 1.0 : (smax < -1.0 ? -1.0 : smax);
-                const double bound = 2.0 * acos(smax) / 3.141592653589793 - 1e-9;
-                if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
+            if (certify) {
+                if (c > cap || (overflow && *overflow)) st |= 1u;
+                if (c < (u32)kk) st |= 4u;
+                if (st == 0) {
+                    const double dk = (double)unordered_f32((u32)(sorted[kk - 1] >> 32));
+                    const double t = (double)thr[q];
+                    const double eps = filter_eps(0, xn2_max, qn2[q], eps_a, eps_b);
+                    const double lo2 = t + qn2[q] - eps;  // smallest squared distance a non-candidate can have
+                    const double bound = lo2 > 0.0 ? sqrt(lo2) * (1.0 - 1e-6) : 0.0;
+                    if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
+                }
             }
+            status[q] = st;
+            if (cnt_out) cnt_out[q] = c;
         }
-        status[q] = st;
     }
-}
+};
 
+struct DenseFinalizeCos {
+    const u32* cnt;
+    u32 cap;
+    int kk;
+    long long id_base;
+    const float* thr;
+    double eps;
+    int certify;
+    double* out_dist;
+    long long* out_idx;
+    u32* status;
+    u32* cnt_out;
+    const u32* overflow;
+    int q0;
+    __device__ __forceinline__ void operator()(int ql, const K128* sorted, int k) const {
+        const int q = q0 + ql;
+        for (int j = threadIdx.x; j < k; j += blockDim.x) {
+            const K128 key = sorted[j];
+            const bool pad = key.hi == ~0ull && key.lo == ~0ull;
+            out_dist[(long long)q * k + j] = pad ? (double)__builtin_inff() : unordered_f64(key.hi);
+            out_idx[(long long)q * k + j] = pad ? -1ll : id_base + (long long)(key.lo & 0xffffffffull);
+        }
+        if (threadIdx.x == 0) {
+            u32 st = 0;
+            const u32 c = cnt[q];
+            if (certify) {
+                if (c > cap || (overflow && *overflow)) st |= 1u;
+                if (c < (u32)kk) st |= 4u;
+                if (st == 0) {
+                    const double dk = unordered_f64(sorted[kk - 1].hi);
+                    const double t = (double)thr[q];  // threshold on -sim~
+                    // non-candidates: -sim~ > t  =>  sim < -t + eps  =>  dist > 2 acos(min(1,-t+eps))/pi
+                    double smax = -t + eps;
+                    smax = smax > 1.0 ? 1.0 : (smax < -1.0 ? -1.0 : smax);
+                    const double bound = 2.0 * acos(smax) / 3.141592653589793 - 1e-9;
+                    if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
+                }
+            }
+            status[q] = st;
+            if (cnt_out) cnt_out[q] = c;
+        }
+    }
+};
 
 }  // namespace sq

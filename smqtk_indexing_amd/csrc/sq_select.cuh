@@ -135,13 +135,21 @@ __device__ __forceinline__ int pow2_ceil(int v) {
 //     bitonic-sorted in LDS.
 //   Small inputs (M <= 512) or k beyond the sort buffer are bitonic-sorted whole.
 // Requires k <= lds_keys.  Dynamic LDS: (lds_keys + SELECT_SORT_MAX) * sizeof(K).
+// `post(q, out_q, k)` runs in the same workgroup once out[q][0..k) is written (all threads call it):
+// the dense path converts keys to (distance, id) and certifies the query there instead of in a
+// separate launch.
 static constexpr int SELECT_SORT_MAX = 2048;
 
-template <class K>
+struct SelectNoPost {
+    template <class K>
+    __device__ __forceinline__ void operator()(int, const K*, int) const {}
+};
+
+template <class K, class Post = SelectNoPost>
 __global__ __launch_bounds__(1024) void select_topk_kernel(const K* __restrict__ keys,
                                                             const u32* __restrict__ cnt, u32 cap,
                                                             long long stride, int k, int lds_keys,
-                                                            K* __restrict__ out) {
+                                                            K* __restrict__ out, Post post = Post()) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     K* sk = reinterpret_cast<K*>(smem_raw);
     K* so = sk + lds_keys;
@@ -252,6 +260,8 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const K* __restrict__
         __syncthreads();
     }
     for (int i = threadIdx.x; i < k; i += T) dst[i] = (i < kk && i < nsort) ? sorted[i] : KeyOps<K>::maxv();
+    __syncthreads();  // the block's own global writes are visible to all its threads
+    post(q, dst, k);
 }
 
 // ------------------------------------------------------------ block helpers
