@@ -13,13 +13,18 @@
 
 namespace sq {
 
+// (row * mul) mod n: see orig_row
+struct RowPerm {
+    u64 mul, inv;
+};
+
 struct HammingHandle : HandleBase {
     const u64* codes = nullptr;  // device, [n][words]
     DevBuf owned;                // backing store when the library owns the copy
     long long n = 0;
     int words = 0;
     long long id_base = 0;
-    u64 pmul = 1;  // physical row p holds caller row (p * pmul) mod n
+    RowPerm pmul{1, 0};  // physical row p holds caller row (p * pmul.mul) mod n
     // workspace
     DevBuf q_dev, keys, cnt, hist, thr, out_keys, status, out_dist_dev, out_idx_dev, big_keys, seg, bcnt;
     HostPinned status_host;
@@ -50,8 +55,15 @@ struct HammingHandle : HandleBase {
 // low-discrepancy permutation: physical row p holds sorted row (p * pmul) mod n with pmul ~ 0.618 n
 // coprime to n, so any run of consecutive physical rows is spread evenly over the sorted array;
 // keys carry the sorted row, recomputed only for survivors.
-__device__ __forceinline__ u32 orig_row(long long row, u64 pmul, long long n) {
-    return pmul == 1ull ? (u32)row : (u32)(((u64)row * pmul) % (u64)n);
+// (row * mul) mod n without a 64-bit division: Barrett with inv = floor((2^64 - 1) / n); the
+// quotient estimate is at most 2 short.
+__device__ __forceinline__ u32 orig_row(long long row, RowPerm pm, long long n) {
+    if (pm.mul == 1ull) return (u32)row;
+    const u64 x = (u64)row * pm.mul;
+    u64 r = x - __umul64hi(x, pm.inv) * (u64)n;
+    if (r >= (u64)n) r -= (u64)n;
+    if (r >= (u64)n) r -= (u64)n;
+    return (u32)r;
 }
 
 static __global__ void hamming_permute_kernel(const u64* __restrict__ src, long long n, int W, u64 pmul,
@@ -123,7 +135,7 @@ __device__ __forceinline__ void load_codes(const u64* __restrict__ codes, long l
 // mode 0: emit keys with dist <= thr[q] through per-query atomic counters.
 // mode 1: write the key of EVERY code at its own position (keys[q][row]).
 template <int W, int C>
-__global__ __launch_bounds__(256) void hamming_scan_kernel(const u64* __restrict__ codes, long long n, u64 pmul,
+__global__ __launch_bounds__(256) void hamming_scan_kernel(const u64* __restrict__ codes, long long n, RowPerm pmul,
                                                             const u64* __restrict__ qs, int nq,
                                                             const int* __restrict__ thr,
                                                             u64* __restrict__ keys, u32* __restrict__ cnt,
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(256) void hamming_scan_kernel(const u64* __restrict
 // returning atomics on 32 hot counters cost 10x at 32 queries).  Mini-lists:
 // seg[(block*nq + q)*S + slot]; their fills go to bcnt[block*nq + q].
 template <int W, int C>
-__global__ __launch_bounds__(256) void hamming_stream_kernel(const u64* __restrict__ codes, long long n, u64 pmul,
+__global__ __launch_bounds__(256) void hamming_stream_kernel(const u64* __restrict__ codes, long long n, RowPerm pmul,
                                                               const u64* __restrict__ qs, int nq,
                                                               const int* __restrict__ thr, u64* __restrict__ seg,
                                                               u32* __restrict__ bcnt, u32 S) {
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256) void hamming_compact_kernel(const u64* __restr
 }
 
 // Generic word count (W not specialised): one code per thread.
-__global__ __launch_bounds__(256) void hamming_scan_generic_kernel(const u64* __restrict__ codes, long long n, u64 pmul,
+__global__ __launch_bounds__(256) void hamming_scan_generic_kernel(const u64* __restrict__ codes, long long n, RowPerm pmul,
                                                                     int W, const u64* __restrict__ qs, int nq,
                                                                     const int* __restrict__ thr,
                                                                     u64* __restrict__ keys, u32* __restrict__ cnt,
@@ -627,7 +639,7 @@ extern "C" int sq_hamming_create(const uint64_t* codes, int64_t n, int words, in
             };
             while (mul < 2 || gcd(mul, (u64)n) != 1) ++mul;
         }
-        h->pmul = mul;
+        h->pmul = RowPerm{mul, ~0ull / (u64)n};
         const size_t bytes = (size_t)n * words * 8;
         const u64* src = reinterpret_cast<const u64*>(codes);
         DevBuf staged;
