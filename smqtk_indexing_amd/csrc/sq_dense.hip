@@ -34,6 +34,8 @@ struct DenseHandle : HandleBase {
     DevBuf scan;                // bfloat16 scan copy [n_pad][d_pad*2 bytes]
     DevBuf norms;               // float32 |x - c|^2 [n_pad] (cosine: of the rows themselves)
     DevBuf center;              // float32 c [d_pad]: column means (L2), the filter's origin
+    DevBuf cos_nx;              // float64 |x|^2 [n] in the reference order (cosine re-rank)
+    DevBuf cos_nq;              // float64 |q|^2 [nq] of the current call (cosine)
     long long n = 0, n_pad = 0;
     int d = 0, d_pad = 0;
     long long ld = 0;
@@ -45,7 +47,7 @@ struct DenseHandle : HandleBase {
         out_idx_dev, big_keys, scratch;
     HostPinned status_host;
     ~DenseHandle() override {
-        for (DevBuf* b : {&owned, &scan, &norms, &center, &q_dev, &q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt,
+        for (DevBuf* b : {&owned, &scan, &norms, &center, &cos_nx, &cos_nq, &q_dev, &q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt,
                           &keys, &sample, &out_keys, &status, &out_dist_dev, &out_idx_dev, &big_keys, &scratch})
             b->release();
         status_host.release();
@@ -73,15 +75,15 @@ static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long str
     return SQ_OK;
 }
 
-template <int WAVES, int NSTAGE, int KU, int QT, int QP, bool SAMPLE>
+template <int WAVES, int NSTAGE, int KU, int QT, int QP, bool AB, bool SAMPLE>
 static int scan_launch_t(const DenseScanArgs& a, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, SAMPLE>),
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, AB, SAMPLE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, SAMPLE>), dim3((unsigned)(a.nrb * a.nqt)),
+    hipLaunchKernelGGL((dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, AB, SAMPLE>), dim3((unsigned)(a.nrb * a.nqt)),
                        dim3(WAVES * 64), lds, st, a);
     return SQ_OK;
 }
@@ -96,16 +98,17 @@ struct ScanGeom {
 };
 static ScanGeom scan_geometry(int d_pad, int qt, int qp) {
     const int ku = d_pad / KT;
-    const bool qreg = ku <= 1;
+    const bool ab = qt > 1 || qp == 1;   // query fragments in AGPRs (multi-tile batches)
+    const bool qreg = ab || ku <= 1;     // not re-read from an LDS copy
     const int qb = qreg ? 0 : TILE_ROWS * d_pad * 4;
     ScanGeom g{};
     // eight waves (two per SIMD) whenever the query fragments leave room: one tile, or two tiles of one plane
-    g.waves = (qreg && (qt == 1 || (qt == 2 && qp == 1))) ? 8 : 4;
-    if (qreg && g_opt.dense_waves == 4) g.waves = 4;
+    g.waves = (ku <= 1 && (qt == 1 || (qt == 2 && qp == 1))) ? 8 : 4;
+    if (ku <= 1 && g_opt.dense_waves == 4) g.waves = 4;
     int ns = (160 * 1024 - qb - SCAN_LDS_TAIL) / (g.waves * SLOT_BYTES);
     const int ns_max = g.waves == 8 ? 2 : 4;
     if (ns > ns_max) ns = ns_max;
-    if (qt == 1 && g_opt.dense_stages >= 2 && g_opt.dense_stages <= ns) ns = g_opt.dense_stages;
+    if (qt == 1 && !ab && g_opt.dense_stages >= 2 && g_opt.dense_stages <= ns) ns = g_opt.dense_stages;
     g.stages = ns;
     g.lds = (size_t)qb + (size_t)g.waves * ns * SLOT_BYTES + SCAN_LDS_TAIL;
     // staging the query tiles through the ring needs the ring to be at least as large
@@ -116,22 +119,26 @@ static ScanGeom scan_geometry(int d_pad, int qt, int qp) {
 template <int KU, bool SAMPLE>
 static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, int qt, int qp, hipStream_t st) {
     if constexpr (KU <= 1) {
-        if (qt == 4) return qp == 1 ? scan_launch_t<4, 4, KU, 4, 1, SAMPLE>(a, g.lds, st) : scan_launch_t<4, 4, KU, 4, 2, SAMPLE>(a, g.lds, st);
-        if (qt == 2 && qp == 1 && g.waves == 8) return scan_launch_t<8, 2, KU, 2, 1, SAMPLE>(a, g.lds, st);
-        if (qt == 2) return qp == 1 ? scan_launch_t<4, 4, KU, 2, 1, SAMPLE>(a, g.lds, st) : scan_launch_t<4, 4, KU, 2, 2, SAMPLE>(a, g.lds, st);
-        if (g.waves == 8) return scan_launch_t<8, 2, KU, 1, 2, SAMPLE>(a, g.lds, st);
+        if (qt == 4) return qp == 1 ? scan_launch_t<4, 4, KU, 4, 1, true, SAMPLE>(a, g.lds, st) : scan_launch_t<4, 4, KU, 4, 2, true, SAMPLE>(a, g.lds, st);
+        if (qt == 2 && qp == 1 && g.waves == 8) return scan_launch_t<8, 2, KU, 2, 1, true, SAMPLE>(a, g.lds, st);
+        if (qt == 2) return qp == 1 ? scan_launch_t<4, 4, KU, 2, 1, true, SAMPLE>(a, g.lds, st) : scan_launch_t<4, 4, KU, 2, 2, true, SAMPLE>(a, g.lds, st);
+        if (g.waves == 8) return scan_launch_t<8, 2, KU, 1, 2, false, SAMPLE>(a, g.lds, st);
+    } else if (qp == 1) {
+        // d_pad > 128, several query tiles in the batch: all k-units' q_hi fragments in AGPRs (KU * QT * 32 <= 256)
+        if (qt == 2) return scan_launch_t<4, 4, KU, 2, 1, true, SAMPLE>(a, g.lds, st);
+        return fail(SQ_ERR_UNSUPPORTED, "dense scan: no kernel for d_pad=%d qt=%d", KU * KT, qt);
     }
     switch (g.stages) {
-        case 4: return scan_launch_t<4, 4, KU, 1, 2, SAMPLE>(a, g.lds, st);
-        case 3: return scan_launch_t<4, 3, KU, 1, 2, SAMPLE>(a, g.lds, st);
-        default: return scan_launch_t<4, 2, KU, 1, 2, SAMPLE>(a, g.lds, st);
+        case 4: return scan_launch_t<4, 4, KU, 1, 2, false, SAMPLE>(a, g.lds, st);
+        case 3: return scan_launch_t<4, 3, KU, 1, 2, false, SAMPLE>(a, g.lds, st);
+        default: return scan_launch_t<4, 2, KU, 1, 2, false, SAMPLE>(a, g.lds, st);
     }
 }
 
 template <bool SAMPLE>
 static int scan_launch(const DenseScanArgs& a, int d_pad, int qt, int qp, hipStream_t st) {
     const ScanGeom g = scan_geometry(d_pad, qt, qp);
-    if (g.stages < 2 || (qt > 1 && (d_pad != KT || (g.waves == 4 && g.stages != 4))))
+    if (g.stages < 2 || ((qt > 1 || qp == 1) && g.waves == 4 && g.stages != 4))
         return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d qt=%d leaves no room for the LDS ring", d_pad, qt);
     switch (d_pad / KT) {
         case 1: return scan_launch_ku<1, SAMPLE>(a, g, qt, qp, st);
@@ -143,11 +150,16 @@ static int scan_launch(const DenseScanArgs& a, int d_pad, int qt, int qp, hipStr
 }
 
 // Query tiles per wave for a batch of `nqt` 32-query tiles (sq_dense_scan.cuh): one tile keeps the
-// eight-wave HBM-bound configuration; larger batches reuse each streamed row tile for 2 or 4 query tiles.
+// HBM-bound configuration; larger batches reuse each streamed row tile for 2 or 4 query tiles, as
+// many as the register budget allows (four at d_pad = 128, two beyond).
 static int scan_query_tiles(int d_pad, int nqt) {
-    if (d_pad != KT) return 1;
-    if (g_opt.dense_qt == 1 || g_opt.dense_qt == 2 || g_opt.dense_qt == 4) return g_opt.dense_qt;
-    return nqt >= 3 ? 4 : (nqt == 2 ? 2 : 1);
+    const int ku = d_pad / KT;
+    if (nqt <= 1) return 1;
+    int want = nqt >= 3 ? 4 : 2;
+    if (g_opt.dense_qt == 1 || g_opt.dense_qt == 2 || g_opt.dense_qt == 4) want = g_opt.dense_qt;
+    if (ku >= 2 && want > 2) want = 2;  // four tiles of a 256-wide row spill past 512 registers
+    if (ku > 1 && want == 1) return 1;  // forced: the LDS-copy kernel
+    return want;
 }
 
 static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, void* out_dist, long long* out_idx,
@@ -166,7 +178,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     const int qt = scan_query_tiles(d_pad, (nq + TILE_ROWS - 1) / TILE_ROWS);  // query tiles per wave
     // query planes: the multi-tile configuration is MFMA bound, so it drops q_lo (half the MFMAs, twice the
     // product bound: ~1.4x more rows pass the filter) unless asked otherwise
-    const int qp = (qt > 1 && g_opt.dense_qplanes != 2) ? 1 : 2;
+    const int qp = (qt > 1 && (g_opt.dense_qplanes != 2 || d_pad > KT)) ? 1 : 2;
     const int group_q = qt * TILE_ROWS;                                           // queries per scan workgroup
     const int nqt = (nq + group_q - 1) / group_q;                                 // groups of qt query tiles
     const int nq_pad = nqt * group_q;
@@ -199,12 +211,18 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     (void)status;
     // error bound of the bf16 filter score (sq_dense_exact.cuh filter_eps):
     //   products: |x q' - x_hi (q'_hi + q'_lo)| <= (2^-8 + 2^-15) |x||q'|, q' = -2q  ->  eps_a = 2^-7 + 2^-14 (times X|q|)
-    //             (cosine: unit vectors, q' = -q^: half of that; eps_a is kept as the common, looser constant)
+    //             (cosine: unit vectors and q' = -q^ without the factor 2: half of that)
     //   float32 accumulation of 2d+1 terms and the float32 norm                     ->  eps_b = (3d+8) 2^-23
     //   one query plane: |x q' - x_hi q'_hi| <= (2^-8 + 2^-8 + 2^-16) |x||q'|                 ->  eps_a = 2^-6 + 2^-13
-    const double eps_a = qp == 2 ? 0.0078125 + 6.103515625e-05 : 0.015625 + 1.220703125e-04;
+    const double eps_a = (qp == 2 ? 0.0078125 + 6.103515625e-05 : 0.015625 + 1.220703125e-04) * (cosine ? 0.5 : 1.0);
     const double eps_b = (3.0 * d_pad + 8.0) * 1.1920928955078125e-07;
     const size_t l2_lds = (size_t)((d + 3) / 4 * 4) * 4;
+    if (cosine) {
+        SQ_TRY(h->cos_nq.reserve((size_t)nq * 8));
+        hipLaunchKernelGGL(dense_cos_qnorm_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, q, nq, d, h->cos_nq.as<double>());
+    }
+    const double* cnx = h->cos_nx.as<double>();
+    const double* cnq = h->cos_nq.as<double>();
 
     const long long key_stride = small ? n : (long long)cap;
     bool all_fallback = false;
@@ -216,7 +234,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
         if (cosine)
             hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, nq), dim3(256), 0, st, h->db, h->ld, d, q, nullptr, cnt,
-                               (u32)n, n, 0ll, h->keys.as<K128>(), key_stride);
+                               (u32)n, n, 0ll, h->keys.as<K128>(), key_stride, cnx, cnq);
         else
             hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, nq), dim3(256), l2_lds, st, h->db, h->ld, d, q, nullptr,
                                cnt, (u32)n, n, 0ll, h->keys.as<u64>(), key_stride);
@@ -242,7 +260,8 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         // query tile per wave (measured optimum 16-24; 8-12 with four tiles; 4 on a 1.25 M-row shard).
         long long stride = g_opt.sample_stride;
         if (stride <= 0) {
-            stride = (long long)(20.0 * sqrt((double)n / 1e7 * 100.0 / (double)kk / (double)qt) + 0.5);
+            // (the float64 cosine re-rank costs ~3.6x the float32 L2 one per candidate: sqrt of that off the stride)
+            stride = (long long)(20.0 * sqrt((double)n / 1e7 * 100.0 / (double)kk / (double)qt) / (cosine ? 1.9 : 1.0) + 0.5);
             if (stride > 24) stride = 24;
             if (stride < 2) stride = 2;
             if (stride > (long long)cap / (8ll * kk)) stride = (long long)cap / (8ll * kk);  // room in the key lists
@@ -301,12 +320,12 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         h->stats.bytes_scanned = h->n_pad * ((long long)d_pad * 2 + (cosine ? 0 : 4));
         // exact re-rank of the survivors (wave segments -> per-query keys), select, certify
         const int wpb = 2;  // survivor segments per re-rank block (both from one scan workgroup: wv is even)
-        const size_t rr_lds = qt == 1 ? (size_t)32 * (ldq + 4) * 4 : 0;  // the query tile in LDS (one-tile groups)
+        const size_t rr_lds = (qt == 1 && ldq <= 156) ? (size_t)32 * (ldq + 4) * 4 : 0;  // the query tile in LDS (rerank_block)
         const unsigned gxr = (unsigned)((n_waves + wpb - 1) / wpb);
         if (cosine) {
             hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3(gxr), dim3(256), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
                                ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, h->keys.as<K128>(), cnt,
-                               cap, oflag);
+                               cap, oflag, cnx, cnq);
             SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, cap, key_stride, k, nq, h->out_keys.as<K128>(),
                                          DenseFinalizeCos{cnt, cap, kk, h->id_base, thr, eps_a + eps_b, 1, (double*)out_dist,
                                                           out_idx, hs_dev, hs_raw_dev, oflag, 0},
@@ -347,7 +366,8 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         if (gx > 8192) gx = 8192;
         if (cosine) {
             hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, 1), dim3(256), 0, st, h->db, h->ld, d,
-                               q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<K128>(), n);
+                               q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<K128>(), n, cnx,
+                               cnq + qi);
             SQ_TRY(select_launch_t<K128>(h->big_keys.as<K128>(), cnt + qi, (u32)n, n, k, 1,
                                          h->out_keys.as<K128>() + (long long)qi * k,
                                          DenseFinalizeCos{cnt, (u32)n, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx,
@@ -460,6 +480,12 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
             }
             colsum.release();
             centerp = h->center.as<float>();
+        }
+        if (metric == SQ_METRIC_COSINE) {
+            rc = h->cos_nx.reserve((size_t)n * 8);
+            if (rc != SQ_OK) return bail(rc);
+            hipLaunchKernelGGL(dense_cos_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, h->db,
+                               (long long)n, h->ld, d, h->cos_nx.as<double>());
         }
         hipLaunchKernelGGL(dense_rowstats_kernel, dim3((unsigned)(h->n_pad / 32)), dim3(256), 0, 0, h->db, (long long)n,
                            h->ld, d, h->n_pad, h->scratch.as<u32>(), h->norms.as<float>(), invp, centerp);

@@ -67,6 +67,69 @@ __device__ __forceinline__ double cosine_row_f64(const float* __restrict__ x, co
     return cosine_dist_f64(dot, nx, nq);
 }
 
+// The same arithmetic with the two per-vector sums taken out of the per-candidate work: |x|^2 of
+// every row is computed once at index build (dense_cos_norm_kernel) and |q|^2 once per query, both
+// in the order above, so only the dot product is left per candidate; its even / odd accumulators
+// are independent chains and may live in two lanes (`sub` = 0 / 1).  Bit-identical to
+// cosine_row_f64.
+__device__ __forceinline__ double cosine_sumsq_f64(const float* __restrict__ x, int d) {
+    double n0 = 0.0, n1 = 0.0;
+    const int m = d - (d & 1);
+    for (int i = 0; i < m; i += 2) {
+        const double x0 = (double)x[i], x1 = (double)x[i + 1];
+        n0 = __dadd_rn(n0, __dmul_rn(x0, x0));
+        n1 = __dadd_rn(n1, __dmul_rn(x1, x1));
+    }
+    double n = __dadd_rn(n0, n1);
+    if (d & 1) n = __dadd_rn(n, __dmul_rn((double)x[m], (double)x[m]));
+    return n;
+}
+// one lane: both chains
+__device__ __forceinline__ double cosine_dot_f64(const float* __restrict__ x, const float* __restrict__ q, int d) {
+    double d0 = 0.0, d1 = 0.0;
+    const int m = d - (d & 1);
+    for (int i = 0; i < m; i += 2) {
+        d0 = __dadd_rn(d0, __dmul_rn((double)q[i], (double)x[i]));
+        d1 = __dadd_rn(d1, __dmul_rn((double)q[i + 1], (double)x[i + 1]));
+    }
+    double dot = __dadd_rn(d0, d1);
+    if (d & 1) dot = __dadd_rn(dot, __dmul_rn((double)q[m], (double)x[m]));
+    return dot;
+}
+// two lanes: lane `sub` owns the chain over elements of its parity; 16-byte loads when aligned
+__device__ __forceinline__ double cosine_dot_pair_f64(const float* __restrict__ x, const float* __restrict__ q, int d, int sub,
+                                                      bool aligned) {
+    double acc = 0.0;
+    const int m = d - (d & 1);
+    int i = 0;
+    if (aligned) {
+        const int m4 = m & ~3;
+        for (; i < m4; i += 4) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(q + i);
+            acc = __dadd_rn(acc, __dmul_rn((double)qv[sub], (double)xv[sub]));
+            acc = __dadd_rn(acc, __dmul_rn((double)qv[2 + sub], (double)xv[2 + sub]));
+        }
+    }
+    for (; i < m; i += 2) acc = __dadd_rn(acc, __dmul_rn((double)q[i + sub], (double)x[i + sub]));
+    const double other = __shfl_xor(acc, 1);
+    double dot = sub == 0 ? __dadd_rn(acc, other) : __dadd_rn(other, acc);  // dot0 + dot1 in both lanes
+    if (d & 1) dot = __dadd_rn(dot, __dmul_rn((double)q[m], (double)x[m]));
+    return dot;
+}
+
+// |x|^2 per row in the reference order (index build, cosine only).
+static __global__ __launch_bounds__(256) void dense_cos_norm_kernel(const float* __restrict__ db, long long n, long long ld,
+                                                                     int d, double* __restrict__ nx64) {
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row < n) nx64[row] = cosine_sumsq_f64(db + row * ld, d);
+}
+// |q|^2 per query in the reference order.
+static __global__ void dense_cos_qnorm_kernel(const float* __restrict__ q, int nq, int d, double* __restrict__ nq64) {
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi < nq) nq64[qi] = cosine_sumsq_f64(q + (long long)qi * d, d);
+}
+
 // ------------------------------------------------------ exact distance keys
 // One lane per row: numpy's eight interleaved accumulators are eight registers,
 // fed by two 16-byte row loads and two 16-byte LDS (query) reads per 8 elements.
@@ -142,13 +205,16 @@ static __global__ __launch_bounds__(256) void dense_exact_cos_kernel(const float
                                                                const float* __restrict__ q_orig,
                                                                const u32* __restrict__ cand, const u32* __restrict__ cnt,
                                                                u32 cap, long long implicit_n, long long row_offset,
-                                                               K128* __restrict__ keys, long long key_stride) {
+                                                               K128* __restrict__ keys, long long key_stride,
+                                                               const double* __restrict__ nx64,
+                                                               const double* __restrict__ nq64) {
     const int q = blockIdx.y;
     const long long M = cand ? (long long)(cnt[q] < cap ? cnt[q] : cap) : implicit_n;
     const float* qv = q_orig + (long long)q * d;
+    const double qq = nq64[q];
     for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < M; j += (long long)gridDim.x * 256) {
         const long long row = cand ? (long long)cand[(long long)q * cap + j] : row_offset + j;
-        const double dist = cosine_row_f64(db + row * ld, qv, d);
+        const double dist = cosine_dist_f64(cosine_dot_f64(db + row * ld, qv, d), nx64[row], qq);
         keys[(long long)q * key_stride + j] = K128{ordered_f64(dist), (u64)(u32)row};
     }
 }
@@ -219,11 +285,14 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
                                              const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt,
                                              u32 wave_cap, long long n_waves, int waves_per_block,
                                              K* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
-                                             u32* __restrict__ overflow) {
+                                             u32* __restrict__ overflow, const double* __restrict__ nx64,
+                                             const double* __restrict__ nq64) {
     extern __shared__ __attribute__((aligned(16))) float s_qrows[];
     __shared__ u32 s_hist[RERANK_MAX_GROUP], s_base[RERANK_MAX_GROUP], s_fill[RERANK_MAX_GROUP];
     const int ldl = ldq + 4;  // LDS row stride: +16 bytes so that different query rows hit different banks
-    const bool q_in_lds = group_q == 32;
+    // the 32 query vectors of a one-tile group sit in LDS while that costs little occupancy (d <= 156);
+    // wider rows (66 KB at d = 512: two workgroups per CU) and larger groups read them through the cache
+    const bool q_in_lds = group_q == 32 && ldq <= 156;
     const long long w0 = (long long)blockIdx.x * waves_per_block;
     if (w0 >= n_waves) return;
     const u32 q0 = wave_cnt[2 * w0 + 1] * 32u;  // first query of the group (the same for all segments of the block)
@@ -264,7 +333,8 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
         }
     }
     __syncthreads();
-    constexpr int LPR = COSINE ? 1 : 2;  // lanes per entry
+    constexpr int LPR = 2;  // lanes per entry (L2: four of numpy's eight accumulators each; cosine: one parity each)
+    const bool rows_aligned = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(db) & 15u) == 0;
     const int sub = threadIdx.x % LPR;
     for (int wi = 0; wi < waves_per_block; ++wi) {
         const long long w = w0 + wi;
@@ -282,9 +352,12 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
                 mask &= mask - 1;
                 const u32 row = ent.x + (u32)((i & 3) + 8 * (i >> 2));
                 if constexpr (COSINE) {
-                    const double dist = cosine_row_f64(db + (long long)row * ld, qrow, d);
-                    const u32 pos = s_base[ql] + atomicAdd(&s_fill[ql], 1u);
-                    if (pos < cap) keys[(long long)qg * cap + pos] = K128{ordered_f64(dist), (u64)row};
+                    const double dot = cosine_dot_pair_f64(db + (long long)row * ld, qrow, d, sub, rows_aligned);
+                    if (sub == 0) {
+                        const double dist = cosine_dist_f64(dot, nx64[row], nq64[qg]);
+                        const u32 pos = s_base[ql] + atomicAdd(&s_fill[ql], 1u);
+                        if (pos < cap) keys[(long long)qg * cap + pos] = K128{ordered_f64(dist), (u64)row};
+                    }
                 } else {
                     const SqLeafPair pr{db + (long long)row * ld, qrow, sub};
                     const float dist = sqrt_rn_f32(pr.sum(d));
@@ -310,16 +383,16 @@ static __global__ __launch_bounds__(256) void dense_rerank_l2_kernel(
     int waves_per_block, int nq, int group_q, u64* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
     u32* __restrict__ overflow) {
     rerank_block<u64, false>(db, ld, d, q_al, ldq, nq, group_q, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block,
-                             keys, cnt, cap, overflow);
+                             keys, cnt, cap, overflow, nullptr, nullptr);
 }
 
 static __global__ __launch_bounds__(256) void dense_rerank_cos_kernel(
     const float* __restrict__ db, long long ld, int d, const float* __restrict__ q_al, int ldq,
     const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt, u32 wave_cap, long long n_waves,
     int waves_per_block, int nq, int group_q, K128* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
-    u32* __restrict__ overflow) {
+    u32* __restrict__ overflow, const double* __restrict__ nx64, const double* __restrict__ nq64) {
     rerank_block<K128, true>(db, ld, d, q_al, ldq, nq, group_q, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block,
-                             keys, cnt, cap, overflow);
+                             keys, cnt, cap, overflow, nx64, nq64);
 }
 
 // Copy queries into the aligned, padded layout the lane-per-row kernels read.

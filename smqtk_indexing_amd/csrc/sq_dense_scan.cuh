@@ -273,6 +273,11 @@ __device__ __forceinline__ void mfma_fence_in(f32x16 (&acc)[QT], f32x4 (&av)[8])
         asm volatile("s_nop 1"
                      : "+v"(acc[0]), "+v"(acc[1]), "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]),
                        "+v"(av[5]), "+v"(av[6]), "+v"(av[7]));
+    else
+        asm volatile("s_nop 1"
+                     : "+v"(acc[0]), "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]),
+                       "+v"(av[6]), "+v"(av[7]));
+    static_assert(QT == 1 || QT == 2 || QT == 4, "query tiles per wave");
 }
 // the same pad for the norm block (C of every chain's first MFMA) and the A fragments
 __device__ __forceinline__ void mfma_fence_in_c(f32x16& c, f32x4 (&av)[8]) {
@@ -286,9 +291,12 @@ __device__ __forceinline__ void mfma_fence_out(f32x16 (&acc)[QT]) {
         asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
     else if constexpr (QT == 2)
         asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+    else
+        asm volatile("s_nop 15" : "+v"(acc[0]));
 }
 // eight 16-byte LDS reads straight into AGPRs, complete on return
-__device__ __forceinline__ void lds_read8_agpr(f32x4 (&dst)[16], int g0, const u32 (&ad)[8]) {
+template <int N>
+__device__ __forceinline__ void lds_read8_agpr(f32x4 (&dst)[N], int g0, const u32 (&ad)[8]) {
     asm volatile(
         "ds_read_b128 %0, %8\n\t"
         "ds_read_b128 %1, %9\n\t"
@@ -315,11 +323,15 @@ __device__ __forceinline__ void lds_read8_agpr(f32x4 (&dst)[16], int g0, const u
 // multi-tile, MFMA-bound configuration: half the MFMAs for a bound of 2^-7 instead
 // of 2^-8 per product, sq_dense.hip); SAMPLE: write per-lane minima of every
 // visited tile instead of emitting candidates.
-template <int WAVES, int NSTAGE, int KU, int QT, int QP, bool SAMPLE>
+// AB: the query fragments of ALL k-units live in AGPRs and the MFMAs are issued from inline asm
+// (every multi-tile configuration, and d_pad > 128 with more than one query tile in the batch);
+// otherwise they are compiler-managed VGPRs (KU == 1) or re-read from an LDS copy per MFMA
+// (KU > 1: fine while one tile per wave keeps the kernel HBM bound, LDS bound beyond that).
+template <int WAVES, int NSTAGE, int KU, int QT, int QP, bool AB, bool SAMPLE>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(DenseScanArgs a) {
-    static_assert(QP == 2 || (QP == 1 && QT > 1), "one query plane only in the multi-tile configuration");
-    constexpr bool QREG = KU <= 1;  // query fragments live in registers for d_pad <= 128
-    static_assert(QT == 1 || QREG, "several query tiles per wave need the register-resident query fragments");
+    static_assert(AB || (QT == 1 && QP == 2), "several query tiles / one query plane need the AGPR-resident fragments");
+    static_assert(!AB || KU * QT * QP * 32 <= 256, "AGPR budget of the query fragments");
+    constexpr bool QREG = AB || KU <= 1;  // query fragments live in registers (not re-read from LDS)
     constexpr int DPAD = KU * KT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -384,22 +396,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
 
     // B fragments of k-step s: chunk 2s+h of the hi plane (bq[.][2s]) and of the lo plane (bq[.][2s+1]);
     // with QREG (KU == 1) one set per query tile of the group
-    f32x4 bq[QT][16];
+    // AB: bq[t][kc * 8 * QP + ...] for k-unit kc (QP == 1: entry s = hi fragment of k-step s)
+    f32x4 bq[QT][AB ? KU * 8 * QP : 16];
     if constexpr (QREG) {
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             const u32 rowb = (u32)(t * TILE_ROWS + r31) * DPAD * 4;
-            if constexpr (QT > 1) {  // into AGPRs (see mfma_bf16_agpr_b); QP == 1: bq[t][s] = hi fragment of k-step s
+            if constexpr (AB) {  // into AGPRs (see mfma_bf16_agpr_b)
 #pragma unroll
-                for (int g0 = 0; g0 < 8 * QP; g0 += 8) {
-                    u32 ad[8];
+                for (int kc = 0; kc < KU; ++kc)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int g = QP == 2 ? g0 + j : 2 * j;  // (k-step, plane) = (g >> 1, g & 1)
-                        ad[j] = lds_base + rowb + (g & 1) * 256 + ((2 * (g >> 1) + h) ^ (r31 & 15)) * 16;
+                    for (int g0 = 0; g0 < 8 * QP; g0 += 8) {
+                        u32 ad[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int g = QP == 2 ? g0 + j : 2 * j;  // (k-step, plane) = (g >> 1, g & 1)
+                            ad[j] = lds_base + rowb + kc * 512 + (g & 1) * 256 + ((2 * (g >> 1) + h) ^ (r31 & 15)) * 16;
+                        }
+                        lds_read8_agpr(bq[t], kc * 8 * QP + g0, ad);
                     }
-                    lds_read8_agpr(bq[t], g0, ad);
-                }
             } else {
 #pragma unroll
                 for (int g = 0; g < 16; ++g)
@@ -452,7 +467,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     //   the fragments of unit u+1 are read from LDS (av_nxt) under those MFMAs;
     //   the slot of unit u is refilled by the DMA of unit u+NSTAGE as soon as
     //   av_cur is complete.
-    const bool do_dma = QT > 1 || !(a.debug & 2), do_math = QT > 1 || !(a.debug & 1);
+    const bool do_dma = AB || !(a.debug & 2), do_math = AB || !(a.debug & 1);
     auto issue_next = [&]() {
         if (issued < total_units) {
             if (do_dma || issued < NSTAGE)  // ablation: the ring is filled once, then reused
@@ -493,54 +508,69 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     }
     for (long long sel = gw; sel < a.n_sel; sel += nwaves) {
         f32x16 acc[QT];
-        if constexpr (QT > 1) {
-            // ---- KU == 1: one unit per tile.  One wave per SIMD: nothing else hides this wave's side
-            // work, so it sits in the issue shadow of the 16*QT MFMAs (an MFMA holds the vector issue for
-            // 8 of its 32 cycles): the LDS reads of the next unit's fragments behind the first MFMAs, one
-            // of the nine DMA instructions that refill this unit's slot behind every few MFMAs after
-            // that.  The body is specialised on (refill?, read ahead?) so the block is free of branches;
-            // the measurement-only ablations (debug 1 / 2) are not available in this configuration.
-            auto unit = [&](auto iss_c, auto rd_c) {
+        if constexpr (AB) {
+            // ---- One wave per SIMD (or two with little else to do): nothing else hides this wave's
+            // side work, so it sits in the issue shadow of the 8*QP*QT MFMAs of a unit (an MFMA holds the
+            // vector issue for 8 of its 32 cycles): the LDS reads of the next unit's fragments behind
+            // the first MFMAs, one of the DMA instructions that refill this unit's slot behind every
+            // few MFMAs after that.  The body is specialised on (refill?, read ahead?) so the block is
+            // free of branches; the measurement-only ablations (debug 1 / 2) are not available here.
+            auto unit = [&](auto iss_c, auto rd_c, const int kc) {
                 constexpr bool ISS = decltype(iss_c)::value, RD = decltype(rd_c)::value;
 #pragma unroll
                 for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];
                 f32x16 nrm_c;
+                if (kc == 0) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) nrm_c[i] = add_norm ? nrm_nxt[i >> 2][i & 3] : 0.f;
+                    for (int i = 0; i < 16; ++i) nrm_c[i] = add_norm ? nrm_nxt[i >> 2][i & 3] : 0.f;
+                }
                 asm volatile("" ::: "memory");
                 const int units_behind = (int)(issued - loaded - 1);  // younger units that may stay in flight
                 const long long irow0 = iss_sel * a.tile_step * TILE_ROWS;
                 const u32 idst = ring_base + (u32)iss_slot * SLOT_BYTES;
-                const unsigned char* ibase = reinterpret_cast<const unsigned char*>(a.scan) + irow0 * (DPAD * 2);
-                mfma_fence_in_c(nrm_c, av_cur);
+                const unsigned char* ibase = reinterpret_cast<const unsigned char*>(a.scan) + irow0 * (DPAD * 2) + iss_kc * 256;
+                const bool inorm = add_norm && iss_kc == 0;
+                const bool rd_first = rd_kc == 0;
+                if (kc == 0)
+                    mfma_fence_in_c(nrm_c, av_cur);
+                else
+                    mfma_fence_in<QT>(acc, av_cur);
                 constexpr int NSLOT = 8 * QP * QT;             // one slot behind every MFMA
-                constexpr int DMA0 = 6, DSTEP = (NSLOT - DMA0 - 1) / 9;
+                constexpr int DMA0 = NSLOT >= 16 ? 6 : 2, DSTEP = (NSLOT - DMA0 - 1) / 9 > 0 ? (NSLOT - DMA0 - 1) / 9 : 1;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
 #pragma unroll
                     for (int half = 0; half < QP; ++half) {  // two planes: lo first, then hi
 #pragma unroll
                         for (int t = 0; t < QT; ++t) {
-                            const int frag = QP == 2 ? 2 * s + 1 - half : s;
-                            if (s == 0 && half == 0)
+                            const int frag = kc * 8 * QP + (QP == 2 ? 2 * s + 1 - half : s);
+                            if (kc == 0 && s == 0 && half == 0)
                                 mfma_bf16_agpr_b_first(acc[t], av_cur[0], bq[t][frag], nrm_c);
                             else
                                 mfma_bf16_agpr_b(acc[t], av_cur[s], bq[t][frag]);
                             const int slot = (s * QP + half) * QT + t;
                             if constexpr (RD) {
-                                if (slot == 1) {
+                                if (slot == 1 || (NSLOT == 1)) {
                                     if (nine)
                                         wait_units_in_flight<NSTAGE, 9>(units_behind);
                                     else
                                         wait_units_in_flight<NSTAGE, 8>(units_behind);
-                                    read_frags(rd_slot, true);
+                                    read_frags(rd_slot, rd_first);
                                 }
                             }
                             if constexpr (ISS) {
                                 if (slot >= DMA0 && (slot - DMA0) % DSTEP == 0) {
                                     const int j = (slot - DMA0) / DSTEP;
                                     if (j < 8) glds16(ibase, voff[j], idst + (u32)j * 1024);
-                                    if (j == 8 && add_norm) glds4(a.norms + irow0, voff_norm, idst + UNIT_BYTES);
+                                    if (j == 8 && inorm) glds4(a.norms + irow0, voff_norm, idst + UNIT_BYTES);
+                                }
+                                // fewer slots than DMA pieces (8 MFMAs per unit): the rest goes behind the last MFMA
+                                if (slot == NSLOT - 1) {
+#pragma unroll
+                                    for (int j = (NSLOT - 1 - DMA0) / DSTEP + 1; j < 9; ++j) {
+                                        if (j < 8) glds16(ibase, voff[j], idst + (u32)j * 1024);
+                                        if (j == 8 && inorm) glds4(a.norms + irow0, voff_norm, idst + UNIT_BYTES);
+                                    }
                                 }
                             }
                         }
@@ -549,21 +579,28 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 if constexpr (RD) {
                     ++loaded;
                     if (++rd_slot == NSTAGE) rd_slot = 0;
+                    if (++rd_kc == KU) rd_kc = 0;
                 }
                 if constexpr (ISS) {
                     ++issued;
-                    iss_sel += nwaves;
+                    if (++iss_kc == KU) {
+                        iss_kc = 0;
+                        iss_sel += nwaves;
+                    }
                     if (++iss_slot == NSTAGE) iss_slot = 0;
                 }
                 mfma_fence_out<QT>(acc);
             };
-            const bool rd = loaded < total_units, iss = issued < total_units;  // iss implies rd
-            if (iss)
-                unit(std::true_type{}, std::true_type{});
-            else if (rd)
-                unit(std::false_type{}, std::true_type{});
-            else
-                unit(std::false_type{}, std::false_type{});
+#pragma unroll
+            for (int kc = 0; kc < KU; ++kc) {
+                const bool rd = loaded < total_units, iss = issued < total_units;  // iss implies rd
+                if (iss)
+                    unit(std::true_type{}, std::true_type{}, kc);
+                else if (rd)
+                    unit(std::false_type{}, std::true_type{}, kc);
+                else
+                    unit(std::false_type{}, std::false_type{}, kc);
+            }
         } else {
 #pragma unroll
             for (int kc = 0; kc < KU; ++kc) {

@@ -203,6 +203,21 @@ def test_dense_scan_query_tiles_per_wave(metric, nq, qt, qplanes):
     assert st["candidates"] >= nq * 20
 
 
+@pytest.mark.parametrize("metric,d,nq", [("euclidean", 256, 70), ("cosine", 512, 40), ("euclidean", 384, 33),
+                                          ("euclidean", 200, 64)])
+def test_dense_wide_rows_multi_tile_batches(metric, d, nq):
+    """d_pad > 128 with more than one query tile: all k-units' query fragments in AGPRs, two query
+    tiles per wave (the LDS-copy kernel serves single-tile batches only)."""
+    rng = np.random.default_rng(d + nq)
+    db = rng.standard_normal((120_000, d)).astype(np.float32)
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    qs[1] = db[777]
+    idx = _dense_check(db, qs, 15, metric)
+    st = idx.stats()
+    assert st["fallback_queries"] == 0, st
+    assert st["candidates"] >= nq * 15
+
+
 def test_dense_offset_data_is_filtered_around_its_mean():
     """Rows far from the origin (|x| >> spread): the L2 filter scores x - c against q - c (c = column
     means), so its error bound does not swallow the distance differences; no query may need the exact

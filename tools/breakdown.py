@@ -12,10 +12,11 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(3)
 db = torch.empty((n, d), dtype=torch.float32, device=dev).normal_(generator=g)
 _lib.set_option("profile", 1)
-idx = _lib.DenseIndex(db.data_ptr(), n=n, d=d, device_ptr=True, keepalive=db)
+metric = _lib.SQ_METRIC_COSINE if os.environ.get("METRIC", "l2") == "cosine" else _lib.SQ_METRIC_L2
+idx = _lib.DenseIndex(db.data_ptr(), n=n, d=d, metric=metric, device_ptr=True, keepalive=db)
 st = torch.cuda.current_stream().cuda_stream
 q = torch.empty((nq, d), dtype=torch.float32, device=dev).normal_(generator=g)
-od = torch.empty((nq, k), dtype=torch.float32, device=dev); oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
+od = torch.empty((nq, k), dtype=torch.float64 if metric == _lib.SQ_METRIC_COSINE else torch.float32, device=dev); oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
 for r in range(int(os.environ.get("REPS", 10))):
     idx.search_device(q.data_ptr(), nq, k, od.data_ptr(), oi.data_ptr(), st)
