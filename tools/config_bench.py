@@ -36,3 +36,27 @@ if __name__ == "__main__":
     case("C2", 1_000_000, 128, 1024, 100, _lib.SQ_METRIC_L2)
     case("C4_shard", 12_500_000, 512, 256, 100, _lib.SQ_METRIC_COSINE)
     case("C4_shard_32q", 12_500_000, 512, 32, 100, _lib.SQ_METRIC_COSINE)
+
+
+def c1_plugin():
+    """C1: 10k x 128 float32, k = 10, 100 queries through the plugin class (host containers + small exact path)."""
+    from smqtk_indexing_amd._compat import DescriptorMemoryElement
+    from smqtk_indexing_amd.impls.nn_index.hip_bruteforce import HipBruteForceNearestNeighborsIndex
+    rng = np.random.default_rng(1)
+    x = rng.random((10_000, 128), dtype=np.float32)
+    qs = rng.random((100, 128), dtype=np.float32)
+    idx = HipBruteForceNearestNeighborsIndex()
+    t0 = time.perf_counter(); idx.build_index(DescriptorMemoryElement(i).set_vector(v) for i, v in enumerate(x)); build_s = time.perf_counter() - t0
+    qd = [DescriptorMemoryElement(f"q{i}").set_vector(v) for i, v in enumerate(qs)]
+    idx.nn(qd[0], 10)
+    t0 = time.perf_counter()
+    for q in qd: idx.nn(q, 10)
+    single = 100 / (time.perf_counter() - t0)
+    idx.nn_many(qs, 10)
+    t0 = time.perf_counter(); idx.nn_many(qs, 10); many = 100 / (time.perf_counter() - t0)
+    print(json.dumps({"config": "C1_plugin", "rows": 10_000, "dim": 128, "k": 10, "nn_queries_per_s": single,
+                      "nn_many100_queries_per_s": many, "index_build_s": build_s}), flush=True)
+
+
+if __name__ == "__main__" and os.environ.get("C1", "1") == "1":
+    c1_plugin()
