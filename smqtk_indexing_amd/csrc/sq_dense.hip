@@ -9,15 +9,16 @@
 //
 // Structure:
 //   1. dense_scan_kernel (sq_dense_scan.cuh) streams a bfloat16 copy of the
-//      matrix once per 32-query tile: LDS-DMA ring per wave, bf16 MFMA
-//      (x_hi*q_hi + x_hi*q_lo), scores s = |x|^2 - 2 x.q (cosine: -x^.q^)
-//      compared with a per-query threshold; survivors go to candidate lists.
-//      The threshold comes from the same kernel in SAMPLE mode over every S-th
-//      tile + kth_threshold_f32_kernel.
-//   2. dense_exact_*_kernel (sq_dense_exact.cuh) recomputes the distance of every
-//      candidate from the ORIGINAL float32 rows in the REFERENCE arithmetic
+//      matrix (L2: of the rows minus their column means) once per group of 1, 2
+//      or 4 32-query tiles: LDS-DMA ring per wave, bf16 MFMA (x_hi*q_hi
+//      [+ x_hi*q_lo]), scores s = |x|^2 - 2 x.q (cosine: -x^.q^) compared with a
+//      per-query threshold; survivors leave as per-wave lists of (first row,
+//      mask, query) entries.  The threshold comes from the same kernel in SAMPLE
+//      mode over every S-th tile + kth_threshold_f32_kernel.
+//   2. dense_rerank_*_kernel (sq_dense_exact.cuh) recomputes the distance of every
+//      survivor from the ORIGINAL float32 rows in the REFERENCE arithmetic
 //      (float32 subtract, square, numpy pairwise order, correctly rounded sqrt;
-//      cosine in float64) and forms (distance, row) keys.
+//      cosine in float64, scipy's order) and forms (distance, row) keys.
 //   3. select_topk_kernel sorts the keys; its post-op (DenseFinalize*) converts and
 //      CERTIFIES each query against the filter's error bound.  Queries that fail
 //      (or overflow their list) are redone on the exact full-keys path.
@@ -43,12 +44,12 @@ struct DenseHandle : HandleBase {
     long long id_base = 0;
     double xn2_max = 0.0;       // max squared row norm (error bound of the L2 filter)
     // workspace
-    DevBuf q_dev, q_scaled, q_al, qn2, thr, wave_out, wave_cnt, cnt, keys, sample, out_keys, status, out_dist_dev,
+    DevBuf q_dev, q_scaled, q_al, qn2, thr, wave_out, wave_cnt, cnt, keys, sample, out_keys, out_dist_dev,
         out_idx_dev, big_keys, scratch;
     HostPinned status_host;
     ~DenseHandle() override {
         for (DevBuf* b : {&owned, &scan, &norms, &center, &cos_nx, &cos_nq, &q_dev, &q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt,
-                          &keys, &sample, &out_keys, &status, &out_dist_dev, &out_idx_dev, &big_keys, &scratch})
+                          &keys, &sample, &out_keys, &out_dist_dev, &out_idx_dev, &big_keys, &scratch})
             b->release();
         status_host.release();
     }
@@ -190,7 +191,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         SQ_HIP(hipEventRecord(h->ev[1], st));
         SQ_HIP(hipEventRecord(h->ev[2], st));
     }
-    SQ_TRY(h->cnt.reserve((size_t)(nq_pad + nq) * 4));
+    SQ_TRY(h->cnt.reserve((size_t)nq_pad * 4));
     SQ_TRY(h->thr.reserve((size_t)nq_pad * 4));
     SQ_TRY(h->qn2.reserve((size_t)nq_pad * 8));
     SQ_TRY(h->q_scaled.reserve((size_t)nq_pad * d_pad * 4));
@@ -200,7 +201,6 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     float* thr = h->thr.as<float>();
     double* qn2 = h->qn2.as<double>();
     uint4* qs = h->q_scaled.as<uint4>();
-    u32* status = cnt + nq_pad;
     // per-query candidate counts and status words land in pinned host memory straight from the
     // finalisation (no copy launch): [cnt (nq_pad) | status (nq)]
     u32* hs_raw = reinterpret_cast<u32*>(h->status_host.p);
@@ -208,7 +208,6 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     u32* hs_raw_dev = nullptr;
     SQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs_raw_dev), hs_raw, 0));
     u32* hs_dev = hs_raw_dev + nq_pad;
-    (void)status;
     // error bound of the bf16 filter score (sq_dense_exact.cuh filter_eps):
     //   products: |x q' - x_hi (q'_hi + q'_lo)| <= (2^-8 + 2^-15) |x||q'|, q' = -2q  ->  eps_a = 2^-7 + 2^-14 (times X|q|)
     //             (cosine: unit vectors and q' = -q^ without the factor 2: half of that)

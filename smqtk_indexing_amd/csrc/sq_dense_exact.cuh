@@ -395,15 +395,6 @@ static __global__ __launch_bounds__(256) void dense_rerank_cos_kernel(
                              keys, cnt, cap, overflow, nx64, nq64);
 }
 
-// Copy queries into the aligned, padded layout the lane-per-row kernels read.
-static __global__ void dense_align_queries_kernel(const float* __restrict__ q, int nq, int d, int ldq,
-                                                  float* __restrict__ q_al) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)nq * ldq) return;
-    const int r = (int)(i / ldq), c = (int)(i - (long long)r * ldq);
-    q_al[i] = c < d ? q[(long long)r * d + c] : 0.f;
-}
-
 // Plain distance vectors for sq_dense_distances (one query, n gathered rows),
 // in the rows' own dtype like metrics.euclidean_distance (float32 in -> float32
 // out, float64 in -> float64 out); cosine is always float64 (scipy cdist).

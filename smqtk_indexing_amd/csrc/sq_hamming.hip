@@ -3,12 +3,15 @@
 // Replaces the hot loop of LinearHashIndex._nn
 // (smqtk_indexing/impls/hash_index/linear.py:235-240): one python call of
 // metrics.hamming_distance (utils/metrics.py:140-155) per stored code inside
-// heapq.nsmallest.  Here: one streaming pass over the code array
-// (uint64[N][W], coalesced 16-byte loads), XOR + v_bcnt popcount per
-// (code, query) with the query words in scalar registers, a per-query
-// distance threshold taken from a histogram of a 1/S sample of the codes, and
-// emission of (distance, row) keys for everything within the threshold;
-// `select_topk_kernel` then sorts the few survivors.  Integer-exact.
+// heapq.nsmallest.  Here: a persistent grid streams the code array
+// (uint64[N][W], coalesced 16-byte loads, stored in a low-discrepancy
+// permutation of the caller's sorted order), XOR + v_bcnt popcount per
+// (code, query) with the batch's query words in LDS, a per-query integer
+// distance threshold from a histogram of a block sample, survivors
+// (distance, sorted row) into per-(workgroup, query) lists without global
+// atomics, a prefix-sum compaction per query and `select_topk_kernel` over the
+// few survivors.  Small arrays and overflowing queries take the all-keys path.
+// Integer-exact.  DESIGN.md section 4.3.
 #include "sq_select.cuh"
 
 namespace sq {

@@ -560,9 +560,4 @@ static __global__ void fill_u32_kernel(u32* p, long long n, u32 v) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-static __global__ void fill_f32_kernel(float* p, long long n, float v) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 }  // namespace sq
