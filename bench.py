@@ -117,13 +117,19 @@ def main() -> None:
     _lib.set_option("profile", 1)
     index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=_lib.SQ_METRIC_L2, device_ptr=True,
                             id_base=r0, keepalive=db)
-    out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
     if use_dist:
-        # one collective per step: ids and the float32 distance bits travel in one int64 tensor
-        packed = torch.empty((nq, 2 * k), dtype=torch.int64, device=dev)
-        all_packed = torch.empty((world, nq, 2 * k), dtype=torch.int64, device=dev)
-        host_packed = torch.empty((world, nq, 2 * k), dtype=torch.int64, pin_memory=True)
+        # One collective per step and no repacking: the search writes its ids and distances into the
+        # two halves of ONE byte buffer ([ids int64 nq*k][dist float32 nq*k]), that buffer is
+        # all-gathered, and the host merge reads the pinned receive buffer in place.
+        send = torch.empty(nq * k * 12, dtype=torch.uint8, device=dev)
+        out_i = send[: nq * k * 8].view(torch.int64).view(nq, k)
+        out_d = send[nq * k * 8:].view(torch.float32).view(nq, k)
+        recv = torch.empty((world, nq * k * 12), dtype=torch.uint8, device=dev)
+        host_recv = torch.empty((world, nq * k * 12), dtype=torch.uint8, pin_memory=True)
+        host_np = host_recv.numpy().reshape(-1)
+    else:
+        out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     scan_ms, cands, fallbacks = [], [], []
@@ -136,16 +142,11 @@ def main() -> None:
         fallbacks.append(st["fallback_queries"])
         if use_dist:
             # per-shard top-k candidates over xGMI, then the host-side merge (north_star)
-            packed[:, :k] = out_i
-            packed[:, k:] = out_d.view(torch.int32)
-            dist.all_gather_into_tensor(all_packed, packed)
+            dist.all_gather_into_tensor(recv, send)
             if rank == 0:
-                host_packed.copy_(all_packed, non_blocking=True)
+                host_recv.copy_(recv, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
-                hp = host_packed.numpy()
-                gi = np.ascontiguousarray(hp[:, :, :k])
-                gd = np.ascontiguousarray(hp[:, :, k:].astype(np.int32)).view(np.float32)
-                return _lib.merge_topk(gd, gi, k)
+                return _lib.merge_topk_gathered(host_np, world, nq, k, k, np.float32)
             return None
         return out_d, out_i
 

@@ -167,6 +167,14 @@ int sq_rows_destroy(sq_handle_t h);
 int sq_merge_topk(const void* dist, const int64_t* idx, int dist_dtype,
                   int nshards, int nq, int k_in, int k_out,
                   void* out_dist, int64_t* out_idx);
+/* The same merge reading each shard's [nq][k_in] block at a byte stride: the
+ * all-gather can then deliver ids and distances of a shard in ONE buffer
+ * ([ids int64 nq*k_in][dist nq*k_in] per shard) and the merge reads the pinned
+ * receive buffer in place. */
+int sq_merge_topk_strided(const void* dist, const int64_t* idx, int dist_dtype,
+                          int nshards, int nq, int k_in, int k_out,
+                          int64_t dist_shard_stride_bytes, int64_t idx_shard_stride_bytes,
+                          void* out_dist, int64_t* out_idx);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,7 @@ EXPORTS = (
     "sq_set_option", "sq_get_stats", "sq_itq_hash",
     "sq_hamming_create", "sq_hamming_search", "sq_hamming_destroy",
     "sq_dense_create", "sq_dense_search", "sq_dense_destroy",
-    "sq_dense_distances", "sq_merge_topk",
+    "sq_dense_distances", "sq_merge_topk", "sq_merge_topk_strided",
     "sq_rows_create", "sq_rows_rerank", "sq_rows_destroy",
 )
 
@@ -80,6 +80,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_dense_destroy.argtypes = [c_i64]
     lib.sq_dense_distances.argtypes = [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_int, c_vp]
     lib.sq_merge_topk.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]
+    lib.sq_merge_topk_strided.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_vp, c_vp]
     lib.sq_rows_create.argtypes = [c_vp, c_int, c_i64, c_int, c_int, ctypes.POINTER(c_i64)]
     lib.sq_rows_rerank.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]
     lib.sq_rows_destroy.argtypes = [c_i64]
@@ -365,6 +366,23 @@ def merge_topk(dist: np.ndarray, idx: np.ndarray, k_out: int) -> Tuple[np.ndarra
     oi = np.empty((nq, k_out), dtype=np.int64)
     _check(load().sq_merge_topk(_ptr(dist), _ptr(idx), dt, ns, nq, k_in, int(k_out), _ptr(od), _ptr(oi)),
            "sq_merge_topk")
+    return od, oi
+
+
+def merge_topk_gathered(buf: np.ndarray, nshards: int, nq: int, k_in: int, k_out: int,
+                        dist_dtype) -> Tuple[np.ndarray, np.ndarray]:
+    """Host merge straight from the receive buffer of ONE all-gather: ``buf`` is a C-contiguous
+    uint8 array of ``nshards`` blocks, each ``[ids int64 nq*k_in][dist nq*k_in]``."""
+    dist_dtype = np.dtype(dist_dtype)
+    dt = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int32): 2}[dist_dtype]
+    per = nq * k_in * (8 + dist_dtype.itemsize)
+    if buf.dtype != np.uint8 or not buf.flags.c_contiguous or buf.size != nshards * per:
+        raise ValueError("buf must be a contiguous uint8 array of nshards * nq * k_in * (8 + dist size) bytes")
+    od = np.empty((nq, k_out), dtype=dist_dtype)
+    oi = np.empty((nq, k_out), dtype=np.int64)
+    base = buf.ctypes.data
+    _check(load().sq_merge_topk_strided(base + nq * k_in * 8, base, dt, int(nshards), int(nq), int(k_in), int(k_out), per,
+                                        per, _ptr(od), _ptr(oi)), "sq_merge_topk_strided")
     return od, oi
 
 

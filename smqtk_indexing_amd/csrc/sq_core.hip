@@ -103,9 +103,10 @@ extern "C" int sq_get_stats(sq_handle_t hid, sq_stats_t* out) {
 // Each shard list is already sorted by (distance, id) with its padding (id -1) at
 // the end, so a query's result is a k-way merge: k_out steps, each picking the
 // smallest head among the shards (nshards <= 8 on one node: a linear scan).
+// dshard / ishard: distance between consecutive shards' [nq][k_in] blocks, in BYTES
 template <class D>
 static void merge_range(const D* dist, const int64_t* idx, int nshards, int nq, int k_in, int k_out, D* out_dist,
-                        int64_t* out_idx, D pad_value, int q0, int q1) {
+                        int64_t* out_idx, D pad_value, int q0, int q1, size_t dshard, size_t ishard) {
     constexpr int64_t kDone = std::numeric_limits<int64_t>::max();  // id of an exhausted list (sorts last)
     std::vector<int> head((size_t)nshards);
     std::vector<D> hd((size_t)nshards);
@@ -113,10 +114,12 @@ static void merge_range(const D* dist, const int64_t* idx, int nshards, int nq, 
     auto load = [&](int s, int q) {  // cache the head of shard s
         const int hpos = head[(size_t)s];
         if (hpos < k_in) {
-            const size_t at = ((size_t)s * nq + q) * k_in + hpos;
-            if (idx[at] >= 0) {
-                hd[(size_t)s] = dist[at];
-                hi[(size_t)s] = idx[at];
+            const size_t at = (size_t)q * k_in + hpos;
+            const D* ds = reinterpret_cast<const D*>(reinterpret_cast<const char*>(dist) + (size_t)s * dshard);
+            const int64_t* is = reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(idx) + (size_t)s * ishard);
+            if (is[at] >= 0) {
+                hd[(size_t)s] = ds[at];
+                hi[(size_t)s] = is[at];
                 return;
             }
         }
@@ -148,43 +151,59 @@ static void merge_range(const D* dist, const int64_t* idx, int nshards, int nq, 
 
 template <class D>
 static void merge_impl(const D* dist, const int64_t* idx, int nshards, int nq, int k_in, int k_out, D* out_dist,
-                       int64_t* out_idx, D pad_value) {
+                       int64_t* out_idx, D pad_value, size_t dshard, size_t ishard) {
     // a few host threads when the batch is large (the merge is on the timed path of a multi-GPU step)
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)std::min<unsigned>(hw ? hw : 1u, 16u);
     if ((long long)nq * k_out * nshards < 200000) nt = 1;
     nt = std::min(nt, nq);
     if (nt <= 1) {
-        merge_range<D>(dist, idx, nshards, nq, k_in, k_out, out_dist, out_idx, pad_value, 0, nq);
+        merge_range<D>(dist, idx, nshards, nq, k_in, k_out, out_dist, out_idx, pad_value, 0, nq, dshard, ishard);
         return;
     }
     std::vector<std::thread> pool;
     pool.reserve((size_t)nt);
     for (int t = 0; t < nt; ++t) {
         const int q0 = (int)((long long)nq * t / nt), q1 = (int)((long long)nq * (t + 1) / nt);
-        pool.emplace_back(merge_range<D>, dist, idx, nshards, nq, k_in, k_out, out_dist, out_idx, pad_value, q0, q1);
+        pool.emplace_back(merge_range<D>, dist, idx, nshards, nq, k_in, k_out, out_dist, out_idx, pad_value, q0, q1, dshard,
+                          ishard);
     }
     for (auto& th : pool) th.join();
 }
 
-extern "C" int sq_merge_topk(const void* dist, const int64_t* idx, int dist_dtype, int nshards, int nq, int k_in,
-                             int k_out, void* out_dist, int64_t* out_idx) {
+static int merge_dispatch(const void* dist, const int64_t* idx, int dist_dtype, int nshards, int nq, int k_in, int k_out,
+                          void* out_dist, int64_t* out_idx, size_t dshard, size_t ishard, const char* who) {
     if (!dist || !idx || !out_dist || !out_idx || nshards <= 0 || nq <= 0 || k_in <= 0 || k_out <= 0)
-        return fail(SQ_ERR_INVALID, "sq_merge_topk: bad argument");
+        return fail(SQ_ERR_INVALID, "%s: bad argument", who);
     switch (dist_dtype) {
         case 0:
             merge_impl<float>((const float*)dist, idx, nshards, nq, k_in, k_out, (float*)out_dist, out_idx,
-                              std::numeric_limits<float>::infinity());
+                              std::numeric_limits<float>::infinity(), dshard, ishard);
             return SQ_OK;
         case 1:
             merge_impl<double>((const double*)dist, idx, nshards, nq, k_in, k_out, (double*)out_dist, out_idx,
-                               std::numeric_limits<double>::infinity());
+                               std::numeric_limits<double>::infinity(), dshard, ishard);
             return SQ_OK;
         case 2:
             merge_impl<int32_t>((const int32_t*)dist, idx, nshards, nq, k_in, k_out, (int32_t*)out_dist, out_idx,
-                                std::numeric_limits<int32_t>::max());
+                                std::numeric_limits<int32_t>::max(), dshard, ishard);
             return SQ_OK;
         default:
-            return fail(SQ_ERR_INVALID, "sq_merge_topk: unknown dist_dtype %d", dist_dtype);
+            return fail(SQ_ERR_INVALID, "%s: unknown dist_dtype %d", who, dist_dtype);
     }
+}
+
+extern "C" int sq_merge_topk(const void* dist, const int64_t* idx, int dist_dtype, int nshards, int nq, int k_in,
+                             int k_out, void* out_dist, int64_t* out_idx) {
+    const size_t esz = dist_dtype == 1 ? 8 : 4;
+    return merge_dispatch(dist, idx, dist_dtype, nshards, nq, k_in, k_out, out_dist, out_idx, (size_t)nq * k_in * esz,
+                          (size_t)nq * k_in * 8, "sq_merge_topk");
+}
+
+extern "C" int sq_merge_topk_strided(const void* dist, const int64_t* idx, int dist_dtype, int nshards, int nq, int k_in,
+                                     int k_out, int64_t dist_shard_stride, int64_t idx_shard_stride, void* out_dist,
+                                     int64_t* out_idx) {
+    if (dist_shard_stride <= 0 || idx_shard_stride <= 0) return fail(SQ_ERR_INVALID, "sq_merge_topk_strided: bad stride");
+    return merge_dispatch(dist, idx, dist_dtype, nshards, nq, k_in, k_out, out_dist, out_idx, (size_t)dist_shard_stride,
+                          (size_t)idx_shard_stride, "sq_merge_topk_strided");
 }

@@ -37,17 +37,28 @@ def allgather_merge(local_dist, local_idx, k: int, group=None, merge_on: Optiona
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    nq, k_in = int(local_dist.shape[0]), int(local_dist.shape[1])
+    if local_dist.is_cuda:
+        # one collective: [ids int64 nq*k_in][dist nq*k_in] per rank in a byte buffer; the merge reads the
+        # host copy of the receive buffer in place (sq_merge_topk_strided)
+        esz = local_dist.element_size()
+        send = torch.empty(nq * k_in * (8 + esz), dtype=torch.uint8, device=local_dist.device)
+        send[: nq * k_in * 8].view(torch.int64).view(nq, k_in).copy_(local_idx)
+        send[nq * k_in * 8:].view(local_dist.dtype).view(nq, k_in).copy_(local_dist)
+        recv = torch.empty((world, send.numel()), dtype=torch.uint8, device=local_dist.device)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        if merge_on is not None and rank != merge_on:
+            return None
+        host = recv.cpu().numpy().reshape(-1)
+        np_dt = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32}[local_dist.dtype]
+        return _lib.merge_topk_gathered(host, world, nq, k_in, int(k), np_dt)
     gd = torch.empty((world,) + tuple(local_dist.shape), dtype=local_dist.dtype, device=local_dist.device)
     gi = torch.empty((world,) + tuple(local_idx.shape), dtype=local_idx.dtype, device=local_idx.device)
-    if local_dist.is_cuda:
-        dist.all_gather_into_tensor(gd, local_dist.contiguous(), group=group)
-        dist.all_gather_into_tensor(gi, local_idx.contiguous(), group=group)
-    else:
-        dist.all_gather(list(gd.unbind(0)), local_dist.contiguous(), group=group)
-        dist.all_gather(list(gi.unbind(0)), local_idx.contiguous(), group=group)
+    dist.all_gather(list(gd.unbind(0)), local_dist.contiguous(), group=group)
+    dist.all_gather(list(gi.unbind(0)), local_idx.contiguous(), group=group)
     if merge_on is not None and rank != merge_on:
         return None
-    return _lib.merge_topk(gd.cpu().numpy(), gi.cpu().numpy(), int(k))
+    return _lib.merge_topk(gd.numpy(), gi.numpy(), int(k))
 
 
 class ShardedIndex:

@@ -47,6 +47,26 @@ def test_host_merge_orders_by_distance_then_id():
     np.testing.assert_array_equal(oi[0], [1, 2, 8])
 
 
+def test_host_merge_reads_the_gather_buffer_in_place():
+    """sq_merge_topk_strided over the one-buffer all-gather layout equals sq_merge_topk."""
+    ns, nq, k = 3, 4, 5
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.float64, np.int32):
+        d = np.sort((rng.random((ns, nq, k)) * 50).astype(dt), axis=2)
+        i = rng.integers(0, 1000, (ns, nq, k)).astype(np.int64)
+        i[1, 2, 3:] = -1                                            # padding inside a shard list
+        ref = _lib.merge_topk(d, i, 7)
+        es = np.dtype(dt).itemsize
+        buf = np.empty(ns * nq * k * (8 + es), np.uint8)
+        for s in range(ns):
+            o = s * nq * k * (8 + es)
+            buf[o:o + nq * k * 8] = i[s].view(np.uint8).reshape(-1)
+            buf[o + nq * k * 8:o + nq * k * (8 + es)] = d[s].view(np.uint8).reshape(-1)
+        got = _lib.merge_topk_gathered(buf, ns, nq, k, 7, dt)
+        np.testing.assert_array_equal(ref[0], got[0])
+        np.testing.assert_array_equal(ref[1], got[1])
+
+
 def test_bad_arguments_are_reported_not_crashed():
     with pytest.raises(_lib.HipError):
         _lib.merge_topk(np.zeros((1, 1, 1), np.float32), np.zeros((1, 1, 1), np.int64), 0)
