@@ -89,10 +89,15 @@ int sq_get_stats(sq_handle_t h, sq_stats_t* out);
  * bit_vector_to_int_large (utils/bits.py:4-20), i.e. the per-descriptor body
  * of LSHNearestNeighborIndex._build_index (impls/nn_index/lsh.py:316-321):
  *   z = (norm(x) - mean) . rotation   (float64),  bit = z >= 0
- * x: [n][d] of x_dtype; mean: [d] f64; rotation: [d][bits] f64;
- * out_codes: [n][ceil(bits/64)]. */
+ * x: [n][d] of x_dtype; mean: [d] values as f64; rotation: [d][bits] f64;
+ * out_codes: [n][ceil(bits/64)].
+ * mean_dtype: dtype of the MODEL's mean vector.  numpy evaluates
+ * `norm(x) - mean` in the promoted dtype of the two operands (itq.py:404), so
+ * a float32 model applied to float32 descriptors subtracts in float32 (a model
+ * ItqFunctor.fit trained on float32 descriptors has a float32 mean_vec); every
+ * other combination subtracts in float64. */
 int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d,
-                const double* mean, const double* rotation, int bits, int norm_ord,
+                const double* mean, int mean_dtype, const double* rotation, int bits, int norm_ord,
                 uint64_t* out_codes, int mem, void* stream);
 
 /* --------------------------------------------------------------- Hamming

@@ -71,7 +71,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_device_name.argtypes = [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]
     lib.sq_set_option.argtypes = [ctypes.c_char_p, c_i64]
     lib.sq_get_stats.argtypes = [c_i64, ctypes.POINTER(SqStats)]
-    lib.sq_itq_hash.argtypes = [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]
+    lib.sq_itq_hash.argtypes = [c_vp, c_int, c_i64, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]
     lib.sq_hamming_create.argtypes = [c_vp, c_i64, c_int, c_int, c_i64, ctypes.POINTER(c_i64)]
     lib.sq_hamming_search.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]
     lib.sq_hamming_destroy.argtypes = [c_i64]
@@ -198,6 +198,8 @@ def itq_hash(x: np.ndarray, mean: np.ndarray, rotation: np.ndarray, norm_ord: in
         x = x.astype(np.float64, copy=False)
         dt = SQ_DTYPE_F64
     x = np.ascontiguousarray(x)
+    # dtype of the model's mean vector: `x - mean` is evaluated in numpy's promoted dtype (itq.py:404)
+    mdt = SQ_DTYPE_F32 if np.asarray(mean).dtype == np.float32 else SQ_DTYPE_F64
     mean = _host(mean, np.float64)
     rotation = _host(rotation, np.float64)
     n, d = x.shape
@@ -207,15 +209,17 @@ def itq_hash(x: np.ndarray, mean: np.ndarray, rotation: np.ndarray, norm_ord: in
     out = np.empty((n, (bits + 63) // 64), dtype=np.uint64)
     if n == 0:
         return out
-    _check(load().sq_itq_hash(_ptr(x), dt, n, d, _ptr(mean), _ptr(rotation), bits, int(norm_ord), _ptr(out),
+    _check(load().sq_itq_hash(_ptr(x), dt, n, d, _ptr(mean), mdt, _ptr(rotation), bits, int(norm_ord), _ptr(out),
                               SQ_MEM_HOST, None), "sq_itq_hash")
     return out
 
 
 def itq_hash_device(x_ptr: int, x_dtype: int, n: int, d: int, mean_ptr: int, rot_ptr: int, bits: int,
-                    norm_ord: int, out_ptr: int, stream: int = 0) -> None:
-    _check(load().sq_itq_hash(_ptr(x_ptr), x_dtype, n, d, _ptr(mean_ptr), _ptr(rot_ptr), bits, int(norm_ord),
-                              _ptr(out_ptr), SQ_MEM_DEVICE, ctypes.c_void_p(stream or None)), "sq_itq_hash")
+                    norm_ord: int, out_ptr: int, stream: int = 0, mean_dtype: int = SQ_DTYPE_F64) -> None:
+    """Device pointers throughout; ``mean_ptr``: float64[d] values, ``mean_dtype``: the model's dtype."""
+    _check(load().sq_itq_hash(_ptr(x_ptr), x_dtype, n, d, _ptr(mean_ptr), int(mean_dtype), _ptr(rot_ptr), bits,
+                              int(norm_ord), _ptr(out_ptr), SQ_MEM_DEVICE, ctypes.c_void_p(stream or None)),
+           "sq_itq_hash")
 
 
 # ------------------------------------------------------------------- handles

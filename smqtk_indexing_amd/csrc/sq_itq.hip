@@ -38,6 +38,7 @@ struct ItqArgs {
     int d16;            // d rounded up to 16
     const void* nrm;    // [n] row L2 norms in x's dtype (normalize=2), from itq_norms_kernel
     int vec4;           // rows are 4-element aligned (d % 4 == 0, base aligned): vector loads of x
+    int sub32;              // x - mean in float32 (float32 rows and a float32 model mean: numpy's promotion)
     const u32* list;        // optional: only these rows (the filter's uncertain rows, sq_itq_fast.cuh)
     const u32* list_total;  // device count of `list`
 };
@@ -166,7 +167,14 @@ __global__ __launch_bounds__(256, 2) void itq_hash_kernel(ItqArgs a) {
                         if (k < a.d) {
                             T xv = xq[j];
                             if (a.norm == SQ_NORM_L2) xv = div_rn(xv, nrm_l[rt]);
-                            v = __dsub_rn((double)xv, s_mean[k]);
+                            if constexpr (sizeof(T) == 4) {
+                                if (a.sub32)
+                                    v = (double)__fsub_rn(xv, (float)s_mean[k]);  // s_mean[k] is a float32 value
+                                else
+                                    v = __dsub_rn((double)xv, s_mean[k]);
+                            } else {
+                                v = __dsub_rn((double)xv, s_mean[k]);
+                            }
                         }
                         av[rt][j] = v;
                     }
@@ -439,11 +447,13 @@ static int itq_launch(const ItqArgs& a0, hipStream_t st, int device) {
 
 using namespace sq;
 
-extern "C" int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d, const double* mean, const double* rotation,
-                           int bits, int norm_ord, uint64_t* out_codes, int mem, void* stream) {
+extern "C" int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d, const double* mean, int mean_dtype,
+                           const double* rotation, int bits, int norm_ord, uint64_t* out_codes, int mem, void* stream) {
     if (!x || !mean || !rotation || !out_codes || n <= 0 || d <= 0 || bits <= 0)
         return fail(SQ_ERR_INVALID, "sq_itq_hash: bad argument");
     if (x_dtype != SQ_DTYPE_F32 && x_dtype != SQ_DTYPE_F64) return fail(SQ_ERR_INVALID, "sq_itq_hash: unknown dtype %d", x_dtype);
+    if (mean_dtype != SQ_DTYPE_F32 && mean_dtype != SQ_DTYPE_F64)
+        return fail(SQ_ERR_INVALID, "sq_itq_hash: unknown mean dtype %d", mean_dtype);
     if (norm_ord != SQ_NORM_NONE && norm_ord != SQ_NORM_L2)
         return fail(SQ_ERR_UNSUPPORTED, "sq_itq_hash: normalize=%d not supported on the device (None or 2)", norm_ord);
     int device = 0;
@@ -458,6 +468,7 @@ extern "C" int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d, const d
     a.words = words;
     a.pad = words * 64 - bits;
     a.norm = norm_ord;
+    a.sub32 = (x_dtype == SQ_DTYPE_F32 && mean_dtype == SQ_DTYPE_F32) ? 1 : 0;
     a.d16 = (d + 15) / 16 * 16;
     DevBuf dx, dm, dr, dout;
     auto done = [&](int code) {

@@ -70,12 +70,14 @@ static __global__ __launch_bounds__(256) void itq_fast_prep_kernel(const double*
     const int b = pc - pad;
     __shared__ double red[256];
     __shared__ double red2[256];
-    double acc = 0.0, cacc = 0.0, cabs = 0.0;
+    __shared__ double red3[256];
+    double acc = 0.0, cacc = 0.0, cabs = 0.0, macc = 0.0;
     for (int k = threadIdx.x; k < d; k += 256) {
         const double r = b >= 0 ? rot[(long long)k * bits + b] : 0.0;
         acc += r * r;
         cacc += mean[k] * r;
         cabs += fabs(mean[k] * r);
+        macc += mean[k] * mean[k];
         const float rf = (float)r;
         const __bf16 hi = (__bf16)rf;
         const __bf16 lo = (__bf16)(rf - (float)hi);
@@ -97,13 +99,17 @@ static __global__ __launch_bounds__(256) void itq_fast_prep_kernel(const double*
     }
     if (threadIdx.x == 0) colnorm[pc] = (float)(sqrt(red[0]) * (1.0 + 1e-6));
     __syncthreads();
+    const double rnorm = sqrt(red[0]);
+    __syncthreads();
     red[threadIdx.x] = cacc;
     red2[threadIdx.x] = cabs;
+    red3[threadIdx.x] = macc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < o) {
             red[threadIdx.x] += red[threadIdx.x + o];
             red2[threadIdx.x] += red2[threadIdx.x + o];
+            red3[threadIdx.x] += red3[threadIdx.x + o];
         }
         __syncthreads();
     }
@@ -111,7 +117,9 @@ static __global__ __launch_bounds__(256) void itq_fast_prep_kernel(const double*
         // c_b = mean . R_b: the float32 value the filter subtracts, and a bound for its rounding, the
         // float64 summation and the reference's float32 element-wise x/|x| (2^-22 of the terms)
         cb32[pc] = (float)red[0];
-        cberr[pc] = (float)((fabs(red[0]) * 1.2e-7 + red2[0] * 1e-13) * (1.0 + 1e-6));
+        // ... and, when numpy subtracts the mean in float32 (float32 model), the rounding of x_k - mean_k:
+        // <= 2^-24 (|x_k| + |mean_k|) per element; the |mean| part is carried here, the |x| part by eps_rel
+        cberr[pc] = (float)((fabs(red[0]) * 1.2e-7 + red2[0] * 1e-13 + sqrt(red3[0]) * rnorm * 1.2e-7) * (1.0 + 1e-6));
     }
     __syncthreads();
 }

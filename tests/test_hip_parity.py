@@ -393,17 +393,39 @@ def test_itq_filter_matches_float64_kernel(n, d, bits):
     q, _ = np.linalg.qr(rng.standard_normal((d, d)))
     rot = np.ascontiguousarray(q[:, :bits])
     rot[:, 3] = 0.0                         # a degenerate hash bit: z == -mean.R == 0 -> True everywhere
-    for norm, ordv in ((None, _lib.SQ_NORM_NONE), (2, _lib.SQ_NORM_L2)):
-        got = _lib.itq_hash(x, mean, rot, ordv)
-        _lib.set_option("itq_exact", 1)
-        try:
-            exact = _lib.itq_hash(x, mean, rot, ordv)
-        finally:
-            _lib.set_option("itq_exact", 0)
-        np.testing.assert_array_equal(got, exact)
-        z = O.itq_z(x, mean, rot, norm)
-        ref = O.pack_bits_msb(z >= 0)
-        bad = (got != ref).any(axis=1)
-        if bad.any():
-            assert np.abs(z[bad]).min(axis=1).max() < 1e-9
-        assert bad.mean() < 1e-2
+    # a float32 model mean (what ItqFunctor.fit leaves for float32 descriptors): numpy subtracts it in float32
+    for mean_m in (mean, mean.astype(np.float32)):
+        for norm, ordv in ((None, _lib.SQ_NORM_NONE), (2, _lib.SQ_NORM_L2)):
+            got = _lib.itq_hash(x, mean_m, rot, ordv)
+            _lib.set_option("itq_exact", 1)
+            try:
+                exact = _lib.itq_hash(x, mean_m, rot, ordv)
+            finally:
+                _lib.set_option("itq_exact", 0)
+            np.testing.assert_array_equal(got, exact)
+            z = O.itq_z(x, mean_m, rot, norm)
+            ref = O.pack_bits_msb(z >= 0)
+            bad = (got != ref).any(axis=1)
+            if bad.any():
+                assert np.abs(z[bad]).min(axis=1).max() < 1e-9
+            assert bad.mean() < 1e-2
+
+
+@pytest.mark.parametrize("d", [2, 64])
+def test_itq_mean_dtype_follows_numpy_promotion(d):
+    """`x - mean` is float32 arithmetic when both are float32 (a model fitted on float32
+    descriptors) and float64 otherwise; the rounding of the float32 difference can decide a bit."""
+    x = np.zeros((40, d), dtype=np.float32)
+    x[:, 0], x[:, 1] = 1e8, 1.0
+    mean64 = np.zeros(d)
+    mean64[0] = 3.0
+    rot = np.zeros((d, 1))
+    rot[0, 0], rot[1, 0] = 1.0, -99999998.5
+    # float64: 99999997 - 99999998.5 < 0; float32: fl32(99999997) = 1e8 -> 1e8 - 99999998.5 > 0
+    for mean, want in ((mean64, False), (mean64.astype(np.float32), True)):
+        z = O.itq_z(x, mean, rot)
+        assert ((z >= 0) == want).all()
+        got = _lib.itq_hash(x, mean, rot)
+        np.testing.assert_array_equal(got, O.pack_bits_msb(z >= 0))
+    got = _lib.itq_hash(x.astype(np.float64), mean64.astype(np.float32), rot)   # float64 rows: float64 arithmetic
+    np.testing.assert_array_equal(got, O.pack_bits_msb(O.itq_z(x.astype(np.float64), mean64.astype(np.float32), rot) >= 0))
