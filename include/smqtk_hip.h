@@ -100,6 +100,27 @@ int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d,
                 const double* mean, int mean_dtype, const double* rotation, int bits, int norm_ord,
                 uint64_t* out_codes, int mem, void* stream);
 
+/* --------------------------------------------------------------- ITQ fit
+ * The O(n) products of ItqFunctor.fit (impls/lsh_functor/itq.py:291-387) and
+ * _find_itq_rotation (itq.py:239-289) with the descriptor matrix resident on
+ * the device; the d x d eigen-decomposition and the b x b SVD per iteration stay
+ * with the caller (numpy, as in the reference).  d <= 128, bits <= 128.
+ *   create:   x [n][d] of dtype; norm_ord as sq_itq_hash; out_mean[d] = column
+ *             means of norm(x) (itq.py:330)
+ *   set_mean: the mean values the model keeps (numpy stores them in x's dtype)
+ *   cov:      out_cov[d][d] = np.cov((norm(x) - mean).T)          (itq.py:337)
+ *   project:  v = (norm(x) - mean) . pc, pc [d][bits]; v stays on the device
+ *                                                                  (itq.py:362)
+ *   iterate:  ux = sign(v . r), out_c[bits][bits] = ux^T . v   (itq.py:271-275)
+ */
+int sq_itqfit_create(const void* x, int dtype, int64_t n, int d, int norm_ord, int mem,
+                     double* out_mean, sq_handle_t* out);
+int sq_itqfit_set_mean(sq_handle_t h, const double* mean);
+int sq_itqfit_cov(sq_handle_t h, double* out_cov);
+int sq_itqfit_project(sq_handle_t h, const double* pc, int bits);
+int sq_itqfit_iterate(sq_handle_t h, const double* r, double* out_c);
+int sq_itqfit_destroy(sq_handle_t h);
+
 /* --------------------------------------------------------------- Hamming
  * Replaces LinearHashIndex._nn (impls/hash_index/linear.py:206-244):
  * heapq.nsmallest over the set of unique codes keyed by

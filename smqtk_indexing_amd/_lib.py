@@ -39,6 +39,8 @@ EXPORTS = (
     "sq_dense_create", "sq_dense_search", "sq_dense_destroy",
     "sq_dense_distances", "sq_merge_topk", "sq_merge_topk_strided",
     "sq_rows_create", "sq_rows_rerank", "sq_rows_destroy",
+    "sq_itqfit_create", "sq_itqfit_set_mean", "sq_itqfit_cov", "sq_itqfit_project", "sq_itqfit_iterate",
+    "sq_itqfit_destroy",
 )
 
 
@@ -84,6 +86,12 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_rows_create.argtypes = [c_vp, c_int, c_i64, c_int, c_int, ctypes.POINTER(c_i64)]
     lib.sq_rows_rerank.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]
     lib.sq_rows_destroy.argtypes = [c_i64]
+    lib.sq_itqfit_create.argtypes = [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, ctypes.POINTER(c_i64)]
+    lib.sq_itqfit_set_mean.argtypes = [c_i64, c_vp]
+    lib.sq_itqfit_cov.argtypes = [c_i64, c_vp]
+    lib.sq_itqfit_project.argtypes = [c_i64, c_vp, c_int]
+    lib.sq_itqfit_iterate.argtypes = [c_i64, c_vp, c_vp]
+    lib.sq_itqfit_destroy.argtypes = [c_i64]
     for name in EXPORTS:
         if name not in ("sq_last_error",):
             getattr(lib, name).restype = c_int
@@ -434,6 +442,59 @@ class RowMatrix:
     def close(self) -> None:
         if self._h is not None and _lib is not None:
             _lib.sq_rows_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ItqFit:
+    """Device side of ``ItqFunctor.fit`` (``sq_itqfit_*``; itq.py:239-387): the descriptor matrix
+    stays on the device, the caller does the small eigen / SVD problems in numpy."""
+
+    def __init__(self, x: np.ndarray, norm_ord: int = SQ_NORM_NONE):
+        x = np.asarray(x)
+        if x.ndim != 2:
+            raise ValueError("x must be [n, d]")
+        if x.dtype != np.float32:
+            x = x.astype(np.float64, copy=False)
+        x = np.ascontiguousarray(x)
+        self.n, self.d = int(x.shape[0]), int(x.shape[1])
+        self.mean = np.empty(self.d, dtype=np.float64)
+        h = ctypes.c_int64(0)
+        _check(load().sq_itqfit_create(_ptr(x), SQ_DTYPE_F32 if x.dtype == np.float32 else SQ_DTYPE_F64, self.n, self.d,
+                                       int(norm_ord), SQ_MEM_HOST, _ptr(self.mean), ctypes.byref(h)), "sq_itqfit_create")
+        self._h: Optional[int] = h.value
+        self.bits = 0
+
+    def set_mean(self, mean: np.ndarray) -> None:
+        m = _host(np.asarray(mean), np.float64)
+        _check(load().sq_itqfit_set_mean(self._h, _ptr(m)), "sq_itqfit_set_mean")
+
+    def cov(self) -> np.ndarray:
+        out = np.empty((self.d, self.d), dtype=np.float64)
+        _check(load().sq_itqfit_cov(self._h, _ptr(out)), "sq_itqfit_cov")
+        return out
+
+    def project(self, pc: np.ndarray) -> None:
+        pc = _host(np.asarray(pc), np.float64)
+        if pc.ndim != 2 or pc.shape[0] != self.d:
+            raise ValueError("pc must be [d, bits]")
+        self.bits = int(pc.shape[1])
+        _check(load().sq_itqfit_project(self._h, _ptr(pc), self.bits), "sq_itqfit_project")
+
+    def iterate(self, r: np.ndarray) -> np.ndarray:
+        r = _host(np.asarray(r), np.float64)
+        out = np.empty((self.bits, self.bits), dtype=np.float64)
+        _check(load().sq_itqfit_iterate(self._h, _ptr(r), _ptr(out)), "sq_itqfit_iterate")
+        return out
+
+    def close(self) -> None:
+        if self._h is not None and _lib is not None:
+            _lib.sq_itqfit_destroy(self._h)
         self._h = None
 
     def __del__(self):

@@ -15,7 +15,7 @@ reference does, then the codes of the training set are produced on the GPU.
 """
 from io import BytesIO
 import logging
-from typing import Any, Dict, Iterable, Optional, Type, TypeVar, Union
+from typing import Any, Dict, Iterable, Optional, Tuple, Type, TypeVar, Union
 
 import numpy as np
 
@@ -59,8 +59,9 @@ class HipItqFunctor(LshFunctor):
                  rotation_cache: Optional[DataElement] = None,
                  bit_length: int = 8, itq_iterations: int = 50,
                  normalize: Optional[Union[int, float, str]] = None,
-                 random_seed: Optional[int] = None):
+                 random_seed: Optional[int] = None, fit_on_device: bool = True):
         super().__init__()
+        self.fit_on_device = bool(fit_on_device)
         self.mean_vec_cache_elem = mean_vec_cache
         self.rotation_cache_elem = rotation_cache
         self.bit_length = bit_length
@@ -84,6 +85,7 @@ class HipItqFunctor(LshFunctor):
             "itq_iterations": self.itq_iterations,
             "normalize": self.normalize,
             "random_seed": self.random_seed,
+            "fit_on_device": self.fit_on_device,
         })
         if self.mean_vec_cache_elem:
             c["mean_vec_cache"] = to_config_dict(self.mean_vec_cache_elem)
@@ -162,9 +164,37 @@ class HipItqFunctor(LshFunctor):
             r = np.dot(ua, ub.T)
         return r
 
+    def _fit_device(self, x_in: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """(mean_vec, rotation) with the O(n) work of itq.py:330-362 and 271-275 on the device
+        (``sq_itqfit_*``): mean, covariance, PCA projection and, per ITQ iteration, sign(V R) and
+        B^T V.  The d x d eigen-decomposition and the bits x bits SVDs are numpy's, as in the
+        reference.  Descriptors up to 128-d, codes up to 128 bits."""
+        nbits = self.bit_length
+        fit = _lib.ItqFit(x_in, self._norm_ord())
+        try:
+            # np.mean keeps the descriptors' dtype; the model (and everything derived below) uses that value
+            mean_vec = fit.mean.astype(x_in.dtype if x_in.dtype in (np.float32, np.float64) else np.float64)
+            fit.set_mean(mean_vec)
+            evals, evecs = np.linalg.eig(np.atleast_2d(fit.cov()))
+            ranked = sorted(zip(evals, evecs.T), key=lambda p: p[0], reverse=True)
+            pc_top = np.array([p[1] for p in ranked[:nbits]]).T
+            fit.project(np.real(pc_top))
+            if self.random_seed is not None:
+                np.random.seed(self.random_seed)
+            u, _, _ = np.linalg.svd(np.random.randn(nbits, nbits))
+            r = u[:, :nbits]
+            for _ in range(self.itq_iterations):
+                ub, _, ua = np.linalg.svd(fit.iterate(r))
+                r = np.dot(ua, ub.T)
+        finally:
+            fit.close()
+        return mean_vec, np.dot(pc_top, r)
+
     def fit(self, descriptors: Iterable[DescriptorElement], use_multiprocessing: bool = True) -> np.ndarray:
-        """Train mean vector and rotation from descriptors (host, numpy), then
-        return the training set's codes (bool ``[n, bits]``, computed on the GPU)."""
+        """Train mean vector and rotation from descriptors, then return the training set's codes
+        (bool ``[n, bits]``, computed on the GPU).  With ``fit_on_device`` (default) the products
+        over the n descriptors run on the device when they fit its kernels (d <= 128, <= 128 bits,
+        a real-valued PCA basis); otherwise, and always for the small dense linear algebra, numpy."""
         if self.has_model():
             raise RuntimeError("Model components have already been loaded.")
         descr = descriptors if isinstance(descriptors, (list, tuple)) else list(descriptors)
@@ -174,15 +204,19 @@ class HipItqFunctor(LshFunctor):
                              "smaller than requested due to PCA decomposition "
                              "result being bound by number of features.")
         x_in = np.asarray([d.vector() for d in descr])
-        x = self._norm_vector(x_in)
-        mean_vec = np.mean(x, axis=0)
-        x = x - mean_vec
-        cov = np.atleast_2d(np.cov(x.T))
-        evals, evecs = np.linalg.eig(cov)
-        ranked = sorted(zip(evals, evecs.T), key=lambda p: p[0], reverse=True)
-        pc_top = np.array([p[1] for p in ranked[:self.bit_length]]).T
-        r = self._find_itq_rotation(np.dot(x, pc_top), self.itq_iterations)
-        self.mean_vec = mean_vec
-        self.rotation = np.dot(pc_top, r)
+        if (self.fit_on_device and x_in.ndim == 2 and x_in.shape[1] <= 128 and self.bit_length <= 128
+                and x_in.shape[0] > 1 and _lib.usable()):
+            self.mean_vec, self.rotation = self._fit_device(x_in)
+        else:
+            x = self._norm_vector(x_in)
+            mean_vec = np.mean(x, axis=0)
+            x = x - mean_vec
+            cov = np.atleast_2d(np.cov(x.T))
+            evals, evecs = np.linalg.eig(cov)
+            ranked = sorted(zip(evals, evecs.T), key=lambda p: p[0], reverse=True)
+            pc_top = np.array([p[1] for p in ranked[:self.bit_length]]).T
+            r = self._find_itq_rotation(np.dot(x, pc_top), self.itq_iterations)
+            self.mean_vec = mean_vec
+            self.rotation = np.dot(pc_top, r)
         self.save_model()
         return self.get_hash(x_in)
