@@ -12,7 +12,11 @@ the exact tail of ``LSHNearestNeighborIndex._nn``
 
 The descriptor matrix lives in HBM as float32 (faiss.py:696-698 casts the same
 way); ``nn`` calls ``sq_dense_search``.  Ties are returned in insertion order
-(stable sort over rows), which is the canonical (distance, row) order.
+(stable sort over rows), which is the canonical (distance, row) order.  When
+the descriptors are not float32 (SMQTK's default is float64) the wrapper's
+last step is kept as well: the distances of the n results are recomputed from
+the ORIGINAL vectors against the float32 query (faiss.py:776, 818-824) and the
+results are ordered by those.
 """
 import threading
 from typing import Any, Dict, Hashable, Iterable, List, Optional, Sequence, Tuple
@@ -45,6 +49,7 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
         self._elements: List[DescriptorElement] = []
         self._row_of: Dict[Hashable, int] = {}
         self._matrix = np.zeros((0, 0), dtype=np.float32)
+        self._all_f32 = True     # every indexed vector is float32: the float32 search distances are final
         self._dev: Optional[_lib.DenseIndex] = None
 
     def get_config(self) -> Dict[str, Any]:
@@ -55,6 +60,7 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
         self._elements = elements
         self._row_of = {e.uuid(): i for i, e in enumerate(elements)}
         self._matrix = matrix
+        self._all_f32 = all(np.asarray(e.vector()).dtype == np.float32 for e in elements)
         if self._dev is not None:
             self._dev.close()
             self._dev = None
@@ -135,5 +141,13 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
     def _nn(self, d: DescriptorElement, n: int = 1
             ) -> Tuple[Tuple[DescriptorElement, ...], Tuple[float, ...]]:
         with self._lock:
-            idx, dist = self.nn_many(np.asarray(d.vector()).reshape(1, -1), n)
-            return self.elements_of(idx[0]), tuple(float(v) for v in dist[0])
+            q32 = np.asarray(d.vector()).reshape(1, -1).astype(np.float32)      # faiss.py:776
+            idx, dist = self.nn_many(q32, n)
+            elems = self.elements_of(idx[0])
+            if self._all_f32:
+                return elems, tuple(float(v) for v in dist[0])
+            # faiss.py:818-824: distances from the original-dtype vectors, results ordered by them
+            rows = np.vstack([e.vector() for e in elems])
+            exact = _lib.dense_distances(q32[0], rows, self.METRICS[self.distance_method])
+            order = np.argsort(exact, kind="stable")
+            return tuple(elems[i] for i in order), tuple(float(exact[i]) for i in order)

@@ -180,6 +180,24 @@ def test_bruteforce_known_answers():
     assert len(r) == 10 and r[0].uuid() == 0
 
 
+def test_bruteforce_float64_descriptors_get_original_dtype_distances():
+    """faiss.py:776, 818-824: float32 search, then the distances of the n results from the
+    original (float64) vectors against the float32 query, results ordered by them."""
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((5000, 48))                         # float64 descriptors (SMQTK's default dtype)
+    index = HipBruteForceNearestNeighborsIndex()
+    index.build_index(_elems(x))
+    q = rng.standard_normal(48)
+    r, dists = index.nn(DescriptorMemoryElement("q").set_vector(q), 25)
+    q32 = q.astype(np.float32)
+    ref_f32 = O.dense_topk(x.astype(np.float32), q32, 25, "euclidean")[1]          # the float32 search's choice
+    exact = O.dense_distances(x[ref_f32], q32, "euclidean")                       # float64 rows, float32 query
+    order = np.argsort(exact, kind="stable")
+    assert [e.uuid() for e in r] == [int(ref_f32[i]) for i in order]
+    np.testing.assert_array_equal(np.asarray(dists), exact[order])
+    assert np.asarray(dists).dtype == np.float64 and all(b >= a for a, b in zip(dists, dists[1:]))
+
+
 def test_bruteforce_matches_reference_golden(golden):
     g = golden("g5_dense_nn.npz")
     n, d, nq, seed, dist, dt = GI.DENSE_CASES["nrm128"]
