@@ -390,6 +390,30 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     return SQ_OK;
 }
 
+// Large batches run in chunks so that the per-query workspace (candidate key lists of `cap` keys, the
+// sample scores) stays bounded: 4096 queries need ~2.4 GB at the default list size.
+static constexpr int kDenseQueryChunk = 4096;
+
+static int dense_search_chunked(DenseHandle* h, const float* q, int nq, int k, void* out_dist, long long* out_idx,
+                                hipStream_t st) {
+    if (nq <= kDenseQueryChunk) return dense_search_device(h, q, nq, k, out_dist, out_idx, st);
+    const size_t dsz = h->metric == SQ_METRIC_COSINE ? 8 : 4;
+    sq_stats_t total{};
+    for (int q0 = 0; q0 < nq; q0 += kDenseQueryChunk) {
+        const int m = nq - q0 < kDenseQueryChunk ? nq - q0 : kDenseQueryChunk;
+        SQ_TRY(dense_search_device(h, q + (long long)q0 * h->d, m, k, static_cast<char*>(out_dist) + (size_t)q0 * k * dsz,
+                                   out_idx + (long long)q0 * k, st));
+        total.scan_ms += h->stats.scan_ms;
+        total.total_ms += h->stats.total_ms;
+        total.scan_launches += h->stats.scan_launches;
+        total.candidates += h->stats.candidates;
+        total.fallback_queries += h->stats.fallback_queries;
+        total.bytes_scanned += h->stats.bytes_scanned;
+    }
+    h->stats = total;
+    return SQ_OK;
+}
+
 }  // namespace sq
 
 using namespace sq;
@@ -524,13 +548,13 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t dsz = h->metric == SQ_METRIC_COSINE ? 8 : 4;
     if (mem == SQ_MEM_DEVICE)
-        return dense_search_device(h, queries, nq, k, out_dist, reinterpret_cast<long long*>(out_idx), st);
+        return dense_search_chunked(h, queries, nq, k, out_dist, reinterpret_cast<long long*>(out_idx), st);
     const size_t qb = (size_t)nq * h->d * 4;
     SQ_TRY(h->q_dev.reserve(qb));
     SQ_TRY(h->out_dist_dev.reserve((size_t)nq * k * dsz));
     SQ_TRY(h->out_idx_dev.reserve((size_t)nq * k * 8));
     SQ_HIP(hipMemcpyAsync(h->q_dev.p, queries, qb, hipMemcpyHostToDevice, st));
-    SQ_TRY(dense_search_device(h, h->q_dev.as<float>(), nq, k, h->out_dist_dev.p, h->out_idx_dev.as<long long>(), st));
+    SQ_TRY(dense_search_chunked(h, h->q_dev.as<float>(), nq, k, h->out_dist_dev.p, h->out_idx_dev.as<long long>(), st));
     SQ_HIP(hipMemcpyAsync(out_dist, h->out_dist_dev.p, (size_t)nq * k * dsz, hipMemcpyDeviceToHost, st));
     SQ_HIP(hipMemcpyAsync(out_idx, h->out_idx_dev.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
     SQ_HIP(hipStreamSynchronize(st));

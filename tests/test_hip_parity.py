@@ -429,3 +429,17 @@ def test_itq_mean_dtype_follows_numpy_promotion(d):
         np.testing.assert_array_equal(got, O.pack_bits_msb(z >= 0))
     got = _lib.itq_hash(x.astype(np.float64), mean64.astype(np.float32), rot)   # float64 rows: float64 arithmetic
     np.testing.assert_array_equal(got, O.pack_bits_msb(O.itq_z(x.astype(np.float64), mean64.astype(np.float32), rot) >= 0))
+
+
+def test_dense_batches_beyond_the_query_chunk():
+    """More queries than one internal chunk (4096): results and statistics of the chunks are stitched."""
+    rng = np.random.default_rng(4)
+    db = rng.standard_normal((70_000, 64)).astype(np.float32)
+    qs = rng.standard_normal((4500, 64)).astype(np.float32)
+    idx = _lib.DenseIndex(db)
+    d, i = idx.search(qs, 5)
+    for qi in (0, 4095, 4096, 4499):
+        rd, ri = O.dense_topk(db, qs[qi], 5, "euclidean")
+        np.testing.assert_array_equal(i[qi], ri)
+        np.testing.assert_array_equal(d[qi].view(np.uint32), rd.view(np.uint32))
+    assert idx.stats()["candidates"] >= 4500 * 5
