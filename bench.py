@@ -54,7 +54,7 @@ def cpu_baseline(dim: int, k: int, seed: int):
     sort, oracle/cpu_ref.py) timed on this host on a bounded sample of the same
     workload; scaled linearly in rows to the full database and labelled so."""
     from oracle import cpu_ref as O
-    rows, nq = 1_000_000, 8
+    rows, nq = 2_000_000, 32                       # ~15 s of single-thread numpy on the GPU box's host
     rng = np.random.default_rng(seed)
     db = rng.standard_normal((rows, dim), dtype=np.float32)
     qs = rng.standard_normal((nq, dim), dtype=np.float32)
