@@ -36,7 +36,10 @@ __device__ __forceinline__ double cosine_dist_f64(double dot, double nx2, double
     if (fabs(c) > 1.0) c = copysign(1.0, c);
     double dm = 1.0 - c;
     double sim = 1.0 - dm;
-    sim = fmax(fmin(sim, 1.0), -1.0);
+    // a zero vector gives 0/0: scipy's and numpy's clips pass the NaN through and the reference returns
+    // NaN (sorted last by its stable sort).  fmin / fmax would swallow it (distance 0, ranked first).
+    if (sim != sim) return __longlong_as_double(0x7ff8000000000000ll);  // canonical NaN: above +inf as a key
+    sim = sim > 1.0 ? 1.0 : (sim < -1.0 ? -1.0 : sim);
     return 2.0 * acos(sim) / 3.141592653589793;
 }
 

@@ -443,3 +443,25 @@ def test_dense_batches_beyond_the_query_chunk():
         np.testing.assert_array_equal(i[qi], ri)
         np.testing.assert_array_equal(d[qi].view(np.uint32), rd.view(np.uint32))
     assert idx.stats()["candidates"] >= 4500 * 5
+
+
+@pytest.mark.parametrize("n", [300, 90_000])
+def test_cosine_zero_vectors_give_nan_ranked_last(n):
+    """scipy's 0/0 for a zero vector is NaN, numpy's clips keep it and the reference's stable sort puts
+    it last; the device must not turn it into distance 0."""
+    rng = np.random.default_rng(n)
+    db = rng.random((n, 96)).astype(np.float32)
+    db[[17, 201]] = 0.0
+    qs = rng.random((3, 96)).astype(np.float32)
+    qs[2] = 0.0                                                     # a zero query: every distance is NaN
+    k = n if n < 1000 else 50
+    idx = _lib.DenseIndex(db, metric=_lib.SQ_METRIC_COSINE)
+    d, i = idx.search(qs, k)
+    for qi in range(3):
+        rd, ri = O.dense_topk(db, qs[qi], k, "cosine")
+        np.testing.assert_allclose(d[qi], rd, rtol=1e-12, atol=1e-15, equal_nan=True)
+        solid = ~np.isnan(rd)
+        np.testing.assert_array_equal(i[qi][solid], ri[solid])
+        assert np.isnan(d[qi]).sum() == np.isnan(rd).sum()
+    if n < 1000:
+        assert set(i[0][-2:]) == {17, 201} and np.isnan(d[0][-2:]).all()
