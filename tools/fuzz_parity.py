@@ -60,5 +60,64 @@ for c in range(cases):
     except Exception as e:  # noqa: BLE001
         fails += 1
         print(f"FAIL case {c}: n={n} d={d} k={k} nq={nq} {metric} kind={kind}: {type(e).__name__} {e}", flush=True)
-print(f"{cases - fails}/{cases} passed in {time.time() - t0:.0f} s")
+# ---- Hamming: random widths / sizes / tie-heavy code sets
+for c in range(cases // 2):
+    bits = int(rng.choice([1, 7, 33, 64, 70, 128, 192, 256, 320]))
+    n = int(rng.choice([50, 3000, 90_000, 300_000]))
+    k = int(rng.choice([1, 10, 100, 700]))
+    nq = int(rng.choice([1, 5, 40]))
+    w = (bits + 63) // 64
+    low = bool(rng.integers(0, 2))                                   # low-entropy codes: huge tie groups
+    raw = rng.integers(0, 2 ** 63, size=(n, w), dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, w)).astype(np.uint64)
+    if low:
+        raw &= np.uint64(0x0F0F000000000F0F)
+    pad = w * 64 - bits
+    if pad:
+        raw[:, 0] &= np.uint64((1 << (64 - pad)) - 1) if pad < 64 else np.uint64(0)
+    codes = np.unique(raw, axis=0)
+    qs = codes[rng.integers(0, len(codes), nq)].copy()
+    qs[0] ^= np.uint64(1)
+    try:
+        idx = _lib.HammingIndex(codes)
+        dd, ii = idx.search(qs, k)
+        st = idx.stats()
+        for qi in range(min(nq, 3)):
+            rd, ri = O.hamming_topk(codes, qs[qi], k)
+            kk = len(rd)
+            assert np.array_equal(dd[qi, :kk], rd), "hamming dist"
+            assert np.array_equal(ii[qi, :kk], ri), "hamming ids"
+            assert (ii[qi, kk:] == -1).all(), "hamming padding"
+        idx.close()
+        print(f"ok   hamming {c}: n={len(codes)} bits={bits} k={k} nq={nq} low={low} fallback={st['fallback_queries']}", flush=True)
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print(f"FAIL hamming {c}: n={len(codes)} bits={bits} k={k} nq={nq} low={low}: {type(e).__name__} {e}", flush=True)
+
+# ---- ITQ: random dims / bits / dtypes / normalisation / mean dtype
+for c in range(cases // 2):
+    d = int(rng.choice([3, 20, 64, 100, 128, 192, 256, 300]))
+    bits = int(rng.choice([1, 8, 33, 64, 100, 128, 200]))
+    n = int(rng.choice([1, 31, 33, 1000, 40_000]))
+    xdt = np.float32 if rng.integers(0, 2) else np.float64
+    mdt = np.float32 if rng.integers(0, 2) else np.float64
+    norm = None if rng.integers(0, 2) else 2
+    x = (rng.standard_normal((n, d)) * rng.lognormal(0, 1, (n, 1)) + rng.standard_normal(d)).astype(xdt)
+    if n > 3: x[2] = 0
+    mean = x[: max(1, n // 2)].mean(axis=0).astype(mdt)
+    rot = rng.standard_normal((d, bits))
+    try:
+        got = _lib.itq_hash(x, mean, rot, _lib.SQ_NORM_NONE if norm is None else _lib.SQ_NORM_L2)
+        z = O.itq_z(x, mean, rot, norm)
+        ref = O.pack_bits_msb(z >= 0)
+        bad = (got != ref).any(axis=1)
+        if bad.any():
+            scale = np.abs(z[bad]).max(axis=1)
+            assert (np.abs(z[bad]).min(axis=1) <= 1e-9 * np.maximum(scale, 1e-30)).all(), "itq bits"
+        print(f"ok   itq {c}: n={n} d={d} bits={bits} x={xdt.__name__} mean={mdt.__name__} norm={norm} borderline_rows={int(bad.sum())}", flush=True)
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print(f"FAIL itq {c}: n={n} d={d} bits={bits} x={xdt.__name__} mean={mdt.__name__} norm={norm}: {type(e).__name__} {e}", flush=True)
+
+total = cases + 2 * (cases // 2)
+print(f"{total - fails}/{total} passed in {time.time() - t0:.0f} s")
 sys.exit(1 if fails else 0)
