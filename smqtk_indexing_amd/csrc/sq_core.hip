@@ -1,8 +1,11 @@
 // Handle registry, options, error text and the host-side shard merge.
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
+#include <cstring>
 #include <limits>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "sq_common.hpp"
@@ -97,54 +100,199 @@ extern "C" int sq_get_stats(sq_handle_t hid, sq_stats_t* out) {
     return SQ_OK;
 }
 
-// Host-side k-way merge of per-shard sorted lists: concatenate the shard rows
-// of a query, order by (distance, id), keep k_out.  Shard lists are short
-// (k_in <= 16384) so a partial sort per query is ample.
-// Each shard list is already sorted by (distance, id) with its padding (id -1) at
-// the end, so a query's result is a k-way merge: k_out steps, each picking the
-// smallest head among the shards (nshards <= 8 on one node: a linear scan).
+// Host-side k-way merge of per-shard sorted lists (on the timed path of a multi-GPU step).
+// Each shard list is already sorted by (distance, id) with its padding (id -1) at the end, so a
+// query's result is a k-way merge.  Branches on the data are what a scalar merge pays for (a
+// mispredict per comparison), so the inner loop has none: distances become order-preserving
+// unsigned keys, the smallest head is found with a compare/select tree over <= 8 shards at a time,
+// and ties are left in (distance, shard, position) order.  Afterwards every run of equal distance
+// -- extended past k_out to the whole tie group of the last distance -- is put in id order (a
+// no-op test when shards hold increasing id ranges) and the list is cut to k_out.
 // dshard / ishard: distance between consecutive shards' [nq][k_in] blocks, in BYTES
+static inline uint64_t merge_key(float v) {
+    if (v == 0.0f) v = 0.0f;  // -0 and +0 are one distance
+    uint32_t b;
+    std::memcpy(&b, &v, 4);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+static inline uint64_t merge_key(double v) {
+    if (v == 0.0) v = 0.0;
+    uint64_t b;
+    std::memcpy(&b, &v, 8);
+    return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
+}
+static inline uint64_t merge_key(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
+
 template <class D>
 static void merge_range(const D* dist, const int64_t* idx, int nshards, int nq, int k_in, int k_out, D* out_dist,
                         int64_t* out_idx, D pad_value, int q0, int q1, size_t dshard, size_t ishard) {
-    constexpr int64_t kDone = std::numeric_limits<int64_t>::max();  // id of an exhausted list (sorts last)
-    std::vector<int> head((size_t)nshards);
-    std::vector<D> hd((size_t)nshards);
-    std::vector<int64_t> hi((size_t)nshards);
-    auto load = [&](int s, int q) {  // cache the head of shard s
-        const int hpos = head[(size_t)s];
-        if (hpos < k_in) {
-            const size_t at = (size_t)q * k_in + hpos;
-            const D* ds = reinterpret_cast<const D*>(reinterpret_cast<const char*>(dist) + (size_t)s * dshard);
-            const int64_t* is = reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(idx) + (size_t)s * ishard);
-            if (is[at] >= 0) {
-                hd[(size_t)s] = ds[at];
-                hi[(size_t)s] = is[at];
-                return;
-            }
+    constexpr uint64_t kDone = ~0ull;  // key of an exhausted list: above every distance (NaN included)
+    constexpr int kMaxWay = 8;
+    (void)nq;
+    const int total_cap = nshards * k_in;
+    std::vector<D> md((size_t)total_cap), md2;
+    std::vector<int64_t> mi((size_t)total_cap), mi2;
+    std::vector<std::pair<int64_t, D>> run;
+    std::vector<int> seq_store((size_t)total_cap);
+    int* const seq = seq_store.data();  // (position * 8 + shard) of every chosen entry
+    bool any_tie = false;                // per query: some merge_group saw two equal keys in a row
+    // merge `ways` (<= 8) sorted lists into (od, oi): at least `want` entries, then the rest of the last tie group
+    auto merge_group = [&](const D* const* ld, const int64_t* const* li, const int* len, int ways, int want, D* od,
+                           int64_t* oi) -> int {
+        // Heads live in eight scalars (constant indexing only, so they stay in registers) and the
+        // key FOLLOWING each head is kept ready in nxt[]: the loop-carried chain is then the select
+        // tree plus one L1 load, and the key conversion of the next element is off that chain.
+        uint64_t key[kMaxWay], nxt[kMaxWay];
+        int head[kMaxWay];
+        auto key_at = [&](int s, int pos) -> uint64_t { return (s < ways && pos < len[s]) ? merge_key(ld[s][pos]) : kDone; };
+        for (int s = 0; s < kMaxWay; ++s) {
+            head[s] = 0;
+            key[s] = key_at(s, 0);
+            nxt[s] = key_at(s, 1);
         }
-        hd[(size_t)s] = pad_value;  // exhausted, or the rest of the list is padding
-        hi[(size_t)s] = kDone;
+        uint64_t k0 = key[0], k1 = key[1], k2 = key[2], k3 = key[3], k4 = key[4], k5 = key[5], k6 = key[6], k7 = key[7];
+        int n = 0;
+        uint64_t last = 0;
+        bool tie = false;
+        for (;;) {
+            // compare/select tree carrying (key, shard): the lower shard wins equal keys
+            const bool c01 = k1 < k0, c23 = k3 < k2, c45 = k5 < k4, c67 = k7 < k6;
+            const uint64_t m01 = c01 ? k1 : k0, m23 = c23 ? k3 : k2, m45 = c45 ? k5 : k4, m67 = c67 ? k7 : k6;
+            const int i01 = c01 ? 1 : 0, i23 = c23 ? 3 : 2, i45 = c45 ? 5 : 4, i67 = c67 ? 7 : 6;
+            const bool c03 = m23 < m01, c47 = m67 < m45;
+            const uint64_t m03 = c03 ? m23 : m01, m47 = c47 ? m67 : m45;
+            const int i03 = c03 ? i23 : i01, i47 = c47 ? i67 : i45;
+            const bool c07 = m47 < m03;
+            const uint64_t kb = c07 ? m47 : m03;
+            const int best = c07 ? i47 : i03;
+            if (kb == kDone || (n >= want && kb != last)) break;
+            tie |= (kb == last) & (n > 0);
+            const uint64_t nk = nxt[best];
+            const int hp = head[best];
+            seq[n] = hp * kMaxWay + best;
+            ++n;
+            last = kb;
+            head[best] = hp + 1;
+            nxt[best] = hp + 2 < len[best] ? merge_key(ld[best][hp + 2]) : kDone;
+            k0 = best == 0 ? nk : k0;
+            k1 = best == 1 ? nk : k1;
+            k2 = best == 2 ? nk : k2;
+            k3 = best == 3 ? nk : k3;
+            k4 = best == 4 ? nk : k4;
+            k5 = best == 5 ? nk : k5;
+            k6 = best == 6 ? nk : k6;
+            k7 = best == 7 ? nk : k7;
+        }
+        for (int t = 0; t < n; ++t) {  // gather the chosen entries (independent loads)
+            const int sh = seq[t] % kMaxWay, at = seq[t] / kMaxWay;
+            od[t] = ld[sh][at];
+            oi[t] = li[sh][at];
+        }
+        any_tie |= tie;
+        return n;
     };
+    // runs of equal distance into id order (nothing to do when the merges above met no equal keys)
+    auto order_ties = [&](D* od, int64_t* oi, int n) {
+        if (!any_tie) return;
+        int i = 0;
+        while (i < n) {
+            int j = i + 1;
+            bool sorted = true;
+            while (j < n && merge_key(od[j]) == merge_key(od[i])) {
+                sorted &= oi[j - 1] < oi[j];
+                ++j;
+            }
+            if (!sorted) {
+                run.clear();
+                for (int t = i; t < j; ++t) run.emplace_back(oi[t], od[t]);
+                std::sort(run.begin(), run.end(), [](const std::pair<int64_t, D>& x, const std::pair<int64_t, D>& y) {
+                    return x.first < y.first;
+                });
+                for (int t = i; t < j; ++t) {
+                    oi[t] = run[(size_t)(t - i)].first;
+                    od[t] = run[(size_t)(t - i)].second;
+                }
+            }
+            i = j;
+        }
+    };
+    std::vector<const D*> ld((size_t)nshards);
+    std::vector<const int64_t*> li((size_t)nshards);
+    std::vector<int> len((size_t)nshards);
     for (int q = q0; q < q1; ++q) {
         for (int s = 0; s < nshards; ++s) {
-            head[(size_t)s] = 0;
-            load(s, q);
-        }
-        for (int j = 0; j < k_out; ++j) {
-            int best = 0;
-            for (int s = 1; s < nshards; ++s)
-                if (hd[(size_t)s] < hd[(size_t)best] || (hd[(size_t)s] == hd[(size_t)best] && hi[(size_t)s] < hi[(size_t)best]))
-                    best = s;
-            if (hi[(size_t)best] != kDone) {
-                out_dist[(size_t)q * k_out + j] = hd[(size_t)best];
-                out_idx[(size_t)q * k_out + j] = hi[(size_t)best];
-                ++head[(size_t)best];
-                load(best, q);
-            } else {
-                out_dist[(size_t)q * k_out + j] = pad_value;
-                out_idx[(size_t)q * k_out + j] = -1;
+            const D* ds = reinterpret_cast<const D*>(reinterpret_cast<const char*>(dist) + (size_t)s * dshard) + (size_t)q * k_in;
+            const int64_t* is = reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(idx) + (size_t)s * ishard) + (size_t)q * k_in;
+            ld[(size_t)s] = ds;
+            li[(size_t)s] = is;
+            // valid entries: a shard with fewer than k_in rows pads the tail with id -1
+            int n = k_in;
+            if (is[k_in - 1] < 0) {
+                int lo = 0, hi = k_in - 1;  // first padded position
+                while (lo < hi) {
+                    const int mid = (lo + hi) / 2;
+                    if (is[mid] < 0) hi = mid; else lo = mid + 1;
+                }
+                n = lo;
             }
+            len[(size_t)s] = n;
+        }
+        any_tie = false;
+        int n;
+        if (nshards <= kMaxWay) {
+            n = merge_group(ld.data(), li.data(), len.data(), nshards, k_out, md.data(), mi.data());
+        } else {
+            // more than 8 shards: groups of 8 into one buffer, then merge the (id-ordered) group results
+            md2.resize((size_t)total_cap);
+            mi2.resize((size_t)total_cap);
+            std::vector<const D*> gd;
+            std::vector<const int64_t*> gi;
+            std::vector<int> gl;
+            int used = 0;
+            for (int s = 0; s < nshards; s += kMaxWay) {
+                const int ways = std::min(kMaxWay, nshards - s);
+                const int m = merge_group(ld.data() + s, li.data() + s, len.data() + s, ways, k_out, md2.data() + used,
+                                          mi2.data() + used);
+                order_ties(md2.data() + used, mi2.data() + used, m);
+                gd.push_back(md2.data() + used);
+                gi.push_back(mi2.data() + used);
+                gl.push_back(m);
+                used += m;
+            }
+            while (gd.size() > (size_t)kMaxWay) {  // > 64 shards: fold 8 group results at a time
+                std::vector<D> td((size_t)total_cap);
+                std::vector<int64_t> ti((size_t)total_cap);
+                std::vector<const D*> nd;
+                std::vector<const int64_t*> ni;
+                std::vector<int> nl;
+                int u2 = 0;
+                for (size_t g = 0; g < gd.size(); g += kMaxWay) {
+                    const int ways = (int)std::min<size_t>(kMaxWay, gd.size() - g);
+                    const int m = merge_group(gd.data() + g, gi.data() + g, gl.data() + g, ways, k_out, td.data() + u2,
+                                              ti.data() + u2);
+                    order_ties(td.data() + u2, ti.data() + u2, m);
+                    nd.push_back(md2.data() + u2);
+                    ni.push_back(mi2.data() + u2);
+                    nl.push_back(m);
+                    u2 += m;
+                }
+                std::copy(td.begin(), td.begin() + u2, md2.begin());
+                std::copy(ti.begin(), ti.begin() + u2, mi2.begin());
+                gd.swap(nd);
+                gi.swap(ni);
+                gl.swap(nl);
+            }
+            n = merge_group(gd.data(), gi.data(), gl.data(), (int)gd.size(), k_out, md.data(), mi.data());
+        }
+        order_ties(md.data(), mi.data(), n);
+        D* qd = out_dist + (size_t)q * k_out;
+        int64_t* qi = out_idx + (size_t)q * k_out;
+        const int keep = std::min(n, k_out);
+        std::copy(md.begin(), md.begin() + keep, qd);
+        std::copy(mi.begin(), mi.begin() + keep, qi);
+        for (int j = keep; j < k_out; ++j) {
+            qd[j] = pad_value;
+            qi[j] = -1;
         }
     }
 }
@@ -155,7 +303,7 @@ static void merge_impl(const D* dist, const int64_t* idx, int nshards, int nq, i
     // a few host threads when the batch is large (the merge is on the timed path of a multi-GPU step)
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)std::min<unsigned>(hw ? hw : 1u, 16u);
-    if ((long long)nq * k_out * nshards < 200000) nt = 1;
+    if ((long long)nq * k_out < 200000) nt = 1;  // ~1 ms of merging: below that a thread start costs more than it saves
     nt = std::min(nt, nq);
     if (nt <= 1) {
         merge_range<D>(dist, idx, nshards, nq, k_in, k_out, out_dist, out_idx, pad_value, 0, nq, dshard, ishard);

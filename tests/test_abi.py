@@ -67,6 +67,50 @@ def test_host_merge_reads_the_gather_buffer_in_place():
         np.testing.assert_array_equal(ref[1], got[1])
 
 
+@pytest.mark.parametrize("shards,dtype,levels", [(1, np.float32, 0), (2, np.float32, 0), (8, np.float32, 0), (8, np.int32, 9),
+                                                  (8, np.float64, 4), (20, np.float32, 7), (70, np.int32, 5), (5, np.float32, 1)])
+def test_host_merge_equals_a_lexsort_of_the_concatenation(shards, dtype, levels):
+    """Random shard lists -- ragged (padded with id -1), tie-heavy (``levels`` distinct distances) with ids
+    interleaved across shards, signed zeros, NaN distances, more shards than one merge tree takes --
+    against numpy's lexsort on (distance, id).  k_out below, at and above what the shards hold."""
+    rng = np.random.default_rng(shards * 31 + levels)
+    nq, k = 9, 23
+    d = rng.random((shards, nq, k))
+    if levels:
+        d = np.floor(d * levels) / levels
+    d = (d * 40 - (3 if dtype != np.int32 else 0)).astype(dtype)
+    if dtype != np.int32:
+        d[d == 0] = -0.0 if levels else 0.0
+        d[0, 0, :2] = [0.0, -0.0]
+        d[-1, 1, -1] = np.nan                                        # a zero-vector cosine: ranks last
+    ids = (rng.permutation(shards * nq * k).reshape(shards, nq, k) * 3).astype(np.int64)
+    valid = rng.integers(0, k + 1, (shards, nq))
+    valid[0] = k
+    valid[-1, 2] = 0                                                 # an empty shard list
+    for s in range(shards):
+        for q in range(nq):
+            v = valid[s, q]
+            key_d = np.where(np.isnan(d[s, q, :v].astype(np.float64)), np.inf, d[s, q, :v].astype(np.float64))
+            o = np.lexsort((ids[s, q, :v], key_d + 0.0))
+            d[s, q, :v], ids[s, q, :v] = d[s, q, :v][o], ids[s, q, :v][o]
+            ids[s, q, v:] = -1
+            d[s, q, v:] = np.iinfo(np.int32).max if dtype == np.int32 else np.inf
+    for k_out in (1, 17, 23, 60, shards * k + 3):
+        od, oi = _lib.merge_topk(d, ids, k_out)
+        for q in range(nq):
+            keep = ids[:, q, :].reshape(-1) >= 0
+            ad, ai = d[:, q, :].reshape(-1)[keep], ids[:, q, :].reshape(-1)[keep]
+            sort_d = np.where(np.isnan(ad.astype(np.float64)), np.inf, ad.astype(np.float64)) + 0.0
+            if dtype != np.int32:                                    # NaN after +inf
+                sort_d = np.where(np.isnan(ad.astype(np.float64)), np.finfo(np.float64).max, sort_d)
+                sort_d = np.where(np.isposinf(ad.astype(np.float64)), np.finfo(np.float64).max / 2, sort_d)
+            o = np.lexsort((ai, sort_d))[:k_out]
+            m = len(o)
+            np.testing.assert_array_equal(oi[q, :m], ai[o])
+            np.testing.assert_array_equal(od[q, :m], ad[o])
+            assert (oi[q, m:] == -1).all()
+
+
 def test_bad_arguments_are_reported_not_crashed():
     with pytest.raises(_lib.HipError):
         _lib.merge_topk(np.zeros((1, 1, 1), np.float32), np.zeros((1, 1, 1), np.int64), 0)
