@@ -207,7 +207,8 @@ def main() -> None:
             extra[f"batch_{b}"] = {
                 "queries_per_s": b / dt, "ms_per_call": dt * 1e3, "scan_kernel_ms": s_ms,
                 "scan_GBps_per_query_tile": (-(-n_local // 32) * 32) * (-(-d // 128) * 256 + 4) * (-(-b // 32)) / (s_ms * 1e-3) / 1e9 if s_ms > 0 else None,
-                "scan_bf16_TFLOPs_executed": 2 * 2.0 * n_local * (-(-d // 128) * 128) * (-(-b // 32) * 32) / (s_ms * 1e-3) / 1e12 if s_ms > 0 else None,
+                # one 32-query tile runs two bfloat16 query planes (q_hi + q_lo), larger batches one
+                "scan_bf16_TFLOPs_executed": 2 * (2.0 if b <= 32 else 1.0) * n_local * (-(-d // 128) * 128) * (-(-b // 32) * 32) / (s_ms * 1e-3) / 1e12 if s_ms > 0 else None,
             }
 
     # ---- the other two kernels of the hot path on the same resident matrix (BASELINE config C3):
@@ -298,7 +299,7 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "bytes_per_row": d_pad * 2 + 4,
                 "f32_matrix_equivalent_GBps": f32_bytes / (mean_scan_ms * 1e-3) / 1e9 if mean_scan_ms > 0 else None,
-                "mfma_TFLOPs_executed": 2 * 2.0 * n_pad * d_pad * (-(-nq // 32) * 32) / (mean_scan_ms * 1e-3) / 1e12 if mean_scan_ms > 0 else None,
+                "mfma_TFLOPs_executed": 2 * (2.0 if nq <= 32 else 1.0) * n_pad * d_pad * (-(-nq // 32) * 32) / (mean_scan_ms * 1e-3) / 1e12 if mean_scan_ms > 0 else None,
                 "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TF,
             },
         }

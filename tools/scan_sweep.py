@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measurement helper (not part of the product): the dense scan under its measurement options on
 one GPU -- ablations of the single-tile kernel, sample strides, query tiles per wave, batch sizes.
-usage: [N=10000000] [D=128] python tools/scan_sweep.py [ablate] [stride] [qt] [batch]"""
+usage: [N=10000000] [D=128] [NQS=32,128,1024] python tools/scan_sweep.py [ablate] [stride] [qt] [batch]"""
 import os
 import sys
 
@@ -52,8 +52,8 @@ def main():
                           ("512 row blocks", {"dense_blocks": 512})):
             show(tag, 32, *run(32, **opts))
     if "stride" in which:
-        for nq in (32, 128, 1024):
-            for stride in (4, 8, 12, 16, 24):
+        for nq in [int(x) for x in os.environ.get("NQS", "32,128,1024").split(",")]:
+            for stride in (2, 3, 4, 6, 8, 12, 16, 24):
                 show(f"sample_stride={stride}", nq, *run(nq, reps=4, sample_stride=stride))
     if "qt" in which:
         for nq in (64, 128, 1024):
