@@ -79,7 +79,8 @@ int sq_device_name(int device, char* out_name, int name_len, int64_t* out_total_
  * "force_fallback" (0/1: every query takes the exact full-keys path);
  * measurement / test knobs of the dense scan (0 = auto): "dense_qt" (1, 2 or 4
  * query tiles per scan wave), "dense_waves" (4 or 8), "dense_stages" (ring
- * depth), "dense_blocks" (row blocks), "dense_debug" (ablation bits). */
+ * depth), "dense_blocks" (row blocks), "dense_rerank_segments" (survivor
+ * segments per re-rank workgroup), "dense_debug" (ablation bits). */
 int sq_set_option(const char* name, int64_t value);
 int sq_get_stats(sq_handle_t h, sq_stats_t* out);
 

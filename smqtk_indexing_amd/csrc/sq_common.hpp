@@ -56,6 +56,7 @@ struct Options {
     int itq_exact = 0;       // 1 = every row through the float64 ITQ kernel (no bf16 filter)
     int dense_qplanes = 0;       // 0 = auto, 2 = keep q_hi + q_lo also in the multi-tile scan
     int dense_no_center = 0;     // 1 = the dense L2 filter scores the rows as given (no column-mean origin; measurement)
+    int dense_rerank_segments = 0;  // survivor segments per re-rank workgroup (0 = all waves of a scan workgroup; measurement)
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
 };
 extern Options g_opt;

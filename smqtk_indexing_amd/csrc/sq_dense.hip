@@ -22,6 +22,7 @@
 //   3. select_topk_kernel sorts the keys; its post-op (DenseFinalize*) converts and
 //      CERTIFIES each query against the filter's error bound.  Queries that fail
 //      (or overflow their list) are redone on the exact full-keys path.
+#include <algorithm>
 #include <cmath>
 
 #include "sq_dense_exact.cuh"
@@ -318,21 +319,26 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         h->stats.scan_launches = 2;
         h->stats.bytes_scanned = h->n_pad * ((long long)d_pad * 2 + (cosine ? 0 : 4));
         // exact re-rank of the survivors (wave segments -> per-query keys), select, certify
-        const int wpb = 2;  // survivor segments per re-rank block (both from one scan workgroup: wv is even)
+        // A re-rank workgroup takes `wpb` survivor segments of one scan workgroup (its waves share the query
+        // group), 128 threads per segment.  Many small workgroups win: the kernel is a chain of dependent
+        // memory round trips per workgroup, not the per-query atomics (2 vs 8 segments: 37 vs 50 us at 10 M rows).
+        int wpb = 2;
+        if (g_opt.dense_rerank_segments > 0 && wv % g_opt.dense_rerank_segments == 0) wpb = g_opt.dense_rerank_segments;
+        const unsigned rr_threads = (unsigned)std::min(512, 128 * wpb);
         const size_t rr_lds = (qt == 1 && ldq <= 156) ? (size_t)32 * (ldq + 4) * 4 : 0;  // the query tile in LDS (rerank_block)
         const unsigned gxr = (unsigned)((n_waves + wpb - 1) / wpb);
         if (cosine) {
-            hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3(gxr), dim3(256), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
+            hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
                                ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, h->keys.as<K128>(), cnt,
-                               cap, oflag, cnx, cnq);
+                               cap, oflag, cnx, cnq, g_opt.dense_debug);
             SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, cap, key_stride, k, nq, h->out_keys.as<K128>(),
                                          DenseFinalizeCos{cnt, cap, kk, h->id_base, thr, eps_a + eps_b, 1, (double*)out_dist,
                                                           out_idx, hs_dev, hs_raw_dev, oflag, 0},
                                          st));
         } else {
-            hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3(gxr), dim3(256), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
+            hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
                                ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, h->keys.as<u64>(), cnt,
-                               cap, oflag);
+                               cap, oflag, g_opt.dense_debug);
             SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, cap, key_stride, k, nq, h->out_keys.as<u64>(),
                                         DenseFinalizeL2{cnt, cap, kk, h->id_base, thr, qn2, h->xn2_max, eps_a, eps_b, 1,
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0},

@@ -106,7 +106,20 @@ __device__ __forceinline__ double cosine_dot_pair_f64(const float* __restrict__ 
     const int m = d - (d & 1);
     int i = 0;
     if (aligned) {
+        // 16 row vectors (64 elements) requested at a time: the row is a random read from HBM and the
+        // f64 chain behind it is short, so the loads in flight set the pace
         const int m4 = m & ~3;
+        for (; i + 64 <= m4; i += 64) {
+            f32x4 xr[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) xr[v] = *reinterpret_cast<const f32x4*>(x + i + 4 * v);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(q + i + 4 * v);
+                acc = __dadd_rn(acc, __dmul_rn((double)qv[sub], (double)xr[v][sub]));
+                acc = __dadd_rn(acc, __dmul_rn((double)qv[2 + sub], (double)xr[v][2 + sub]));
+            }
+        }
         for (; i < m4; i += 4) {
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
             const f32x4 qv = *reinterpret_cast<const f32x4*>(q + i);
@@ -239,25 +252,32 @@ struct SqLeafPair {
             for (int i = 0; i < n; ++i) r = __fadd_rn(r, term(off + i));
             return r;
         }
+        // A leaf has at most 128 elements (numpy's block size): this lane's 16 row vectors are all requested
+        // before the first is used -- the rows are random 512-byte reads from HBM, and a load/use loop
+        // pays that latency once per unroll group (5 round trips per row at d = 128) instead of once.
+        const int nfull = n - (n % 8);
+        const int nv = nfull / 8;  // 1..16, uniform
+        f32x4 xr[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) xr[v] = *reinterpret_cast<const f32x4*>(x + off + 8 * (v < nv ? v : 0) + 4 * c);
         float r[4];
         {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off + 4 * c);
             const f32x4 qv = *reinterpret_cast<const f32x4*>(q + off + 4 * c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float t = __fsub_rn(xv[j], qv[j]);
+                const float t = __fsub_rn(xr[0][j], qv[j]);
                 r[j] = __fmul_rn(t, t);
             }
         }
-        const int nfull = n - (n % 8);
-#pragma unroll 4
-        for (int i = 8; i < nfull; i += 8) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off + i + 4 * c);
-            const f32x4 qv = *reinterpret_cast<const f32x4*>(q + off + i + 4 * c);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float t = __fsub_rn(xv[j], qv[j]);
-                r[j] = __fadd_rn(r[j], __fmul_rn(t, t));
+        for (int v = 1; v < 16; ++v) {
+            if (v < nv) {
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(q + off + 8 * v + 4 * c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = __fsub_rn(xr[v][j], qv[j]);
+                    r[j] = __fadd_rn(r[j], __fmul_rn(t, t));
+                }
             }
         }
         const float part = __fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3]));
@@ -289,7 +309,7 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
                                              u32 wave_cap, long long n_waves, int waves_per_block,
                                              K* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
                                              u32* __restrict__ overflow, const double* __restrict__ nx64,
-                                             const double* __restrict__ nq64) {
+                                             const double* __restrict__ nq64, int debug) {
     extern __shared__ __attribute__((aligned(16))) float s_qrows[];
     __shared__ u32 s_hist[RERANK_MAX_GROUP], s_base[RERANK_MAX_GROUP], s_fill[RERANK_MAX_GROUP];
     const int ldl = ldq + 4;  // LDS row stride: +16 bytes so that different query rows hit different banks
@@ -323,7 +343,8 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
     __syncthreads();
     if (threadIdx.x < group_q) {
         const u32 hcount = s_hist[threadIdx.x];
-        s_base[threadIdx.x] = hcount ? atomicAdd(&cnt[q0 + threadIdx.x], hcount) : 0u;
+        // (debug 32 / 64: measurement ablations -- no reservation / rows from a cache-resident range; results are garbage)
+        s_base[threadIdx.x] = (hcount && !(debug & 32)) ? atomicAdd(&cnt[q0 + threadIdx.x], hcount) : 0u;
     }
     if (q_in_lds) {
         const int vpr = ldq / 4;  // 16-byte vectors per query row (ldq % 4 == 0, rows 16-byte aligned)
@@ -353,7 +374,8 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
             while (mask) {
                 const int i = __ffs((int)mask) - 1;
                 mask &= mask - 1;
-                const u32 row = ent.x + (u32)((i & 3) + 8 * (i >> 2));
+                u32 row = ent.x + (u32)((i & 3) + 8 * (i >> 2));
+                if (debug & 64) row &= 1023u;
                 if constexpr (COSINE) {
                     const double dot = cosine_dot_pair_f64(db + (long long)row * ld, qrow, d, sub, rows_aligned);
                     if (sub == 0) {
@@ -380,22 +402,22 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
 // overflowed its segment raises `overflow` (every query of the call then takes
 // the exact path; only degenerate thresholds get there).
 // q_al: queries copied to [nq_pad][ldq] floats, ldq % 4 == 0, 16-byte aligned.
-static __global__ __launch_bounds__(256) void dense_rerank_l2_kernel(
+static __global__ __launch_bounds__(512) void dense_rerank_l2_kernel(
     const float* __restrict__ db, long long ld, int d, const float* __restrict__ q_al, int ldq,
     const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt, u32 wave_cap, long long n_waves,
     int waves_per_block, int nq, int group_q, u64* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
-    u32* __restrict__ overflow) {
+    u32* __restrict__ overflow, int debug) {
     rerank_block<u64, false>(db, ld, d, q_al, ldq, nq, group_q, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block,
-                             keys, cnt, cap, overflow, nullptr, nullptr);
+                             keys, cnt, cap, overflow, nullptr, nullptr, debug);
 }
 
-static __global__ __launch_bounds__(256) void dense_rerank_cos_kernel(
+static __global__ __launch_bounds__(512) void dense_rerank_cos_kernel(
     const float* __restrict__ db, long long ld, int d, const float* __restrict__ q_al, int ldq,
     const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt, u32 wave_cap, long long n_waves,
     int waves_per_block, int nq, int group_q, K128* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
-    u32* __restrict__ overflow, const double* __restrict__ nx64, const double* __restrict__ nq64) {
+    u32* __restrict__ overflow, const double* __restrict__ nx64, const double* __restrict__ nq64, int debug) {
     rerank_block<K128, true>(db, ld, d, q_al, ldq, nq, group_q, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block,
-                             keys, cnt, cap, overflow, nx64, nq64);
+                             keys, cnt, cap, overflow, nx64, nq64, debug);
 }
 
 // Plain distance vectors for sq_dense_distances (one query, n gathered rows),

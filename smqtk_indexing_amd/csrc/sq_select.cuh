@@ -221,15 +221,31 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const K* __restrict__
                 if (KeyOps<K>::prefix_eq(key, prefix, b)) atomicAdd(&hist[KeyOps<K>::byte(key, b)], 1u);
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                u32 need = sh_rem, c = 0, v = 0;
-                for (; v < 255; ++v) {
-                    if (c + hist[v] >= need) break;
-                    c += hist[v];
+            if (threadIdx.x < 64) {
+                // first bin whose inclusive running count reaches `need` (bin 255 if none does): wave 0
+                // scans the 256 bins, four per lane -- one thread walking them costs ~10 us per digit
+                const int l = threadIdx.x;
+                const u32 need = sh_rem;
+                const u32 h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+                const u32 s4 = h0 + h1 + h2 + h3;
+                u32 inc = s4;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const u32 t = __shfl_up(inc, o);
+                    if (l >= o) inc += t;
                 }
-                sh_sel = v;
-                sh_rem = need - c;
-                sh_stop = (hist[v] == need - c) ? 1u : 0u;  // the whole bin is wanted: no finer digit needed
+                const u32 exc = inc - s4;
+                const u32 total = __shfl(inc, 63);
+                const bool none = total < need;                       // cannot happen for a consistent count
+                const bool mine = none ? l == 63 : (exc < need && need <= inc);
+                if (mine) {
+                    u32 c = exc, v = 4u * l, hv = h0;
+                    if (c + h0 < need) { c += h0; v++; hv = h1;
+                        if (c + h1 < need) { c += h1; v++; hv = h2;
+                            if (c + h2 < need) { c += h2; v++; hv = h3; } } }
+                    sh_sel = v;
+                    sh_rem = need - c;
+                    sh_stop = (hv == need - c) ? 1u : 0u;  // the whole bin is wanted: no finer digit needed
+                }
             }
             __syncthreads();
             KeyOps<K>::set_byte(prefix, b, sh_sel);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measurement helper (not part of the product): the dense scan under its measurement options on
 one GPU -- ablations of the single-tile kernel, sample strides, query tiles per wave, batch sizes.
-usage: [N=10000000] [D=128] [NQS=32,128,1024] python tools/scan_sweep.py [ablate] [stride] [qt] [batch]"""
+usage: [N=10000000] [D=128] [NQS=32,128,1024] python tools/scan_sweep.py [ablate] [stride] [qt] [rerank] [batch]"""
 import os
 import sys
 
@@ -49,7 +49,10 @@ def main():
     if "ablate" in which:   # dma_only / no_emit return garbage on purpose: every query then takes the exact path
         for tag, opts in (("default", {}), ("dma_only (debug 1)", {"dense_debug": 1}), ("no_emit (debug 4)", {"dense_debug": 4}),
                           ("4 waves", {"dense_waves": 4}), ("4 waves, 4 stages", {"dense_waves": 4, "dense_stages": 4}),
-                          ("512 row blocks", {"dense_blocks": 512})):
+                          ("512 row blocks", {"dense_blocks": 512}),
+                          ("rerank: no reservation atomics (debug 32)", {"dense_debug": 32}),
+                          ("rerank: cache-resident rows (debug 64)", {"dense_debug": 64}),
+                          ("rerank: both (debug 96)", {"dense_debug": 96})):
             show(tag, 32, *run(32, **opts))
     if "stride" in which:
         for nq in [int(x) for x in os.environ.get("NQS", "32,128,1024").split(",")]:
@@ -60,6 +63,10 @@ def main():
             for qt in (1, 2, 4):
                 for qp in (0, 2):
                     show(f"dense_qt={qt} qplanes={qp or 'auto'}", nq, *run(nq, reps=4, dense_qt=qt, dense_qplanes=qp))
+    if "rerank" in which:
+        for nq in [int(x) for x in os.environ.get("NQS", "32,256").split(",")]:
+            for seg in (1, 2, 4, 8):
+                show(f"dense_rerank_segments={seg}", nq, *run(nq, reps=6, dense_rerank_segments=seg))
     if "batch" in which:
         for nq in (1, 32, 64, 128, 256, 1024):
             show("auto", nq, *run(nq, reps=4))
