@@ -118,6 +118,84 @@ for c in range(cases // 2):
         fails += 1
         print(f"FAIL itq {c}: n={n} d={d} bits={bits} x={xdt.__name__} mean={mdt.__name__} norm={norm}: {type(e).__name__} {e}", flush=True)
 
-total = cases + 2 * (cases // 2)
+# ---- re-rank stage (sq_rows_rerank): random candidate lists, both dtypes and metrics
+for c in range(cases // 2):
+    dt = np.float32 if rng.integers(0, 2) else np.float64
+    n = int(rng.choice([1, 40, 3000, 50_000]))
+    d = int(rng.choice([1, 5, 64, 96, 128, 200, 512]))
+    k = int(rng.choice([1, 10, 100, 400]))
+    nq = int(rng.choice([1, 4, 17]))
+    name = str(rng.choice(["euclidean", "cosine"]))
+    rows = data(n, d, int(rng.integers(0, 5))).astype(dt)
+    qs = data(nq, d, 0).astype(dt)
+    cands = [rng.integers(0, n, int(rng.choice([0, 1, 7, 300, 5000]))) for _ in range(nq)]   # duplicates allowed
+    off = np.zeros(nq + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in cands])
+    flat = np.concatenate(cands).astype(np.int64) if off[-1] else np.zeros(0, np.int64)
+    try:
+        m = _lib.RowMatrix(rows)
+        dist, pos = m.rerank(qs, _lib.SQ_METRIC_L2 if name == "euclidean" else _lib.SQ_METRIC_COSINE, flat, off, k)
+        for qi, cd in enumerate(cands):
+            full = O.dense_distances(rows[cd], qs[qi], name) if len(cd) else np.zeros(0)
+            order = np.argsort(full, kind="stable")[:k]
+            kk = len(order)
+            assert (pos[qi, kk:] == -1).all(), "rows padding"
+            if name == "euclidean":
+                assert np.array_equal(pos[qi, :kk], order), "rows order"
+                assert np.array_equal(dist[qi, :kk], full[order]), "rows dist"
+            else:
+                assert np.allclose(dist[qi, :kk], full[order], rtol=1e-12, atol=1e-15, equal_nan=True), "rows cos dist"
+                mism = pos[qi, :kk] != order
+                if mism.any():
+                    a, b = full[pos[qi, :kk][mism]], full[order[mism]]
+                    assert np.all((np.abs(a - b) < 1e-14) | (np.isnan(a) & np.isnan(b))), "rows cos order"
+        m.close()
+        print(f"ok   rows {c}: n={n} d={d} k={k} nq={nq} {name} {dt.__name__}", flush=True)
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print(f"FAIL rows {c}: n={n} d={d} k={k} nq={nq} {name} {dt.__name__}: {type(e).__name__} {e}", flush=True)
+
+# ---- the LSH plugin: device mirror (CSR expansion + device re-rank) against the host path
+from smqtk_indexing_amd._compat import DescriptorMemoryElement, MemoryDescriptorSet, MemoryKeyValueStore
+from smqtk_indexing_amd.impls.hash_index.hip_linear import HipLinearHashIndex
+from smqtk_indexing_amd.impls.lsh_functor.hip_itq import HipItqFunctor
+from smqtk_indexing_amd.impls.nn_index.hip_lsh import HipLSHNearestNeighborIndex
+for c in range(max(2, cases // 8)):
+    dt = np.float32 if rng.integers(0, 2) else np.float64
+    n = int(rng.choice([200, 2000, 6000]))
+    d = int(rng.choice([8, 64, 100]))
+    bits = int(rng.choice([4, 10, 24]))
+    name = str(rng.choice(["euclidean", "cosine"]))
+    use_hi = bool(rng.integers(0, 2))
+    x = data(n, d, int(rng.choice([0, 3]))).astype(dt)
+    try:
+        f = HipItqFunctor(bit_length=min(bits, d), itq_iterations=4, random_seed=int(rng.integers(0, 100)))
+        f.fit([DescriptorMemoryElement(i).set_vector(v) for i, v in enumerate(x[: max(50, n // 5)])])
+        idxs = []
+        for device in (True, False):
+            ix = HipLSHNearestNeighborIndex(f, MemoryDescriptorSet(), MemoryKeyValueStore(),
+                                            HipLinearHashIndex() if use_hi else None, distance_method=name,
+                                            device_rerank=device)
+            ix.build_index([DescriptorMemoryElement(i).set_vector(v) for i, v in enumerate(x)])
+            idxs.append(ix)
+        dev, host = idxs
+        qv = data(5, d, 0).astype(dt)
+        qv[0] = x[rng.integers(0, n)]
+        qs = [DescriptorMemoryElement(f"q{i}").set_vector(v) for i, v in enumerate(qv)]
+        for nn in (1, 13, 120):
+            batch = dev.nn_many(qs, nn)
+            for q, b in zip(qs, batch):
+                for (ra, da), (rb, db_) in ((dev.nn(q, nn), host.nn(q, nn)), (b, host.nn(q, nn))):
+                    assert len(ra) == len(rb), "lsh count"
+                    assert np.allclose(da, db_, rtol=1e-12, atol=0, equal_nan=True), "lsh dist"
+                    da = np.asarray(da)
+                    if len(da) > 1 and (da[1:] != da[:-1]).all():
+                        assert [e.uuid() for e in ra] == [e.uuid() for e in rb], "lsh order"
+        print(f"ok   lsh {c}: n={n} d={d} bits={min(bits, d)} {name} {dt.__name__} hash_index={use_hi}", flush=True)
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print(f"FAIL lsh {c}: n={n} d={d} bits={min(bits, d)} {name} {dt.__name__} hash_index={use_hi}: {type(e).__name__} {e}", flush=True)
+
+total = cases + 3 * (cases // 2) + max(2, cases // 8)
 print(f"{total - fails}/{total} passed in {time.time() - t0:.0f} s")
 sys.exit(1 if fails else 0)
