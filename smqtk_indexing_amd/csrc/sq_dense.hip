@@ -23,6 +23,7 @@
 //      CERTIFIES each query against the filter's error bound.  Queries that fail
 //      (or overflow their list) are redone on the exact full-keys path.
 #include <algorithm>
+#include <vector>
 #include <cmath>
 
 #include "sq_dense_exact.cuh"
@@ -46,11 +47,11 @@ struct DenseHandle : HandleBase {
     double xn2_max = 0.0;       // max squared row norm (error bound of the L2 filter)
     // workspace
     DevBuf q_dev, q_scaled, q_al, qn2, thr, wave_out, wave_cnt, cnt, keys, sample, out_keys, out_dist_dev,
-        out_idx_dev, big_keys, scratch;
+        out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch;
     HostPinned status_host;
     ~DenseHandle() override {
         for (DevBuf* b : {&owned, &scan, &norms, &center, &cos_nx, &cos_nq, &q_dev, &q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt,
-                          &keys, &sample, &out_keys, &out_dist_dev, &out_idx_dev, &big_keys, &scratch})
+                          &keys, &sample, &out_keys, &out_dist_dev, &out_idx_dev, &big_keys, &fb_sample, &fb_keys, &fb_out, &scratch})
             b->release();
         status_host.release();
     }
@@ -234,10 +235,10 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
         if (cosine)
             hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, nq), dim3(256), 0, st, h->db, h->ld, d, q, nullptr, cnt,
-                               (u32)n, n, 0ll, h->keys.as<K128>(), key_stride, cnx, cnq);
+                               (u32)n, n, 0ll, h->keys.as<K128>(), key_stride, cnx, cnq, nullptr, 0);
         else
             hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, nq), dim3(256), l2_lds, st, h->db, h->ld, d, q, nullptr,
-                               cnt, (u32)n, n, 0ll, h->keys.as<u64>(), key_stride);
+                               cnt, (u32)n, n, 0ll, h->keys.as<u64>(), key_stride, nullptr, 0);
         if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
         h->stats.scan_launches = 1;
         h->stats.bytes_scanned = n * (long long)d * 4;
@@ -360,34 +361,113 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         }
         for (int qi = 0; qi < nq; ++qi) h->stats.candidates += hs_raw[qi];
     }
-    // exact full-keys path, one query at a time: keys for all n rows -> radix select
-    for (int qi = 0; qi < nq; ++qi) {
-        const bool need = all_fallback || (!small && (hs[qi] != 0 || force_fb));
-        if (!need) continue;
-        h->stats.fallback_queries++;
-        SQ_TRY(h->big_keys.reserve((size_t)n * key_bytes));
-        hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, cnt + qi, 1ll, (u32)n);
+    // Exact full-keys path, a group of up to 8 queries per pass over the matrix (dense_exact_group_kernel):
+    // exact keys for all n rows, then a two-level select -- the k-th smallest of every fb_stride-th exact
+    // distance bounds the k-th of all, the keys at or below it (~2 k fb_stride of them) are compacted by the
+    // whole device and the one-workgroup select runs on those.  (That select over all n keys directly: 13 ms
+    // per query at 10 M rows against 1.2 ms for the keys.)  Ties that overflow the compacted list, or too few
+    // finite distances, go on to the select over all keys.
+    long long fb_stride = std::min<long long>(64, std::min<long long>((long long)cap / (4ll * kk), n / (8ll * kk)));
+    if (n < 65536 || fb_stride < 2 || (g_opt.dense_debug & 128)) fb_stride = 0;  // debug 128: measurement, full select
+    const long long fb_ns = fb_stride ? (n + fb_stride - 1) / fb_stride : 0;
+    std::vector<int> todo;
+    for (int qi = 0; qi < nq; ++qi)
+        if (all_fallback || (!small && (hs[qi] != 0 || force_fb))) todo.push_back(qi);
+    // group size: the key arrays of a group stay under 4 GB; rows beyond the group kernel's depth go one by one
+    int gmax = (int)std::min<long long>(EXACT_GROUP, std::max<long long>(1, (4ll << 30) / (n * (long long)key_bytes)));
+    if (d > (128 << EXACT_GROUP_DEPTH) || (g_opt.dense_debug & 256)) gmax = 1;    // debug 256: measurement, one query per pass
+    const size_t grp_lds = (size_t)EXACT_GROUP * ((d + 3) / 4 * 4) * 4;
+    const bool grp_ok = grp_lds <= 160 * 1024 - 256 && d <= (128 << EXACT_GROUP_DEPTH);
+    if (grp_ok && !todo.empty()) {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_exact_group_kernel<false, u64>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)grp_lds));
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_exact_group_kernel<true, K128>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)grp_lds));
+    }
+    for (size_t t0 = 0; t0 < todo.size(); t0 += (size_t)gmax) {
+        const int gn = (int)std::min<size_t>((size_t)gmax, todo.size() - t0);
+        ExactGroup grp{};
+        for (int g = 0; g < EXACT_GROUP; ++g) grp.idx[g] = todo[t0 + (size_t)(g < gn ? g : 0)];
+        grp.count = gn;
+        h->stats.fallback_queries += gn;
+        SQ_TRY(h->big_keys.reserve((size_t)gn * n * key_bytes));
+        float* fb_sample = nullptr;
+        float* fb_thr = nullptr;
+        u32* fb_cnt = nullptr;
+        if (fb_stride) {
+            SQ_TRY(h->fb_sample.reserve((size_t)gn * fb_ns * 4 + 256));
+            SQ_TRY(h->fb_keys.reserve((size_t)gn * cap * key_bytes));
+            fb_thr = h->fb_sample.as<float>();               // [8] thresholds | [8] counts | samples
+            fb_cnt = reinterpret_cast<u32*>(fb_thr + 8);
+            fb_sample = fb_thr + 64;
+        }
         unsigned gx = (unsigned)((n + 255) / 256);
         if (gx > 8192) gx = 8192;
-        if (cosine) {
-            hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, 1), dim3(256), 0, st, h->db, h->ld, d,
-                               q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<K128>(), n, cnx,
-                               cnq + qi);
-            SQ_TRY(select_launch_t<K128>(h->big_keys.as<K128>(), cnt + qi, (u32)n, n, k, 1,
-                                         h->out_keys.as<K128>() + (long long)qi * k,
-                                         DenseFinalizeCos{cnt, (u32)n, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx,
-                                                          hs_dev, nullptr, nullptr, qi},
-                                         st));
-        } else {
-            hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, 1), dim3(256), l2_lds, st, h->db, h->ld, d,
-                               q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<u64>(), n);
-            SQ_TRY(select_launch_t<u64>(h->big_keys.as<u64>(), cnt + qi, (u32)n, n, k, 1,
-                                        h->out_keys.as<u64>() + (long long)qi * k,
-                                        DenseFinalizeL2{cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 0,
-                                                        (float*)out_dist, out_idx, hs_dev, nullptr, nullptr, qi},
-                                        st));
+        if (grp_ok) {
+            if (cosine)
+                hipLaunchKernelGGL((dense_exact_group_kernel<true, K128>), dim3(gx), dim3(256), grp_lds, st, h->db, h->ld, d, q,
+                                   grp, n, h->big_keys.as<K128>(), fb_sample, fb_ns, (int)fb_stride, cnx, cnq);
+            else
+                hipLaunchKernelGGL((dense_exact_group_kernel<false, u64>), dim3(gx), dim3(256), grp_lds, st, h->db, h->ld, d, q,
+                                   grp, n, h->big_keys.as<u64>(), fb_sample, fb_ns, (int)fb_stride, nullptr, nullptr);
+        } else {  // one query per pass (gmax == 1 here)
+            const int qi = grp.idx[0];
+            if (cosine)
+                hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, 1), dim3(256), 0, st, h->db, h->ld, d,
+                                   q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<K128>(), n, cnx,
+                                   cnq + qi, fb_sample, (int)fb_stride);
+            else
+                hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, 1), dim3(256), l2_lds, st, h->db, h->ld, d,
+                                   q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<u64>(), n,
+                                   fb_sample, (int)fb_stride);
         }
         h->stats.scan_launches++;
+        h->stats.bytes_scanned += n * (long long)d * 4;
+        bool done[EXACT_GROUP] = {false, false, false, false, false, false, false, false};
+        if (fb_stride) {
+            hipLaunchKernelGGL((kth_threshold_f32_kernel<KthIdentity>), dim3(gn), dim3(1024), 0, st, fb_sample, fb_ns, kk, fb_thr,
+                               KthIdentity{});
+            hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, fb_cnt, (long long)gn, 0u);
+            const unsigned gc = (unsigned)std::min<long long>((n + 1023) / 1024, 512);
+            if (cosine) {
+                hipLaunchKernelGGL((dense_compact_keys_kernel<K128>), dim3(gc, gn), dim3(256), 0, st, h->big_keys.as<K128>(), n,
+                                   fb_thr, h->fb_keys.as<K128>(), cap, fb_cnt);
+                SQ_TRY(h->fb_out.reserve((size_t)gn * k * key_bytes));
+                SQ_TRY(select_launch_t<K128>(h->fb_keys.as<K128>(), fb_cnt, cap, (long long)cap, k, gn, h->fb_out.as<K128>(),
+                                             DenseFinalizeCos{fb_cnt, cap, kk, h->id_base, thr, 0.0, 2, (double*)out_dist, out_idx,
+                                                              hs_dev, nullptr, nullptr, 0, grp},
+                                             st));
+            } else {
+                hipLaunchKernelGGL((dense_compact_keys_kernel<u64>), dim3(gc, gn), dim3(256), 0, st, h->big_keys.as<u64>(), n,
+                                   fb_thr, h->fb_keys.as<u64>(), cap, fb_cnt);
+                SQ_TRY(h->fb_out.reserve((size_t)gn * k * key_bytes));
+                SQ_TRY(select_launch_t<u64>(h->fb_keys.as<u64>(), fb_cnt, cap, (long long)cap, k, gn, h->fb_out.as<u64>(),
+                                            DenseFinalizeL2{fb_cnt, cap, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 2,
+                                                            (float*)out_dist, out_idx, hs_dev, nullptr, nullptr, 0, grp},
+                                            st));
+            }
+            SQ_HIP(hipStreamSynchronize(st));  // the status words of the group are in hs now
+            SQ_HIP(hipGetLastError());
+            for (int g = 0; g < gn; ++g) done[g] = hs[grp.idx[g]] == 0;
+        }
+        for (int g = 0; g < gn; ++g) {
+            if (done[g]) continue;
+            const int qi = grp.idx[g];
+            hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, cnt + qi, 1ll, (u32)n);
+            if (cosine) {
+                SQ_TRY(select_launch_t<K128>(h->big_keys.as<K128>() + (long long)g * n, cnt + qi, (u32)n, n, k, 1,
+                                             h->out_keys.as<K128>() + (long long)qi * k,
+                                             DenseFinalizeCos{cnt, (u32)n, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx,
+                                                              hs_dev, nullptr, nullptr, qi},
+                                             st));
+            } else {
+                SQ_TRY(select_launch_t<u64>(h->big_keys.as<u64>() + (long long)g * n, cnt + qi, (u32)n, n, k, 1,
+                                            h->out_keys.as<u64>() + (long long)qi * k,
+                                            DenseFinalizeL2{cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 0,
+                                                            (float*)out_dist, out_idx, hs_dev, nullptr, nullptr, qi},
+                                            st));
+            }
+        }
     }
     if (h->stats.fallback_queries) {
         SQ_HIP(hipStreamSynchronize(st));

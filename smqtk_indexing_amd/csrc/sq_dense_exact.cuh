@@ -202,7 +202,8 @@ static __global__ __launch_bounds__(256) void dense_exact_l2_kernel(const float*
                                                               const float* __restrict__ q_orig,
                                                               const u32* __restrict__ cand, const u32* __restrict__ cnt,
                                                               u32 cap, long long implicit_n, long long row_offset,
-                                                              u64* __restrict__ keys, long long key_stride) {
+                                                              u64* __restrict__ keys, long long key_stride,
+                                                              float* __restrict__ sample, int sample_stride) {
     extern __shared__ __attribute__((aligned(16))) float s_q[];
     const int q = blockIdx.y;
     const long long M = cand ? (long long)(cnt[q] < cap ? cnt[q] : cap) : implicit_n;
@@ -214,6 +215,8 @@ static __global__ __launch_bounds__(256) void dense_exact_l2_kernel(const float*
         const SqLeafLane w{db + row * ld, s_q};
         const float dist = sqrt_rn_f32(w.sum(d));
         keys[(long long)q * key_stride + j] = ((u64)ordered_f32(dist) << 32) | (u64)(u32)row;
+        // every sample_stride-th exact distance feeds the threshold of the two-level select (one query per launch)
+        if (sample && j % sample_stride == 0) sample[j / sample_stride] = dist == dist ? dist : __builtin_inff();
     }
 }
 
@@ -223,7 +226,8 @@ static __global__ __launch_bounds__(256) void dense_exact_cos_kernel(const float
                                                                u32 cap, long long implicit_n, long long row_offset,
                                                                K128* __restrict__ keys, long long key_stride,
                                                                const double* __restrict__ nx64,
-                                                               const double* __restrict__ nq64) {
+                                                               const double* __restrict__ nq64,
+                                                               float* __restrict__ sample, int sample_stride) {
     const int q = blockIdx.y;
     const long long M = cand ? (long long)(cnt[q] < cap ? cnt[q] : cap) : implicit_n;
     const float* qv = q_orig + (long long)q * d;
@@ -232,6 +236,215 @@ static __global__ __launch_bounds__(256) void dense_exact_cos_kernel(const float
         const long long row = cand ? (long long)cand[(long long)q * cap + j] : row_offset + j;
         const double dist = cosine_dist_f64(cosine_dot_f64(db + row * ld, qv, d), nx64[row], qq);
         keys[(long long)q * key_stride + j] = K128{ordered_f64(dist), (u64)(u32)row};
+        if (sample && j % sample_stride == 0) sample[j / sample_stride] = dist == dist ? __double2float_ru(dist) : __builtin_inff();
+    }
+}
+
+// The exact path for a GROUP of queries: one lane per row, the row's elements held in registers a
+// leaf (<= 128 elements) at a time and reused for all G queries (in LDS, broadcast reads), so the
+// matrix is read from HBM once per group instead of once per query.  Arithmetic and order are those
+// of the one-query kernels above (numpy pairwise float32 for L2; scipy's two float64 chains for
+// cosine).  HBM bound up to ~12 queries per pass at 3 VALU operations per element and query.
+// keys: [G][n]; sample: [G][ns] (every sample_stride-th distance, see dense_compact_keys_kernel) or null.
+// Dynamic LDS: G * round_up(d, 4) floats.  Rows 16-byte aligned.
+static constexpr int EXACT_GROUP = 8;
+static constexpr int EXACT_GROUP_DEPTH = 6;  // rows up to 128 * 2^6 = 8192 elements
+struct ExactGroup {
+    int idx[EXACT_GROUP];  // query indices of the group (unused slots repeat the first)
+    int count;
+};
+
+template <bool COSINE, class K>
+static __global__ __launch_bounds__(256) void dense_exact_group_kernel(const float* __restrict__ db, long long ld, int d,
+                                                                       const float* __restrict__ q_all, ExactGroup grp,
+                                                                       long long n, K* __restrict__ keys,
+                                                                       float* __restrict__ sample, long long ns,
+                                                                       int sample_stride, const double* __restrict__ nx64,
+                                                                       const double* __restrict__ nq64) {
+    constexpr int G = EXACT_GROUP;
+    extern __shared__ __attribute__((aligned(16))) float s_qg[];
+    const int dq = (d + 3) / 4 * 4;
+    for (int i = threadIdx.x; i < G * dq; i += 256) {
+        const int g = i / dq, c = i - g * dq;
+        s_qg[i] = c < d ? q_all[(long long)grp.idx[g] * d + c] : 0.f;
+    }
+    __syncthreads();
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long long)gridDim.x * 256) {
+        const float* x = db + j * ld;
+        if constexpr (!COSINE) {
+            float acc[G];
+            auto leaf = [&](int off, int m, float (&v)[G]) {
+                if (m < 8) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        float r = 0.f;
+                        for (int i = 0; i < m; ++i) {
+                            const float t = __fsub_rn(x[off + i], s_qg[g * dq + off + i]);
+                            r = __fadd_rn(r, __fmul_rn(t, t));
+                        }
+                        v[g] = r;
+                    }
+                    return;
+                }
+                const int nfull = m - (m % 8);
+                const int nv = nfull / 4;  // 2..32 vectors of this leaf, all requested before the first use
+                f32x4 xr[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) xr[u] = *reinterpret_cast<const f32x4*>(x + off + 4 * (u < nv ? u : 0));
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float* qg = s_qg + g * dq + off;
+                    float r[8];
+                    {
+                        const f32x4 q0 = *reinterpret_cast<const f32x4*>(qg), q1 = *reinterpret_cast<const f32x4*>(qg + 4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float t0 = __fsub_rn(xr[0][c], q0[c]), t1 = __fsub_rn(xr[1][c], q1[c]);
+                            r[c] = __fmul_rn(t0, t0);
+                            r[4 + c] = __fmul_rn(t1, t1);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 2; u < 32; u += 2) {
+                        if (u < nv) {
+                            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qg + 4 * u);
+                            const f32x4 q1 = *reinterpret_cast<const f32x4*>(qg + 4 * u + 4);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float t0 = __fsub_rn(xr[u][c], q0[c]), t1 = __fsub_rn(xr[u + 1][c], q1[c]);
+                                r[c] = __fadd_rn(r[c], __fmul_rn(t0, t0));
+                                r[4 + c] = __fadd_rn(r[4 + c], __fmul_rn(t1, t1));
+                            }
+                        }
+                    }
+                    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                                          __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+                    for (int i = nfull; i < m; ++i) {
+                        const float t = __fsub_rn(x[off + i], qg[i]);
+                        res = __fadd_rn(res, __fmul_rn(t, t));
+                    }
+                    v[g] = res;
+                }
+            };
+            pw_tree_multi<float, G, EXACT_GROUP_DEPTH>(leaf, d, acc);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g < grp.count) {
+                    const float dist = sqrt_rn_f32(acc[g]);
+                    keys[(long long)g * n + j] = ((u64)ordered_f32(dist) << 32) | (u64)(u32)j;
+                    if (sample && j % sample_stride == 0) sample[(long long)g * ns + j / sample_stride] = dist == dist ? dist : __builtin_inff();
+                }
+            }
+        } else {
+            double d0[G], d1[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) d0[g] = d1[g] = 0.0;
+            const int m = d - (d & 1);
+            const int m4 = m & ~3;
+            int i = 0;
+            for (; i + 64 <= m4; i += 64) {  // 16 row vectors requested at a time
+                f32x4 xr[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) xr[u] = *reinterpret_cast<const f32x4*>(x + i + 4 * u);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float* qg = s_qg + g * dq + i;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const f32x4 qv = *reinterpret_cast<const f32x4*>(qg + 4 * u);
+                        d0[g] = __dadd_rn(d0[g], __dmul_rn((double)qv[0], (double)xr[u][0]));
+                        d1[g] = __dadd_rn(d1[g], __dmul_rn((double)qv[1], (double)xr[u][1]));
+                        d0[g] = __dadd_rn(d0[g], __dmul_rn((double)qv[2], (double)xr[u][2]));
+                        d1[g] = __dadd_rn(d1[g], __dmul_rn((double)qv[3], (double)xr[u][3]));
+                    }
+                }
+            }
+            for (; i < m; i += 2) {
+                const float x0 = x[i], x1 = x[i + 1];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    d0[g] = __dadd_rn(d0[g], __dmul_rn((double)s_qg[g * dq + i], (double)x0));
+                    d1[g] = __dadd_rn(d1[g], __dmul_rn((double)s_qg[g * dq + i + 1], (double)x1));
+                }
+            }
+            const double nx = nx64[j];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g < grp.count) {
+                    double dot = __dadd_rn(d0[g], d1[g]);
+                    if (d & 1) dot = __dadd_rn(dot, __dmul_rn((double)s_qg[g * dq + m], (double)x[m]));
+                    const double dist = cosine_dist_f64(dot, nx, nq64[grp.idx[g]]);
+                    keys[(long long)g * n + j] = K128{ordered_f64(dist), (u64)(u32)j};
+                    if (sample && j % sample_stride == 0)
+                        sample[(long long)g * ns + j / sample_stride] = dist == dist ? __double2float_ru(dist) : __builtin_inff();
+                }
+            }
+        }
+    }
+}
+
+// Two-level select of the exact path: keys whose distance is <= *thr (an exact distance of a sampled
+// row with at least k sampled rows at or below it) are appended to `out`; *cnt counts them all, also
+// beyond `cap` (the caller then selects over the full key array instead).
+__device__ __forceinline__ bool key_within(u64 key, float t) { return (u32)(key >> 32) <= ordered_f32(t); }
+__device__ __forceinline__ bool key_within(const K128& key, float t) { return key.hi <= ordered_f64((double)t); }
+
+template <class K>
+static __global__ __launch_bounds__(256) void dense_compact_keys_kernel(const K* __restrict__ keys, long long n,
+                                                                        const float* __restrict__ thr, K* __restrict__ out,
+                                                                        u32 cap, u32* __restrict__ cnt) {
+    keys += (long long)blockIdx.y * n;  // one query of the group per grid row
+    out += (long long)blockIdx.y * cap;
+    cnt += blockIdx.y;
+    const float t = thr[blockIdx.y];
+    // Survivors are rare (~2 k sample_stride of n).  A workgroup stages its own in LDS (wave-aggregated LDS
+    // atomics) and reserves their place in `out` with ONE global atomic at the end: returning atomics on one
+    // address serialise in L2 at ~7 ns each, and one per surviving wave made them the whole kernel (0.6 ms
+    // for eight 10 M-key arrays).  A workgroup with more survivors than the stage holds (tie groups) sends
+    // the excess straight to `out`.
+    constexpr int U = 4, STAGE = 2048;
+    __shared__ K s_keys[STAGE];
+    __shared__ u32 s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const long long step = (long long)gridDim.x * 256 * U;
+    const long long n_up = (n + 63) / 64 * 64;  // whole waves take part in the ballots
+    const int lane = threadIdx.x & 63;
+    for (long long j0 = (long long)blockIdx.x * 256 * U + threadIdx.x; j0 < n_up; j0 += step) {
+        K key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {  // four keys per lane, all requested before the first is looked at
+            const long long j = j0 + (long long)u * 256;
+            key[u] = j < n ? keys[j] : K{};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long j = j0 + (long long)u * 256;
+            const bool pass = j < n && key_within(key[u], t);
+            const u64 m = __ballot(pass);
+            if (m == 0) continue;
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&s_n, (u32)__popcll(m));
+            base = __shfl(base, 0);
+            if (pass) {
+                const u32 pos = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < (u32)STAGE) {
+                    s_keys[pos] = key[u];
+                } else {
+                    const u32 gpos = atomicAdd(cnt, 1u);
+                    if (gpos < cap) out[gpos] = key[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const u32 staged = s_n < (u32)STAGE ? s_n : (u32)STAGE;
+    if (staged == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(cnt, staged);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < staged; i += 256) {
+        const u32 gpos = s_base + i;
+        if (gpos < cap) out[gpos] = s_keys[i];
     }
 }
 
@@ -511,6 +724,8 @@ struct DenseThrPost {
 
 // --------------------------------------------------------------- finalize
 // status bits: 1 candidate overflow, 2 certification failed, 4 fewer than kk candidates
+// certify: 0 = nothing to check (all rows were candidates), 1 = counts and the filter bound,
+// 2 = counts only (two-level select of the exact path: the threshold is itself an exact distance)
 // Post-ops of select_topk_kernel (one workgroup per query, all threads call): keys -> (distance, id),
 // certification, status word.  `status` and `cnt_out` may be host-mapped memory: the host then only
 // has to synchronise the stream.  q0: index of the launch's first query in the per-query arrays
@@ -530,8 +745,9 @@ struct DenseFinalizeL2 {
     u32* cnt_out;
     const u32* overflow;
     int q0;
+    ExactGroup sel = ExactGroup{{0, 0, 0, 0, 0, 0, 0, 0}, 0};  // count > 0: query ql of the launch is sel.idx[ql], its count cnt[ql]
     __device__ __forceinline__ void operator()(int ql, const u64* sorted, int k) const {
-        const int q = q0 + ql;
+        const int q = sel.count ? sel.idx[ql] : q0 + ql;
         for (int j = threadIdx.x; j < k; j += blockDim.x) {
             const u64 key = sorted[j];
             const bool pad = key == ~0ull;
@@ -540,11 +756,11 @@ struct DenseFinalizeL2 {
         }
         if (threadIdx.x == 0) {
             u32 st = 0;
-            const u32 c = cnt[q];
+            const u32 c = cnt[sel.count ? ql : q];
             if (certify) {
                 if (c > cap || (overflow && *overflow)) st |= 1u;
                 if (c < (u32)kk) st |= 4u;
-                if (st == 0) {
+                if (st == 0 && certify == 1) {
                     const double dk = (double)unordered_f32((u32)(sorted[kk - 1] >> 32));
                     const double t = (double)thr[q];
                     const double eps = filter_eps(0, xn2_max, qn2[q], eps_a, eps_b);
@@ -573,8 +789,9 @@ struct DenseFinalizeCos {
     u32* cnt_out;
     const u32* overflow;
     int q0;
+    ExactGroup sel = ExactGroup{{0, 0, 0, 0, 0, 0, 0, 0}, 0};
     __device__ __forceinline__ void operator()(int ql, const K128* sorted, int k) const {
-        const int q = q0 + ql;
+        const int q = sel.count ? sel.idx[ql] : q0 + ql;
         for (int j = threadIdx.x; j < k; j += blockDim.x) {
             const K128 key = sorted[j];
             const bool pad = key.hi == ~0ull && key.lo == ~0ull;
@@ -583,11 +800,11 @@ struct DenseFinalizeCos {
         }
         if (threadIdx.x == 0) {
             u32 st = 0;
-            const u32 c = cnt[q];
+            const u32 c = cnt[sel.count ? ql : q];
             if (certify) {
                 if (c > cap || (overflow && *overflow)) st |= 1u;
                 if (c < (u32)kk) st |= 4u;
-                if (st == 0) {
+                if (st == 0 && certify == 1) {
                     const double dk = unordered_f64(sorted[kk - 1].hi);
                     const double t = (double)thr[q];  // threshold on -sim~
                     // non-candidates: -sim~ > t  =>  sim < -t + eps  =>  dist > 2 acos(min(1,-t+eps))/pi

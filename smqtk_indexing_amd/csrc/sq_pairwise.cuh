@@ -100,6 +100,62 @@ __device__ __forceinline__ T pw_tree(L&& leaf, int n) {
     }
 }
 
+// The same walk for G sums that share their leaves' inputs (G queries against one row): `leaf(off, n, v)`
+// fills the G leaf sums, the pending left sums are G shift registers of depth D (n <= 128 * 2^D).
+template <class T, int G, int D, class L>
+__device__ __forceinline__ void pw_tree_multi(L&& leaf, int n, T (&out)[G]) {
+    if (n <= 128) {
+        leaf(0, n, out);
+        return;
+    }
+    T st[D][G];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) st[i][g] = (T)0;
+    unsigned path = 0;
+    int depth = 0, off = 0, m = n;
+    for (;;) {
+        while (m > 128) {
+            m = pw_split(m);
+            path &= ~(1u << depth);
+            ++depth;
+        }
+        leaf(off, m, out);
+        while (depth > 0 && ((path >> (depth - 1)) & 1u)) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) out[g] = add_rn(st[0][g], out[g]);
+#pragma unroll
+            for (int i = 0; i + 1 < D; ++i)
+#pragma unroll
+                for (int g = 0; g < G; ++g) st[i][g] = st[i + 1][g];
+            --depth;
+        }
+        if (depth == 0) return;
+#pragma unroll
+        for (int i = D - 1; i > 0; --i)
+#pragma unroll
+            for (int g = 0; g < G; ++g) st[i][g] = st[i - 1][g];
+#pragma unroll
+        for (int g = 0; g < G; ++g) st[0][g] = out[g];
+        path |= 1u << (depth - 1);
+        off = 0;
+        m = n;
+        for (int i = 0; i + 1 < depth; ++i) {
+            const int m2 = pw_split(m);
+            if ((path >> i) & 1u) {
+                off += m2;
+                m -= m2;
+            } else {
+                m = m2;
+            }
+        }
+        const int m2 = pw_split(m);
+        off += m2;
+        m -= m2;
+    }
+}
+
 template <class T, class F>
 __device__ __forceinline__ T np_pairwise_sum(F term, int n, int j8) {
     return pw_tree<T>([&](int off, int m) { return pw_leaf<T>(term, off, m, j8); }, n);

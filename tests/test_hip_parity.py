@@ -134,6 +134,36 @@ def _dense_check(db, qs, k, metric="euclidean", exact_dist=True):
     return idx
 
 
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_dense_exact_path_two_level_select(metric):
+    """The exact path (forced here; also what rows wider than the scan covers take) selects in two
+    levels -- sampled exact threshold, device-wide compaction, select over the survivors -- and goes
+    on to the select over all keys when ties overflow the compacted list or k is too large for it."""
+    rng = np.random.default_rng(21)
+    _lib.set_option("force_fallback", 1)
+    db = rng.standard_normal((200_000, 64)).astype(np.float32)
+    db[1000:1400] = db[7]                                   # a 400-row tie group inside the top-k
+    qs = rng.standard_normal((3, 64)).astype(np.float32)
+    qs[0] = db[7]
+    for k in (1, 100, 3000, 16_000 if metric == "euclidean" else 7000):   # 16 000: no room for a sample stride, full select
+        idx = _dense_check(db, qs, k, metric)
+        assert idx.stats()["fallback_queries"] == 3
+    # every row the same: the compacted list overflows, the full select answers in id order
+    same = np.repeat(rng.standard_normal((1, 32)).astype(np.float32), 150_000, axis=0)
+    _dense_check(same, qs[:2, :32].copy(), 10, metric)
+    if metric == "cosine":                                  # zero rows (NaN distance) among the sampled rows
+        z = rng.standard_normal((100_000, 16)).astype(np.float32)
+        z[::3] = 0.0
+        idx = _lib.DenseIndex(z, metric=_lib.SQ_METRIC_COSINE)
+        d, i = idx.search(z[1:2], 50)
+        rd, ri = O.dense_topk(z, z[1], 50, "cosine")
+        np.testing.assert_allclose(d[0], rd, rtol=1e-12, atol=1e-15)
+    _lib.set_option("force_fallback", 0)
+    wide = rng.standard_normal((70_000, 700)).astype(np.float32)   # wider than the MFMA scan: exact path only
+    idx = _dense_check(wide, wide[:2] + 0.01, 20, metric)
+    assert idx.stats()["fallback_queries"] == 2
+
+
 @pytest.mark.parametrize("tag", list(GI.DENSE_CASES))
 @pytest.mark.parametrize("metric", ["euclidean", "cosine"])
 def test_dense_golden_cases(golden, tag, metric):

@@ -12,6 +12,7 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(3)
 db = torch.empty((n, d), dtype=torch.float32, device=dev).normal_(generator=g)
 _lib.set_option("profile", 1)
+_lib.set_option("force_fallback", int(os.environ.get("FORCE_FB", 0)))
 _lib.set_option("dense_debug", int(os.environ.get("DEBUG", 0)))   # ablation bits (results are garbage then)
 metric = _lib.SQ_METRIC_COSINE if os.environ.get("METRIC", "l2") == "cosine" else _lib.SQ_METRIC_L2
 idx = _lib.DenseIndex(db.data_ptr(), n=n, d=d, metric=metric, device_ptr=True, keepalive=db)
@@ -19,7 +20,12 @@ st = torch.cuda.current_stream().cuda_stream
 q = torch.empty((nq, d), dtype=torch.float32, device=dev).normal_(generator=g)
 od = torch.empty((nq, k), dtype=torch.float64 if metric == _lib.SQ_METRIC_COSINE else torch.float32, device=dev); oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
+import time
 for r in range(int(os.environ.get("REPS", 10))):
+    t0 = time.perf_counter()
     idx.search_device(q.data_ptr(), nq, k, od.data_ptr(), oi.data_ptr(), st)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+print(f"last call wall {wall * 1e3:.3f} ms")
 s = idx.stats()
 print({kk: s[kk] for kk in ("scan_ms", "total_ms", "candidates", "fallback_queries")})
