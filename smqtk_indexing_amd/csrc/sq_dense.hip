@@ -46,11 +46,12 @@ struct DenseHandle : HandleBase {
     long long id_base = 0;
     double xn2_max = 0.0;       // max squared row norm (error bound of the L2 filter)
     // workspace
+    DevBuf norms1;  // L2: |x|^2 (1 - alpha) for one query plane (`norms`: two planes)
     DevBuf q_dev, q_scaled, q_al, qn2, thr, wave_out, wave_cnt, cnt, keys, sample, out_keys, out_dist_dev,
         out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch;
     HostPinned status_host;
     ~DenseHandle() override {
-        for (DevBuf* b : {&owned, &scan, &norms, &center, &cos_nx, &cos_nq, &q_dev, &q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt,
+        for (DevBuf* b : {&owned, &scan, &norms, &norms1, &center, &cos_nx, &cos_nq, &q_dev, &q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt,
                           &keys, &sample, &out_keys, &out_dist_dev, &out_idx_dev, &big_keys, &fb_sample, &fb_keys, &fb_out, &scratch})
             b->release();
         status_host.release();
@@ -152,6 +153,12 @@ static int scan_launch(const DenseScanArgs& a, int d_pad, int qt, int qp, hipStr
     }
 }
 
+// Error coefficients of the filter score (derivation at their use in dense_search_device); the index build
+// needs them too: the L2 scan starts from row norms shrunk by the row's share of the bound.
+static constexpr double kEpsA2 = 0.0078125 + 6.103515625e-05;   // two query planes: 2^-7 + 2^-14
+static constexpr double kEpsA1 = 0.015625 + 1.220703125e-04;    // one query plane:  2^-6 + 2^-13
+static double dense_eps_b(int d_pad) { return (3.0 * d_pad + 8.0) * 1.1920928955078125e-07; }
+
 // Query tiles per wave for a batch of `nqt` 32-query tiles (sq_dense_scan.cuh): one tile keeps the
 // HBM-bound configuration; larger batches reuse each streamed row tile for 2 or 4 query tiles, as
 // many as the register budget allows (four at d_pad = 128, two beyond).
@@ -215,8 +222,8 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     //             (cosine: unit vectors and q' = -q^ without the factor 2: half of that)
     //   float32 accumulation of 2d+1 terms and the float32 norm                     ->  eps_b = (3d+8) 2^-23
     //   one query plane: |x q' - x_hi q'_hi| <= (2^-8 + 2^-8 + 2^-16) |x||q'|                 ->  eps_a = 2^-6 + 2^-13
-    const double eps_a = (qp == 2 ? 0.0078125 + 6.103515625e-05 : 0.015625 + 1.220703125e-04) * (cosine ? 0.5 : 1.0);
-    const double eps_b = (3.0 * d_pad + 8.0) * 1.1920928955078125e-07;
+    const double eps_a = (qp == 2 ? kEpsA2 : kEpsA1) * (cosine ? 0.5 : 1.0);
+    const double eps_b = dense_eps_b(d_pad);
     const size_t l2_lds = (size_t)((d + 3) / 4 * 4) * 4;
     if (cosine) {
         SQ_TRY(h->cos_nq.reserve((size_t)nq * 8));
@@ -249,7 +256,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
                                          st));
         } else {
             SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, (u32)n, key_stride, k, nq, h->out_keys.as<u64>(),
-                                        DenseFinalizeL2{cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 0,
+                                        DenseFinalizeL2{cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0,
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, nullptr, 0},
                                         st));
         }
@@ -290,7 +297,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
                            qn2, thr, cnt, oflag, h->q_al.as<float>(), ldq, h->center.p ? h->center.as<float>() : nullptr);
         DenseScanArgs a{};
         a.scan = h->scan.as<uint4>();
-        a.norms = cosine ? nullptr : h->norms.as<float>();
+        a.norms = cosine ? nullptr : (qp == 1 ? h->norms1.as<float>() : h->norms.as<float>());  // n' of this plane count
         a.n = n;
         a.n_tiles = n_tiles;
         a.qs = qs;
@@ -309,7 +316,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         if (ns_tiles < (long long)nrb * wv) a.nrb = (int)(((ns_tiles + wv - 1) / wv + 7) / 8 * 8);
         SQ_TRY(scan_launch<true>(a, d_pad, qt, qp, st));
         hipLaunchKernelGGL((kth_threshold_f32_kernel<DenseThrPost>), dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr,
-                           DenseThrPost{qn2, cosine ? 1 : 0, h->xn2_max, eps_a, eps_b});
+                           DenseThrPost{qn2, cosine ? 1 : 0, filter_bound(cosine ? 1 : 0, eps_a, eps_b, h->xn2_max)});
         // full pass
         a.tile_step = 1;
         a.n_sel = n_tiles;
@@ -341,7 +348,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
                                ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, h->keys.as<u64>(), cnt,
                                cap, oflag, g_opt.dense_debug);
             SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, cap, key_stride, k, nq, h->out_keys.as<u64>(),
-                                        DenseFinalizeL2{cnt, cap, kk, h->id_base, thr, qn2, h->xn2_max, eps_a, eps_b, 1,
+                                        DenseFinalizeL2{cnt, cap, kk, h->id_base, thr, qn2, 0.5 * eps_a + eps_b, 1,
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0},
                                         st));
         }
@@ -442,7 +449,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
                                    fb_thr, h->fb_keys.as<u64>(), cap, fb_cnt);
                 SQ_TRY(h->fb_out.reserve((size_t)gn * k * key_bytes));
                 SQ_TRY(select_launch_t<u64>(h->fb_keys.as<u64>(), fb_cnt, cap, (long long)cap, k, gn, h->fb_out.as<u64>(),
-                                            DenseFinalizeL2{fb_cnt, cap, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 2,
+                                            DenseFinalizeL2{fb_cnt, cap, kk, h->id_base, thr, qn2, 0.0, 2,
                                                             (float*)out_dist, out_idx, hs_dev, nullptr, nullptr, 0, grp},
                                             st));
             }
@@ -463,7 +470,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
             } else {
                 SQ_TRY(select_launch_t<u64>(h->big_keys.as<u64>() + (long long)g * n, cnt + qi, (u32)n, n, k, 1,
                                             h->out_keys.as<u64>() + (long long)qi * k,
-                                            DenseFinalizeL2{cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0.0, 0.0, 0,
+                                            DenseFinalizeL2{cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0,
                                                             (float*)out_dist, out_idx, hs_dev, nullptr, nullptr, qi},
                                             st));
             }
@@ -596,8 +603,22 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
             hipLaunchKernelGGL(dense_cos_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, h->db,
                                (long long)n, h->ld, d, h->cos_nx.as<double>());
         }
+        float* norms1p = nullptr;
+        double shrink2 = 1.0, shrink1 = 1.0;
+        if (metric == SQ_METRIC_L2) {
+            // the row's share alpha |x|^2 of the filter's error bound comes off the stored norm (FilterBound)
+            rc = h->norms1.reserve((size_t)h->n_pad * 4);
+            if (rc != SQ_OK) {
+                inv.release();
+                return bail(rc);
+            }
+            norms1p = h->norms1.as<float>();
+            shrink2 = 1.0 - filter_bound(0, kEpsA2, dense_eps_b(d_pad), 0.0).alpha;
+            shrink1 = 1.0 - filter_bound(0, kEpsA1, dense_eps_b(d_pad), 0.0).alpha;
+        }
         hipLaunchKernelGGL(dense_rowstats_kernel, dim3((unsigned)(h->n_pad / 32)), dim3(256), 0, 0, h->db, (long long)n,
-                           h->ld, d, h->n_pad, h->scratch.as<u32>(), h->norms.as<float>(), invp, centerp);
+                           h->ld, d, h->n_pad, h->scratch.as<u32>(), h->norms.as<float>(), invp, centerp, norms1p, shrink2,
+                           shrink1);
         if (d_pad <= MAX_DPAD) {
             rc = h->scan.reserve((size_t)h->n_pad * d_pad * 2);
             if (rc != SQ_OK) {

@@ -689,32 +689,50 @@ __global__ __launch_bounds__(256) void dense_distances_kernel(const T* __restric
     }
 }
 
-// The sampled threshold T is the score of an actual row.  The scan emits with
-// T + slack so that a query whose k-th neighbour IS that row still certifies:
-// slack covers twice the filter's error bound plus the relative rounding of
-// the exact distance (DESIGN.md "certification").
-// Error bound of the filter score (bf16x3 MFMA):
-//   L2:     eps = eps_a * X*|q| + eps_b * (X^2 + 2 X |q|)      (X^2 = max squared row norm)
-//   cosine: eps = eps_a + eps_b                                  (unit vectors)
-__device__ __forceinline__ double filter_eps(int cosine, double xn2_max, double qn2, double eps_a, double eps_b) {
-    if (cosine) return eps_a + eps_b;
-    const double xq = sqrt(xn2_max * qn2);
-    return eps_a * xq + eps_b * (xn2_max + 2.0 * xq);
+// Error model of the filter score (bf16 MFMA), per row:
+//   |s~ - s| <= eps_a |x||q| + eps_b (|x|^2 + 2|x||q|),   s = |x|^2 - 2 x.q
+//   L2: with |x||q| <= (|x|^2 + |q|^2)/2 this is <= alpha |x|^2 + beta |q|^2,
+//       alpha = eps_a/2 + 2 eps_b, beta = eps_a/2 + eps_b.  The row's share is folded into the stored norm
+//       (the scan starts from n' = RD(|x|^2 (1 - alpha))), so the kernel's score s~' obeys
+//           s - (2 alpha + eps_b)|x|^2 - beta|q|^2  <=  s~'  <=  s + beta|q|^2
+//       and a heavy-tailed norm distribution costs nothing: a far row carries its own slack.
+//   cosine: unit vectors, eps = eps_a + eps_b.
+struct FilterBound {
+    double alpha, beta, eps_b;  // L2
+    double eps_cos;             // cosine
+    double xn2_max;             // largest squared row norm
+};
+__device__ __host__ __forceinline__ FilterBound filter_bound(int cosine, double eps_a, double eps_b, double xn2_max) {
+    return FilterBound{0.5 * eps_a + 2.0 * eps_b, 0.5 * eps_a + eps_b, eps_b, eps_a + eps_b, xn2_max};
 }
 
-// T -> T' = T + slack, rounded up (applied by kth_threshold_f32_kernel as it stores the threshold).
+// The sampled threshold T is the kernel score of an actual row with at least k sampled rows at or below
+// it.  T -> T' such that every row of the true top-k has kernel score <= T' (applied by
+// kth_threshold_f32_kernel as it stores the threshold):
+//   L2: rows with s~' <= T have |x| <= rho, gamma rho^2 - 2|q| rho - (beta|q|^2 + T) = 0, gamma = 1 - 2alpha - eps_b
+//       (from the lower bound above and x.q <= |x||q|), so the true k-th score is
+//       <= U = T + (2alpha + eps_b) min(rho^2, X^2) + beta|q|^2, and a row with s <= U has s~' <= U + beta|q|^2.
+//       (+ 4e-6 |T + |q|^2|: rounding of the float32 numpy-order distance the certification compares with.)
+//   cosine: T' = T + 2 eps.
 struct DenseThrPost {
     const double* qn2;
     int cosine;
-    double xn2_max, eps_a, eps_b;
+    FilterBound fb;
     __device__ __forceinline__ float operator()(int q, float t) const {
         if (!(t < __builtin_inff())) return t;
         double slack;
-        const double eps = filter_eps(cosine, xn2_max, qn2[q], eps_a, eps_b);
-        if (cosine)
-            slack = 2.0 * eps + 1e-8;
-        else
-            slack = 2.0 * eps + 4e-6 * fabs((double)t + qn2[q]);
+        if (cosine) {
+            slack = 2.0 * fb.eps_cos + 1e-8;
+        } else {
+            const double Q = qn2[q];
+            const double gamma = 1.0 - 2.0 * fb.alpha - fb.eps_b;
+            const double c = fb.beta * Q + (double)t;
+            const double disc = Q + gamma * c;
+            double rho = (sqrt(Q) + sqrt(disc > 0.0 ? disc : 0.0)) / gamma;
+            double rho2 = rho * rho * (1.0 + 1e-9);
+            if (rho2 > fb.xn2_max) rho2 = fb.xn2_max;
+            slack = (2.0 * fb.alpha + fb.eps_b) * rho2 + 2.0 * fb.beta * Q + 4e-6 * fabs((double)t + Q);
+        }
         // round up so the float threshold is never below T + slack
         float r = (float)((double)t + slack);
         if ((double)r < (double)t + slack) r = __uint_as_float(__float_as_uint(r) + (r >= 0.f ? 1 : -1));
@@ -737,7 +755,7 @@ struct DenseFinalizeL2 {
     long long id_base;
     const float* thr;
     const double* qn2;
-    double xn2_max, eps_a, eps_b;
+    double beta;  // FilterBound::beta: a non-candidate (s~' > T') has s > T' - beta |q|^2
     int certify;
     float* out_dist;
     long long* out_idx;
@@ -763,8 +781,7 @@ struct DenseFinalizeL2 {
                 if (st == 0 && certify == 1) {
                     const double dk = (double)unordered_f32((u32)(sorted[kk - 1] >> 32));
                     const double t = (double)thr[q];
-                    const double eps = filter_eps(0, xn2_max, qn2[q], eps_a, eps_b);
-                    const double lo2 = t + qn2[q] - eps;  // smallest squared distance a non-candidate can have
+                    const double lo2 = t + qn2[q] * (1.0 - beta);  // smallest squared distance a non-candidate can have
                     const double bound = lo2 > 0.0 ? sqrt(lo2) * (1.0 - 1e-6) : 0.0;
                     if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
                 }

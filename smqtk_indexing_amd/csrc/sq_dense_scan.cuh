@@ -116,7 +116,9 @@ static __global__ __launch_bounds__(256) void dense_rowstats_kernel(const float*
                                                                      u32* __restrict__ max_bits,
                                                                      float* __restrict__ norms,
                                                                      float* __restrict__ inv_norm,
-                                                                     const float* __restrict__ center) {
+                                                                     const float* __restrict__ center,
+                                                                     float* __restrict__ norms1, double shrink2,
+                                                                     double shrink1) {
     const int lane8 = threadIdx.x & 7;
     const long long row = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
     const long long r = row < n ? row : n - 1;
@@ -143,11 +145,15 @@ static __global__ __launch_bounds__(256) void dense_rowstats_kernel(const float*
     acc += __shfl_xor(acc, 2);
     acc += __shfl_xor(acc, 4);
     if (lane8 == 0 && row < n_pad) {
+        // L2: the scan starts a row's score from |x|^2 (1 - alpha), rounded down -- the row's share of its
+        // own error bound, one array per query-plane count; cosine: plain |x|^2 (unused by the scan)
         if (row < n) {
-            norms[row] = (float)acc;
+            norms[row] = __double2float_rd(acc * shrink2);
+            if (norms1) norms1[row] = __double2float_rd(acc * shrink1);
             if (inv_norm) inv_norm[row] = acc > 0.0 ? (float)(1.0 / sqrt(acc)) : 0.f;
         } else {
             norms[row] = 0.f;
+            if (norms1) norms1[row] = 0.f;
         }
     }
     // one atomic per workgroup for the largest squared norm (one per row serialised 10 M atomics on one
