@@ -44,7 +44,7 @@ def parse_args():
                     help="skip the ITQ / Hamming timings reported beside the headline metric")
     ap.add_argument("--force-collective", action="store_true",
                     help="testing: run the all-gather + merge path even with one rank (launch under torch.distributed.run)")
-    ap.add_argument("--extra-batches", type=str, default="1,1024",
+    ap.add_argument("--extra-batches", type=str, default="1,128,1024",
                     help="other batch sizes measured after the timed region (N=1 only); '' to skip")
     return ap.parse_args()
 
