@@ -258,41 +258,65 @@ __global__ __launch_bounds__(256) void hamming_stream_kernel(const u64* __restri
     for (int i = tid; i < nq; i += 256) bcnt[(long long)blockIdx.x * nq + i] = lcnt[i];
 }
 
-// One workgroup per query: concatenate the G blocks' mini-lists into keys[q][..]
-// (prefix sum over the fills, no atomics) and publish the total in cnt[q]; a
-// mini-list that overflowed its S slots marks the query (cnt = cap + 1) so that
-// it is recomputed on the exact path.
+// Concatenate the G blocks' mini-lists of a query into keys[q][..] (prefix sum over the fills, no
+// atomics) and publish the total in cnt[q]; a mini-list that overflowed its S slots marks the query
+// (cnt = cap + 1) so that it is recomputed on the exact path.  Grid (nq, COMPACT_SLICES): every
+// workgroup scans all G fills (G <= 2048: eight per thread, wave scan) and copies the lists of its
+// slice -- one workgroup per query with a one-thread prefix loop took 55 us for 32 queries.
+static constexpr int COMPACT_SLICES = 8;
 __global__ __launch_bounds__(256) void hamming_compact_kernel(const u64* __restrict__ seg,
                                                                const u32* __restrict__ bcnt, int G, int nq, u32 S,
                                                                u64* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
                                                                long long key_stride) {
     __shared__ u32 s_off[2049];
+    __shared__ u32 s_wave[4];
     __shared__ u32 s_over;
     const int q = blockIdx.x;
     if (threadIdx.x == 0) s_over = 0u;
     __syncthreads();
-    // G <= 2048: thread t owns blocks t, t+256, ...
-    for (int g = threadIdx.x; g < G; g += 256) {
-        u32 c = bcnt[(long long)g * nq + q];
-        if (c > S) {
-            s_over = 1u;
-            c = S;
+    // thread t owns fills 8t .. 8t+7
+    u32 c[8], sum = 0;
+    bool over = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int g = 8 * threadIdx.x + i;
+        u32 v = g < G ? bcnt[(long long)g * nq + q] : 0u;
+        if (v > S) {
+            over = true;
+            v = S;
         }
-        s_off[g + 1] = c;
+        c[i] = v;
+        sum += v;
     }
-    if (threadIdx.x == 0) s_off[0] = 0u;
+    if (over) s_over = 1u;
+    u32 inc = sum;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_wave[wv] = inc;
     __syncthreads();
-    if (threadIdx.x == 0)
-        for (int g = 1; g <= G; ++g) s_off[g] += s_off[g - 1];  // G <= 2048 serial adds: a few us, off the scan's path
+    u32 base = inc - sum;
+    for (int w = 0; w < wv; ++w) base += s_wave[w];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int g = 8 * threadIdx.x + i;
+        if (g <= G) s_off[g] = base;
+        base += c[i];
+    }
+    if (threadIdx.x == 255) s_off[2048] = base;  // G == 2048: the total has no owner above
     __syncthreads();
     const u32 total = s_off[G];
-    for (int g = threadIdx.x >> 3; g < G; g += 32) {  // 8 lanes per mini-list
-        const u32 b0 = s_off[g], c = s_off[g + 1] - b0;
+    const int per = (G + COMPACT_SLICES - 1) / COMPACT_SLICES;
+    const int g0 = blockIdx.y * per, g1 = min(G, g0 + per);
+    for (int g = g0 + (threadIdx.x >> 3); g < g1; g += 32) {  // 8 lanes per mini-list
+        const u32 b0 = s_off[g], n_e = s_off[g + 1] - b0;
         const u64* src = seg + ((long long)g * nq + q) * S;
-        for (u32 e = threadIdx.x & 7; e < c; e += 8)
+        for (u32 e = threadIdx.x & 7; e < n_e; e += 8)
             if (b0 + e < cap) keys[(long long)q * key_stride + b0 + e] = src[e];
     }
-    if (threadIdx.x == 0) cnt[q] = s_over ? cap + 1u : total;
+    if (threadIdx.x == 0 && blockIdx.y == 0) cnt[q] = s_over ? cap + 1u : total;
 }
 
 // Generic word count (W not specialised): one code per thread.
@@ -391,7 +415,8 @@ __global__ void hamming_thr_kernel(const u32* __restrict__ hist, int nq, int bit
 // sorted keys -> (distance, global id); status bit0 = candidate overflow.
 __global__ void hamming_finalize_kernel(const u64* __restrict__ sorted, const u32* __restrict__ cnt, u32 cap,
                                         int nq, int k, long long id_base, int* __restrict__ out_dist,
-                                        long long* __restrict__ out_idx, u32* __restrict__ status, int kk) {
+                                        long long* __restrict__ out_idx, u32* __restrict__ status, int kk,
+                                        u32* __restrict__ host_words, int host_nq, int q0) {
     const int q = blockIdx.x;
     for (int j = threadIdx.x; j < k; j += blockDim.x) {
         u64 key = sorted[(long long)q * k + j];
@@ -401,7 +426,13 @@ __global__ void hamming_finalize_kernel(const u64* __restrict__ sorted, const u3
     }
     if (threadIdx.x == 0) {
         u32 c = cnt[q];
-        status[q] = (c > cap ? 1u : 0u) | (c < (u32)kk ? 4u : 0u);
+        const u32 stw = (c > cap ? 1u : 0u) | (c < (u32)kk ? 4u : 0u);
+        status[q] = stw;
+        // pinned host copy [status (nq) | counts (nq)]: the host only synchronises the stream (no copy launches)
+        if (host_words) {
+            host_words[q0 + q] = stw;
+            host_words[host_nq + q0 + q] = c;
+        }
     }
 }
 
@@ -495,6 +526,9 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
     SQ_TRY(h->out_keys.reserve((size_t)nq * k * 8));
     SQ_TRY(h->status.reserve((size_t)nq * 4));
     SQ_TRY(h->status_host.reserve((size_t)nq * 8));
+    u32* hs = reinterpret_cast<u32*>(h->status_host.p);  // [status (nq) | counts (nq)]
+    u32* hs_dev = nullptr;
+    SQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs_dev), hs, 0));
     u32* cnt = h->cnt.as<u32>();
     int* thr = h->thr.as<int>();
     u64* okeys = h->out_keys.as<u64>();
@@ -513,7 +547,7 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         h->stats.bytes_scanned = n * W * 8;
         SQ_TRY(select_launch(keys, cnt, (u32)n, key_stride, k, nq, okeys, st));
         hipLaunchKernelGGL(hamming_finalize_kernel, dim3(nq), dim3(256), 0, st, okeys, cnt, (u32)n, nq, k, h->id_base,
-                           out_dist, out_idx, status, kk);
+                           out_dist, out_idx, status, kk, hs_dev, nq, 0);
     } else {
         int step = g_opt.sample_stride > 0 ? g_opt.sample_stride : 64;
         // keep the sample comfortably larger than k
@@ -523,7 +557,7 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         SQ_TRY(h->hist.reserve((size_t)nq * (bits + 1) * 4));
         u32* hist = h->hist.as<u32>();
         SQ_HIP(hipMemsetAsync(hist, 0, (size_t)nq * (bits + 1) * 4, st));
-        SQ_HIP(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));
+        if (!(W == 1 || W == 2 || W == 4)) SQ_HIP(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));  // the compaction writes cnt itself
         hist_dispatch(h, qs, nq, bits, hist, step, st);
         hipLaunchKernelGGL(hamming_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, hist, nq, bits, kk, thr);
         if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
@@ -559,7 +593,7 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
                 else
                     hipLaunchKernelGGL((hamming_stream_kernel<4, 2>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
                                        thr + q0, seg, bcnt, S);
-                hipLaunchKernelGGL(hamming_compact_kernel, dim3(nqc), dim3(256), 0, st, seg, bcnt, G, nqc, S,
+                hipLaunchKernelGGL(hamming_compact_kernel, dim3(nqc, COMPACT_SLICES), dim3(256), 0, st, seg, bcnt, G, nqc, S,
                                    keys + (long long)q0 * key_stride, cnt + q0, cap, key_stride);
             }
         } else {
@@ -570,13 +604,11 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         h->stats.bytes_scanned = n * W * 8;
         SQ_TRY(select_launch(keys, cnt, cap, key_stride, k, nq, okeys, st));
         hipLaunchKernelGGL(hamming_finalize_kernel, dim3(nq), dim3(256), 0, st, okeys, cnt, cap, nq, k, h->id_base,
-                           out_dist, out_idx, status, kk);
+                           out_dist, out_idx, status, kk, hs_dev, nq, 0);
     }
     if (prof) SQ_HIP(hipEventRecord(h->ev[3], st));
-    // one small D2H + sync: the host decides whether any query needs the exact path
-    u32* hs = reinterpret_cast<u32*>(h->status_host.p);
-    SQ_HIP(hipMemcpyAsync(hs, status, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    SQ_HIP(hipMemcpyAsync(hs + nq, cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    // status words and candidate counts are in pinned host memory once the stream drains (written by the
+    // finalisation): the host decides whether any query needs the exact path
     SQ_HIP(hipStreamSynchronize(st));
     SQ_HIP(hipGetLastError());
     if (prof) {
@@ -598,7 +630,7 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
             SQ_TRY(select_launch(bk, cnt + q, (u32)n, n, k, 1, okeys + (long long)q * k, st));
             hipLaunchKernelGGL(hamming_finalize_kernel, dim3(1), dim3(256), 0, st, okeys + (long long)q * k, cnt + q,
                                (u32)n, 1, k, h->id_base, out_dist + (long long)q * k, out_idx + (long long)q * k,
-                               status + q, kk);
+                               status + q, kk, nullptr, 0, 0);
             h->stats.scan_launches++;
         }
     }
