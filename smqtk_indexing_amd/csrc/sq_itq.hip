@@ -234,6 +234,124 @@ __global__ __launch_bounds__(256, 2) void itq_hash_kernel(ItqArgs a) {
     }
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+
+// The filter's undecided bits, one float64 evaluation each: z_b = sum_k v_k R[k][b], v as the float64
+// kernel above forms it (x / |x| in float32 with numpy's norm, minus the mean in the promoted dtype).
+// Workgroups (w, 0..3) share segment w of the filter's output; 32 lanes per entry (row, column tile,
+// mask of undecided columns): lane l holds elements 4l..4l+3 of every 128-element stretch, so the row
+// (a random 512-byte read) and the column of the column-major float64 copy of R arrive as whole
+// cache lines.  The filter already stored the sign of its own estimate; the bit is set to the float64
+// sign in place.  (A whole-row float64 MFMA recompute of the ~4 % of rows owning such a bit cost
+// 0.31 ms at 10 M x 128 -> 64 bits -- 64x the flops needed; one or eight lanes per entry cost as much:
+// every 16-byte piece of a row then pulls its own cache line through L2.)
+static constexpr int ITQ_FIX_PARTS = 4;
+static __global__ __launch_bounds__(256) void itq_fix_bits_kernel(ItqArgs a, const u64* __restrict__ seg,
+                                                                  const u32* __restrict__ seg_cnt, long long seg_cap,
+                                                                  const double* __restrict__ rt64) {
+    const long long w = blockIdx.x;
+    const u32 cnt = seg_cnt[w];
+    const int l32 = threadIdx.x & 31, slot = (threadIdx.x >> 5) + 8 * blockIdx.y;
+    const float* X = reinterpret_cast<const float*>(a.x);
+    constexpr u32 STEP = 8 * ITQ_FIX_PARTS;
+    u64 ent_next = slot < (int)cnt ? seg[w * seg_cap + slot] : 0ull;
+    for (u32 e = slot; e < cnt; e += STEP) {  // uniform within a 32-lane half wave
+        // per entry the dependent chain is entry -> (row | R column) -> sum: the next entry is requested a turn
+        // early and the result goes out as a fire-and-forget atomic
+        const u64 ent = ent_next;
+        if (e + STEP < cnt) ent_next = seg[w * seg_cap + e + STEP];
+        const long long row = (long long)((u32)(ent >> 32) & 0x3fffffffu);
+        const int ct = (int)(ent >> 62);
+        u32 mask = (u32)ent;
+        const float* xr = X + row * a.d;
+        // the first (usually only) undecided column's slice of R: requested together with the row
+        f64x2_t rfirst[2][2];
+        {
+            const double* rcol = rt64 + (long long)(ct * 32 + __ffs((int)mask) - 1) * a.d;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k = 128 * t + 4 * l32;
+                rfirst[t][0] = rfirst[t][1] = f64x2_t{0.0, 0.0};
+                if (k < a.d) {
+                    rfirst[t][0] = *reinterpret_cast<const f64x2_t*>(rcol + k);
+                    rfirst[t][1] = *reinterpret_cast<const f64x2_t*>(rcol + k + 2);
+                }
+            }
+        }
+        // this lane's elements: 4 l32 + 128 t + 0..3, t < d/128 rounded up; v = x/|x| - mean formed once
+        double v[2][4];  // d <= 256
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k = 128 * t + 4 * l32;
+            const bool in = k < a.d;
+            f32x4_t xv = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (in) xv = *reinterpret_cast<const f32x4_t*>(xr + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[t][j] = (double)xv[j];  // raw value for now
+        }
+        float nrm = 1.f;
+        if (a.norm == SQ_NORM_L2) {
+            // numpy's pairwise order needs the row's own layout: eight cooperating lanes (np_pairwise_sum), every
+            // aligned group of 8 computes the same value
+            auto term = [xr](int i) { return mul_rn(xr[i], xr[i]); };
+            nrm = sqrt_rn(np_pairwise_sum<float>(term, a.d, threadIdx.x & 7));
+            if (nrm == 0.f) nrm = 1.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k = 128 * t + 4 * l32;
+            if (k < a.d) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float xe = (float)v[t][j];
+                    if (a.norm == SQ_NORM_L2) xe = div_rn(xe, nrm);
+                    v[t][j] = a.sub32 ? (double)__fsub_rn(xe, (float)a.mean[k + j]) : __dsub_rn((double)xe, a.mean[k + j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[t][j] = 0.0;
+            }
+        }
+        bool first = true;
+        while (mask) {  // nearly always one bit
+            const int pc = ct * 32 + __ffs((int)mask) - 1;   // padded column; the filter only flags pc >= pad
+            mask &= mask - 1;
+            const double* rcol = rt64 + (long long)pc * a.d;   // column pc of R, contiguous (itq_fast_prep_kernel)
+            double z = 0.0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k = 128 * t + 4 * l32;
+                if (k < a.d) {
+                    f64x2_t r0 = rfirst[t][0], r1 = rfirst[t][1];
+                    if (!first) {
+                        r0 = *reinterpret_cast<const f64x2_t*>(rcol + k);
+                        r1 = *reinterpret_cast<const f64x2_t*>(rcol + k + 2);
+                    }
+                    z = __fma_rn(v[t][0], r0[0], z);
+                    z = __fma_rn(v[t][1], r0[1], z);
+                    z = __fma_rn(v[t][2], r1[0], z);
+                    z = __fma_rn(v[t][3], r1[1], z);
+                }
+            }
+            z += __shfl_xor(z, 16);
+            z += __shfl_xor(z, 8);
+            z += __shfl_xor(z, 4);
+            z += __shfl_xor(z, 2);
+            z += __shfl_xor(z, 1);
+            first = false;
+            if (l32 == 0) {  // set the bit to the float64 sign (no read of the word: nothing to wait for)
+                unsigned long long* word = reinterpret_cast<unsigned long long*>(a.out + row * a.words + (pc >> 6));
+                const unsigned long long bit = 1ull << (63 - (pc & 63));
+                if (z >= 0.0)
+                    atomicOr(word, bit);
+                else
+                    atomicAnd(word, ~bit);
+            }
+        }
+    }
+}
+
 template <class T, int CT>
 static int itq_launch_t(const ItqArgs& a0, hipStream_t st, int device) {
     ItqArgs a = a0;
@@ -339,8 +457,8 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
     const long long n_tiles = (a.n + 31) / 32;
     const int nrb = cu_count(device);
     const long long nwaves = (long long)nrb * g.waves;
-    const long long seg_cap = ((n_tiles + nwaves - 1) / nwaves) * 32;
-    // one stream-ordered scratch block: colnorm | c_b | c_b error | R image | norms | segments | counts | list | total
+    const long long seg_cap = ((n_tiles + nwaves - 1) / nwaves) * 32 * g.ct;  // every (row, column tile) of a wave's tiles
+    // one stream-ordered scratch block: colnorm | c_b | c_b error | R image | segments | counts | R^T float64
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -350,9 +468,8 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
     const size_t o_cn = take((size_t)pc * 4), o_cb = take((size_t)pc * 4), o_cbe = take((size_t)pc * 4);
     const size_t o_img = take((size_t)pc * ((a.d + 127) / 128 * 128) * 4);
     const bool l2 = a.norm == SQ_NORM_L2;
-    const size_t o_nrm = take(l2 ? (size_t)a.n * 4 : 0);
-    const size_t o_seg = take((size_t)nwaves * seg_cap * 4), o_cnt = take((size_t)nwaves * 4);
-    const size_t o_list = take((size_t)a.n * 4), o_tot = take(4);
+    const size_t o_seg = take((size_t)nwaves * seg_cap * 8), o_cnt = take((size_t)nwaves * 4);
+    const size_t o_rt = take((size_t)pc * a.d * 8);
     {
         // keep the stream-ordered pool's memory across calls: by default it is handed back at every
         // synchronisation and each call would pay for ~100 MB of fresh allocation
@@ -376,7 +493,8 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
     };
     hipLaunchKernelGGL(itq_fast_prep_kernel, dim3((unsigned)pc), dim3(256), 0, st, a.mean, a.rot, a.d, a.bits, a.pad,
                        reinterpret_cast<unsigned short*>(base + o_img), reinterpret_cast<float*>(base + o_cn),
-                       reinterpret_cast<float*>(base + o_cb), reinterpret_cast<float*>(base + o_cbe));
+                       reinterpret_cast<float*>(base + o_cb), reinterpret_cast<float*>(base + o_cbe),
+                       reinterpret_cast<double*>(base + o_rt));
     ItqFastArgs fa{};
     fa.x = reinterpret_cast<const float*>(a.x);
     fa.n = a.n;
@@ -393,7 +511,7 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
     fa.words = a.words;
     fa.pad = a.pad;
     fa.bits = a.bits;
-    fa.seg = reinterpret_cast<u32*>(base + o_seg);
+    fa.seg = reinterpret_cast<u64*>(base + o_seg);
     fa.seg_cnt = reinterpret_cast<u32*>(base + o_cnt);
     fa.seg_cap = seg_cap;
     fa.n_tiles = n_tiles;
@@ -401,20 +519,9 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
     fa.nstage = g.stages;
     int rc = l2 ? itq_fast_dispatch<true>(fa, g, st) : itq_fast_dispatch<false>(fa, g, st);
     if (rc != SQ_OK) return done(rc);
-    hipLaunchKernelGGL(itq_fast_compact_kernel, dim3((unsigned)nwaves), dim3(256), 0, st, fa.seg, fa.seg_cnt, seg_cap,
-                       (int)nwaves, reinterpret_cast<u32*>(base + o_list), reinterpret_cast<u32*>(base + o_tot));
-    ItqArgs ex = a;  // the float64 kernel's view of the same job, restricted to the listed rows
-    if (l2) {
-        // numpy-order norms (the exact kernel divides by them element-wise) of the listed rows only
-        hipLaunchKernelGGL((itq_norms_kernel<float>), dim3((unsigned)(4 * cu_count(device))), dim3(256), 0, st,
-                           reinterpret_cast<const float*>(a.x), a.n, a.d, reinterpret_cast<float*>(base + o_nrm),
-                           reinterpret_cast<const u32*>(base + o_list), reinterpret_cast<const u32*>(base + o_tot));
-        ex.nrm = base + o_nrm;
-    }
-    ex.list = reinterpret_cast<const u32*>(base + o_list);
-    ex.list_total = reinterpret_cast<const u32*>(base + o_tot);
-    if (ex.words == 1) rc = itq_launch_t<float, 4>(ex, st, device);
-    else rc = itq_launch_t<float, 8>(ex, st, device);
+    // the undecided bits, one float64 dot product each, straight from the per-wave segments
+    hipLaunchKernelGGL(itq_fix_bits_kernel, dim3((unsigned)nwaves, ITQ_FIX_PARTS), dim3(256), 0, st, a, fa.seg, fa.seg_cnt, seg_cap,
+                       reinterpret_cast<const double*>(base + o_rt));
     return done(rc);
 }
 
@@ -423,7 +530,7 @@ static int itq_launch(const ItqArgs& a0, hipStream_t st, int device) {
     ItqArgs a = a0;
     if constexpr (sizeof(T) == 4) {
         const ItqFastGeom g = itq_fast_geometry(a.d, a.words);
-        if (g.stages >= 2 && a.n >= 32 && a.n < (1ll << 32) && (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 &&
+        if (g.stages >= 2 && a.n >= 32 && a.n < (1ll << 30) && (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 &&
             !g_opt.itq_exact)
             return itq_fast_path(a, g, st, device);
     }

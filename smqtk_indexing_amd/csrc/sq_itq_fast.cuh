@@ -11,8 +11,9 @@
 // v_mfma_f32_32x32x16_bf16 and finishes with z~ = (x . R_b) s - c_b, where
 // s = 1/|x| (normalize=2, |x| from the same pass) or 1 and c_b = mean . R_b is a
 // float64 product rounded once.  Bits with |z~| > eps(row, column) are final;
-// rows that own any other bit (a few per cent) are listed and recomputed by the
-// float64 kernel, so every code is exactly what the float64 evaluation gives.
+// the others (one in ~2500) are listed as (row, column tile, mask) entries and
+// evaluated in float64 one bit at a time (itq_fix_bits_kernel, sq_itq.hip), so
+// every code is exactly what the float64 evaluation gives.
 //
 // Error bound.  x = x_hi + x_lo + dx, |dx_k| <= 2^-16 |x_k| and
 // the same for R (after its float32 rounding); the dropped x_lo R_lo is
@@ -48,7 +49,7 @@ struct ItqFastArgs {
     float eps_rel;         // 3 * 2^-16 + 3d * 2^-24 + 2^-20 (+ 2^-18 for normalize=2): times |R_b| |x|
     u64* out;              // [n][words]
     int words, pad, bits;  // pad = words*64 - bits leading zero columns
-    u32* seg;              // [waves of the launch][seg_cap] rows that need the float64 evaluation
+    u64* seg;              // [waves of the launch][seg_cap] undecided (row | column tile << 30) << 32 | 32-column mask
     u32* seg_cnt;          // [waves of the launch]
     long long seg_cap;
     long long n_tiles;
@@ -65,7 +66,8 @@ static __global__ __launch_bounds__(256) void itq_fast_prep_kernel(const double*
                                                                     unsigned short* __restrict__ rimage,
                                                                     float* __restrict__ colnorm,
                                                                     float* __restrict__ cb32,
-                                                                    float* __restrict__ cberr) {
+                                                                    float* __restrict__ cberr,
+                                                                    double* __restrict__ rt64) {
     const int pc = blockIdx.x;
     const int b = pc - pad;
     __shared__ double red[256];
@@ -74,6 +76,7 @@ static __global__ __launch_bounds__(256) void itq_fast_prep_kernel(const double*
     double acc = 0.0, cacc = 0.0, cabs = 0.0, macc = 0.0;
     for (int k = threadIdx.x; k < d; k += 256) {
         const double r = b >= 0 ? rot[(long long)k * bits + b] : 0.0;
+        rt64[(long long)pc * d + k] = r;  // column-major float64 copy: the per-bit float64 evaluation reads whole columns
         acc += r * r;
         cacc += mean[k] * r;
         cabs += fabs(mean[k] * r);
@@ -124,41 +127,6 @@ static __global__ __launch_bounds__(256) void itq_fast_prep_kernel(const double*
     __syncthreads();
 }
 
-// Pack the per-wave lists of rows into one list; block w copies segment w.
-static __global__ __launch_bounds__(256) void itq_fast_compact_kernel(const u32* __restrict__ seg,
-                                                                       const u32* __restrict__ seg_cnt,
-                                                                       long long seg_cap, int nseg,
-                                                                       u32* __restrict__ list,
-                                                                       u32* __restrict__ total) {
-    __shared__ u32 red[256];
-    const int w = blockIdx.x;
-    u32 below = 0, all = 0;
-    for (int i = threadIdx.x; i < nseg; i += 256) {
-        const u32 c = seg_cnt[i];
-        all += c;
-        if (i < w) below += c;
-    }
-    red[threadIdx.x] = below;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    const u32 off = red[0];
-    __syncthreads();
-    if (w == 0) {
-        red[threadIdx.x] = all;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) *total = red[0];
-    }
-    const u32 c = seg_cnt[w];
-    for (u32 i = threadIdx.x; i < c; i += 256) list[off + i] = seg[(long long)w * seg_cap + i];
-}
-
 // WAVES per workgroup, NSTAGE ring slots per wave, KU = d/64 units per 32-row tile, CT = padded
 // hash bits / 32 column tiles.  The kernel accumulates x . R on the raw rows and finishes with
 // z~ = (x . R_b) * s - mean . R_b, s = 1/|x| of the row for normalize=2 (NORMED; |x| from the same
@@ -206,7 +174,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
     const long long nwaves = (long long)a.nrb * WAVES;
     const long long my_tiles = wave_id < a.n_tiles ? (a.n_tiles - wave_id + nwaves - 1) / nwaves : 0;
     const long long total_units = my_tiles * KU;
-    u32* myseg = a.seg + wave_id * a.seg_cap;
+    u64* myseg = a.seg + wave_id * a.seg_cap;
 
     // lane L < 32 finalises row L of a tile: accumulator register my_i of lane half my_h holds it
     const int my_i = (r31 & 3) | ((r31 >> 3) << 2), my_h = (r31 >> 2) & 1;
@@ -339,22 +307,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
             for (int o = 16; o > 0; o >>= 1) umax = fmaxf(umax, __shfl_xor(umax, o));
             U = sqrtf(umax) * 1.0001f;  // the largest |x| of the tile
         }
-        u32 half_word[CT];
-        u32 flagged = 0;
+        u32 half_word[CT], unc_mask[CT];  // this lane's row: sign bits and undecided columns of every column tile
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float rs = 1.f;
             if constexpr (NORMED) rs = __shfl(rowscale, (i & 3) + 8 * (i >> 2) + 4 * h);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                if (i == 0) half_word[ct] = 0;
+                if (i == 0) half_word[ct] = unc_mask[ct] = 0;
                 const float eps = cnorm[ct] * U + cberr[ct];  // cnorm carries eps_rel
                 const float z = acc[ct][i] * rs - cb[ct];
                 const u64 pos = __ballot(z >= 0.f);
                 const u64 unc = __ballot(cvalid[ct] && !(fabsf(z) > eps));
                 if (i == my_i) {  // this lane's row sits in register i of lane half my_h
                     half_word[ct] = __brev(my_h ? (u32)(pos >> 32) : (u32)pos);  // column 0 -> most significant
-                    flagged |= my_h ? (u32)(unc >> 32) : (u32)unc;
+                    unc_mask[ct] = my_h ? (u32)(unc >> 32) : (u32)unc;                  // bit c = column c of the tile
                 }
             }
         }
@@ -368,13 +335,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
                 a.out[row * a.words + w] = v;
             }
         }
-        const bool need = mine && flagged != 0;
-        const u64 nb = __ballot(need);
-        if (need) {
-            const u32 p = wcount + __builtin_amdgcn_mbcnt_hi((u32)(nb >> 32), __builtin_amdgcn_mbcnt_lo((u32)nb, 0u));
-            myseg[p] = (u32)row;
+        // undecided bits: one entry per (row, column tile) that has any, for the float64 evaluation of
+        // exactly those bits (itq_fix_bits_kernel)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const bool need = mine && unc_mask[ct] != 0;
+            const u64 nb = __ballot(need);
+            if (need) {
+                const u32 p = wcount + __builtin_amdgcn_mbcnt_hi((u32)(nb >> 32), __builtin_amdgcn_mbcnt_lo((u32)nb, 0u));
+                myseg[p] = ((u64)((u32)row | ((u32)ct << 30)) << 32) | (u64)unc_mask[ct];
+            }
+            wcount += (u32)__popcll(nb);
         }
-        wcount += (u32)__popcll(nb);
     }
     if (lane == 0) a.seg_cnt[wave_id] = wcount;
 }
