@@ -53,7 +53,8 @@ def main():
                           ("rerank: no reservation atomics (debug 32)", {"dense_debug": 32}),
                           ("rerank: cache-resident rows (debug 64)", {"dense_debug": 64}),
                           ("rerank: both (debug 96)", {"dense_debug": 96})):
-            show(tag, 32, *run(32, **opts))
+            nq_ab = int(os.environ.get("NQ_ABLATE", 32))
+            show(tag, nq_ab, *run(nq_ab, **opts))
     if "stride" in which:
         for nq in [int(x) for x in os.environ.get("NQS", "32,128,1024").split(",")]:
             for stride in (2, 3, 4, 6, 8, 12, 16, 24):
