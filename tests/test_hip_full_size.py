@@ -1,0 +1,212 @@
+"""
+BASELINE.json's FULL per-GPU sizes on one MI355X, checked through size-independent
+properties: the oracle (numpy, one core) cannot produce a 10 M-row answer in seconds, so the
+checks are (a) structural -- ascending distances, a query that is a row finds itself first;
+(b) the returned distances recomputed by the oracle from the returned rows (a few hundred rows,
+bit-exact); (c) COMPLETENESS against a plain torch evaluation of every distance on the same
+device -- integer exact for Hamming and for ITQ's packed codes, a tolerance band around the k-th
+distance for the floating-point metrics (torch sums in another order); (d) the partition
+property: two half-shards with id offsets, merged on the host, equal the whole index.
+
+Data is generated on the device (torch); nothing here reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as O
+from smqtk_indexing_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _popcount64(x):
+    """SWAR popcount of int64 tensors taken as 64 raw bits."""
+    x = x - ((x >> 1) & 0x5555555555555555)
+    x = (x & 0x3333333333333333) + ((x >> 2) & 0x3333333333333333)
+    x = (x + (x >> 4)) & 0x0F0F0F0F0F0F0F0F
+    return (x * 0x0101010101010101) >> 56
+
+
+def _search_dense(index, q, k, cosine=False):
+    nq = q.shape[0]
+    od = torch.empty((nq, k), dtype=torch.float64 if cosine else torch.float32, device=q.device)
+    oi = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+    index.search_device(q.data_ptr(), nq, k, od.data_ptr(), oi.data_ptr(), _stream())
+    torch.cuda.synchronize()
+    return od.cpu().numpy(), oi.cpu().numpy()
+
+
+def test_dense_l2_10m_x_128_properties():
+    """The north-star shape: 10 M x 128 float32, k = 100."""
+    dev = _dev()
+    n, d, k = 10_000_000, 128, 100
+    g = torch.Generator(device=dev)
+    g.manual_seed(101)
+    db = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for s in range(0, n, 1 << 21):
+        db[s:s + (1 << 21)].normal_(generator=g)
+    q = torch.empty((6, d), dtype=torch.float32, device=dev).normal_(generator=g)
+    q[0] = db[1_234_567]
+    q[1] = db[n - 1] + 0.01
+    index = _lib.DenseIndex(db.data_ptr(), n=n, d=d, device_ptr=True, keepalive=db)
+    dist, ids = _search_dense(index, q, k)
+    assert index.stats()["fallback_queries"] == 0
+    qh = q.cpu().numpy()
+    assert ids[0, 0] == 1_234_567 and dist[0, 0] == 0.0
+    assert ids[1, 0] == n - 1
+    for j in range(q.shape[0]):
+        assert (np.diff(dist[j]) >= 0).all() and len(set(ids[j].tolist())) == k
+        assert ids[j].min() >= 0 and ids[j].max() < n
+        rows = db[torch.from_numpy(ids[j]).to(dev)].cpu().numpy()
+        # (b) the float32 distances are the reference's own arithmetic on the returned rows
+        np.testing.assert_array_equal(dist[j].view(np.uint32), O.dense_distances(rows, qh[j], "euclidean").view(np.uint32))
+        # (c) completeness: no row clearly nearer than the k-th is missing (torch float32, other summation order)
+        kth = float(dist[j, -1])
+        got = torch.from_numpy(ids[j]).to(dev)
+        near_total, within = 0, 0
+        for s in range(0, n, 1 << 21):
+            blk = db[s:s + (1 << 21)]
+            dd = torch.sqrt(((blk - q[j]) ** 2).sum(dim=1))
+            near = torch.nonzero(dd < kth * (1.0 - 1e-4)).flatten() + s
+            near_total += int(near.numel())
+            assert bool(torch.isin(near, got).all()), "a row nearer than the k-th neighbour is missing"
+            within += int((dd <= kth * (1.0 + 1e-4)).sum())
+        assert near_total <= k and within >= k
+    # (d) partition: two half-shards with id offsets + host merge == the whole index
+    half = n // 2
+    lo = _lib.DenseIndex(db.data_ptr(), n=half, d=d, device_ptr=True, keepalive=db)
+    hi = _lib.DenseIndex(db[half:].data_ptr(), n=n - half, d=d, device_ptr=True, id_base=half, keepalive=db)
+    d0, i0 = _search_dense(lo, q, k)
+    d1, i1 = _search_dense(hi, q, k)
+    md, mi = _lib.merge_topk(np.stack([d0, d1]), np.stack([i0, i1]), k)
+    np.testing.assert_array_equal(mi, ids)
+    np.testing.assert_array_equal(md.view(np.uint32), dist.view(np.uint32))
+    for h in (index, lo, hi):
+        h.close()
+
+
+def test_dense_cosine_12m_x_512_shard_properties():
+    """One shard of BASELINE config 4 (100 M x 512 cosine over 8 GPUs): 12.5 M x 512."""
+    dev = _dev()
+    n, d, k = 12_500_000, 512, 100
+    g = torch.Generator(device=dev)
+    g.manual_seed(102)
+    db = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for s in range(0, n, 1 << 20):
+        db[s:s + (1 << 20)].normal_(generator=g)
+    q = torch.empty((3, d), dtype=torch.float32, device=dev).normal_(generator=g)
+    q[0] = db[7_654_321] * 3.0            # same direction: distance ~0
+    index = _lib.DenseIndex(db.data_ptr(), n=n, d=d, metric=_lib.SQ_METRIC_COSINE, device_ptr=True, keepalive=db)
+    dist, ids = _search_dense(index, q, k, cosine=True)
+    assert index.stats()["fallback_queries"] == 0
+    qh = q.cpu().numpy()
+    assert ids[0, 0] == 7_654_321 and dist[0, 0] < 1e-6
+    for j in range(q.shape[0]):
+        assert (np.diff(dist[j]) >= 0).all() and len(set(ids[j].tolist())) == k
+        rows = db[torch.from_numpy(ids[j]).to(dev)].cpu().numpy()
+        np.testing.assert_allclose(dist[j], O.dense_distances(rows, qh[j], "cosine"), rtol=1e-12, atol=1e-15)
+        # completeness against a float64 torch evaluation of the reference formula 2 acos(sim) / pi
+        kth = float(dist[j, -1])
+        got = torch.from_numpy(ids[j]).to(dev)
+        q64 = q[j].double()
+        qn = torch.sqrt((q64 * q64).sum())
+        near_total, within = 0, 0
+        for s in range(0, n, 1 << 20):
+            blk = db[s:s + (1 << 20)].double()
+            sim = (blk @ q64) / (torch.sqrt((blk * blk).sum(dim=1)) * qn)
+            dd = 2.0 * torch.arccos(sim.clamp(-1.0, 1.0)) / np.pi
+            near = torch.nonzero(dd < kth - 1e-9).flatten() + s
+            near_total += int(near.numel())
+            assert bool(torch.isin(near, got).all()), "a row nearer than the k-th neighbour is missing"
+            within += int((dd <= kth + 1e-9).sum())
+        assert near_total <= k and within >= k
+    index.close()
+
+
+def test_hamming_125m_x_256bit_shard_exact():
+    """One shard of BASELINE config 5 (1 B x 256-bit codes over 8 GPUs): 125 M codes; the whole
+    answer is integer exact against torch (xor, popcount, top-k of (distance, row) keys)."""
+    dev = _dev()
+    n, w, k = 125_000_000, 4, 100
+    g = torch.Generator(device=dev)
+    g.manual_seed(103)
+    codes = torch.empty((n, w), dtype=torch.int64, device=dev)
+    for s in range(0, n, 1 << 24):
+        e = min(n, s + (1 << 24))
+        codes[s:e] = torch.randint(-2 ** 63, 2 ** 63 - 1, (e - s, w), dtype=torch.int64, device=dev, generator=g)
+    q = torch.randint(-2 ** 63, 2 ** 63 - 1, (3, w), dtype=torch.int64, device=dev, generator=g)
+    q[0] = codes[77_777_777]
+    q[1] = codes[5]
+    q[1, 3] ^= 1                          # one bit away from row 5
+    index = _lib.HammingIndex(codes.data_ptr(), n=n, words=w, device_ptr=True, id_base=1_000, keepalive=codes)
+    od = torch.empty((3, k), dtype=torch.int32, device=dev)
+    oi = torch.empty((3, k), dtype=torch.int64, device=dev)
+    index.search_device(q.data_ptr(), 3, k, od.data_ptr(), oi.data_ptr(), _stream())
+    torch.cuda.synchronize()
+    assert index.stats()["fallback_queries"] == 0
+    assert int(oi[0, 0]) == 77_777_777 + 1_000 and int(od[0, 0]) == 0
+    assert int(oi[1, 0]) == 5 + 1_000 and int(od[1, 0]) == 1
+    rows = torch.arange(n, dtype=torch.int64, device=dev)
+    for j in range(3):
+        dist = torch.zeros(n, dtype=torch.int64, device=dev)
+        for c in range(w):
+            dist += _popcount64(codes[:, c] ^ q[j, c])
+        key = (dist << 32) | rows
+        want = torch.topk(key, k, largest=False, sorted=True).values
+        assert torch.equal(od[j].to(torch.int64), want >> 32)
+        assert torch.equal(oi[j], (want & 0xFFFFFFFF) + 1_000)
+        del dist, key
+    index.close()
+
+
+@pytest.mark.parametrize("normalize", [None, 2])
+def test_itq_10m_x_128_codes_equal_float64_torch(normalize):
+    """BASELINE config 3's hashing: 10 M x 128 float32 -> 64-bit codes, every row against a float64
+    torch evaluation of (norm(x) - mean) . R (rows with a |z| below 1e-9 of its scale excluded:
+    there the reference's own sign depends on its BLAS summation order)."""
+    dev = _dev()
+    n, d, bits = 10_000_000, 128, 64
+    g = torch.Generator(device=dev)
+    g.manual_seed(104)
+    x = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for s in range(0, n, 1 << 21):
+        x[s:s + (1 << 21)].normal_(generator=g)
+    x[12_345] = 0.0                        # a zero row: z = -mean . R
+    rot_np, _ = np.linalg.qr(np.random.default_rng(9).standard_normal((d, d)))
+    rot = torch.from_numpy(np.ascontiguousarray(rot_np[:, :bits])).to(dev)
+    mean = (x[:200_000].double() / (torch.linalg.norm(x[:200_000].double(), dim=1, keepdim=True) if normalize else 1.0)).mean(dim=0).contiguous()
+    out = torch.empty((n, 1), dtype=torch.int64, device=dev)
+    _lib.itq_hash_device(x.data_ptr(), 0, n, d, mean.data_ptr(), rot.data_ptr(), bits,
+                         _lib.SQ_NORM_L2 if normalize else _lib.SQ_NORM_NONE, out.data_ptr(), _stream())
+    torch.cuda.synchronize()
+    shifts = (63 - torch.arange(bits, device=dev)).to(torch.int64)
+    bad = 0
+    for s in range(0, n, 1 << 20):
+        blk = x[s:s + (1 << 20)]
+        if normalize:
+            nrm = torch.linalg.norm(blk, dim=1, keepdim=True)        # float32 norm, like numpy on float32 rows
+            nrm = torch.where(nrm == 0, torch.ones_like(nrm), nrm)
+            v = (blk / nrm).double() - mean
+        else:
+            v = blk.double() - mean
+        z = v @ rot
+        code = ((z >= 0).to(torch.int64) << shifts).sum(dim=1)       # MSB first; wraps into the sign bit like the packed word
+        differ = code != out[s:s + (1 << 20), 0]
+        if bool(differ.any()):
+            zz = z[differ]
+            scale = zz.abs().max(dim=1).values.clamp_min(1e-30)
+            # a differing row must owe it to a borderline bit.  normalize=2: torch's float32 norm may be an ulp
+            # off numpy's pairwise one, which moves z by ~1e-7 of its scale
+            assert bool((zz.abs().min(dim=1).values <= (1e-6 if normalize else 1e-9) * scale).all())
+            bad += int(differ.sum())
+    assert bad <= (3000 if normalize else 4)
