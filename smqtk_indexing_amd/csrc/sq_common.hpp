@@ -57,6 +57,7 @@ struct Options {
     int dense_qplanes = 0;       // 0 = auto, 2 = keep q_hi + q_lo also in the multi-tile scan
     int dense_no_center = 0;     // 1 = the dense L2 filter scores the rows as given (no column-mean origin; measurement)
     int dense_rerank_segments = 0;  // survivor segments per re-rank workgroup (0 = all waves of a scan workgroup; measurement)
+    int merge_threads = 0;       // host threads of the shard merge (0 = by size)
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
 };
 extern Options g_opt;

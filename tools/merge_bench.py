@@ -17,6 +17,7 @@ def main():
     a = [int(x) for x in sys.argv[1:]]
     shapes = [tuple(a[i:i + 3]) for i in range(0, len(a), 3)] or [(8, 256, 100), (8, 32, 100), (2, 64, 100), (1, 256, 100), (8, 1024, 100)]
     rng = np.random.default_rng(0)
+    _lib.set_option("merge_threads", int(os.environ.get("THREADS", 0)))
     for world, nq, k in shapes:
         per = nq * k * 12
         buf = np.empty((world, per), dtype=np.uint8)
