@@ -119,3 +119,166 @@ def hamming_shard(codes_shard, row0: int, group=None) -> ShardedIndex:
     s = ShardedIndex(local_search, group)
     s.index = index  # type: ignore[attr-defined]
     return s
+
+
+class MutableShardedIndex:
+    """Row shards that accept mutations ("Mutations"; not on the timed path).
+
+    * ``append(rows)`` -- every rank calls it with the same rows; they go to the shard with the fewest
+      live rows (lowest rank on ties) and get the next global ids, so every shard stays in ascending id
+      order and the canonical (distance, id) tie order survives mutation.  Returns the new ids.
+    * ``remove(ids)`` -- tombstones: the owning shard marks the rows dead; ``KeyError`` on every rank,
+      before anything changes, when an id is not live anywhere (the reference's
+      ``remove_from_index`` contract, nearest_neighbor_index.py:84-94 / lsh.py:385-450).  A shard whose
+      dead rows exceed ``compact_at`` of its rows drops them and rebuilds its local index.
+    * ``search(queries, k)`` -- each shard answers ``k + dead`` locally, drops dead rows, maps local rows to
+      global ids, then the usual all-gather + host merge.
+
+    ``build_local(rows) -> search(queries, k) -> (dist [nq,k], local_row [nq,k])`` builds the per-shard
+    searcher (padding: row -1); :func:`dense_local_builder` / :func:`hamming_local_builder` wrap the HIP
+    indexes, the CPU tests pass an oracle-backed one.  ``rows`` is a torch tensor (CUDA on a GPU box).
+    The only collectives of a mutation are all-gathers / all-reduces of a few integers.
+    """
+
+    def __init__(self, rows, row0: int, n_total: int, build_local: Callable, group=None, compact_at: float = 0.25,
+                 dist_dtype=None):
+        import torch
+        import torch.distributed as dist
+
+        self.group, self.build_local, self.compact_at = group, build_local, float(compact_at)
+        self.pad_dtype = dist_dtype if dist_dtype is not None else torch.float32   # distances of an empty shard
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.rows = rows
+        self.ids = torch.arange(int(row0), int(row0) + int(rows.shape[0]), dtype=torch.int64)
+        self.dead = torch.zeros(int(rows.shape[0]), dtype=torch.bool)
+        self.next_id = int(n_total)
+        self.live = self._gather_int(int(rows.shape[0]))       # live rows of every shard, identical on all ranks
+        self._local = build_local(rows) if rows.shape[0] else None
+
+    # ------------------------------------------------------------ helpers
+    def _gather_int(self, v: int):
+        import torch
+        import torch.distributed as dist
+        dev = self.rows.device if self.rows.is_cuda else torch.device("cpu")
+        mine = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+        outs = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        dist.all_gather(outs, mine, group=self.group)
+        return [int(x.item()) for x in outs]
+
+    def _rebuild(self) -> None:
+        self._local = self.build_local(self.rows) if self.rows.shape[0] else None
+
+    def count(self) -> int:
+        return int(sum(self.live))
+
+    # ---------------------------------------------------------- mutations
+    def append(self, new_rows):
+        import torch
+        m = int(new_rows.shape[0])
+        ids = torch.arange(self.next_id, self.next_id + m, dtype=torch.int64)
+        self.next_id += m
+        target = min(range(self.world), key=lambda r: (self.live[r], r))
+        if m and self.rank == target:
+            add = new_rows.to(self.rows.device, self.rows.dtype)
+            self.rows = torch.cat([self.rows, add], dim=0) if self.rows.shape[0] else add.contiguous()
+            self.ids = torch.cat([self.ids, ids])
+            self.dead = torch.cat([self.dead, torch.zeros(m, dtype=torch.bool)])
+            self._rebuild()
+        self.live[target] += m
+        return ids.numpy()
+
+    def remove(self, ids) -> None:
+        import torch
+        want = torch.as_tensor(np.asarray(list(ids), dtype=np.int64))
+        if want.numel() != torch.unique(want).numel():
+            raise KeyError("duplicate ids")
+        # local rows are in ascending id order: binary search
+        pos = torch.searchsorted(self.ids, want)
+        pos_c = pos.clamp(max=max(int(self.ids.numel()) - 1, 0))
+        hit = (pos < self.ids.numel()) & (self.ids[pos_c] == want) & ~self.dead[pos_c] if self.ids.numel() else \
+            torch.zeros_like(want, dtype=torch.bool)
+        found = self._gather_int(int(hit.sum()))
+        if sum(found) != int(want.numel()):
+            raise KeyError("some ids are not in the index")        # nothing modified, on every rank
+        self.dead[pos_c[hit]] = True
+        for r in range(self.world):
+            self.live[r] -= found[r]
+        n_dead = int(self.dead.sum())
+        if n_dead and n_dead > self.compact_at * int(self.dead.numel()):
+            keep = ~self.dead
+            self.rows = self.rows[keep.to(self.rows.device)].contiguous()
+            self.ids, self.dead = self.ids[keep], torch.zeros(int(keep.sum()), dtype=torch.bool)
+            self._rebuild()
+
+    # -------------------------------------------------------------- search
+    def search(self, queries, k: int, merge_on: Optional[int] = None):
+        import torch
+        nq = int(queries.shape[0])
+        n_local, n_dead = int(self.dead.numel()), int(self.dead.sum())
+        kk = min(n_local, int(k) + n_dead)
+        if self._local is not None and kk > 0:
+            d, r = self._local(queries, kk)
+            d, r = d.cpu(), r.cpu()
+        else:
+            d, r = None, None
+        dt = d.dtype if d is not None else self.pad_dtype
+        pad = torch.iinfo(dt).max if not dt.is_floating_point else float("inf")
+        od = torch.full((nq, int(k)), pad, dtype=dt)
+        oi = torch.full((nq, int(k)), -1, dtype=torch.int64)
+        if d is not None:
+            ok = (r >= 0) & ~self.dead[r.clamp(min=0)]
+            # stable left-compaction of the live entries of every row
+            order = torch.argsort((~ok).to(torch.int8), dim=1, stable=True)[:, : int(k)]
+            live_sorted = torch.gather(ok, 1, order)
+            dd, rr = torch.gather(d, 1, order), torch.gather(r, 1, order)
+            m = min(int(k), kk)
+            od[:, :m] = torch.where(live_sorted, dd, torch.full_like(dd, pad))[:, :m]
+            oi[:, :m] = torch.where(live_sorted, self.ids[rr.clamp(min=0)], torch.full_like(rr, -1))[:, :m]
+        dev = self.rows.device if self.rows.is_cuda else torch.device("cpu")
+        return allgather_merge(od.to(dev), oi.to(dev), int(k), self.group, merge_on)
+
+
+
+def dense_local_builder(metric: int = 0) -> Callable:
+    """``build_local`` for :class:`MutableShardedIndex` over CUDA float32 rows (HIP dense index, local row ids)."""
+    import torch
+    from . import _lib
+    ddt = torch.float64 if metric == _lib.SQ_METRIC_COSINE else torch.float32
+
+    def build(rows):
+        index = _lib.DenseIndex(rows.data_ptr(), n=rows.shape[0], d=rows.shape[1], metric=metric, device_ptr=True,
+                                keepalive=rows)
+
+        def search(queries, k):
+            q = queries.to(rows.device, torch.float32).contiguous()
+            od = torch.empty((q.shape[0], k), dtype=ddt, device=q.device)
+            oi = torch.empty((q.shape[0], k), dtype=torch.int64, device=q.device)
+            index.search_device(q.data_ptr(), q.shape[0], k, od.data_ptr(), oi.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+            torch.cuda.current_stream().synchronize()
+            return od, oi
+        search.index = index  # type: ignore[attr-defined]
+        return search
+    return build
+
+
+def hamming_local_builder() -> Callable:
+    """``build_local`` for :class:`MutableShardedIndex` over CUDA int64-viewed packed codes."""
+    import torch
+    from . import _lib
+
+    def build(codes):
+        index = _lib.HammingIndex(codes.data_ptr(), n=codes.shape[0], words=codes.shape[1], device_ptr=True,
+                                  keepalive=codes)
+
+        def search(queries, k):
+            q = queries.to(codes.device, torch.int64).contiguous()
+            od = torch.empty((q.shape[0], k), dtype=torch.int32, device=q.device)
+            oi = torch.empty((q.shape[0], k), dtype=torch.int64, device=q.device)
+            index.search_device(q.data_ptr(), q.shape[0], k, od.data_ptr(), oi.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+            torch.cuda.current_stream().synchronize()
+            return od, oi
+        search.index = index  # type: ignore[attr-defined]
+        return search
+    return build

@@ -71,6 +71,84 @@ def _worker(rank: int, world: int, port: int, kind: str, out_dir: str) -> None:
     dist.destroy_process_group()
 
 
+def _mutation_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    """SURVEY 8e "Mutations": appends to the least-full shard, tombstones + compaction, KeyError before any
+    change; after every step the sharded answer equals the oracle over the live (id -> row) set."""
+    import torch
+    import torch.distributed as dist
+    from smqtk_indexing_amd.distributed import MutableShardedIndex, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)
+    d, k = 16, 12
+    db = rng.standard_normal((301, d)).astype(np.float32)
+    db[250] = db[3]                                   # a cross-shard tie
+    qs = rng.standard_normal((5, d)).astype(np.float32)
+    qs[0] = db[3]
+
+    def build_local(rows):                            # oracle-backed shard searcher (no GPU here)
+        mat = rows.numpy()
+
+        def search(queries, kk):
+            qn = np.asarray(queries, dtype=np.float32)
+            dd = np.full((len(qn), kk), np.inf, np.float32)
+            ii = np.full((len(qn), kk), -1, np.int64)
+            for j, q in enumerate(qn):
+                a, b = O.dense_topk(mat, q, kk)
+                dd[j, :len(a)], ii[j, :len(b)] = a, b
+            return torch.from_numpy(dd), torch.from_numpy(ii)
+        return search
+
+    r0, r1 = shard_range(len(db), world, rank)
+    idx = MutableShardedIndex(torch.from_numpy(db[r0:r1].copy()), r0, len(db), build_local, compact_at=0.1)
+    live = {i: db[i] for i in range(len(db))}
+
+    def check():
+        ids = np.array(sorted(live))
+        mat = np.stack([live[i] for i in ids])
+        got = idx.search(torch.from_numpy(qs), k)
+        assert idx.count() == len(live)
+        for j, q in enumerate(qs):
+            rd, ri = O.dense_topk(mat, q, k)          # ids ascending -> canonical (distance, id) order
+            np.testing.assert_array_equal(got[1][j, :len(ri)], ids[ri])
+            np.testing.assert_array_equal(got[0][j, :len(rd)], rd)
+
+    check()
+    new = rng.standard_normal((40, d)).astype(np.float32)
+    new[5] = db[3]                                    # ties with two existing rows, larger id
+    nid = idx.append(torch.from_numpy(new))
+    assert list(nid) == list(range(301, 341))
+    live.update({int(i): v for i, v in zip(nid, new)})
+    assert idx.live == [151, 150 + 40]                # the second shard held fewer rows: it takes the batch
+    check()
+    with pytest.raises(KeyError):
+        idx.remove([3, 99999])                        # unknown id: nothing changes anywhere
+    check()
+    gone = [3, 250, 17, 300, 305] + list(range(100, 140))
+    idx.remove(gone)                                  # 45 rows: the first shard passes 10 % dead and compacts
+    for g in gone:
+        del live[g]
+    check()
+    with pytest.raises(KeyError):
+        idx.remove([17])                              # already removed
+    nid2 = idx.append(torch.from_numpy(new[:3] + 1))
+    live.update({int(i): v for i, v in zip(nid2, new[:3] + 1)})
+    check()
+    if rank == 0:
+        open(os.path.join(out_dir, "ok_mut"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_mutations_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_mutation_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok_mut").exists()
+
+
 @pytest.mark.parametrize("kind", ["dense", "hamming"])
 def test_sharded_search_gloo_world2(tmp_path, kind):
     import torch.multiprocessing as mp

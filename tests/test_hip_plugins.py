@@ -408,3 +408,71 @@ def test_sharded_index_rccl_world1():
             np.testing.assert_array_equal(d[j], rd)
     finally:
         dist.destroy_process_group()
+
+
+def test_mutable_sharded_index_rccl_world1():
+    """SURVEY 8e "Mutations" on the real backend with one rank: the HIP dense / Hamming indexes behind
+    MutableShardedIndex -- append (new ids), tombstones (answered with k + dead), compaction, KeyError."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from smqtk_indexing_amd.distributed import MutableShardedIndex, dense_local_builder, hamming_local_builder
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29519"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(31)
+        db = rng.standard_normal((70_000, 64)).astype(np.float32)
+        db[60_000] = db[11]
+        qs = rng.standard_normal((4, 64)).astype(np.float32)
+        qs[0] = db[11]
+        idx = MutableShardedIndex(torch.from_numpy(db).to(dev), 0, len(db), dense_local_builder(), compact_at=0.01)
+        live = {i: db[i] for i in range(len(db))}
+
+        def check(k=30):
+            ids = np.array(sorted(live))
+            mat = np.stack([live[i] for i in ids])
+            d, i = idx.search(torch.from_numpy(qs).to(dev), k)
+            for j in range(len(qs)):
+                rd, ri = O.dense_topk(mat, qs[j], k)
+                np.testing.assert_array_equal(i[j], ids[ri])
+                np.testing.assert_array_equal(d[j].view(np.uint32), rd.view(np.uint32))
+        check()
+        new = rng.standard_normal((500, 64)).astype(np.float32)
+        new[7] = db[11]
+        nid = idx.append(torch.from_numpy(new))
+        live.update({int(a): v for a, v in zip(nid, new)})
+        check()
+        gone = [11, 60_000, int(nid[7])] + list(range(200, 260))
+        idx.remove(gone)                              # 63 tombstones: below the 1 % compaction mark
+        assert int(idx.dead.sum()) == 63
+        for g_ in gone:
+            del live[g_]
+        check()
+        with pytest.raises(KeyError):
+            idx.remove([11])
+        idx.remove(list(range(1000, 1800)))           # passes 1 %: the shard compacts and rebuilds
+        assert int(idx.dead.sum()) == 0 and idx.count() == len(live) - 800
+        for g_ in range(1000, 1800):
+            del live[g_]
+        check()
+        # packed codes
+        codes = np.unique(rng.integers(0, 2 ** 63, size=(90_000, 1), dtype=np.int64).astype(np.uint64), axis=0)
+        rng.shuffle(codes)                            # arbitrary row order: ids are positions
+        hidx = MutableShardedIndex(torch.from_numpy(codes.view(np.int64)).to(dev), 0, len(codes), hamming_local_builder(),
+                                   dist_dtype=torch.int32)
+        hidx.remove([5, 6, 7])
+        keep = np.ones(len(codes), bool)
+        keep[[5, 6, 7]] = False
+        d, i = hidx.search(torch.from_numpy(codes[4:8].view(np.int64)).to(dev), 10)
+        ids = np.nonzero(keep)[0]
+        for j in range(4):
+            dist_all = np.array([bin(int(c) ^ int(codes[4 + j, 0])).count("1") for c in codes[keep, 0]])
+            order = np.lexsort((ids, dist_all))[:10]
+            np.testing.assert_array_equal(i[j], ids[order])
+            np.testing.assert_array_equal(d[j], dist_all[order])
+    finally:
+        dist.destroy_process_group()
