@@ -161,10 +161,13 @@ def main() -> None:
     scan_ms.clear(), cands.clear(), fallbacks.clear()
     fence()
     t0 = time.perf_counter()
+    marks = [t0]
     for _ in range(args.steps):
         result = step()
+        marks.append(time.perf_counter())   # a step ends synchronised (the search waits for its status words)
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = np.diff(np.asarray(marks)) * 1e3
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -278,6 +281,7 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "step_ms_p10_p50_p90": [float(np.percentile(step_ms, p)) for p in (10, 50, 90)],   # rank 0's own clock
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
