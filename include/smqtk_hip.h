@@ -152,6 +152,14 @@ int sq_hamming_destroy(sq_handle_t h);
  * required for borrowing; otherwise pass host memory and the library pads). */
 int sq_dense_create(const float* db, int64_t n, int d, int metric, int mem,
                     int64_t id_base, sq_handle_t* out);
+/* Append n_add rows ([n_add][d] float32, host or device) to an index that owns its matrix (created from
+ * host memory); the new rows get the next row ids (id_base + old n ...).  Only the new rows cross PCIe and only
+ * their statistics / scan-copy rows are built; the L2 filter keeps the origin chosen at create.
+ * What FaissNearestNeighborsIndex._update_index does with add_with_ids of the new vectors only
+ * (impls/nn_index/faiss.py:561-640), in place of a rebuild, when no existing descriptor is replaced.
+ * SQ_ERR_UNSUPPORTED for an index that borrows a device matrix (the caller owns that allocation). */
+int sq_dense_append(sq_handle_t h, const float* rows, int64_t n_add, int mem);
+
 /* queries: [nq][d] f32.  out_dist: float32 [nq][k] for SQ_METRIC_L2,
  * float64 [nq][k] for SQ_METRIC_COSINE.  out_idx int64 [nq][k]. */
 int sq_dense_search(sq_handle_t h, const float* queries, int nq, int k,

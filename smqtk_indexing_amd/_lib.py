@@ -36,7 +36,7 @@ EXPORTS = (
     "sq_last_error", "sq_version", "sq_device_count", "sq_device_name",
     "sq_set_option", "sq_get_stats", "sq_itq_hash",
     "sq_hamming_create", "sq_hamming_search", "sq_hamming_destroy",
-    "sq_dense_create", "sq_dense_search", "sq_dense_destroy",
+    "sq_dense_create", "sq_dense_append", "sq_dense_search", "sq_dense_destroy",
     "sq_dense_distances", "sq_merge_topk", "sq_merge_topk_strided",
     "sq_rows_create", "sq_rows_rerank", "sq_rows_destroy",
     "sq_itqfit_create", "sq_itqfit_set_mean", "sq_itqfit_cov", "sq_itqfit_project", "sq_itqfit_iterate",
@@ -78,6 +78,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_hamming_search.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]
     lib.sq_hamming_destroy.argtypes = [c_i64]
     lib.sq_dense_create.argtypes = [c_vp, c_i64, c_int, c_int, c_int, c_i64, ctypes.POINTER(c_i64)]
+    lib.sq_dense_append.argtypes = [c_i64, c_vp, c_i64, c_int]
     lib.sq_dense_search.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]
     lib.sq_dense_destroy.argtypes = [c_i64]
     lib.sq_dense_distances.argtypes = [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_int, c_vp]
@@ -335,6 +336,22 @@ class DenseIndex(_Handle):
         _check(load().sq_dense_search(self.handle, _ptr(q), nq, int(k), _ptr(dist), _ptr(idx), SQ_MEM_HOST, None),
                "sq_dense_search")
         return dist, idx
+
+    def append(self, rows, n: Optional[int] = None, device_ptr: bool = False) -> None:
+        """Append rows (``[m, d]`` float32 host array, or a device pointer + ``n``) to an index created from host
+        memory; they get the next row ids.  ``sq_dense_append``."""
+        if device_ptr:
+            assert n is not None
+            ptr, mem, m = _ptr(rows), SQ_MEM_DEVICE, int(n)
+        else:
+            rows = _host(rows, np.float32)
+            if rows.ndim != 2 or rows.shape[1] != self.d:
+                raise ValueError("rows must be float32[m, d]")
+            ptr, mem, m = _ptr(rows), SQ_MEM_HOST, int(rows.shape[0])
+        if m == 0:
+            return
+        _check(load().sq_dense_append(self.handle, ptr, m, mem), "sq_dense_append")
+        self.n += m
 
     def search_device(self, q_ptr: int, nq: int, k: int, out_dist_ptr: int, out_idx_ptr: int, stream: int = 0) -> None:
         _check(load().sq_dense_search(self.handle, _ptr(q_ptr), int(nq), int(k), _ptr(out_dist_ptr),

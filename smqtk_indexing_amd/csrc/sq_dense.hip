@@ -507,6 +507,83 @@ static int dense_search_chunked(DenseHandle* h, const float* q, int nq, int k, v
     return SQ_OK;
 }
 
+// Row statistics and the bfloat16 scan copy of rows [row_base, n) -- row_base a multiple of 32 -- plus the padding
+// rows of the last tile: the whole matrix at create (row_base = 0), the new rows on append.  The buffers are
+// already large enough (dense_grow); the largest squared norm accumulates across calls.
+static int dense_build_rows(DenseHandle* h, long long row_base) {
+    const long long n = h->n, n_pad = h->n_pad;
+    const int d = h->d, d_pad = h->d_pad;
+    const bool cosine = h->metric == SQ_METRIC_COSINE;
+    SQ_TRY(h->scratch.reserve(256));
+    float prev = (float)h->xn2_max;
+    SQ_HIP(hipMemset(h->scratch.p, 0, 256));
+    SQ_HIP(hipMemcpy(h->scratch.p, &prev, 4, hipMemcpyHostToDevice));  // non-negative floats order like their bits
+    DevBuf inv;  // cosine: 1/|x| of the rows being built, indexed by row - row_base
+    float* invp = nullptr;
+    if (cosine) {
+        SQ_TRY(inv.reserve((size_t)(n_pad - row_base) * 4));
+        invp = inv.as<float>() - row_base;
+        hipLaunchKernelGGL(dense_cos_norm_kernel, dim3((unsigned)((n - row_base + 255) / 256)), dim3(256), 0, 0, h->db, n,
+                           h->ld, d, h->cos_nx.as<double>(), row_base);
+    }
+    float* centerp = h->center.p ? h->center.as<float>() : nullptr;
+    float* norms1p = nullptr;
+    double shrink2 = 1.0, shrink1 = 1.0;
+    if (!cosine) {
+        // the row's share alpha |x|^2 of the filter's error bound comes off the stored norm (FilterBound)
+        norms1p = h->norms1.as<float>();
+        shrink2 = 1.0 - filter_bound(0, kEpsA2, dense_eps_b(d_pad), 0.0).alpha;
+        shrink1 = 1.0 - filter_bound(0, kEpsA1, dense_eps_b(d_pad), 0.0).alpha;
+    }
+    hipLaunchKernelGGL(dense_rowstats_kernel, dim3((unsigned)((n_pad - row_base) / 32)), dim3(256), 0, 0, h->db, n, h->ld,
+                       d, n_pad, h->scratch.as<u32>(), h->norms.as<float>(), invp, centerp, norms1p, shrink2, shrink1,
+                       row_base);
+    if (d_pad <= MAX_DPAD) {
+        const long long chunks = (n_pad - row_base) * (long long)(d_pad / 8);
+        hipLaunchKernelGGL(dense_build_scan_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, 0, h->db, n,
+                           h->ld, d, d_pad, n_pad, invp, centerp, h->scan.as<uint4>(), row_base);
+    }
+    u32 bits = 0;
+    hipError_t e = hipMemcpy(&bits, h->scratch.p, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    inv.release();
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "dense index build failed: %s", hipGetErrorString(e));
+    float f;
+    memcpy(&f, &bits, 4);
+    h->xn2_max = (double)f;
+    return SQ_OK;
+}
+
+// Room for `n_new` rows in every per-row buffer, contents kept (grown by half again at least, so a stream of
+// small appends copies the matrix O(log) times).
+static int grow_keep(DevBuf& b, size_t used, size_t need) {
+    if (need <= b.cap) return SQ_OK;
+    DevBuf nb;
+    SQ_TRY(nb.reserve(std::max(need, used + used / 2)));
+    if (used && b.p) {
+        if (hipMemcpy(nb.p, b.p, used, hipMemcpyDeviceToDevice) != hipSuccess) {
+            nb.release();
+            return fail(SQ_ERR_HIP, "device copy failed while growing an index buffer");
+        }
+    }
+    b.release();
+    b = nb;
+    return SQ_OK;
+}
+static int dense_grow(DenseHandle* h, long long n_new) {
+    const long long n_pad_new = (n_new + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+    const bool cosine = h->metric == SQ_METRIC_COSINE;
+    if (h->owned.p || h->n == 0) {
+        SQ_TRY(grow_keep(h->owned, (size_t)h->n * h->ld * 4, (size_t)n_new * h->ld * 4));
+        h->db = h->owned.as<float>();
+    }
+    SQ_TRY(grow_keep(h->norms, (size_t)h->n_pad * 4, (size_t)n_pad_new * 4));
+    if (!cosine) SQ_TRY(grow_keep(h->norms1, (size_t)h->n_pad * 4, (size_t)n_pad_new * 4));
+    if (cosine) SQ_TRY(grow_keep(h->cos_nx, (size_t)h->n * 8, (size_t)n_new * 8));
+    if (h->d_pad <= MAX_DPAD) SQ_TRY(grow_keep(h->scan, (size_t)h->n_pad * h->d_pad * 2, (size_t)n_pad_new * h->d_pad * 2));
+    return SQ_OK;
+}
+
 }  // namespace sq
 
 using namespace sq;
@@ -559,87 +636,65 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
         h->db = h->owned.as<float>();
         h->ld = ldo;
     }
+    // the filter's origin (L2): the column means (float64 sums over row blocks); rows appended later keep it
+    if (metric == SQ_METRIC_L2 && d_pad <= MAX_DPAD && !g_opt.dense_no_center) {
+        int rc = h->center.reserve((size_t)d_pad * 4);
+        if (rc != SQ_OK) return bail(rc);
+        DevBuf colsum;
+        rc = colsum.reserve((size_t)d * 8);
+        if (rc != SQ_OK) return bail(rc);
+        if (hipMemset(colsum.p, 0, (size_t)d * 8) != hipSuccess) {
+            colsum.release();
+            return bail(fail(SQ_ERR_HIP, "memset failed"));
+        }
+        const long long rpb = 512;
+        hipLaunchKernelGGL(dense_colsum_kernel, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, 0, h->db,
+                           (long long)n, h->ld, d, rpb, colsum.as<double>());
+        hipLaunchKernelGGL(dense_center_kernel, dim3((d_pad + 255) / 256), dim3(256), 0, 0, colsum.as<double>(),
+                           (long long)n, d, d_pad, h->center.as<float>());
+        if (hipDeviceSynchronize() != hipSuccess) {
+            colsum.release();
+            return bail(fail(SQ_ERR_HIP, "sq_dense_create: column means failed"));
+        }
+        colsum.release();
+    }
     // row statistics, then the bfloat16 scan copy (skipped for rows wider than the scan kernel covers)
     {
-        int rc = h->scratch.reserve(256);
+        int rc = h->norms.reserve((size_t)h->n_pad * 4);
+        if (rc == SQ_OK && metric == SQ_METRIC_L2) rc = h->norms1.reserve((size_t)h->n_pad * 4);
+        if (rc == SQ_OK && metric == SQ_METRIC_COSINE) rc = h->cos_nx.reserve((size_t)n * 8);
+        if (rc == SQ_OK && d_pad <= MAX_DPAD) rc = h->scan.reserve((size_t)h->n_pad * d_pad * 2);
+        if (rc == SQ_OK) rc = dense_build_rows(h, 0);
         if (rc != SQ_OK) return bail(rc);
-        if (hipMemset(h->scratch.p, 0, 256) != hipSuccess) return bail(fail(SQ_ERR_HIP, "memset failed"));
-        rc = h->norms.reserve((size_t)h->n_pad * 4);
-        if (rc != SQ_OK) return bail(rc);
-        DevBuf inv;
-        float* invp = nullptr;
-        if (metric == SQ_METRIC_COSINE) {
-            rc = inv.reserve((size_t)h->n_pad * 4);
-            if (rc != SQ_OK) return bail(rc);
-            invp = inv.as<float>();
-        }
-        float* centerp = nullptr;
-        if (metric == SQ_METRIC_L2 && d_pad <= MAX_DPAD && !g_opt.dense_no_center) {
-            // the filter's origin: the column means (float64 sums over row blocks)
-            rc = h->center.reserve((size_t)d_pad * 4);
-            if (rc != SQ_OK) return bail(rc);
-            DevBuf colsum;
-            rc = colsum.reserve((size_t)d * 8);
-            if (rc != SQ_OK) return bail(rc);
-            if (hipMemset(colsum.p, 0, (size_t)d * 8) != hipSuccess) {
-                colsum.release();
-                return bail(fail(SQ_ERR_HIP, "memset failed"));
-            }
-            const long long rpb = 512;
-            hipLaunchKernelGGL(dense_colsum_kernel, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, 0, h->db,
-                               (long long)n, h->ld, d, rpb, colsum.as<double>());
-            hipLaunchKernelGGL(dense_center_kernel, dim3((d_pad + 255) / 256), dim3(256), 0, 0, colsum.as<double>(),
-                               (long long)n, d, d_pad, h->center.as<float>());
-            if (hipDeviceSynchronize() != hipSuccess) {
-                colsum.release();
-                return bail(fail(SQ_ERR_HIP, "sq_dense_create: column means failed"));
-            }
-            colsum.release();
-            centerp = h->center.as<float>();
-        }
-        if (metric == SQ_METRIC_COSINE) {
-            rc = h->cos_nx.reserve((size_t)n * 8);
-            if (rc != SQ_OK) return bail(rc);
-            hipLaunchKernelGGL(dense_cos_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, h->db,
-                               (long long)n, h->ld, d, h->cos_nx.as<double>());
-        }
-        float* norms1p = nullptr;
-        double shrink2 = 1.0, shrink1 = 1.0;
-        if (metric == SQ_METRIC_L2) {
-            // the row's share alpha |x|^2 of the filter's error bound comes off the stored norm (FilterBound)
-            rc = h->norms1.reserve((size_t)h->n_pad * 4);
-            if (rc != SQ_OK) {
-                inv.release();
-                return bail(rc);
-            }
-            norms1p = h->norms1.as<float>();
-            shrink2 = 1.0 - filter_bound(0, kEpsA2, dense_eps_b(d_pad), 0.0).alpha;
-            shrink1 = 1.0 - filter_bound(0, kEpsA1, dense_eps_b(d_pad), 0.0).alpha;
-        }
-        hipLaunchKernelGGL(dense_rowstats_kernel, dim3((unsigned)(h->n_pad / 32)), dim3(256), 0, 0, h->db, (long long)n,
-                           h->ld, d, h->n_pad, h->scratch.as<u32>(), h->norms.as<float>(), invp, centerp, norms1p, shrink2,
-                           shrink1);
-        if (d_pad <= MAX_DPAD) {
-            rc = h->scan.reserve((size_t)h->n_pad * d_pad * 2);
-            if (rc != SQ_OK) {
-                inv.release();
-                return bail(rc);
-            }
-            const long long chunks = h->n_pad * (long long)(d_pad / 8);
-            hipLaunchKernelGGL(dense_build_scan_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, 0, h->db,
-                               (long long)n, h->ld, d, d_pad, h->n_pad, invp, centerp, h->scan.as<uint4>());
-        }
-        u32 bits = 0;
-        hipError_t e = hipMemcpy(&bits, h->scratch.p, 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        inv.release();
-        if (e != hipSuccess) return bail(fail(SQ_ERR_HIP, "sq_dense_create: index build failed: %s", hipGetErrorString(e)));
-        float f;
-        memcpy(&f, &bits, 4);
-        h->xn2_max = (double)f;
     }
     *out = register_handle(h);
     return SQ_OK;
+}
+
+extern "C" int sq_dense_append(sq_handle_t hid, const float* rows, int64_t n_add, int mem) {
+    auto* h = static_cast<DenseHandle*>(lookup_handle(hid, H_DENSE));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_dense_append: unknown handle");
+    if (!rows || n_add <= 0) return fail(SQ_ERR_INVALID, "sq_dense_append: bad argument");
+    std::lock_guard<std::mutex> l(h->mu);
+    if (!h->owned.p) return fail(SQ_ERR_UNSUPPORTED, "sq_dense_append: the index borrows the caller's device matrix");
+    const long long n_old = h->n, n_new = n_old + n_add;
+    if (n_new >= (1ll << 32)) return fail(SQ_ERR_UNSUPPORTED, "sq_dense_append: more than 2^32-1 rows per shard");
+    SQ_HIP(hipSetDevice(h->device));
+    SQ_TRY(dense_grow(h, n_new));
+    float* dst = h->owned.as<float>() + n_old * h->ld;
+    const hipMemcpyKind kind = mem == SQ_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    hipError_t e;
+    if (h->ld == h->d) {
+        e = hipMemcpy(dst, rows, (size_t)n_add * h->d * 4, kind);
+    } else {
+        e = hipMemset(dst, 0, (size_t)n_add * h->ld * 4);
+        if (e == hipSuccess) e = hipMemcpy2D(dst, (size_t)h->ld * 4, rows, (size_t)h->d * 4, (size_t)h->d * 4, (size_t)n_add, kind);
+    }
+    if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_dense_append: copy failed: %s", hipGetErrorString(e));
+    h->n = n_new;
+    h->n_pad = (n_new + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+    // the tile the old rows ended in is rebuilt together with the new ones (its padding rows become real rows)
+    return dense_build_rows(h, n_old / TILE_ROWS * TILE_ROWS);
 }
 
 extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, int k, void* out_dist, int64_t* out_idx,

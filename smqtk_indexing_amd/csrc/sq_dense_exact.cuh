@@ -136,8 +136,8 @@ __device__ __forceinline__ double cosine_dot_pair_f64(const float* __restrict__ 
 
 // |x|^2 per row in the reference order (index build, cosine only).
 static __global__ __launch_bounds__(256) void dense_cos_norm_kernel(const float* __restrict__ db, long long n, long long ld,
-                                                                     int d, double* __restrict__ nx64) {
-    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+                                                                     int d, double* __restrict__ nx64, long long row_base) {
+    const long long row = row_base + (long long)blockIdx.x * 256 + threadIdx.x;
     if (row < n) nx64[row] = cosine_sumsq_f64(db + row * ld, d);
 }
 // |q|^2 per query in the reference order.

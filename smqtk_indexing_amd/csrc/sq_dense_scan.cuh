@@ -81,9 +81,9 @@ static __global__ __launch_bounds__(256) void dense_build_scan_kernel(const floa
                                                                        long long n_pad,
                                                                        const float* __restrict__ row_scale,
                                                                        const float* __restrict__ center,
-                                                                       uint4* __restrict__ scan) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+                                                                       uint4* __restrict__ scan, long long row_base) {
     const int cpr = d_pad / 8;  // chunks per row
+    const long long idx = row_base * cpr + (long long)blockIdx.x * 256 + threadIdx.x;  // rows from row_base on (append)
     if (idx >= n_pad * cpr) return;
     const long long row = idx / cpr;
     const int cc = (int)(idx - row * cpr);
@@ -118,9 +118,9 @@ static __global__ __launch_bounds__(256) void dense_rowstats_kernel(const float*
                                                                      float* __restrict__ inv_norm,
                                                                      const float* __restrict__ center,
                                                                      float* __restrict__ norms1, double shrink2,
-                                                                     double shrink1) {
+                                                                     double shrink1, long long row_base) {
     const int lane8 = threadIdx.x & 7;
-    const long long row = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const long long row = row_base + (long long)blockIdx.x * 32 + (threadIdx.x >> 3);  // rows from row_base on (append)
     const long long r = row < n ? row : n - 1;
     const float* x = db + r * ld;
     double acc = 0.0;

@@ -103,10 +103,21 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
             new: Dict[Hashable, DescriptorElement] = {}
             for d in descriptors:
                 new[d.uuid()] = d
-            kept = [e for e in self._elements if e.uuid() not in new]
-            keep_rows = [self._row_of[e.uuid()] for e in kept]
             add = list(new.values())
             add_m = self._to_matrix(add)
+            if self._elements and self._dev is not None and add_m.shape[1] == self._matrix.shape[1] \
+                    and not any(u in self._row_of for u in new):
+                # nothing replaced: the new rows go behind the resident matrix (sq_dense_append, what
+                # faiss.py:561-640 does with add_with_ids), no rebuild and no re-upload of the old rows
+                self._dev.append(add_m)
+                base = len(self._elements)
+                self._elements.extend(add)
+                self._row_of.update({e.uuid(): base + i for i, e in enumerate(add)})
+                self._matrix = np.vstack([self._matrix, add_m])
+                self._all_f32 = self._all_f32 and all(np.asarray(e.vector()).dtype == np.float32 for e in add)
+                return
+            kept = [e for e in self._elements if e.uuid() not in new]
+            keep_rows = [self._row_of[e.uuid()] for e in kept]
             if kept:
                 matrix = np.vstack([self._matrix[keep_rows], add_m])
             else:

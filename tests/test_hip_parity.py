@@ -164,6 +164,42 @@ def test_dense_exact_path_two_level_select(metric):
     assert idx.stats()["fallback_queries"] == 2
 
 
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_dense_append_equals_a_fresh_index(metric):
+    """sq_dense_append: rows added behind a resident matrix (partial last tile, several appends, one
+    that forces the buffers to grow) answer exactly like an index built from the concatenation."""
+    rng = np.random.default_rng(41)
+    m = _lib.SQ_METRIC_L2 if metric == "euclidean" else _lib.SQ_METRIC_COSINE
+    d = 96
+    parts = [rng.standard_normal((n, d)).astype(np.float32) + (0.5 if i else 0.0) for i, n in enumerate((70_003, 1_000, 37, 120_000))]
+    parts[1][5] = parts[0][9]                                        # a tie between an old and an appended row
+    qs = rng.standard_normal((5, d)).astype(np.float32)
+    qs[0] = parts[0][9]
+    grown = _lib.DenseIndex(parts[0], metric=m)
+    for upto in range(1, len(parts)):
+        grown.append(parts[upto])
+        whole = np.vstack(parts[: upto + 1])
+        assert grown.n == len(whole)
+        fresh = _lib.DenseIndex(whole, metric=m)
+        for k in (1, 40):
+            gd, gi = grown.search(qs, k)
+            fd, fi = fresh.search(qs, k)
+            np.testing.assert_array_equal(gi, fi)
+            np.testing.assert_array_equal(gd.view(np.uint64 if metric == "cosine" else np.uint32),
+                                          fd.view(np.uint64 if metric == "cosine" else np.uint32))
+        rd, ri = O.dense_topk(whole, qs[0], 40, metric)
+        np.testing.assert_array_equal(gi[0], ri)
+        fresh.close()
+    grown.close()
+    # an index over a borrowed device matrix cannot grow in place
+    import torch
+    t = torch.from_numpy(parts[0][:4096]).cuda()
+    b = _lib.DenseIndex(t.data_ptr(), n=4096, d=d, metric=m, device_ptr=True, keepalive=t)
+    with pytest.raises(_lib.HipError):
+        b.append(parts[1])
+    b.close()
+
+
 @pytest.mark.parametrize("tag", list(GI.DENSE_CASES))
 @pytest.mark.parametrize("metric", ["euclidean", "cosine"])
 def test_dense_golden_cases(golden, tag, metric):

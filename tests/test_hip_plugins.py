@@ -476,3 +476,26 @@ def test_mutable_sharded_index_rccl_world1():
             np.testing.assert_array_equal(d[j], dist_all[order])
     finally:
         dist.destroy_process_group()
+
+
+def test_bruteforce_update_appends_on_the_device():
+    """update_index with only new uuids takes sq_dense_append (no rebuild); with a replaced uuid it rebuilds.
+    Either way the answers are those of a freshly built index."""
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((66_000, 32)).astype(np.float32)
+    idx = HipBruteForceNearestNeighborsIndex()
+    idx.build_index(_elems(x[:65_700]))
+    q = DescriptorMemoryElement("q").set_vector(x[65_800] + 0.001)
+    idx.nn(q, 3)                                                  # the device copy exists from here on
+    dev = idx._dev
+    idx.update_index(_elems(x[65_700:], base=65_700))
+    assert idx._dev is dev and dev.n == 66_000                    # appended in place
+    r, dist = idx.nn(q, 5)
+    fresh = HipBruteForceNearestNeighborsIndex()
+    fresh.build_index(_elems(x))
+    r2, dist2 = fresh.nn(q, 5)
+    assert [e.uuid() for e in r] == [e.uuid() for e in r2] and r[0].uuid() == 65_800
+    assert dist == dist2
+    idx.update_index([DescriptorMemoryElement(7).set_vector(x[65_800] + 0.0001)])   # replaces uuid 7: rebuild
+    assert idx._dev is not dev and idx.count() == 66_000
+    assert idx.nn(q, 1)[0][0].uuid() == 7
