@@ -77,7 +77,8 @@ int sq_device_name(int device, char* out_name, int name_len, int64_t* out_total_
 /* options: "profile" (0/1: record hipEvents so sq_get_stats reports ms),
  * "sample_stride" (0 = auto), "candidate_cap" (0 = auto),
  * "force_fallback" (0/1: every query takes the exact full-keys path),
- * "merge_threads" (host threads of sq_merge_topk, 0 = by size);
+ * "merge_threads" (host threads of sq_merge_topk, 0 = by size),
+ * "spin_wait_us" (a search polls its stream this long before it blocks; default 2000, 0 = block at once);
  * measurement / test knobs of the dense scan (0 = auto): "dense_qt" (1, 2 or 4
  * query tiles per scan wave), "dense_waves" (4 or 8), "dense_stages" (ring
  * depth), "dense_blocks" (row blocks), "dense_rerank_segments" (survivor

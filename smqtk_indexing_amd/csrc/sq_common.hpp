@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -58,9 +60,29 @@ struct Options {
     int dense_no_center = 0;     // 1 = the dense L2 filter scores the rows as given (no column-mean origin; measurement)
     int dense_rerank_segments = 0;  // survivor segments per re-rank workgroup (0 = all waves of a scan workgroup; measurement)
     int merge_threads = 0;       // host threads of the shard merge (0 = by size)
+    int spin_wait_us = 2000;     // searches poll the stream this long before blocking (0 = block at once)
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
 };
 extern Options g_opt;
+
+// Wait for a stream the way a latency-bound caller wants to: poll hipStreamQuery for a while (a search is
+// a fraction of a millisecond; the blocking wait's wake-up costs tens of microseconds of it), then block.
+// Option "spin_wait_us" (default 2000; 0 = always block).
+inline hipError_t stream_wait(hipStream_t st) {
+    const long long budget_us = g_opt.spin_wait_us;
+    if (budget_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int i = 0; i < 64; ++i) {
+                const hipError_t e = hipStreamQuery(st);
+                if (e != hipErrorNotReady) return e;
+            }
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > budget_us)
+                break;
+        }
+    }
+    return hipStreamSynchronize(st);
+}
 
 // ------------------------------------------------------- device buffer (RAII)
 struct DevBuf {

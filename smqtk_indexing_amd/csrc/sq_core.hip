@@ -86,6 +86,7 @@ extern "C" int sq_set_option(const char* name, int64_t value) {
     else if (n == "hamming_no_permute") g_opt.hamming_no_permute = (int)value;
     else if (n == "dense_no_center") g_opt.dense_no_center = (int)value;
     else if (n == "merge_threads") g_opt.merge_threads = (int)value;
+    else if (n == "spin_wait_us") g_opt.spin_wait_us = (int)value;
     else if (n == "dense_rerank_segments") g_opt.dense_rerank_segments = (int)value;
     else if (n == "dense_qplanes") g_opt.dense_qplanes = (int)value;
     else return fail(SQ_ERR_INVALID, "sq_set_option: unknown option '%s'", name);

@@ -357,7 +357,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     }
     if (prof) SQ_HIP(hipEventRecord(h->ev[3], st));
     if (!all_fallback) {
-        SQ_HIP(hipStreamSynchronize(st));  // counts and status words are in hs_raw / hs now
+        SQ_HIP(stream_wait(st));  // counts and status words are in hs_raw / hs now
         SQ_HIP(hipGetLastError());
         if (prof) {
             float t1 = 0, t2 = 0;
@@ -453,7 +453,7 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
                                                             (float*)out_dist, out_idx, hs_dev, nullptr, nullptr, 0, grp},
                                             st));
             }
-            SQ_HIP(hipStreamSynchronize(st));  // the status words of the group are in hs now
+            SQ_HIP(stream_wait(st));  // the status words of the group are in hs now
             SQ_HIP(hipGetLastError());
             for (int g = 0; g < gn; ++g) done[g] = hs[grp.idx[g]] == 0;
         }

@@ -609,7 +609,7 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
     if (prof) SQ_HIP(hipEventRecord(h->ev[3], st));
     // status words and candidate counts are in pinned host memory once the stream drains (written by the
     // finalisation): the host decides whether any query needs the exact path
-    SQ_HIP(hipStreamSynchronize(st));
+    SQ_HIP(stream_wait(st));
     SQ_HIP(hipGetLastError());
     if (prof) {
         float a = 0, b = 0;

@@ -200,7 +200,7 @@ extern "C" int sq_rows_rerank(sq_handle_t hid, const void* queries, int nq, int 
     if (rc != SQ_OK) return rc;
     SQ_HIP(hipMemcpyAsync(out_dist, h->out_dist.p, (size_t)nq * k * dsz, hipMemcpyDeviceToHost, st));
     SQ_HIP(hipMemcpyAsync(out_pos, h->out_pos.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
-    SQ_HIP(hipStreamSynchronize(st));
+    SQ_HIP(stream_wait(st));
     return SQ_OK;
 }
 
