@@ -182,11 +182,13 @@ def main() -> None:
         qn = queries[:2].cpu().numpy()
         gd, gi = idx_sub.search(qn, k)
         dbh = db[:sub].cpu().numpy()
-        ok = True
+        ok, hits = True, 0
         for j in range(qn.shape[0]):
             rd, ri = O.dense_topk(dbh, qn[j], k)
             ok &= bool(np.array_equal(gi[j], ri) and np.array_equal(gd[j].view(np.uint32), rd.view(np.uint32)))
-        parity = {"rows": sub, "queries": int(qn.shape[0]), "bit_identical_topk": ok}
+            hits += len(set(gi[j].tolist()) & set(ri.tolist()))
+        parity = {"rows": sub, "queries": int(qn.shape[0]), "bit_identical_topk": ok,
+                  "recall_at_k": hits / float(k * qn.shape[0])}
         del dbh
         idx_sub.close()
 
