@@ -8,7 +8,8 @@ HBM bandwidth of the scan kernel against the ~8 TB/s peak (BASELINE.json).
 
 A "step" is one search call: 32 queries per GPU through the whole hot path
 (query prep -> sampled threshold -> MFMA scan of the shard -> exact re-rank ->
-top-k select -> certification [-> all-gather + host merge when N > 1]).
+top-k select -> certification [-> all-gather + host merge when N > 1; rank 0 merges batch i on a
+host thread while the GPUs search batch i + 1, every merge inside the timed region]).
 The database (10M rows in total) is row-sharded over the N ranks and already
 resident in HBM; a step carries 32*N queries (weak scaling: the per-GPU MFMA
 work per step is fixed; the per-GPU HBM bytes shrink with the shard).
@@ -125,8 +126,17 @@ def main() -> None:
         out_i = send[: nq * k * 8].view(torch.int64).view(nq, k)
         out_d = send[nq * k * 8:].view(torch.float32).view(nq, k)
         recv = torch.empty((world, nq * k * 12), dtype=torch.uint8, device=dev)
-        host_recv = torch.empty((world, nq * k * 12), dtype=torch.uint8, pin_memory=True)
-        host_np = host_recv.numpy().reshape(-1)
+        # Rank 0 merges batch i on a host thread (distributed.PipelinedMerger) while the GPUs search batch
+        # i + 1: two pinned receive buffers alternate, a buffer is refilled only after its merge was collected.
+        # Every merge finishes inside the timed region (the last one is collected before the closing fence).
+        host_recv = [torch.empty((world, nq * k * 12), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        host_np = [h.numpy().reshape(-1) for h in host_recv]
+        merger = None
+        pending = [None, None]   # ticket of the merge reading host_recv[j]
+        if rank == 0:
+            from smqtk_indexing_amd.distributed import PipelinedMerger
+            merger = PipelinedMerger()
+        step_no = [0]
     else:
         out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
         out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
@@ -144,11 +154,25 @@ def main() -> None:
             # per-shard top-k candidates over xGMI, then the host-side merge (north_star)
             dist.all_gather_into_tensor(recv, send)
             if rank == 0:
-                host_recv.copy_(recv, non_blocking=True)
+                j = step_no[0] & 1
+                step_no[0] += 1
+                res = merger.result(pending[j]) if pending[j] is not None else None   # batch i - 2: long done
+                host_recv[j].copy_(recv, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
-                return _lib.merge_topk_gathered(host_np, world, nq, k, k, np.float32)
+                pending[j] = merger.submit(host_np[j], world, nq, k, k, np.float32)
+                return res
             return None
         return out_d, out_i
+
+    def drain():
+        """Collect the merges still in flight (rank 0): part of the timed region."""
+        out = None
+        if use_dist and rank == 0:
+            for j in range(2):
+                if pending[j] is not None:
+                    out = merger.result(pending[j])
+                    pending[j] = None
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -158,6 +182,7 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
+    drain()
     scan_ms.clear(), cands.clear(), fallbacks.clear()
     fence()
     t0 = time.perf_counter()
@@ -165,6 +190,9 @@ def main() -> None:
     for _ in range(args.steps):
         result = step()
         marks.append(time.perf_counter())   # a step ends synchronised (the search waits for its status words)
+    last = drain()
+    if last is not None:
+        result = last
     fence()
     elapsed = time.perf_counter() - t0
     step_ms = np.diff(np.asarray(marks)) * 1e3
@@ -172,6 +200,12 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- one rank through the collective path: the merged answer must be the shard's own answer
+    if use_dist and world == 1 and result is not None:
+        md, mi = result
+        assert np.array_equal(mi, out_i.cpu().numpy()) and np.array_equal(md, out_d.cpu().numpy()), \
+            "merged result differs from the shard's top-k"
 
     # ---- parity spot check against the oracle (outside the timed region)
     parity = None
@@ -294,7 +328,7 @@ def main() -> None:
                 "db_rows_total": n_total, "db_rows_per_gpu": n_local, "dim": d, "k": k,
                 "queries_per_step": nq, "queries_per_step_per_gpu": args.queries_per_gpu,
                 "sharding": "rows" if world > 1 else "none",
-                "collective": "all_gather(top-k dist,idx) + host merge" if use_dist else "none",
+                "collective": "all_gather(top-k dist,idx) + host merge (on a host thread, under the next batch's search)" if use_dist else "none",
                 "mean_candidates_per_query": float(np.mean(cands)) / nq if cands else None,
                 "fallback_queries": int(np.sum(fallbacks)) if fallbacks else 0,
             },
@@ -342,6 +376,8 @@ def main() -> None:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if use_dist:
+        if merger is not None:
+            merger.close()
         dist.barrier()
         dist.destroy_process_group()
     index.close()

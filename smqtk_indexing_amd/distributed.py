@@ -282,3 +282,56 @@ def hamming_local_builder() -> Callable:
         search.index = index  # type: ignore[attr-defined]
         return search
     return build
+
+
+class PipelinedMerger:
+    """Host merges of gathered top-k buffers on a worker thread, so that rank 0 merges batch i while the
+    GPUs already search batch i + 1 (the merge is ``sq_merge_topk_strided``: a ctypes call, the GIL is
+    released for its duration).  ``submit`` hands over a receive buffer (one all-gather's host copy,
+    ``[shards][ids int64 nq*k | dist nq*k]``) and returns a ticket; ``result(ticket)`` waits for that merge.
+    Depth is the caller's business: a buffer must not be refilled before its ticket has been collected.
+    """
+
+    def __init__(self):
+        import queue
+        import threading
+        self._jobs: "queue.Queue" = queue.Queue()
+        self._done = {}
+        self._cv = threading.Condition()
+        self._next = 0
+        self._thread = threading.Thread(target=self._run, name="sq-merge", daemon=True)
+        self._thread.start()
+
+    def _run(self) -> None:
+        from . import _lib
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            ticket, buf, shards, nq, k_in, k_out, dt = job
+            try:
+                res = _lib.merge_topk_gathered(buf, shards, nq, k_in, k_out, dt)
+            except Exception as ex:  # noqa: BLE001 -- handed to the caller of result()
+                res = ex
+            with self._cv:
+                self._done[ticket] = res
+                self._cv.notify_all()
+
+    def submit(self, buf: np.ndarray, shards: int, nq: int, k_in: int, k_out: int, dist_dtype) -> int:
+        ticket = self._next
+        self._next += 1
+        self._jobs.put((ticket, buf, int(shards), int(nq), int(k_in), int(k_out), dist_dtype))
+        return ticket
+
+    def result(self, ticket: int):
+        with self._cv:
+            while ticket not in self._done:
+                self._cv.wait()
+            res = self._done.pop(ticket)
+        if isinstance(res, Exception):
+            raise res
+        return res
+
+    def close(self) -> None:
+        self._jobs.put(None)
+        self._thread.join()

@@ -111,6 +111,33 @@ def test_host_merge_equals_a_lexsort_of_the_concatenation(shards, dtype, levels)
             assert (oi[q, m:] == -1).all()
 
 
+def test_pipelined_merger_matches_the_direct_merge():
+    """The worker-thread merger used by the multi-GPU bench: several buffers in flight, results by ticket,
+    errors surfaced at result()."""
+    from smqtk_indexing_amd.distributed import PipelinedMerger
+    rng = np.random.default_rng(12)
+    shards, nq, k = 4, 6, 9
+    bufs = []
+    for _ in range(5):
+        d = np.sort(rng.random((shards, nq, k)).astype(np.float32), axis=2)
+        i = rng.permutation(shards * nq * k).reshape(shards, nq, k).astype(np.int64)
+        buf = np.empty((shards, nq * k * 12), np.uint8)
+        for s_ in range(shards):
+            buf[s_, :nq * k * 8] = i[s_].view(np.uint8).reshape(-1)
+            buf[s_, nq * k * 8:] = d[s_].view(np.uint8).reshape(-1)
+        bufs.append((buf.reshape(-1), _lib.merge_topk(d, i, k)))
+    pm = PipelinedMerger()
+    tickets = [pm.submit(b, shards, nq, k, k, np.float32) for b, _ in bufs]
+    for t, (_, ref) in reversed(list(zip(tickets, bufs))):          # collected out of order
+        od, oi = pm.result(t)
+        np.testing.assert_array_equal(od, ref[0])
+        np.testing.assert_array_equal(oi, ref[1])
+    bad = pm.submit(np.zeros(7, np.uint8), shards, nq, k, k, np.float32)   # wrong buffer size
+    with pytest.raises(ValueError):
+        pm.result(bad)
+    pm.close()
+
+
 def test_bad_arguments_are_reported_not_crashed():
     with pytest.raises(_lib.HipError):
         _lib.merge_topk(np.zeros((1, 1, 1), np.float32), np.zeros((1, 1, 1), np.int64), 0)
