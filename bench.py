@@ -8,8 +8,9 @@ HBM bandwidth of the scan kernel against the ~8 TB/s peak (BASELINE.json).
 
 A "step" is one search call: 32 queries per GPU through the whole hot path
 (query prep -> sampled threshold -> MFMA scan of the shard -> exact re-rank ->
-top-k select -> certification [-> all-gather + host merge when N > 1; rank 0 merges batch i on a
-host thread while the GPUs search batch i + 1, every merge inside the timed region]).
+top-k select -> certification [-> all-gather + host merge when N > 1: the all-gather of batch i and its
+copy to pinned memory run on their own streams under the search of batch i + 1, rank 0 merges on a host
+thread meanwhile; every batch is merged inside the timed region]).
 The database (10M rows in total) is row-sharded over the N ranks and already
 resident in HBM; a step carries 32*N queries (weak scaling: the per-GPU MFMA
 work per step is fixed; the per-GPU HBM bytes shrink with the shard).
@@ -118,25 +119,16 @@ def main() -> None:
     _lib.set_option("profile", 1)
     index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=_lib.SQ_METRIC_L2, device_ptr=True,
                             id_base=r0, keepalive=db)
+    pipe = None
     if use_dist:
-        # One collective per step and no repacking: the search writes its ids and distances into the
-        # two halves of ONE byte buffer ([ids int64 nq*k][dist float32 nq*k]), that buffer is
-        # all-gathered, and the host merge reads the pinned receive buffer in place.
-        send = torch.empty(nq * k * 12, dtype=torch.uint8, device=dev)
-        out_i = send[: nq * k * 8].view(torch.int64).view(nq, k)
-        out_d = send[nq * k * 8:].view(torch.float32).view(nq, k)
-        recv = torch.empty((world, nq * k * 12), dtype=torch.uint8, device=dev)
-        # Rank 0 merges batch i on a host thread (distributed.PipelinedMerger) while the GPUs search batch
-        # i + 1: two pinned receive buffers alternate, a buffer is refilled only after its merge was collected.
-        # Every merge finishes inside the timed region (the last one is collected before the closing fence).
-        host_recv = [torch.empty((world, nq * k * 12), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-        host_np = [h.numpy().reshape(-1) for h in host_recv]
-        merger = None
-        pending = [None, None]   # ticket of the merge reading host_recv[j]
-        if rank == 0:
-            from smqtk_indexing_amd.distributed import PipelinedMerger
-            merger = PipelinedMerger()
-        step_no = [0]
+        # One collective per step and no repacking: the search writes its ids and distances into the two halves
+        # of ONE byte buffer ([ids int64 nq*k][dist float32 nq*k]), that buffer is all-gathered and the host merge
+        # reads the pinned copy of the receive buffer in place.  distributed.PipelinedShardedSearch keeps the
+        # collective and the merge off the critical path: the all-gather of batch i (RCCL's stream) and its copy
+        # to pinned memory (a side stream) run under the search of batch i + 1, rank 0 merges batch i - 1 on a
+        # host thread meanwhile; results arrive two submits later and every one of them inside the timed region.
+        from smqtk_indexing_amd.distributed import PipelinedShardedSearch
+        pipe = PipelinedShardedSearch(index, nq, k, torch.float32, merge_on=0, device=dev)
     else:
         out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
         out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
@@ -145,36 +137,23 @@ def main() -> None:
     scan_ms, cands, fallbacks = [], [], []
 
     def step():
-        index.search_device(queries.data_ptr(), nq, k, out_d.data_ptr(), out_i.data_ptr(), stream)
+        if use_dist:
+            res = pipe.submit(queries)       # per-shard top-k over xGMI, then the host-side merge (north_star)
+        else:
+            index.search_device(queries.data_ptr(), nq, k, out_d.data_ptr(), out_i.data_ptr(), stream)
+            res = (out_d, out_i)
         st = index.stats()
         scan_ms.append(st["scan_ms"])
         cands.append(st["candidates"])
         fallbacks.append(st["fallback_queries"])
-        if use_dist:
-            # per-shard top-k candidates over xGMI, then the host-side merge (north_star)
-            dist.all_gather_into_tensor(recv, send)
-            if rank == 0:
-                j = step_no[0] & 1
-                step_no[0] += 1
-                res = merger.result(pending[j]) if pending[j] is not None else None   # batch i - 2: long done
-                host_recv[j].copy_(recv, non_blocking=True)
-                cur = torch.cuda.current_stream()
-                while not cur.query():      # poll like the library's searches do (the blocking wait's wake-up is ~10 us)
-                    pass
-                pending[j] = merger.submit(host_np[j], world, nq, k, k, np.float32)
-                return res
-            return None
-        return out_d, out_i
+        return res
 
     def drain():
-        """Collect the merges still in flight (rank 0): part of the timed region."""
-        out = None
-        if use_dist and rank == 0:
-            for j in range(2):
-                if pending[j] is not None:
-                    out = merger.result(pending[j])
-                    pending[j] = None
-        return out
+        """Collect the batches still in flight (collective + merge): part of the timed region."""
+        if use_dist:
+            out = pipe.flush()
+            return out[-1] if out else None
+        return None
 
     def fence():
         torch.cuda.synchronize()
@@ -206,7 +185,8 @@ def main() -> None:
     # ---- one rank through the collective path: the merged answer must be the shard's own answer
     if use_dist and world == 1 and result is not None:
         md, mi = result
-        assert np.array_equal(mi, out_i.cpu().numpy()) and np.array_equal(md, out_d.cpu().numpy()), \
+        jl = (pipe.i - 1) & 1
+        assert np.array_equal(mi, pipe.out_i[jl].cpu().numpy()) and np.array_equal(md, pipe.out_d[jl].cpu().numpy()), \
             "merged result differs from the shard's top-k"
 
     # ---- parity spot check against the oracle (outside the timed region)
@@ -330,7 +310,7 @@ def main() -> None:
                 "db_rows_total": n_total, "db_rows_per_gpu": n_local, "dim": d, "k": k,
                 "queries_per_step": nq, "queries_per_step_per_gpu": args.queries_per_gpu,
                 "sharding": "rows" if world > 1 else "none",
-                "collective": "all_gather(top-k dist,idx) + host merge (on a host thread, under the next batch's search)" if use_dist else "none",
+                "collective": "all_gather(top-k dist,idx) + host merge, both overlapped with the next batch's search" if use_dist else "none",
                 "mean_candidates_per_query": float(np.mean(cands)) / nq if cands else None,
                 "fallback_queries": int(np.sum(fallbacks)) if fallbacks else 0,
             },
@@ -378,8 +358,7 @@ def main() -> None:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if use_dist:
-        if merger is not None:
-            merger.close()
+        pipe.close()
         dist.barrier()
         dist.destroy_process_group()
     index.close()

@@ -335,3 +335,100 @@ class PipelinedMerger:
     def close(self) -> None:
         self._jobs.put(None)
         self._thread.join()
+
+
+class PipelinedShardedSearch:
+    """Batches through a sharded index with the collective and the merge off the critical path.
+
+    ``submit(queries)`` runs the local search of batch i on the pipeline's own compute stream (the C ABI call
+    returns when the shard's answer is in the send buffer), starts the all-gather of batch i asynchronously
+    (RCCL's stream) and, on the merging rank, the copy of the gathered buffer to pinned host memory on torch's
+    current stream -- both run under the search of batch i + 1 -- then hands batch i - 1's host buffer to the
+    merge thread (:class:`PipelinedMerger`) and returns the merged result of batch i - 2 (``None`` for the
+    first two calls and on the other ranks).  ``flush()`` returns the results still in flight, oldest first.
+    Two send / receive / host buffers alternate; every reuse is ordered behind the previous user.
+    ``index``: ``_lib.DenseIndex`` or ``_lib.HammingIndex`` over the rank's shard (ids already global).
+    """
+
+    def __init__(self, index, nq: int, k: int, dist_dtype, group=None, merge_on: int = 0, device=None):
+        import torch
+        import torch.distributed as dist
+        self.index, self.nq, self.k, self.group = index, int(nq), int(k), group
+        self.world, self.rank, self.merge_on = dist.get_world_size(group), dist.get_rank(group), merge_on
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        esz = torch.empty(0, dtype=dist_dtype).element_size()
+        self.np_dt = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32}[dist_dtype]
+        per = self.nq * self.k * (8 + esz)
+        self.send = [torch.empty(per, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.out_i = [s[: self.nq * self.k * 8].view(torch.int64).view(self.nq, self.k) for s in self.send]
+        self.out_d = [s[self.nq * self.k * 8:].view(dist_dtype).view(self.nq, self.k) for s in self.send]
+        self._ptr_d = [t.data_ptr() for t in self.out_d]
+        self._ptr_i = [t.data_ptr() for t in self.out_i]
+        self.recv = [torch.empty((self.world, per), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.work = [None, None]
+        self.i = 0
+        self.compute = torch.cuda.Stream(device=dev)     # the searches; collectives and copies stay on the current stream
+        self._compute_handle = self.compute.cuda_stream
+        self.merging = self.rank == merge_on
+        if self.merging:
+            self.host = [torch.empty((self.world, per), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            self.host_np = [h.numpy().reshape(-1) for h in self.host]
+            self.copied = [torch.cuda.Event(), torch.cuda.Event()]   # host[j] holds the gathered buffer of its batch
+            self.copy_pending = [False, False]
+            self.ticket = [None, None]                                # merge reading host[j]
+            self.merger = PipelinedMerger()
+
+    def _merge_ready(self, j: int) -> None:
+        """Batch in buffer j: its host copy is complete -> to the merge thread."""
+        if self.copy_pending[j]:
+            ev = self.copied[j]
+            while not ev.query():
+                pass
+            self.copy_pending[j] = False
+            self.ticket[j] = self.merger.submit(self.host_np[j], self.world, self.nq, self.k, self.k, self.np_dt)
+
+    def submit(self, queries):
+        import torch.distributed as dist
+        j = self.i & 1
+        self.i += 1
+        w = self.work[j]
+        if w is not None:
+            # batch i - 2's all-gather read send[j] and wrote recv[j]; it finished long ago -- make it formal
+            while not w.is_completed():
+                pass
+            self.work[j] = None
+        self.index.search_device(queries.data_ptr(), self.nq, self.k, self._ptr_d[j], self._ptr_i[j], self._compute_handle)
+        ready = None
+        if self.merging and self.ticket[j] is not None:
+            ready = self.merger.result(self.ticket[j])     # batch i - 2: merged under the search that just returned
+            self.ticket[j] = None
+        # the search call returned: send[j] is complete on the device (the call waits for its stream)
+        self.work[j] = w = dist.all_gather_into_tensor(self.recv[j], self.send[j], group=self.group, async_op=True)
+        if self.merging:
+            w.wait()                                       # orders the current stream (not the host) behind the gather
+            self.host[j].copy_(self.recv[j], non_blocking=True)
+            self.copied[j].record()
+            self.copy_pending[j] = True
+            self._merge_ready(j ^ 1)                       # batch i - 1: gathered and copied under this search
+        return ready
+
+    def flush(self):
+        out = []
+        if self.merging:
+            last = (self.i - 1) & 1 if self.i else 0
+            for j in (last ^ 1, last):                     # oldest first
+                self._merge_ready(j)
+            for j in (last ^ 1, last):
+                if self.ticket[j] is not None:
+                    out.append(self.merger.result(self.ticket[j]))
+                    self.ticket[j] = None
+        for j in range(2):
+            if self.work[j] is not None:
+                self.work[j].wait()
+                self.work[j] = None
+        return out
+
+    def close(self) -> None:
+        self.flush()
+        if self.merging:
+            self.merger.close()

@@ -499,3 +499,43 @@ def test_bruteforce_update_appends_on_the_device():
     idx.update_index([DescriptorMemoryElement(7).set_vector(x[65_800] + 0.0001)])   # replaces uuid 7: rebuild
     assert idx._dev is not dev and idx.count() == 66_000
     assert idx.nn(q, 1)[0][0].uuid() == 7
+
+
+def test_pipelined_sharded_search_rccl_world1():
+    """PipelinedShardedSearch: the all-gather and the host merge of a batch run under the next batch's
+    search; results come back two submits later, in order, and equal the direct search."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from smqtk_indexing_amd.distributed import PipelinedShardedSearch
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29521"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(17)
+        db = torch.from_numpy(rng.standard_normal((120_000, 64)).astype(np.float32)).to(dev)
+        index = _lib.DenseIndex(db.data_ptr(), n=db.shape[0], d=64, device_ptr=True, id_base=500, keepalive=db)
+        nq, k = 7, 15
+        batches = [torch.from_numpy(rng.standard_normal((nq, 64)).astype(np.float32)).to(dev) for _ in range(6)]
+        pipe = PipelinedShardedSearch(index, nq, k, torch.float32, device=dev)
+        got = []
+        for i, q in enumerate(batches):
+            r = pipe.submit(q)
+            assert (r is None) == (i < 2)
+            if r is not None:
+                got.append(r)
+        got += pipe.flush()
+        assert len(got) == len(batches) and pipe.flush() == []
+        for q, (d, i) in zip(batches, got):
+            rd, ri = index.search(q.cpu().numpy(), k)
+            np.testing.assert_array_equal(i, ri)
+            np.testing.assert_array_equal(d.view(np.uint32), rd.view(np.uint32))
+        r = pipe.submit(batches[0])                                   # usable again after a flush
+        assert r is None and len(pipe.flush()) == 1
+        pipe.close()
+        index.close()
+    finally:
+        dist.destroy_process_group()
