@@ -8,9 +8,9 @@ HBM bandwidth of the scan kernel against the ~8 TB/s peak (BASELINE.json).
 
 A "step" is one search call: 32 queries per GPU through the whole hot path
 (query prep -> sampled threshold -> MFMA scan of the shard -> exact re-rank ->
-top-k select -> certification [-> all-gather + host merge when N > 1: the all-gather of batch i and its
-copy to pinned memory run on their own streams under the search of batch i + 1, rank 0 merges on a host
-thread meanwhile; every batch is merged inside the timed region]).
+top-k select -> certification [-> all-gather + host merge when N > 1: rank 0 merges batch i on a host
+thread while the GPUs search batch i + 1 (--overlap-collective: the all-gather and the pinned copy too);
+every batch is merged inside the timed region]).
 The database (10M rows in total) is row-sharded over the N ranks and already
 resident in HBM; a step carries 32*N queries (weak scaling: the per-GPU MFMA
 work per step is fixed; the per-GPU HBM bytes shrink with the shard).
@@ -46,6 +46,9 @@ def parse_args():
                     help="skip the ITQ / Hamming timings reported beside the headline metric")
     ap.add_argument("--force-collective", action="store_true",
                     help="testing: run the all-gather + merge path even with one rank (launch under torch.distributed.run)")
+    ap.add_argument("--overlap-collective", action="store_true",
+                    help="N > 1: also run the all-gather and the pinned copy of batch i under the search of batch i + 1 "
+                         "(distributed.PipelinedShardedSearch); default: only the host merge is overlapped")
     ap.add_argument("--extra-batches", type=str, default="1,128,1024",
                     help="other batch sizes measured after the timed region (N=1 only); '' to skip")
     return ap.parse_args()
@@ -120,15 +123,30 @@ def main() -> None:
     index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=_lib.SQ_METRIC_L2, device_ptr=True,
                             id_base=r0, keepalive=db)
     pipe = None
-    if use_dist:
-        # One collective per step and no repacking: the search writes its ids and distances into the two halves
-        # of ONE byte buffer ([ids int64 nq*k][dist float32 nq*k]), that buffer is all-gathered and the host merge
-        # reads the pinned copy of the receive buffer in place.  distributed.PipelinedShardedSearch keeps the
-        # collective and the merge off the critical path: the all-gather of batch i (RCCL's stream) and its copy
-        # to pinned memory (a side stream) run under the search of batch i + 1, rank 0 merges batch i - 1 on a
-        # host thread meanwhile; results arrive two submits later and every one of them inside the timed region.
+    merger = None
+    if use_dist and args.overlap_collective:
+        # distributed.PipelinedShardedSearch keeps the collective AND the merge off the critical path: the all-gather
+        # of batch i (asynchronous, RCCL's stream) and its copy to pinned memory run under the search of batch i + 1,
+        # rank 0 merges batch i - 1 on a host thread meanwhile; results arrive two submits later.
         from smqtk_indexing_amd.distributed import PipelinedShardedSearch
         pipe = PipelinedShardedSearch(index, nq, k, torch.float32, merge_on=0, device=dev)
+    elif use_dist:
+        # One collective per step and no repacking: the search writes its ids and distances into the two halves of
+        # ONE byte buffer ([ids int64 nq*k][dist float32 nq*k]), that buffer is all-gathered, and the host merge
+        # reads the pinned copy of the receive buffer in place.  Rank 0 merges batch i on a host thread
+        # (distributed.PipelinedMerger) while the GPUs search batch i + 1: two pinned buffers alternate, a buffer is
+        # refilled only after its merge was collected.  Every merge finishes inside the timed region.
+        send = torch.empty(nq * k * 12, dtype=torch.uint8, device=dev)
+        out_i = send[: nq * k * 8].view(torch.int64).view(nq, k)
+        out_d = send[nq * k * 8:].view(torch.float32).view(nq, k)
+        recv = torch.empty((world, nq * k * 12), dtype=torch.uint8, device=dev)
+        host_recv = [torch.empty((world, nq * k * 12), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        host_np = [h.numpy().reshape(-1) for h in host_recv]
+        pending = [None, None]   # ticket of the merge reading host_recv[j]
+        if rank == 0:
+            from smqtk_indexing_amd.distributed import PipelinedMerger
+            merger = PipelinedMerger()
+        step_no = [0]
     else:
         out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
         out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
@@ -137,7 +155,7 @@ def main() -> None:
     scan_ms, cands, fallbacks = [], [], []
 
     def step():
-        if use_dist:
+        if pipe is not None:
             res = pipe.submit(queries)       # per-shard top-k over xGMI, then the host-side merge (north_star)
         else:
             index.search_device(queries.data_ptr(), nq, k, out_d.data_ptr(), out_i.data_ptr(), stream)
@@ -146,14 +164,32 @@ def main() -> None:
         scan_ms.append(st["scan_ms"])
         cands.append(st["candidates"])
         fallbacks.append(st["fallback_queries"])
+        if use_dist and pipe is None:
+            dist.all_gather_into_tensor(recv, send)
+            res = None
+            if rank == 0:
+                j = step_no[0] & 1
+                step_no[0] += 1
+                res = merger.result(pending[j]) if pending[j] is not None else None   # batch i - 2: long done
+                host_recv[j].copy_(recv, non_blocking=True)
+                cur = torch.cuda.current_stream()
+                while not cur.query():      # poll like the library's searches do (the blocking wait's wake-up is ~10 us)
+                    pass
+                pending[j] = merger.submit(host_np[j], world, nq, k, k, np.float32)
         return res
 
     def drain():
-        """Collect the batches still in flight (collective + merge): part of the timed region."""
-        if use_dist:
-            out = pipe.flush()
-            return out[-1] if out else None
-        return None
+        """Collect the batches still in flight (merge; with --overlap-collective also the gather): timed."""
+        out = None
+        if pipe is not None:
+            got = pipe.flush()
+            out = got[-1] if got else None
+        elif use_dist and rank == 0:
+            for j in ((step_no[0] & 1), (step_no[0] & 1) ^ 1):   # oldest first
+                if pending[j] is not None:
+                    out = merger.result(pending[j])
+                    pending[j] = None
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -185,8 +221,8 @@ def main() -> None:
     # ---- one rank through the collective path: the merged answer must be the shard's own answer
     if use_dist and world == 1 and result is not None:
         md, mi = result
-        jl = (pipe.i - 1) & 1
-        assert np.array_equal(mi, pipe.out_i[jl].cpu().numpy()) and np.array_equal(md, pipe.out_d[jl].cpu().numpy()), \
+        ref_i, ref_d = (pipe.out_i[(pipe.i - 1) & 1], pipe.out_d[(pipe.i - 1) & 1]) if pipe is not None else (out_i, out_d)
+        assert np.array_equal(mi, ref_i.cpu().numpy()) and np.array_equal(md, ref_d.cpu().numpy()), \
             "merged result differs from the shard's top-k"
 
     # ---- parity spot check against the oracle (outside the timed region)
@@ -310,7 +346,8 @@ def main() -> None:
                 "db_rows_total": n_total, "db_rows_per_gpu": n_local, "dim": d, "k": k,
                 "queries_per_step": nq, "queries_per_step_per_gpu": args.queries_per_gpu,
                 "sharding": "rows" if world > 1 else "none",
-                "collective": "all_gather(top-k dist,idx) + host merge, both overlapped with the next batch's search" if use_dist else "none",
+                "collective": ("all_gather(top-k dist,idx) + host merge, both under the next batch's search" if pipe is not None else
+                               "all_gather(top-k dist,idx) + host merge (merge on a host thread under the next batch's search)") if use_dist else "none",
                 "mean_candidates_per_query": float(np.mean(cands)) / nq if cands else None,
                 "fallback_queries": int(np.sum(fallbacks)) if fallbacks else 0,
             },
@@ -358,7 +395,10 @@ def main() -> None:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if use_dist:
-        pipe.close()
+        if pipe is not None:
+            pipe.close()
+        if merger is not None:
+            merger.close()
         dist.barrier()
         dist.destroy_process_group()
     index.close()
