@@ -190,6 +190,10 @@ int sq_dense_distances(const void* query, const void* rows, int dtype, int64_t n
  * otherwise (+inf padding); out_pos: int64[nq][k] positions into the query's
  * candidate list (-1 padding). */
 int sq_rows_create(const void* rows, int dtype, int64_t n, int d, int mem, sq_handle_t* out);
+/* Append n_add rows (the handle's dtype, host or device memory) behind a matrix created from host memory; they
+ * get the next row numbers.  The LSH index's update_index (impls/nn_index/lsh.py:331-383) then uploads only
+ * the new descriptors instead of the whole set. */
+int sq_rows_append(sq_handle_t h, const void* rows, int64_t n_add, int mem);
 int sq_rows_rerank(sq_handle_t h, const void* queries, int nq, int metric,
                    const int64_t* cand_rows, const int64_t* cand_offsets, int k,
                    void* out_dist, int64_t* out_pos, void* stream);

@@ -38,7 +38,7 @@ EXPORTS = (
     "sq_hamming_create", "sq_hamming_search", "sq_hamming_destroy",
     "sq_dense_create", "sq_dense_append", "sq_dense_search", "sq_dense_destroy",
     "sq_dense_distances", "sq_merge_topk", "sq_merge_topk_strided",
-    "sq_rows_create", "sq_rows_rerank", "sq_rows_destroy",
+    "sq_rows_create", "sq_rows_append", "sq_rows_rerank", "sq_rows_destroy",
     "sq_itqfit_create", "sq_itqfit_set_mean", "sq_itqfit_cov", "sq_itqfit_project", "sq_itqfit_iterate",
     "sq_itqfit_destroy",
 )
@@ -85,6 +85,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_merge_topk.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]
     lib.sq_merge_topk_strided.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, c_vp, c_vp]
     lib.sq_rows_create.argtypes = [c_vp, c_int, c_i64, c_int, c_int, ctypes.POINTER(c_i64)]
+    lib.sq_rows_append.argtypes = [c_i64, c_vp, c_i64, c_int]
     lib.sq_rows_rerank.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]
     lib.sq_rows_destroy.argtypes = [c_i64]
     lib.sq_itqfit_create.argtypes = [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, ctypes.POINTER(c_i64)]
@@ -430,6 +431,18 @@ class RowMatrix:
         _check(load().sq_rows_create(_ptr(rows), SQ_DTYPE_F32 if rows.dtype == np.float32 else SQ_DTYPE_F64,
                                      self.n, self.d, SQ_MEM_HOST, ctypes.byref(h)), "sq_rows_create")
         self._h: Optional[int] = h.value
+
+    def append(self, rows: np.ndarray) -> None:
+        """Rows ``[m, d]`` of the matrix's dtype behind the resident ones (``sq_rows_append``)."""
+        if self._h is None:
+            raise HipError("RowMatrix is closed")
+        rows = np.ascontiguousarray(np.asarray(rows), dtype=self.dtype)
+        if rows.ndim != 2 or rows.shape[1] != self.d:
+            raise ValueError("rows must be [m, d]")
+        if rows.shape[0] == 0:
+            return
+        _check(load().sq_rows_append(self._h, _ptr(rows), int(rows.shape[0]), SQ_MEM_HOST), "sq_rows_append")
+        self.n += int(rows.shape[0])
 
     def rerank(self, queries: np.ndarray, metric: int, cand_rows: np.ndarray, cand_offsets: np.ndarray,
                k: int) -> Tuple[np.ndarray, np.ndarray]:

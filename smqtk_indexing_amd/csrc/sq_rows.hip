@@ -150,6 +150,33 @@ extern "C" int sq_rows_create(const void* rows, int dtype, int64_t n, int d, int
     return SQ_OK;
 }
 
+extern "C" int sq_rows_append(sq_handle_t hid, const void* rows, int64_t n_add, int mem) {
+    auto* h = static_cast<RowsHandle*>(lookup_handle(hid, H_ROWS));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_rows_append: unknown handle");
+    if (!rows || n_add <= 0) return fail(SQ_ERR_INVALID, "sq_rows_append: bad argument");
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->owned.p) return fail(SQ_ERR_UNSUPPORTED, "sq_rows_append: the matrix is borrowed from the caller");
+    SQ_HIP(hipSetDevice(h->device));
+    const size_t esz = h->dtype == SQ_DTYPE_F32 ? 4 : 8;
+    const size_t used = (size_t)h->n * h->d * esz, need = (size_t)(h->n + n_add) * h->d * esz;
+    if (need > h->owned.cap) {  // grow by half again at least, contents kept
+        DevBuf nb;
+        SQ_TRY(nb.reserve(std::max(need, used + used / 2)));
+        if (hipMemcpy(nb.p, h->owned.p, used, hipMemcpyDeviceToDevice) != hipSuccess) {
+            nb.release();
+            return fail(SQ_ERR_HIP, "sq_rows_append: device copy failed");
+        }
+        h->owned.release();
+        h->owned = nb;
+        h->rows = h->owned.p;
+    }
+    if (hipMemcpy(static_cast<char*>(h->owned.p) + used, rows, need - used,
+                  mem == SQ_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) != hipSuccess)
+        return fail(SQ_ERR_HIP, "sq_rows_append: copy failed");
+    h->n += n_add;
+    return SQ_OK;
+}
+
 extern "C" int sq_rows_rerank(sq_handle_t hid, const void* queries, int nq, int metric, const int64_t* cand_rows,
                               const int64_t* cand_offsets, int k, void* out_dist, int64_t* out_pos, void* stream) {
     auto* h = static_cast<RowsHandle*>(lookup_handle(hid, H_ROWS));

@@ -58,7 +58,12 @@ class _DeviceMirror:
         self.uuids = uuids
         self.dtype = matrix.dtype
         self.rows = _lib.RowMatrix(matrix)
-        codes, inverse = np.unique(packed, axis=0, return_inverse=True)
+        self.packed = np.ascontiguousarray(packed)               # [N, W] code of every row
+        self._index_codes()
+
+    def _index_codes(self) -> None:
+        """Unique ascending codes and the CSR map code id -> rows, from the per-row codes."""
+        codes, inverse = np.unique(self.packed, axis=0, return_inverse=True)
         inverse = np.asarray(inverse).reshape(-1)
         self.codes = np.ascontiguousarray(codes)                 # [C, W] ascending (= HipLinearHashIndex order)
         order = np.argsort(inverse, kind="stable")               # rows grouped by code id, row order inside a bucket
@@ -67,6 +72,14 @@ class _DeviceMirror:
         self.own_index: Optional[HipLinearHashIndex] = None      # for hash_index=None
         self.checked_codes: Optional[np.ndarray] = None          # hash_index code array last compared with self.codes
         self.checked_ok = False
+
+    def append(self, uuids: List[Hashable], matrix: np.ndarray, packed: np.ndarray) -> None:
+        """New descriptors behind the resident ones: only they are uploaded (sq_rows_append); the code list
+        and the CSR map are rebuilt on the host (code ids shift when a new code lands between old ones)."""
+        self.rows.append(np.ascontiguousarray(matrix, dtype=self.dtype))
+        self.uuids.extend(uuids)
+        self.packed = np.vstack([self.packed, np.ascontiguousarray(packed)])
+        self._index_codes()
 
     def expand(self, code_ids: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """code ids ``[nq, m]`` (-1 = none) -> (candidate rows concatenated, offsets ``[nq+1]``),
@@ -303,10 +316,13 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
     def _update_index(self, descriptors: Iterable[DescriptorElement]) -> None:
         with self._model_lock:
             self._guard()
-            for_set, for_hash = itertools.tee(descriptors, 2)
-            self.descriptor_set.add_many_descriptors(for_set)
-            elems = list(for_hash)
-            hv, keys = self._hash_many([d.vector() for d in elems])
+            elems = list(descriptors)
+            # a pure append (no uuid replaced, no uuid twice) can extend the device mirror in place
+            uids = [d.uuid() for d in elems]
+            fresh = len(set(uids)) == len(uids) and not any(self.descriptor_set.has_descriptor(u) for u in uids)
+            self.descriptor_set.add_many_descriptors(elems)
+            vectors = [d.vector() for d in elems]
+            hv, keys = self._hash_many(vectors)
             update: Dict[Hashable, Set[Hashable]] = {}
             for d, key in zip(elems, keys):
                 if key not in update:
@@ -316,7 +332,20 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
             self._count_cache = None
             if self.hash_index is not None:
                 self.hash_index.update_index(hv)
-            self._drop_mirror()  # rebuilt from the descriptor set at the next query
+            m = self._mirror
+            appended = False
+            if m is not None and fresh and elems:
+                try:
+                    mat = np.asarray(vectors)
+                    if mat.ndim == 2 and mat.dtype == m.dtype and mat.shape[1] == m.rows.d:
+                        # only the new descriptors are uploaded (sq_rows_append); lsh.py:364-378 likewise touches
+                        # only the new descriptors' buckets
+                        m.append(uids, mat, pack_bits_msb(np.asarray(hv).astype(bool)))
+                        appended = True
+                except ValueError:
+                    appended = False
+            if not appended:
+                self._drop_mirror()  # rebuilt from the descriptor set at the next query
 
     def _remove_from_index(self, uids: Iterable[Hashable]) -> None:
         with self._model_lock:

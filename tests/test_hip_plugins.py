@@ -539,3 +539,34 @@ def test_pipelined_sharded_search_rccl_world1():
         index.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("hash_index", [True, False])
+def test_lsh_update_appends_to_the_device_mirror(hash_index):
+    """update_index with new uuids only keeps the device mirror and uploads just the new descriptors
+    (sq_rows_append); the answers are those of an index built from everything.  A replaced uuid drops the mirror."""
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((4000, 48)).astype(np.float32)
+    f = HipItqFunctor(bit_length=10, itq_iterations=4, random_seed=1)
+    f.fit([DescriptorMemoryElement(i).set_vector(v) for i, v in enumerate(x[:600])])
+
+    def make(rows):
+        idx = HipLSHNearestNeighborIndex(f, MemoryDescriptorSet(), MemoryKeyValueStore(),
+                                         HipLinearHashIndex() if hash_index else None, distance_method="euclidean")
+        idx.build_index(_elems(rows))
+        return idx
+
+    grown, whole = make(x[:3000]), make(x)
+    qs = [DescriptorMemoryElement(f"q{i}").set_vector(v) for i, v in enumerate(rng.standard_normal((5, 48)).astype(np.float32))]
+    grown.nn(qs[0], 3)
+    mirror = grown._mirror
+    assert mirror is not None
+    grown.update_index(_elems(x[3000:3600], base=3000))
+    grown.update_index(_elems(x[3600:], base=3600))
+    assert grown._mirror is mirror and mirror.rows.n == 4000 and len(mirror.uuids) == 4000
+    for q in qs:
+        for n in (1, 20):
+            (ra, da), (rb, db) = grown.nn(q, n), whole.nn(q, n)
+            assert da == db and [e.uuid() for e in ra] == [e.uuid() for e in rb]
+    grown.update_index([DescriptorMemoryElement(5).set_vector(x[5] + 1.0)])     # replaces uuid 5
+    assert grown._mirror is None
