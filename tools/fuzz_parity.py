@@ -39,7 +39,13 @@ for c in range(cases):
     if kind == 1 and d > 1: db[rng.integers(0, n)] = 0.0                               # a zero row
     m = _lib.SQ_METRIC_L2 if metric == "euclidean" else _lib.SQ_METRIC_COSINE
     try:
-        idx = _lib.DenseIndex(db, metric=m)
+        if n > 64 and rng.integers(0, 3) == 0:            # built in pieces: create + sq_dense_append
+            cuts = np.sort(rng.choice(np.arange(1, n), size=int(rng.integers(1, 4)), replace=False))
+            idx = _lib.DenseIndex(db[:cuts[0]], metric=m)
+            for a_, b_ in zip(cuts, list(cuts[1:]) + [n]):
+                idx.append(db[a_:b_])
+        else:
+            idx = _lib.DenseIndex(db, metric=m)
         dd, ii = idx.search(qs, k)
         st = idx.stats()
         for qi in rng.choice(nq, size=min(nq, 4), replace=False):
