@@ -514,6 +514,7 @@ struct SqLeafPair {
 // stages its 32 query vectors in LDS (dynamic LDS: 32 * (ldq + 4) floats); larger
 // groups read the query rows through the cache.
 static constexpr int RERANK_MAX_GROUP = 128;
+static constexpr int RERANK_STAGE_STRIDE = 68;  // floats per staged row piece: 64 + 4 (272 bytes)
 
 template <class K, bool COSINE>
 __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long long ld, int d,
@@ -573,6 +574,77 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
     constexpr int LPR = 2;  // lanes per entry (L2: four of numpy's eight accumulators each; cosine: one parity each)
     const bool rows_aligned = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(db) & 15u) == 0;
     const int sub = threadIdx.x % LPR;
+    if constexpr (COSINE) {
+        // Wide rows (d % 64 == 0: the 512-wide shards of BASELINE config 4): a pair walking its row 16 bytes at
+        // a time leaves each 128-byte line of 32 different rows to be touched by eight separate wave loads, and
+        // with a CU's waves all doing that the lines fall out of the vector cache in between (1.97 ms for 860 k
+        // candidates = 0.9 TB/s of L2 refetches).  Here a wave fetches the current rows of its 32 pairs
+        // TOGETHER, 64 elements at a time: 16 lanes per row and instruction, whole lines, into a per-wave LDS
+        // stage (row stride 272 bytes: two-way bank conflicts at most), and each pair then reads its row's piece
+        // from the stage.  The arithmetic and its order are untouched (scipy's two chains, one per lane).
+        __shared__ __attribute__((aligned(16))) float s_stage[4][32 * RERANK_STAGE_STRIDE];
+        if (rows_aligned && (d & 63) == 0 && blockDim.x <= 256 && !(debug & 512)) {
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, pair = lane >> 1;
+            float* stage = s_stage[wv];
+            for (int wi = 0; wi < waves_per_block; ++wi) {
+                const long long w = w0 + wi;
+                if (w >= n_waves) break;
+                u32 c = wave_cnt[2 * w];
+                c = c > wave_cap ? wave_cap : c;
+                const u32 per_round = blockDim.x / LPR;
+                for (u32 e0 = 0; e0 < c; e0 += per_round) {   // uniform trip count: the waves work in lockstep below
+                    const u32 e = e0 + threadIdx.x / LPR;
+                    const bool live = e < c;
+                    const uint2 ent = live ? wave_out[w * wave_cap + e] : make_uint2(0u, 0u);
+                    const u32 ql = ent.y & 0xffffu;
+                    const u32 qg = q0 + ql;
+                    const float* qrow = q_in_lds ? s_qrows + ql * ldl : q_al + (long long)qg * ldq;
+                    u32 mask = live ? ent.y >> 16 : 0u;
+                    while (__any(mask != 0)) {
+                        const bool has = mask != 0;
+                        const int i = has ? __ffs((int)mask) - 1 : 0;
+                        mask &= mask - 1;                       // 0 stays 0
+                        u32 row = has ? ent.x + (u32)((i & 3) + 8 * (i >> 2)) : 0u;
+                        if (debug & 64) row &= 1023u;
+                        double acc = 0.0;
+                        for (int k0 = 0; k0 < d; k0 += 64) {
+                            f32x4 v[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int slot = 4 * j + (lane >> 4);
+                                const u32 r = (u32)__shfl((int)row, 2 * slot);
+                                v[j] = *reinterpret_cast<const f32x4*>(db + (long long)r * ld + k0 + 4 * (lane & 15));
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                *reinterpret_cast<f32x4*>(stage + (4 * j + (lane >> 4)) * RERANK_STAGE_STRIDE + 4 * (lane & 15)) = v[j];
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            const float* sx = stage + pair * RERANK_STAGE_STRIDE;
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) {
+                                const f32x4 xv = *reinterpret_cast<const f32x4*>(sx + 4 * u);
+                                const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + k0 + 4 * u);
+                                acc = __dadd_rn(acc, __dmul_rn((double)qv[sub], (double)xv[sub]));
+                                acc = __dadd_rn(acc, __dmul_rn((double)qv[2 + sub], (double)xv[2 + sub]));
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();   // the stage is rewritten by the next piece
+                        }
+                        const double other = __shfl_xor(acc, 1);
+                        const double dot = sub == 0 ? __dadd_rn(acc, other) : __dadd_rn(other, acc);  // dot0 + dot1
+                        if (has && sub == 0) {
+                            const double dist = cosine_dist_f64(dot, nx64[row], nq64[qg]);
+                            const u32 pos = s_base[ql] + atomicAdd(&s_fill[ql], 1u);
+                            if (pos < cap) keys[(long long)qg * cap + pos] = K128{ordered_f64(dist), (u64)row};
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
     for (int wi = 0; wi < waves_per_block; ++wi) {
         const long long w = w0 + wi;
         if (w >= n_waves) break;
