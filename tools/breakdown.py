@@ -13,6 +13,7 @@ g = torch.Generator(device=dev); g.manual_seed(3)
 db = torch.empty((n, d), dtype=torch.float32, device=dev).normal_(generator=g)
 _lib.set_option("profile", 1)
 _lib.set_option("force_fallback", int(os.environ.get("FORCE_FB", 0)))
+_lib.set_option("sample_stride", int(os.environ.get("SAMPLE_STRIDE", 0)))
 _lib.set_option("dense_debug", int(os.environ.get("DEBUG", 0)))   # ablation bits (results are garbage then)
 metric = _lib.SQ_METRIC_COSINE if os.environ.get("METRIC", "l2") == "cosine" else _lib.SQ_METRIC_L2
 idx = _lib.DenseIndex(db.data_ptr(), n=n, d=d, metric=metric, device_ptr=True, keepalive=db)
