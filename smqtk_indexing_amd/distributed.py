@@ -130,7 +130,8 @@ class MutableShardedIndex:
     * ``remove(ids)`` -- tombstones: the owning shard marks the rows dead; ``KeyError`` on every rank,
       before anything changes, when an id is not live anywhere (the reference's
       ``remove_from_index`` contract, nearest_neighbor_index.py:84-94 / lsh.py:385-450).  A shard whose
-      dead rows exceed ``compact_at`` of its rows drops them and rebuilds its local index.
+      dead rows exceed ``compact_at`` of its rows (or ``max_dead``: a shard answers ``k + dead`` locally and the
+      kernels cap k) drops them and rebuilds its local index.
     * ``search(queries, k)`` -- each shard answers ``k + dead`` locally, drops dead rows, maps local rows to
       global ids, then the usual all-gather + host merge.
 
@@ -141,11 +142,12 @@ class MutableShardedIndex:
     """
 
     def __init__(self, rows, row0: int, n_total: int, build_local: Callable, group=None, compact_at: float = 0.25,
-                 dist_dtype=None):
+                 dist_dtype=None, max_dead: int = 1024):
         import torch
         import torch.distributed as dist
 
         self.group, self.build_local, self.compact_at = group, build_local, float(compact_at)
+        self.max_dead = int(max_dead)   # a shard answers k + dead locally: keep that under the kernels' k limit
         self.pad_dtype = dist_dtype if dist_dtype is not None else torch.float32   # distances of an empty shard
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.rows = rows
@@ -204,7 +206,7 @@ class MutableShardedIndex:
         for r in range(self.world):
             self.live[r] -= found[r]
         n_dead = int(self.dead.sum())
-        if n_dead and n_dead > self.compact_at * int(self.dead.numel()):
+        if n_dead and (n_dead > self.compact_at * int(self.dead.numel()) or n_dead > self.max_dead):
             keep = ~self.dead
             self.rows = self.rows[keep.to(self.rows.device)].contiguous()
             self.ids, self.dead = self.ids[keep], torch.zeros(int(keep.sum()), dtype=torch.bool)
