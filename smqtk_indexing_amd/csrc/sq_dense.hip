@@ -330,7 +330,9 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         // A re-rank workgroup takes `wpb` survivor segments of one scan workgroup (its waves share the query
         // group), 128 threads per segment.  Many small workgroups win: the kernel is a chain of dependent
         // memory round trips per workgroup, not the per-query atomics (2 vs 8 segments: 37 vs 50 us at 10 M rows).
-        int wpb = 2;
+        // (L2, four-wave scan workgroups, i.e. multi-tile batches: 4 measured 2 % faster than 2; the cosine kernel's
+        // row stage is sized for 256 threads)
+        int wpb = (wv == 4 && !cosine) ? 4 : 2;
         if (g_opt.dense_rerank_segments > 0 && wv % g_opt.dense_rerank_segments == 0) wpb = g_opt.dense_rerank_segments;
         const unsigned rr_threads = (unsigned)std::min(512, 128 * wpb);
         const size_t rr_lds = (qt == 1 && ldq <= 156) ? (size_t)32 * (ldq + 4) * 4 : 0;  // the query tile in LDS (rerank_block)
