@@ -61,8 +61,31 @@ __global__ __launch_bounds__(256) void rows_rerank_keys_kernel(const T* __restri
                 keys[(long long)qi * maxc + p] = K128{ordered_f64(sqrt((double)s)), (u64)p};
         }
     } else {
+        // scipy's order (cosine_row_t): three sums, each an even and an odd chain -- lane 0 of the group runs the
+        // even chains, lane 1 the odd ones (both lanes of a candidate are live or idle together)
+        const int par = j8 & 1;
+        double dot = 0.0, nx = 0.0, nq = 0.0;
+        if (j8 < 2) {
+            const int m = d - (d & 1);
+            for (int i = par; i < m; i += 2) {
+                const double xv = (double)x[i], qv = (double)q[i];
+                dot = __dadd_rn(dot, __dmul_rn(qv, xv));
+                nx = __dadd_rn(nx, __dmul_rn(xv, xv));
+                nq = __dadd_rn(nq, __dmul_rn(qv, qv));
+            }
+        }
+        const double dot_o = __shfl_xor(dot, 1), nx_o = __shfl_xor(nx, 1), nq_o = __shfl_xor(nq, 1);
         if (j8 == 0 && p < c) {
-            const double dist = cosine_row_t<T>(x, q, d);
+            dot = __dadd_rn(dot, dot_o);   // even + odd, as the one-lane form adds them
+            nx = __dadd_rn(nx, nx_o);
+            nq = __dadd_rn(nq, nq_o);
+            if (d & 1) {
+                const double xv = (double)x[d - 1], qv = (double)q[d - 1];
+                dot = __dadd_rn(dot, __dmul_rn(qv, xv));
+                nx = __dadd_rn(nx, __dmul_rn(xv, xv));
+                nq = __dadd_rn(nq, __dmul_rn(qv, qv));
+            }
+            const double dist = cosine_dist_f64(dot, nx, nq);
             if constexpr (sizeof(K) == 16) keys[(long long)qi * maxc + p] = K128{ordered_f64(dist), (u64)p};
         }
     }
