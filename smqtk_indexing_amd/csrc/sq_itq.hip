@@ -449,6 +449,22 @@ static int itq_fast_dispatch(const ItqFastArgs& fa, const ItqFastGeom& g, hipStr
 #undef SQ_ITQF_CASE
 }
 
+// Keep the stream-ordered pool's memory across calls: by default it is handed back at every synchronisation
+// and each call would pay for fresh allocations (~100 MB for a 10 M-row hash call).
+static void keep_pool_memory(int device) {
+    static std::mutex mu;
+    static bool kept[64] = {};
+    std::lock_guard<std::mutex> l(mu);
+    if (device >= 0 && device < 64 && !kept[device]) {
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        kept[device] = true;
+    }
+}
+
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 // float32 rows through the filter; the rows it cannot decide through the float64 kernel.
@@ -470,21 +486,7 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
     const bool l2 = a.norm == SQ_NORM_L2;
     const size_t o_seg = take((size_t)nwaves * seg_cap * 8), o_cnt = take((size_t)nwaves * 4);
     const size_t o_rt = take((size_t)pc * a.d * 8);
-    {
-        // keep the stream-ordered pool's memory across calls: by default it is handed back at every
-        // synchronisation and each call would pay for ~100 MB of fresh allocation
-        static std::mutex mu;
-        static bool kept[64] = {};
-        std::lock_guard<std::mutex> l(mu);
-        if (device >= 0 && device < 64 && !kept[device]) {
-            hipMemPool_t pool;
-            if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-                uint64_t keep = ~0ull;
-                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-            }
-            kept[device] = true;
-        }
-    }
+    keep_pool_memory(device);
     unsigned char* base = nullptr;
     SQ_HIP(hipMallocAsync(reinterpret_cast<void**>(&base), off, st));
     auto done = [&](int rc) {
@@ -577,14 +579,6 @@ extern "C" int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d, const d
     a.norm = norm_ord;
     a.sub32 = (x_dtype == SQ_DTYPE_F32 && mean_dtype == SQ_DTYPE_F32) ? 1 : 0;
     a.d16 = (d + 15) / 16 * 16;
-    DevBuf dx, dm, dr, dout;
-    auto done = [&](int code) {
-        dx.release();
-        dm.release();
-        dr.release();
-        dout.release();
-        return code;
-    };
     if (mem == SQ_MEM_DEVICE) {
         a.x = x;
         a.mean = mean;
@@ -592,23 +586,30 @@ extern "C" int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d, const d
         a.out = reinterpret_cast<u64*>(out_codes);
         return x_dtype == SQ_DTYPE_F32 ? itq_launch<float>(a, st, device) : itq_launch<double>(a, st, device);
     }
-    int rc;
-    if ((rc = dx.reserve((size_t)n * d * esz)) != SQ_OK) return done(rc);
-    if ((rc = dm.reserve((size_t)d * 8)) != SQ_OK) return done(rc);
-    if ((rc = dr.reserve((size_t)d * bits * 8)) != SQ_OK) return done(rc);
-    if ((rc = dout.reserve((size_t)n * words * 8)) != SQ_OK) return done(rc);
-    if (hipMemcpyAsync(dx.p, x, (size_t)n * d * esz, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(dm.p, mean, (size_t)d * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(dr.p, rotation, (size_t)d * bits * 8, hipMemcpyHostToDevice, st) != hipSuccess)
+    // Host buffers: ONE stream-ordered allocation for rows | mean | rotation | codes (the pool keeps the memory
+    // across calls).  Four hipMalloc / hipFree pairs per call made hashing one query vector -- what every
+    // LSHNearestNeighborIndex.nn does first -- cost 94 us.
+    keep_pool_memory(device);
+    const size_t o_x = 0, o_m = align256(o_x + (size_t)n * d * esz), o_r = align256(o_m + (size_t)d * 8);
+    const size_t o_out = align256(o_r + (size_t)d * bits * 8), total = o_out + (size_t)n * words * 8;
+    unsigned char* base = nullptr;
+    SQ_HIP(hipMallocAsync(reinterpret_cast<void**>(&base), total, st));
+    auto done = [&](int code) {
+        (void)hipFreeAsync(base, st);
+        return code;
+    };
+    if (hipMemcpyAsync(base + o_x, x, (size_t)n * d * esz, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(base + o_m, mean, (size_t)d * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(base + o_r, rotation, (size_t)d * bits * 8, hipMemcpyHostToDevice, st) != hipSuccess)
         return done(fail(SQ_ERR_HIP, "sq_itq_hash: H2D copy failed"));
-    a.x = dx.p;
-    a.mean = dm.as<double>();
-    a.rot = dr.as<double>();
-    a.out = dout.as<u64>();
-    rc = x_dtype == SQ_DTYPE_F32 ? itq_launch<float>(a, st, device) : itq_launch<double>(a, st, device);
+    a.x = base + o_x;
+    a.mean = reinterpret_cast<const double*>(base + o_m);
+    a.rot = reinterpret_cast<const double*>(base + o_r);
+    a.out = reinterpret_cast<u64*>(base + o_out);
+    const int rc = x_dtype == SQ_DTYPE_F32 ? itq_launch<float>(a, st, device) : itq_launch<double>(a, st, device);
     if (rc != SQ_OK) return done(rc);
-    if (hipMemcpyAsync(out_codes, dout.p, (size_t)n * words * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
+    if (hipMemcpyAsync(out_codes, base + o_out, (size_t)n * words * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        stream_wait(st) != hipSuccess)
         return done(fail(SQ_ERR_HIP, "sq_itq_hash: kernel or D2H copy failed: %s", hipGetErrorString(hipGetLastError())));
     return done(SQ_OK);
 }
