@@ -175,6 +175,16 @@ int sq_dense_destroy(sq_handle_t h);
 int sq_dense_distances(const void* query, const void* rows, int dtype, int64_t n, int d,
                        int metric, void* out, int mem, void* stream);
 
+/* The same hashing with the MODEL resident: mean (values as f64, `mean_dtype` = the model's dtype, see above) and
+ * rotation [d][bits] f64 are uploaded once; sq_itq_model_hash then moves only the rows and the codes (small
+ * batches through pinned staging).  What ItqFunctor.get_hash costs per query vector in
+ * LSHNearestNeighborIndex._nn (impls/nn_index/lsh.py:473): without this every call re-uploads the rotation. */
+int sq_itq_model_create(const double* mean, int mean_dtype, const double* rotation, int d, int bits,
+                        int norm_ord, sq_handle_t* out);
+int sq_itq_model_hash(sq_handle_t model, const void* x, int x_dtype, int64_t n, uint64_t* out_codes,
+                      int mem, void* stream);
+int sq_itq_model_destroy(sq_handle_t model);
+
 /* ------------------------------------------------------- LSH re-rank stage
  * Replaces the tail of LSHNearestNeighborIndex._nn (impls/nn_index/lsh.py:
  * 499-519): fetch every candidate descriptor, one distance call per row

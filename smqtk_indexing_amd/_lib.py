@@ -35,6 +35,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 EXPORTS = (
     "sq_last_error", "sq_version", "sq_device_count", "sq_device_name",
     "sq_set_option", "sq_get_stats", "sq_itq_hash",
+    "sq_itq_model_create", "sq_itq_model_hash", "sq_itq_model_destroy",
     "sq_hamming_create", "sq_hamming_search", "sq_hamming_destroy",
     "sq_dense_create", "sq_dense_append", "sq_dense_search", "sq_dense_destroy",
     "sq_dense_distances", "sq_merge_topk", "sq_merge_topk_strided",
@@ -74,6 +75,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_set_option.argtypes = [ctypes.c_char_p, c_i64]
     lib.sq_get_stats.argtypes = [c_i64, ctypes.POINTER(SqStats)]
     lib.sq_itq_hash.argtypes = [c_vp, c_int, c_i64, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]
+    lib.sq_itq_model_create.argtypes = [c_vp, c_int, c_vp, c_int, c_int, c_int, ctypes.POINTER(c_i64)]
+    lib.sq_itq_model_hash.argtypes = [c_i64, c_vp, c_int, c_i64, c_vp, c_int, c_vp]
+    lib.sq_itq_model_destroy.argtypes = [c_i64]
     lib.sq_hamming_create.argtypes = [c_vp, c_i64, c_int, c_int, c_i64, ctypes.POINTER(c_i64)]
     lib.sq_hamming_search.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]
     lib.sq_hamming_destroy.argtypes = [c_i64]
@@ -254,6 +258,43 @@ class _Handle:
 
     def stats(self) -> dict:
         return get_stats(self.handle)
+
+
+class ItqModel(_Handle):
+    """ItqFunctor's model resident on the device (``sq_itq_model_*``): repeated small ``hash`` calls move
+    only the rows and the codes."""
+    _destroy_name = "sq_itq_model_destroy"
+
+    def __init__(self, mean: np.ndarray, rotation: np.ndarray, norm_ord: int = SQ_NORM_NONE):
+        super().__init__()
+        # dtype of the model's mean vector: `x - mean` is evaluated in numpy's promoted dtype (itq.py:404)
+        mdt = SQ_DTYPE_F32 if np.asarray(mean).dtype == np.float32 else SQ_DTYPE_F64
+        mean = _host(mean, np.float64)
+        rotation = _host(rotation, np.float64)
+        if mean.ndim != 1 or rotation.ndim != 2 or rotation.shape[0] != mean.shape[0]:
+            raise ValueError("mean must be [d] and rotation [d, bits]")
+        self.d, self.bits = int(rotation.shape[0]), int(rotation.shape[1])
+        h = ctypes.c_int64(0)
+        _check(load().sq_itq_model_create(_ptr(mean), mdt, _ptr(rotation), self.d, self.bits, int(norm_ord),
+                                          ctypes.byref(h)), "sq_itq_model_create")
+        self.handle = int(h.value)
+
+    def hash(self, x: np.ndarray) -> np.ndarray:
+        """Packed codes uint64[n, ceil(bits/64)] of the rows of ``x`` (host array, float32 or float64)."""
+        x = np.asarray(x)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError("x must be [n, d]")
+        if x.dtype == np.float32:
+            dt = SQ_DTYPE_F32
+        else:
+            x = x.astype(np.float64, copy=False)
+            dt = SQ_DTYPE_F64
+        x = np.ascontiguousarray(x)
+        out = np.empty((x.shape[0], (self.bits + 63) // 64), dtype=np.uint64)
+        if x.shape[0]:
+            _check(load().sq_itq_model_hash(self.handle, _ptr(x), dt, int(x.shape[0]), _ptr(out), SQ_MEM_HOST, None),
+                   "sq_itq_model_hash")
+        return out
 
 
 class HammingIndex(_Handle):

@@ -137,7 +137,7 @@ struct HostPinned {
 };
 
 // ------------------------------------------------------------------ handles
-enum HandleKind { H_HAMMING = 1, H_DENSE = 2, H_ROWS = 3, H_FIT = 4 };
+enum HandleKind { H_HAMMING = 1, H_DENSE = 2, H_ROWS = 3, H_FIT = 4, H_ITQ = 5 };
 
 struct HandleBase {
     int kind = 0;

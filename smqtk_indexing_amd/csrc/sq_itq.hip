@@ -613,3 +613,105 @@ extern "C" int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d, const d
         return done(fail(SQ_ERR_HIP, "sq_itq_hash: kernel or D2H copy failed: %s", hipGetErrorString(hipGetLastError())));
     return done(SQ_OK);
 }
+
+// ------------------------------------------------------------------ resident model
+// ItqFunctor's model (mean, rotation) kept on the device, with pinned staging for small batches: hashing ONE query
+// vector -- the first thing every LSHNearestNeighborIndex.nn does (lsh.py:473) -- otherwise uploads the 64 KB
+// rotation and the mean from pageable memory on every call (95 us per query, most of it copies).
+namespace sq {
+struct ItqModelHandle : HandleBase {
+    DevBuf mean, rot, x_dev, out_dev;
+    HostPinned stage;   // [rows | codes] of one small batch
+    int d = 0, bits = 0, norm = SQ_NORM_NONE, mean_dtype = SQ_DTYPE_F64;
+    ~ItqModelHandle() override {
+        for (DevBuf* b : {&mean, &rot, &x_dev, &out_dev}) b->release();
+        stage.release();
+    }
+};
+}  // namespace sq
+
+extern "C" int sq_itq_model_create(const double* mean, int mean_dtype, const double* rotation, int d, int bits,
+                                   int norm_ord, sq_handle_t* out) {
+    if (!mean || !rotation || !out || d <= 0 || bits <= 0) return fail(SQ_ERR_INVALID, "sq_itq_model_create: bad argument");
+    if (mean_dtype != SQ_DTYPE_F32 && mean_dtype != SQ_DTYPE_F64)
+        return fail(SQ_ERR_INVALID, "sq_itq_model_create: unknown mean dtype %d", mean_dtype);
+    if (norm_ord != SQ_NORM_NONE && norm_ord != SQ_NORM_L2)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_itq_model_create: normalize=%d not supported on the device (None or 2)", norm_ord);
+    auto* h = new ItqModelHandle();
+    h->kind = H_ITQ;
+    h->d = d;
+    h->bits = bits;
+    h->norm = norm_ord;
+    h->mean_dtype = mean_dtype;
+    auto bail = [&](int rc) {
+        delete h;
+        return rc;
+    };
+    if (hipGetDevice(&h->device) != hipSuccess) return bail(fail(SQ_ERR_HIP, "sq_itq_model_create: no HIP device"));
+    int rc = h->mean.reserve((size_t)d * 8);
+    if (rc == SQ_OK) rc = h->rot.reserve((size_t)d * bits * 8);
+    if (rc != SQ_OK) return bail(rc);
+    if (hipMemcpy(h->mean.p, mean, (size_t)d * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->rot.p, rotation, (size_t)d * bits * 8, hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(SQ_ERR_HIP, "sq_itq_model_create: H2D copy failed"));
+    *out = register_handle(h);
+    return SQ_OK;
+}
+
+extern "C" int sq_itq_model_hash(sq_handle_t hid, const void* x, int x_dtype, int64_t n, uint64_t* out_codes, int mem,
+                                 void* stream) {
+    auto* h = static_cast<ItqModelHandle*>(lookup_handle(hid, H_ITQ));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_itq_model_hash: unknown handle");
+    if (!x || !out_codes || n <= 0) return fail(SQ_ERR_INVALID, "sq_itq_model_hash: bad argument");
+    if (x_dtype != SQ_DTYPE_F32 && x_dtype != SQ_DTYPE_F64) return fail(SQ_ERR_INVALID, "sq_itq_model_hash: unknown dtype %d", x_dtype);
+    std::lock_guard<std::mutex> lock(h->mu);
+    SQ_HIP(hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int words = (h->bits + 63) / 64;
+    const size_t esz = x_dtype == SQ_DTYPE_F32 ? 4 : 8;
+    ItqArgs a{};
+    a.n = n;
+    a.d = h->d;
+    a.bits = h->bits;
+    a.words = words;
+    a.pad = words * 64 - h->bits;
+    a.norm = h->norm;
+    a.sub32 = (x_dtype == SQ_DTYPE_F32 && h->mean_dtype == SQ_DTYPE_F32) ? 1 : 0;
+    a.d16 = (h->d + 15) / 16 * 16;
+    a.mean = h->mean.as<double>();
+    a.rot = h->rot.as<double>();
+    if (mem == SQ_MEM_DEVICE) {
+        a.x = x;
+        a.out = reinterpret_cast<u64*>(out_codes);
+        return x_dtype == SQ_DTYPE_F32 ? itq_launch<float>(a, st, h->device) : itq_launch<double>(a, st, h->device);
+    }
+    const size_t xb = (size_t)n * h->d * esz, ob = (size_t)n * words * 8;
+    SQ_TRY(h->x_dev.reserve(xb));
+    SQ_TRY(h->out_dev.reserve(ob));
+    // small batches go through pinned staging (an asynchronous copy from pageable memory is a blocking staged copy)
+    const bool staged = xb + ob <= (1u << 20);
+    const void* src = x;
+    void* dst = out_codes;
+    if (staged) {
+        SQ_TRY(h->stage.reserve(xb + ob));
+        memcpy(h->stage.p, x, xb);
+        src = h->stage.p;
+        dst = static_cast<char*>(h->stage.p) + xb;
+    }
+    SQ_HIP(hipMemcpyAsync(h->x_dev.p, src, xb, hipMemcpyHostToDevice, st));
+    a.x = h->x_dev.p;
+    a.out = h->out_dev.as<u64>();
+    SQ_TRY(x_dtype == SQ_DTYPE_F32 ? itq_launch<float>(a, st, h->device) : itq_launch<double>(a, st, h->device));
+    SQ_HIP(hipMemcpyAsync(dst, h->out_dev.p, ob, hipMemcpyDeviceToHost, st));
+    SQ_HIP(stream_wait(st));
+    if (staged) memcpy(out_codes, dst, ob);
+    return SQ_OK;
+}
+
+extern "C" int sq_itq_model_destroy(sq_handle_t hid) {
+    auto* h = remove_handle(hid, H_ITQ);
+    if (!h) return fail(SQ_ERR_INVALID, "sq_itq_model_destroy: unknown handle");
+    (void)hipSetDevice(h->device);
+    delete h;
+    return SQ_OK;
+}

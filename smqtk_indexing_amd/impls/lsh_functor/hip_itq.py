@@ -134,7 +134,20 @@ class HipItqFunctor(LshFunctor):
             raise ValueError("expected an [n, d] matrix")
         if x.dtype != np.float32:
             x = x.astype(np.float64)       # ints / float16 etc. upcast like numpy would
-        return _lib.itq_hash(x, self.mean_vec, np.real(self.rotation), self._norm_ord())
+        return self._device_model().hash(x)
+
+    def _device_model(self) -> "_lib.ItqModel":
+        """The model resident on the device (sq_itq_model_*), rebuilt when mean_vec / rotation / normalize change
+        (they are plain attributes, as in the reference, so identity and norm are what can be checked)."""
+        key = (id(self.mean_vec), id(self.rotation), self._norm_ord())
+        cached = getattr(self, "_model_cache", None)
+        if cached is None or cached[0] != key:
+            if cached is not None:
+                cached[1].close()
+            # the arrays are kept alive with the key so that an id cannot be reused by another array
+            cached = (key, _lib.ItqModel(self.mean_vec, np.real(self.rotation), self._norm_ord()), self.mean_vec, self.rotation)
+            self._model_cache = cached
+        return cached[1]
 
     def get_hash(self, descriptor: np.ndarray) -> np.ndarray:
         """Boolean hash vector of one descriptor (or bool ``[n, bits]`` of a matrix)."""

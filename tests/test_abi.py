@@ -160,6 +160,10 @@ def test_argument_validation_through_the_raw_abi():
     assert lib.sq_hamming_search(12345, x.ctypes.data, 1, 1, x.ctypes.data, x.ctypes.data, 0, null) != 0
     assert b"unknown handle" in lib.sq_last_error()
     assert lib.sq_dense_search(12345, x.ctypes.data, 1, 1, x.ctypes.data, x.ctypes.data, 0, null) != 0
+    assert lib.sq_itq_model_hash(12345, x.ctypes.data, 0, 4, x.ctypes.data, 0, null) != 0
+    assert b"sq_itq_model_hash: unknown handle" in lib.sq_last_error()
+    assert lib.sq_itq_model_create(x.ctypes.data, 7, x.ctypes.data, 8, 4, -1, ctypes.byref(h)) != 0   # unknown mean dtype
+    assert lib.sq_rows_append(12345, x.ctypes.data, 4, 0) != 0 and lib.sq_itq_model_destroy(12345) != 0
     assert lib.sq_dense_append(12345, x.ctypes.data, 4, 0) != 0
     assert b"sq_dense_append: unknown handle" in lib.sq_last_error()
     assert lib.sq_rows_create(x.ctypes.data, 7, 4, 8, 0, ctypes.byref(h)) != 0                # unknown dtype

@@ -531,3 +531,28 @@ def test_cosine_zero_vectors_give_nan_ranked_last(n):
         assert np.isnan(d[qi]).sum() == np.isnan(rd).sum()
     if n < 1000:
         assert set(i[0][-2:]) == {17, 201} and np.isnan(d[0][-2:]).all()
+
+
+@pytest.mark.parametrize("norm", [None, 2])
+@pytest.mark.parametrize("mean_dt", [np.float32, np.float64])
+def test_itq_resident_model_equals_one_shot_hash(norm, mean_dt):
+    """sq_itq_model_*: the model uploaded once gives the codes of sq_itq_hash -- single rows through the pinned
+    staging, a large batch without it, float32 and float64 rows, both mean dtypes."""
+    rng = np.random.default_rng(61)
+    d, bits = 96, 40
+    x = rng.standard_normal((200_000, d)).astype(np.float32)
+    x[3] = 0.0
+    mean = x[:5000].mean(axis=0).astype(mean_dt)
+    rot = rng.standard_normal((d, bits))
+    no = _lib.SQ_NORM_NONE if norm is None else _lib.SQ_NORM_L2
+    model = _lib.ItqModel(mean, rot, no)
+    for rows in (x[:1], x[3:4], x[:33], x, x[:50].astype(np.float64)):
+        np.testing.assert_array_equal(model.hash(rows), _lib.itq_hash(rows, mean, rot, no))
+    z = O.itq_z(x[:2000], mean, rot, norm)
+    ref = O.pack_bits_msb(z >= 0)
+    got = model.hash(x[:2000])
+    bad = (got != ref).any(axis=1)
+    assert bad.sum() <= 1
+    model.close()
+    with pytest.raises(_lib.HipError):
+        model.hash(x[:1])

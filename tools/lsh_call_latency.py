@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Measurement helper: wall time of the three device calls behind one LSH query (hash, Hamming search, re-rank)."""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -18,6 +20,9 @@ def t(fn, reps=200):
     for _ in range(reps): fn()
     return (time.perf_counter() - t0) / reps * 1e6
 print("itq_hash 1 row: %.1f us" % t(lambda: _lib.itq_hash(q1, mean, rot, _lib.SQ_NORM_NONE)))
+model = _lib.ItqModel(mean, rot)
+assert np.array_equal(model.hash(x[:5000]), codes[:5000])
+print("resident model, 1 row: %.1f us" % t(lambda: model.hash(q1)))
 qc = _lib.itq_hash(q1, mean, rot, _lib.SQ_NORM_NONE)
 print("hamming search 1 q, k=100: %.1f us" % t(lambda: hidx.search(qc, 100)))
 cand = rng.integers(0, n, 300).astype(np.int64); off = np.array([0, 300], np.int64)
