@@ -136,6 +136,49 @@ struct HostPinned {
     }
 };
 
+// Small host buffers travel through pinned staging: an "asynchronous" copy from or to pageable memory is a
+// blocking staged copy inside the runtime (~10-15 us each; a one-query search makes three to five of them).
+// in(): memcpy into the pinned block, asynchronous H2D from there.  out(): asynchronous D2H into the block;
+// finish() -- after the stream has drained -- copies the pieces to the caller's buffers.  Calls above
+// kStageMax bytes in total copy directly.
+struct PinnedStage {
+    static constexpr size_t kStageMax = 1u << 20;
+    HostPinned pin;
+    size_t used = 0;
+    bool on = false;
+    struct Out {
+        void* dst;
+        size_t off, bytes;
+    };
+    Out outs[4];
+    int n_out = 0;
+    int begin(size_t total_bytes) {
+        used = 0;
+        n_out = 0;
+        on = total_bytes <= kStageMax;
+        return on ? pin.reserve(total_bytes + 64 * 8) : SQ_OK;
+    }
+    hipError_t in(void* dev, const void* host, size_t bytes, hipStream_t st) {
+        if (!on) return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st);
+        char* at = static_cast<char*>(pin.p) + used;
+        memcpy(at, host, bytes);
+        used += (bytes + 63) / 64 * 64;
+        return hipMemcpyAsync(dev, at, bytes, hipMemcpyHostToDevice, st);
+    }
+    hipError_t out(void* host, const void* dev, size_t bytes, hipStream_t st) {
+        if (!on || n_out >= 4) return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st);
+        outs[n_out++] = Out{host, used, bytes};
+        char* at = static_cast<char*>(pin.p) + used;
+        used += (bytes + 63) / 64 * 64;
+        return hipMemcpyAsync(at, dev, bytes, hipMemcpyDeviceToHost, st);
+    }
+    void finish() {  // the stream has been waited for
+        for (int i = 0; i < n_out; ++i) memcpy(outs[i].dst, static_cast<char*>(pin.p) + outs[i].off, outs[i].bytes);
+        n_out = 0;
+    }
+    void release() { pin.release(); }
+};
+
 // ------------------------------------------------------------------ handles
 enum HandleKind { H_HAMMING = 1, H_DENSE = 2, H_ROWS = 3, H_FIT = 4, H_ITQ = 5 };
 

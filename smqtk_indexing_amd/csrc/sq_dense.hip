@@ -50,11 +50,13 @@ struct DenseHandle : HandleBase {
     DevBuf q_dev, q_scaled, q_al, qn2, thr, wave_out, wave_cnt, cnt, keys, sample, out_keys, out_dist_dev,
         out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch;
     HostPinned status_host;
+    PinnedStage stage;
     ~DenseHandle() override {
         for (DevBuf* b : {&owned, &scan, &norms, &norms1, &center, &cos_nx, &cos_nq, &q_dev, &q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt,
                           &keys, &sample, &out_keys, &out_dist_dev, &out_idx_dev, &big_keys, &fb_sample, &fb_keys, &fb_out, &scratch})
             b->release();
         status_host.release();
+        stage.release();
     }
 };
 
@@ -717,11 +719,13 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
     SQ_TRY(h->q_dev.reserve(qb));
     SQ_TRY(h->out_dist_dev.reserve((size_t)nq * k * dsz));
     SQ_TRY(h->out_idx_dev.reserve((size_t)nq * k * 8));
-    SQ_HIP(hipMemcpyAsync(h->q_dev.p, queries, qb, hipMemcpyHostToDevice, st));
+    SQ_TRY(h->stage.begin(qb + (size_t)nq * k * (dsz + 8)));
+    SQ_HIP(h->stage.in(h->q_dev.p, queries, qb, st));
     SQ_TRY(dense_search_chunked(h, h->q_dev.as<float>(), nq, k, h->out_dist_dev.p, h->out_idx_dev.as<long long>(), st));
-    SQ_HIP(hipMemcpyAsync(out_dist, h->out_dist_dev.p, (size_t)nq * k * dsz, hipMemcpyDeviceToHost, st));
-    SQ_HIP(hipMemcpyAsync(out_idx, h->out_idx_dev.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
-    SQ_HIP(hipStreamSynchronize(st));
+    SQ_HIP(h->stage.out(out_dist, h->out_dist_dev.p, (size_t)nq * k * dsz, st));
+    SQ_HIP(h->stage.out(out_idx, h->out_idx_dev.p, (size_t)nq * k * 8, st));
+    SQ_HIP(stream_wait(st));
+    h->stage.finish();
     return SQ_OK;
 }
 

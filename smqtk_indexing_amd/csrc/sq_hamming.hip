@@ -31,6 +31,7 @@ struct HammingHandle : HandleBase {
     // workspace
     DevBuf q_dev, keys, cnt, hist, thr, out_keys, status, out_dist_dev, out_idx_dev, big_keys, seg, bcnt;
     HostPinned status_host;
+    PinnedStage stage;
     ~HammingHandle() override {
         owned.release();
         q_dev.release();
@@ -46,6 +47,7 @@ struct HammingHandle : HandleBase {
         seg.release();
         bcnt.release();
         status_host.release();
+        stage.release();
     }
 };
 
@@ -727,12 +729,14 @@ extern "C" int sq_hamming_search(sq_handle_t hid, const uint64_t* queries, int n
     SQ_TRY(h->q_dev.reserve(qb));
     SQ_TRY(h->out_dist_dev.reserve((size_t)nq * k * 4));
     SQ_TRY(h->out_idx_dev.reserve((size_t)nq * k * 8));
-    SQ_HIP(hipMemcpyAsync(h->q_dev.p, queries, qb, hipMemcpyHostToDevice, st));
+    SQ_TRY(h->stage.begin(qb + (size_t)nq * k * 12));
+    SQ_HIP(h->stage.in(h->q_dev.p, queries, qb, st));
     SQ_TRY(hamming_search_device(h, h->q_dev.as<u64>(), nq, k, h->out_dist_dev.as<int>(),
                                  h->out_idx_dev.as<long long>(), st));
-    SQ_HIP(hipMemcpyAsync(out_dist, h->out_dist_dev.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
-    SQ_HIP(hipMemcpyAsync(out_idx, h->out_idx_dev.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
-    SQ_HIP(hipStreamSynchronize(st));
+    SQ_HIP(h->stage.out(out_dist, h->out_dist_dev.p, (size_t)nq * k * 4, st));
+    SQ_HIP(h->stage.out(out_idx, h->out_idx_dev.p, (size_t)nq * k * 8, st));
+    SQ_HIP(stream_wait(st));
+    h->stage.finish();
     return SQ_OK;
 }
 

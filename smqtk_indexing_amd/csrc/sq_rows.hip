@@ -22,7 +22,9 @@ struct RowsHandle : HandleBase {
     long long n = 0;
     int d = 0;
     DevBuf q_dev, cand_dev, off_dev, cnt_dev, keys, out_keys, out_dist, out_pos;
+    PinnedStage stage;
     ~RowsHandle() override {
+        stage.release();
         for (DevBuf* b : {&owned, &q_dev, &cand_dev, &off_dev, &cnt_dev, &keys, &out_keys, &out_dist, &out_pos}) b->release();
     }
 };
@@ -237,9 +239,10 @@ extern "C" int sq_rows_rerank(sq_handle_t hid, const void* queries, int nq, int 
     SQ_TRY(h->cnt_dev.reserve((size_t)nq * 4));
     SQ_TRY(h->out_dist.reserve((size_t)nq * k * dsz));
     SQ_TRY(h->out_pos.reserve((size_t)nq * k * 8));
-    SQ_HIP(hipMemcpyAsync(h->q_dev.p, queries, (size_t)nq * h->d * esz, hipMemcpyHostToDevice, st));
-    SQ_HIP(hipMemcpyAsync(h->cand_dev.p, cand_rows, (size_t)total * 8, hipMemcpyHostToDevice, st));
-    SQ_HIP(hipMemcpyAsync(h->off_dev.p, cand_offsets, (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, st));
+    SQ_TRY(h->stage.begin((size_t)nq * h->d * esz + (size_t)total * 8 + (size_t)(nq + 1) * 8 + (size_t)nq * k * (dsz + 8)));
+    SQ_HIP(h->stage.in(h->q_dev.p, queries, (size_t)nq * h->d * esz, st));
+    SQ_HIP(h->stage.in(h->cand_dev.p, cand_rows, (size_t)total * 8, st));
+    SQ_HIP(h->stage.in(h->off_dev.p, cand_offsets, (size_t)(nq + 1) * 8, st));
     int rc;
     if (k64)
         rc = rows_rerank_t<float, u64>(h, nq, metric, maxc, k, st);
@@ -248,9 +251,10 @@ extern "C" int sq_rows_rerank(sq_handle_t hid, const void* queries, int nq, int 
     else
         rc = rows_rerank_t<double, K128>(h, nq, metric, maxc, k, st);
     if (rc != SQ_OK) return rc;
-    SQ_HIP(hipMemcpyAsync(out_dist, h->out_dist.p, (size_t)nq * k * dsz, hipMemcpyDeviceToHost, st));
-    SQ_HIP(hipMemcpyAsync(out_pos, h->out_pos.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+    SQ_HIP(h->stage.out(out_dist, h->out_dist.p, (size_t)nq * k * dsz, st));
+    SQ_HIP(h->stage.out(out_pos, h->out_pos.p, (size_t)nq * k * 8, st));
     SQ_HIP(stream_wait(st));
+    h->stage.finish();
     return SQ_OK;
 }
 
