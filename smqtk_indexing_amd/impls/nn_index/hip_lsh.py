@@ -240,8 +240,11 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
         hi = self._mirror_hash_index(m)
         if hi is None:
             return None
-        hv, _ = self._hash_many(list(vectors))
-        qp = pack_bits_msb(np.asarray(hv).astype(bool))
+        if hasattr(self.lsh_functor, "get_hash_packed"):
+            qp = self.lsh_functor.get_hash_packed(vectors)      # packed codes straight from the device  # type: ignore[attr-defined]
+        else:
+            hv, _ = self._hash_many(list(vectors))
+            qp = pack_bits_msb(np.asarray(hv).astype(bool))
         w = m.codes.shape[1]
         if qp.shape[1] < w:
             qp = np.pad(qp, ((0, 0), (w - qp.shape[1], 0)))
