@@ -6,15 +6,30 @@ HBM bandwidth of the scan kernel against the ~8 TB/s peak (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one search call: 32 queries per GPU through the whole hot path
+A "step" is one search call: `--queries` (default 32) queries through the whole hot path
 (query prep -> sampled threshold -> MFMA scan of the shard -> exact re-rank ->
-top-k select -> certification [-> all-gather + host merge when N > 1: rank 0 merges batch i on a host
-thread while the GPUs search batch i + 1 (--overlap-collective: the all-gather and the pinned copy too);
-every batch is merged inside the timed region]).
-The database (10M rows in total) is row-sharded over the N ranks and already
-resident in HBM; a step carries 32*N queries (weak scaling: the per-GPU MFMA
-work per step is fixed; the per-GPU HBM bytes shrink with the shard).
-One process per GPU (torch.distributed / RCCL); rank 0 prints ONE JSON line.
+top-k select -> certification [-> all-gather + host merge when N > 1]).
+
+Scaling definition (STRONG): the database (`--rows`, 10M in total) is row-sharded over the N
+ranks and already resident in HBM, and EVERY N -- N = 1 included -- answers the same
+`--queries` queries per step, so `value` at N GPUs over `value` at 1 GPU is the speed-up of
+the same job.  (Round 1 grew the batch with N; that compared different jobs.)  Larger total
+batches are measured after the timed region and reported as `other_batches` at every N.
+
+Searches are pipelined (`sq_dense_search` with SQ_MEM_DEVICE_ASYNC, include/smqtk_hip.h):
+the kernels of step i + 1 are enqueued while step i runs and the status words of step i are
+read one call later, so the device never waits for the host; every step's results are final
+and every merge is collected before the closing fence (`--sync-search`: one blocking call per
+step, the round-1 behaviour).  One process per GPU (torch.distributed / RCCL); rank 0 prints
+ONE JSON line.
+
+Other workloads (reported with the same contract, not the driver's default):
+    --workload lsh_c3        BASELINE config 3: 10M x 128 -> 64-bit ITQ codes -> Hamming top-n
+                             -> bucket expansion -> exact re-rank (HipLSH pipeline on device),
+                             queries/s AND recall@k against the exact brute-force ground truth
+    --data {normal,uniform,clustered,nonneg}, --metric {l2,cosine}
+                             other descriptor distributions / the cosine metric for the
+                             brute-force workload (candidates per query, fallbacks)
 """
 import argparse
 import json
@@ -39,18 +54,23 @@ def parse_args():
     ap.add_argument("--rows", type=int, default=10_000_000, help="database rows in total (all shards)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--queries-per-gpu", type=int, default=32)
+    ap.add_argument("--queries", type=int, default=32, help="queries per step in total -- the same at every N")
+    ap.add_argument("--queries-per-gpu", type=int, default=0,
+                    help="(round-1 semantics, kept for experiments) queries per step = this x N; overrides --queries")
+    ap.add_argument("--workload", choices=["bruteforce", "lsh_c3"], default="bruteforce")
+    ap.add_argument("--data", choices=["normal", "uniform", "clustered", "nonneg"], default="normal")
+    ap.add_argument("--metric", choices=["l2", "cosine"], default="l2")
+    ap.add_argument("--sync-search", action="store_true", help="one blocking search call per step (no pipelining)")
+    ap.add_argument("--async-streams", type=int, default=0, help="option dense_async_streams (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--no-other-paths", action="store_true",
                     help="skip the ITQ / Hamming timings reported beside the headline metric")
     ap.add_argument("--force-collective", action="store_true",
                     help="testing: run the all-gather + merge path even with one rank (launch under torch.distributed.run)")
-    ap.add_argument("--overlap-collective", action="store_true",
-                    help="N > 1: also run the all-gather and the pinned copy of batch i under the search of batch i + 1 "
-                         "(distributed.PipelinedShardedSearch); default: only the host merge is overlapped")
-    ap.add_argument("--extra-batches", type=str, default="1,128,1024",
-                    help="other batch sizes measured after the timed region (N=1 only); '' to skip")
+    ap.add_argument("--extra-batches", type=str, default="1,128,256,1024",
+                    help="other total batch sizes measured after the timed region; '' to skip")
+    ap.add_argument("--lsh-n", type=int, default=0, help="lsh_c3: nearest codes asked of the hash index (0 = k)")
     return ap.parse_args()
 
 
@@ -71,125 +91,110 @@ def cpu_baseline(dim: int, k: int, seed: int):
     return rows, nq, dt
 
 
-def main() -> None:
-    args = parse_args()
-    # Only the one JSON line may reach stdout: libraries (RCCL prints a version banner) write to
-    # fd 1 too, so fd 1 is pointed at stderr for the run and the line goes to the saved descriptor.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    import torch
-    import torch.distributed as dist
-    from smqtk_indexing_amd import _lib
+def make_rows(torch, kind: str, n: int, d: int, dev, seed: int, chunk: int = 1 << 20):
+    """Synthetic float32 descriptors generated on the device, chunk by chunk.
+    normal: N(0,1) (SURVEY 8d north-star set).  uniform: U[0,1) (C1's distribution).  nonneg: ReLU-like,
+    max(N(0,1), 0) (half the entries exactly zero).  clustered: 1024 Gaussian centres N(0,1), rows = centre +
+    0.25 N(0,1) (tight clusters: many near-ties around every query)."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    out = torch.empty((n, d), dtype=torch.float32, device=dev)
+    centres = None
+    if kind == "clustered":
+        gc = torch.Generator(device=dev)
+        gc.manual_seed(99)                      # the same centres on every rank and for the queries
+        centres = torch.empty((1024, d), dtype=torch.float32, device=dev).normal_(generator=gc)
+    for s in range(0, n, chunk):
+        e = min(s + chunk, n)
+        blk = out[s:e]
+        if kind == "uniform":
+            blk.uniform_(generator=gen)
+        else:
+            blk.normal_(generator=gen)
+            if kind == "nonneg":
+                blk.clamp_(min=0)
+            elif kind == "clustered":
+                which = torch.randint(0, 1024, (e - s,), device=dev, generator=gen)
+                blk.mul_(0.25).add_(centres[which])
+    return out
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_collective
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)
 
+def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     n_total, d, k = args.rows, args.dim, args.k
-    nq = args.queries_per_gpu * world
+    nq = args.queries_per_gpu * world if args.queries_per_gpu > 0 else args.queries
+    metric = _lib.SQ_METRIC_COSINE if args.metric == "cosine" else _lib.SQ_METRIC_L2
+    ddt = torch.float64 if args.metric == "cosine" else torch.float32
     # contiguous row shards (SURVEY.md section 8e)
     per = (n_total + world - 1) // world
     r0 = min(rank * per, n_total)
     r1 = min(r0 + per, n_total)
     n_local = r1 - r0
 
-    # synthetic N(0,1) descriptors generated on the device, shard by shard
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(3 + rank)
-    db = torch.empty((n_local, d), dtype=torch.float32, device=dev)
-    chunk = 1 << 20
-    for s in range(0, n_local, chunk):
-        e = min(s + chunk, n_local)
-        db[s:e].normal_(generator=gen)
-    gq = torch.Generator(device=dev)
-    gq.manual_seed(1234)                     # identical queries on every rank
-    queries = torch.empty((nq, d), dtype=torch.float32, device=dev).normal_(generator=gq)
+    db = make_rows(torch, args.data, n_local, d, dev, 3 + rank)
+    max_b = max([nq] + [int(x) for x in args.extra_batches.split(",") if x])
+    all_q = make_rows(torch, args.data, max_b, d, dev, 1234)     # identical queries on every rank
+    queries = all_q[:nq].contiguous()
     torch.cuda.synchronize()
 
     _lib.set_option("profile", 1)
-    index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=_lib.SQ_METRIC_L2, device_ptr=True,
-                            id_base=r0, keepalive=db)
-    pipe = None
-    merger = None
-    if use_dist and args.overlap_collective:
-        # distributed.PipelinedShardedSearch keeps the collective AND the merge off the critical path: the all-gather
-        # of batch i (asynchronous, RCCL's stream) and its copy to pinned memory run under the search of batch i + 1,
-        # rank 0 merges batch i - 1 on a host thread meanwhile; results arrive two submits later.
-        from smqtk_indexing_amd.distributed import PipelinedShardedSearch
-        pipe = PipelinedShardedSearch(index, nq, k, torch.float32, merge_on=0, device=dev)
-    elif use_dist:
-        # One collective per step and no repacking: the search writes its ids and distances into the two halves of
-        # ONE byte buffer ([ids int64 nq*k][dist float32 nq*k]), that buffer is all-gathered, and the host merge
-        # reads the pinned copy of the receive buffer in place.  Rank 0 merges batch i on a host thread
-        # (distributed.PipelinedMerger) while the GPUs search batch i + 1: two pinned buffers alternate, a buffer is
-        # refilled only after its merge was collected.  Every merge finishes inside the timed region.
-        send = torch.empty(nq * k * 12, dtype=torch.uint8, device=dev)
-        out_i = send[: nq * k * 8].view(torch.int64).view(nq, k)
-        out_d = send[nq * k * 8:].view(torch.float32).view(nq, k)
-        recv = torch.empty((world, nq * k * 12), dtype=torch.uint8, device=dev)
-        host_recv = [torch.empty((world, nq * k * 12), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-        host_np = [h.numpy().reshape(-1) for h in host_recv]
-        pending = [None, None]   # ticket of the merge reading host_recv[j]
-        if rank == 0:
-            from smqtk_indexing_amd.distributed import PipelinedMerger
-            merger = PipelinedMerger()
-        step_no = [0]
-    else:
-        out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
-        out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    if args.async_streams:
+        _lib.set_option("dense_async_streams", args.async_streams)
+    index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=metric, device_ptr=True, id_base=r0, keepalive=db)
     stream = torch.cuda.current_stream().cuda_stream
+    use_async = not args.sync_search
 
     scan_ms, cands, fallbacks = [], [], []
 
-    def step():
-        if pipe is not None:
-            res = pipe.submit(queries)       # per-shard top-k over xGMI, then the host-side merge (north_star)
-        else:
-            index.search_device(queries.data_ptr(), nq, k, out_d.data_ptr(), out_i.data_ptr(), stream)
-            res = (out_d, out_i)
+    def note_stats():
         st = index.stats()
-        scan_ms.append(st["scan_ms"])
-        cands.append(st["candidates"])
-        fallbacks.append(st["fallback_queries"])
-        if use_dist and pipe is None:
-            dist.all_gather_into_tensor(recv, send)
-            res = None
-            if rank == 0:
-                j = step_no[0] & 1
-                step_no[0] += 1
-                res = merger.result(pending[j]) if pending[j] is not None else None   # batch i - 2: long done
-                host_recv[j].copy_(recv, non_blocking=True)
-                cur = torch.cuda.current_stream()
-                while not cur.query():      # poll like the library's searches do (the blocking wait's wake-up is ~10 us)
-                    pass
-                pending[j] = merger.submit(host_np[j], world, nq, k, k, np.float32)
-        return res
+        if st["scan_launches"]:
+            scan_ms.append(st["scan_ms"])
+            cands.append(st["candidates"])
+            fallbacks.append(st["fallback_queries"])
 
-    def drain():
-        """Collect the batches still in flight (merge; with --overlap-collective also the gather): timed."""
-        out = None
-        if pipe is not None:
-            got = pipe.flush()
-            out = got[-1] if got else None
-        elif use_dist and rank == 0:
-            for j in ((step_no[0] & 1), (step_no[0] & 1) ^ 1):   # oldest first
-                if pending[j] is not None:
-                    out = merger.result(pending[j])
-                    pending[j] = None
-        return out
+    class Runner:
+        """`nq_` queries per step through the index (and, with several ranks, the all-gather + host merge)."""
+
+        def __init__(self, nq_, q_):
+            self.nq, self.q = nq_, q_
+            self.pipe = None
+            if use_dist:
+                from smqtk_indexing_amd.distributed import PipelinedShardedSearch
+                # the all-gather of a finished batch (asynchronous, RCCL's stream), its copy to pinned memory and the
+                # host merge (rank 0, a worker thread) run under the searches of the following batches
+                self.pipe = PipelinedShardedSearch(index, nq_, k, ddt, merge_on=0, device=dev, use_async=use_async)
+            else:
+                self.od = [torch.empty((nq_, k), dtype=ddt, device=dev) for _ in range(2)]
+                self.oi = [torch.empty((nq_, k), dtype=torch.int64, device=dev) for _ in range(2)]
+                self.i = 0
+
+        def step(self):
+            if self.pipe is not None:
+                res = self.pipe.submit(self.q)
+            else:
+                j = self.i & 1
+                self.i += 1
+                fn = index.search_device_async if use_async else index.search_device
+                fn(self.q.data_ptr(), self.nq, k, self.od[j].data_ptr(), self.oi[j].data_ptr(), stream)
+                res = None
+            note_stats()        # the last FINISHED call (the previous step when pipelined)
+            return res
+
+        def drain(self):
+            """Finish what is in flight (searches; with several ranks the gathers and merges too): timed."""
+            if self.pipe is not None:
+                got = self.pipe.flush()
+                note_stats()
+                return got[-1] if got else None
+            if use_async:
+                index.sync()
+                note_stats()
+            j = (self.i - 1) & 1
+            return self.od[j], self.oi[j]
+
+        def close(self):
+            if self.pipe is not None:
+                self.pipe.close()
 
     def fence():
         torch.cuda.synchronize()
@@ -197,76 +202,100 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    run = Runner(nq, queries)
     for _ in range(args.warmup):
-        step()
-    drain()
+        run.step()
+    run.drain()
     scan_ms.clear(), cands.clear(), fallbacks.clear()
     fence()
     t0 = time.perf_counter()
-    marks = [t0]
     for _ in range(args.steps):
-        result = step()
-        marks.append(time.perf_counter())   # a step ends synchronised (the search waits for its status words)
-    last = drain()
-    if last is not None:
-        result = last
+        run.step()
+    result = run.drain()
     fence()
     elapsed = time.perf_counter() - t0
-    step_ms = np.diff(np.asarray(marks)) * 1e3
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    n_stats = len(scan_ms)
+    head_scan_ms = float(np.mean(scan_ms)) if scan_ms else 0.0
+    head_cands = float(np.mean(cands)) / nq if cands else None
+    head_fb = int(np.sum(fallbacks)) if fallbacks else 0
 
     # ---- one rank through the collective path: the merged answer must be the shard's own answer
     if use_dist and world == 1 and result is not None:
         md, mi = result
-        ref_i, ref_d = (pipe.out_i[(pipe.i - 1) & 1], pipe.out_d[(pipe.i - 1) & 1]) if pipe is not None else (out_i, out_d)
-        assert np.array_equal(mi, ref_i.cpu().numpy()) and np.array_equal(md, ref_d.cpu().numpy()), \
+        od = torch.empty((nq, k), dtype=ddt, device=dev)
+        oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        index.search_device(queries.data_ptr(), nq, k, od.data_ptr(), oi.data_ptr(), stream)
+        assert np.array_equal(mi, oi.cpu().numpy()) and np.array_equal(md, od.cpu().numpy()), \
             "merged result differs from the shard's top-k"
+    run.close()
 
     # ---- parity spot check against the oracle (outside the timed region)
     parity = None
     if not args.no_parity_check and world == 1:
         from oracle import cpu_ref as O
         sub = min(n_local, 2_000_000)
-        idx_sub = _lib.DenseIndex(db.data_ptr(), n=sub, d=d, device_ptr=True, keepalive=db)
+        idx_sub = _lib.DenseIndex(db.data_ptr(), n=sub, d=d, metric=metric, device_ptr=True, keepalive=db)
         qn = queries[:2].cpu().numpy()
         gd, gi = idx_sub.search(qn, k)
         dbh = db[:sub].cpu().numpy()
         ok, hits = True, 0
         for j in range(qn.shape[0]):
-            rd, ri = O.dense_topk(dbh, qn[j], k)
-            ok &= bool(np.array_equal(gi[j], ri) and np.array_equal(gd[j].view(np.uint32), rd.view(np.uint32)))
+            if args.metric == "cosine":
+                rd, ri = O.dense_topk(dbh, qn[j], k, metric="cosine")
+                ok &= bool(np.array_equal(gi[j], ri) and np.allclose(gd[j], rd, rtol=1e-12, atol=0))
+            else:
+                rd, ri = O.dense_topk(dbh, qn[j], k)
+                ok &= bool(np.array_equal(gi[j], ri) and np.array_equal(gd[j].view(np.uint32), rd.view(np.uint32)))
             hits += len(set(gi[j].tolist()) & set(ri.tolist()))
-        parity = {"rows": sub, "queries": int(qn.shape[0]), "bit_identical_topk": ok,
-                  "recall_at_k": hits / float(k * qn.shape[0])}
+        # the pipelined (asynchronous) calls must give what the blocking call gives
+        ga = [torch.empty((2, k), dtype=ddt, device=dev) for _ in range(2)]
+        gb = [torch.empty((2, k), dtype=torch.int64, device=dev) for _ in range(2)]
+        q2 = queries[:2].contiguous()
+        for j in range(3):
+            idx_sub.search_device_async(q2.data_ptr(), 2, k, ga[j & 1].data_ptr(), gb[j & 1].data_ptr(), stream)
+        idx_sub.sync()
+        ok_async = all(np.array_equal(gb[j].cpu().numpy(), gi) and np.array_equal(ga[j].cpu().numpy(), gd) for j in range(2))
+        parity = {"rows": sub, "queries": int(qn.shape[0]),
+                  "bit_identical_topk" if args.metric == "l2" else "identical_idx_dist_1e-12": ok,
+                  "recall_at_k": hits / float(k * qn.shape[0]), "async_equals_sync": bool(ok_async)}
         del dbh
         idx_sub.close()
 
+    # ---- other total batch sizes, same shards, after the timed region (every N: the N = 1 run gives the reference)
     extra = {}
-    if world == 1 and args.extra_batches:
-        for b in [int(x) for x in args.extra_batches.split(",") if x]:
-            qb = torch.empty((b, d), dtype=torch.float32, device=dev).normal_(generator=gq)
-            od = torch.empty((b, k), dtype=torch.float32, device=dev)
-            oi = torch.empty((b, k), dtype=torch.int64, device=dev)
-            reps = 3 if b >= 256 else 10
-            index.search_device(qb.data_ptr(), b, k, od.data_ptr(), oi.data_ptr(), stream)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            sm = []
-            for _ in range(reps):
-                index.search_device(qb.data_ptr(), b, k, od.data_ptr(), oi.data_ptr(), stream)
-                sm.append(index.stats()["scan_ms"])
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / reps
-            s_ms = float(np.mean(sm))
-            extra[f"batch_{b}"] = {
-                "queries_per_s": b / dt, "ms_per_call": dt * 1e3, "scan_kernel_ms": s_ms,
-                "scan_GBps_per_query_tile": (-(-n_local // 32) * 32) * (-(-d // 128) * 256 + 4) * (-(-b // 32)) / (s_ms * 1e-3) / 1e9 if s_ms > 0 else None,
-                # one 32-query tile runs two bfloat16 query planes (q_hi + q_lo), larger batches one
-                "scan_bf16_TFLOPs_executed": 2 * (2.0 if b <= 32 else 1.0) * n_local * (-(-d // 128) * 128) * (-(-b // 32) * 32) / (s_ms * 1e-3) / 1e12 if s_ms > 0 else None,
-            }
+    for b in [int(x) for x in args.extra_batches.split(",") if x]:
+        if b == nq:
+            continue
+        qb = all_q[:b].contiguous()
+        rb = Runner(b, qb)
+        reps = 6 if b >= 256 else 12
+        rb.step()
+        rb.drain()
+        scan_ms.clear(), cands.clear(), fallbacks.clear()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            rb.step()
+        rb.drain()
+        fence()
+        dt = (time.perf_counter() - t1) / reps
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        rb.close()
+        s_ms = float(np.mean(scan_ms)) if scan_ms else 0.0
+        qp = 2.0 if b <= 32 else 1.0    # one 32-query tile runs two bfloat16 query planes (q_hi + q_lo), larger batches one
+        extra[f"batch_{b}"] = {
+            "queries_per_s": b / dt, "ms_per_step": dt * 1e3, "scan_kernel_ms": s_ms,
+            "mean_candidates_per_query": float(np.mean(cands)) / b if cands else None,
+            "fallback_queries": int(np.sum(fallbacks)) if fallbacks else 0,
+            "scan_bf16_TFLOPs_executed": 2 * qp * n_local * (-(-d // 128) * 128) * (-(-b // 32) * 32) / (s_ms * 1e-3) / 1e12 if s_ms > 0 else None,
+        }
 
     # ---- the other two kernels of the hot path on the same resident matrix (BASELINE config C3):
     # ITQ codes of all rows, then Hamming top-k over the unique codes.  Outside the timed region.
@@ -298,7 +327,9 @@ def main() -> None:
                                 "frac_of_hbm_peak": (n_local * d * 4 + n_local * 8) / dt / 1e9 / HBM_PEAK_GBS}
         ucodes = torch.unique(codes.view(-1), sorted=True).contiguous()   # int64 order != uint64 order: timing only
         hidx = _lib.HammingIndex(ucodes.data_ptr(), n=int(ucodes.numel()), words=1, device_ptr=True, keepalive=ucodes)
-        for hq in (32, 1024):
+        gq = torch.Generator(device=dev)
+        gq.manual_seed(77)
+        for hq in (1, 32, 1024):
             qc = ucodes[torch.randint(0, ucodes.numel(), (hq,), device=dev, generator=gq)].contiguous()
             hd = torch.empty((hq, k), dtype=torch.int32, device=dev)
             hi_ = torch.empty((hq, k), dtype=torch.int64, device=dev)
@@ -311,22 +342,24 @@ def main() -> None:
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = nq * args.steps / elapsed
-        mean_scan_ms = float(np.mean(scan_ms)) if scan_ms else 0.0
-        # Bytes one full-pass launch has to read: the bfloat16 scan copy (d_pad*2 bytes per row) plus the
-        # float32 |x|^2 per row.  SURVEY 8(d) prices a pass at N*d*4 bytes (the float32
-        # matrix); the scan copy halves that, so the float32-equivalent rate is reported beside it and
-        # `achieved`/`frac` use only the bytes the kernel really streams.
+        cosine = args.metric == "cosine"
+        # Bytes one full-pass launch streams: the bfloat16 scan copy (d_pad*2 bytes per row) plus the float32
+        # |x|^2 per row for L2.  SURVEY 8(d) prices a pass at N*d*4 bytes (the float32 matrix);
+        # the kernel gets the same exact answers from about half of that, so BOTH fractions are printed:
+        # `frac` from the bytes really streamed (<= 1 by construction), `frac_survey_8d` from N*d*4 (> 1 means
+        # the float32 matrix is not what is being read).
         d_pad = -(-d // 128) * 128
         n_pad = -(-n_local // 32) * 32
-        alg_bytes = float(n_pad) * (d_pad * 2 + 4)
+        streamed = float(n_pad) * (d_pad * 2 + (0 if cosine else 4))
         f32_bytes = float(n_local) * d * 4
-        traffic = None
+        replay = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
-        if os.path.isfile(tpath) and n_local == 10_000_000 and d == 128:
-            # HBM bytes of one full-pass launch from the PMC passes of the last committed profile
-            # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes)
-            traffic = json.load(open(tpath)).get("dense_scan_full_pass_hbm_bytes")
-        achieved = alg_bytes / (mean_scan_ms * 1e-3) / 1e9 if mean_scan_ms > 0 else 0.0
+        if os.path.isfile(tpath) and n_local == 10_000_000 and d == 128 and not cosine:
+            tj = json.load(open(tpath))
+            replay = {"hbm_bytes_per_launch": tj.get("dense_scan_full_pass_hbm_bytes"), "file": "profiles/latest_traffic.json",
+                      "note": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the committed profile"}
+        achieved = streamed / (head_scan_ms * 1e-3) / 1e9 if head_scan_ms > 0 else 0.0
+        qp = 2.0 if nq <= 32 else 1.0
         line = {
             "metric": "queries/sec, exact brute-force L2 kNN k=100 over 10Mx128 float32 (recall@100 = 1.0 by construction); scan HBM GB/s vs 8 TB/s peak",
             "value": value,
@@ -335,30 +368,40 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "step_ms_p10_p50_p90": [float(np.percentile(step_ms, p)) for p in (10, 50, 90)],   # rank 0's own clock
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic N(0,1) float32 descriptors generated on device; queries N(0,1)",
+            "dtype": "f32 results (distances bit-identical to numpy float32); filter arithmetic bf16 MFMA (x_hi*(q_hi+q_lo)), exact re-rank f32"
+                     if not cosine else "f64 results (cosine, 1e-12); filter arithmetic bf16 MFMA, exact re-rank f64",
+            "data": f"synthetic {args.data} float32 descriptors generated on device; queries from the same distribution",
             "config": {
-                "workload": f"bruteforce_l2_{n_total}x{d}_k{k}",
+                "workload": f"bruteforce_{args.metric}_{n_total}x{d}_k{k}",
                 "db_rows_total": n_total, "db_rows_per_gpu": n_local, "dim": d, "k": k,
-                "queries_per_step": nq, "queries_per_step_per_gpu": args.queries_per_gpu,
+                "queries_per_step": nq,
+                "scaling_definition": "strong: fixed rows in total (row-sharded over the ranks) and the same queries per step at every N, N = 1 included",
+                "search_calls": "pipelined (SQ_MEM_DEVICE_ASYNC): status of step i read after step i+1 is enqueued" if use_async else "one blocking call per step",
                 "sharding": "rows" if world > 1 else "none",
-                "collective": ("all_gather(top-k dist,idx) + host merge, both under the next batch's search" if pipe is not None else
-                               "all_gather(top-k dist,idx) + host merge (merge on a host thread under the next batch's search)") if use_dist else "none",
-                "mean_candidates_per_query": float(np.mean(cands)) / nq if cands else None,
-                "fallback_queries": int(np.sum(fallbacks)) if fallbacks else 0,
+                "collective": "all_gather(top-k dist,idx) + host merge, both under the following batches' searches" if use_dist else "none",
+                "mean_candidates_per_query": head_cands,
+                "fallback_queries": head_fb,
+                "steps_with_stats": n_stats,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "dense_scan_kernel (full pass)", "kernel_ms": mean_scan_ms,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "bytes_per_row": d_pad * 2 + 4,
-                "f32_matrix_equivalent_GBps": f32_bytes / (mean_scan_ms * 1e-3) / 1e9 if mean_scan_ms > 0 else None,
-                "mfma_TFLOPs_executed": 2 * (2.0 if nq <= 32 else 1.0) * n_pad * d_pad * (-(-nq // 32) * 32) / (mean_scan_ms * 1e-3) / 1e12 if mean_scan_ms > 0 else None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "traffic_replayed": replay,
+                "kernel": "dense_scan_kernel (full pass)", "kernel_ms": head_scan_ms,
+                "bytes_definition": "achieved/frac: bytes the kernel streams per launch = n_pad*(2*d_pad + 4) (bf16 scan copy + f32 norms)",
+                "streamed_bytes_per_launch": streamed,
+                "bytes_per_row": d_pad * 2 + (0 if cosine else 4),
+                "algorithmic_bytes_survey_8d": f32_bytes,
+                "achieved_survey_8d": f32_bytes / (head_scan_ms * 1e-3) / 1e9 if head_scan_ms > 0 else None,
+                "frac_survey_8d": f32_bytes / (head_scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if head_scan_ms > 0 else None,
+                "frac_survey_8d_note": "SURVEY 8(d) prices a pass at N*d*4 (the float32 matrix); a fraction above 1 says the kernel does not read that matrix: it streams the half-size bf16 copy and only the re-rank touches float32 rows",
+                "frac_step": streamed / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "frac_step_note": "streamed bytes / ms_per_step / peak: the whole search step (sample pass, threshold, re-rank, select, launch gaps) priced as if it were the scan",
+                "mfma_TFLOPs_executed": 2 * qp * n_pad * d_pad * (-(-nq // 32) * 32) / (head_scan_ms * 1e-3) / 1e12 if head_scan_ms > 0 else None,
                 "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TF,
             },
         }
@@ -372,13 +415,28 @@ def main() -> None:
             rows, cq, dt = cpu_baseline(d, k, 7)
             line["cpu_baseline"] = {
                 "value": cq / dt * rows / n_total, "unit": "queries/s", "cores": 1, "kind": "port",
-                "sample": f"oracle/cpu_ref.dense_topk: {cq} queries x {rows} rows x {d} f32 in {dt:.2f} s on 1 thread "
+                "sample": f"oracle/cpu_ref.dense_topk (VECTORISED numpy restatement of euclidean_distance + stable sort, not the "
+                          f"per-row Python loop of lsh.py:511): {cq} queries x {rows} rows x {d} f32 in {dt:.2f} s on 1 thread "
                           f"(host has {len(os.sched_getaffinity(0))} cores); scaled linearly in rows to {n_total}",
+            }
+            # what SMQTK executes today -- one Python distance call per candidate row (lsh.py:511)
+            from oracle import cpu_ref as O
+            rng = np.random.default_rng(7)
+            rows_l = 200_000
+            dbl = rng.standard_normal((rows_l, d), dtype=np.float32)
+            ql = rng.standard_normal(d, dtype=np.float32)
+            t1 = time.perf_counter()
+            dl = [O.euclidean_distance(ql, r) for r in dbl]
+            sorted(range(rows_l), key=dl.__getitem__)[:k]
+            dtl = time.perf_counter() - t1
+            line["cpu_baseline_reference_loop"] = {
+                "value": 1.0 / dtl * rows_l / n_total, "unit": "queries/s", "cores": 1,
+                "kind": "port (per-row Python loop, the shape of lsh.py:505-519)",
+                "sample": f"1 query x {rows_l} rows in {dtl:.2f} s; scaled linearly in rows to {n_total}",
             }
             # what a vectorised CPU implementation reaches on the same sample -- |x|^2 - 2 x.q through
             # BLAS on every host thread numpy's BLAS uses, argpartition for the top k.  Not order-exact; a reported
             # baseline only (neither the oracle nor the product).
-            rng = np.random.default_rng(7)
             rows_v, nq_v = 2_000_000, 32
             dbv = rng.standard_normal((rows_v, d), dtype=np.float32)
             qv = rng.standard_normal((nq_v, d), dtype=np.float32)
@@ -392,16 +450,49 @@ def main() -> None:
                 "kind": "numpy BLAS + argpartition (not order-exact)",
                 "sample": f"{nq_v} queries x {rows_v} rows x {d} f32 in {dtv:.3f} s; scaled linearly in rows to {n_total}",
             }
+        emit(line)
+    index.close()
+
+
+def main() -> None:
+    args = parse_args()
+    # Only the one JSON line may reach stdout: libraries (RCCL prints a version banner) write to
+    # fd 1 too, so fd 1 is pointed at stderr for the run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    import torch.distributed as dist
+    from smqtk_indexing_amd import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    def emit(line):
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
+    if args.workload == "lsh_c3":
+        from tools.lsh_c3 import run as lsh_run
+        lsh_run(args, torch, dist, _lib, world, rank, dev, use_dist, emit, make_rows)
+    else:
+        bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit)
     if use_dist:
-        if pipe is not None:
-            pipe.close()
-        if merger is not None:
-            merger.close()
         dist.barrier()
         dist.destroy_process_group()
-    index.close()
 
 
 if __name__ == "__main__":

@@ -16,7 +16,13 @@
  *   - `mem` says where caller buffers live: SQ_MEM_HOST (library stages them
  *     through its own device workspace; the call is synchronous) or
  *     SQ_MEM_DEVICE (pointers are HIP device pointers on the current device;
- *     work is enqueued on `stream` and the call returns without syncing).
+ *     work is enqueued on `stream`).  The search calls (sq_dense_search,
+ *     sq_hamming_search) return when the results are final: each query's
+ *     answer is certified on the device and the host reads the status words
+ *     (an uncertified query is redone on the exact path), so the call waits
+ *     for its own kernels.  sq_itq_hash / sq_dense_distances with device
+ *     buffers only enqueue.  SQ_MEM_DEVICE_ASYNC (sq_dense_search only) is
+ *     the pipelined form: see sq_dense_search.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *   - all matrices are C-contiguous, row-major.
  *   - hash codes are uint64[n][words], word 0 most significant, bit 0 of the
@@ -46,6 +52,7 @@ extern "C" {
 
 #define SQ_MEM_HOST 0
 #define SQ_MEM_DEVICE 1
+#define SQ_MEM_DEVICE_ASYNC 2 /* sq_dense_search: enqueue and return, results final one call later */
 
 #define SQ_METRIC_L2 0     /* utils/metrics.py:73-86 euclidean_distance */
 #define SQ_METRIC_COSINE 1 /* utils/metrics.py:89-137 cosine_distance (pos_vectors=True) */
@@ -149,8 +156,9 @@ int sq_hamming_destroy(sq_handle_t h);
  * ascending sort, first k.  L2 distances are float32 and bit-identical to
  * numpy's evaluation of metrics.py:86 (same subtraction, square, pairwise
  * summation order and sqrt); cosine distances are float64.
- * With SQ_MEM_DEVICE the matrix is borrowed (row stride d, d % 64 == 0
- * required for borrowing; otherwise pass host memory and the library pads). */
+ * With SQ_MEM_DEVICE the matrix is borrowed (row stride d; the pointer must
+ * be 16-byte aligned and d % 4 == 0, otherwise pass host memory and the
+ * library pads the rows). */
 int sq_dense_create(const float* db, int64_t n, int d, int metric, int mem,
                     int64_t id_base, sq_handle_t* out);
 /* Append n_add rows ([n_add][d] float32, host or device) to an index that owns its matrix (created from
@@ -165,6 +173,15 @@ int sq_dense_append(sq_handle_t h, const float* rows, int64_t n_add, int mem);
  * float64 [nq][k] for SQ_METRIC_COSINE.  out_idx int64 [nq][k]. */
 int sq_dense_search(sq_handle_t h, const float* queries, int nq, int k,
                     void* out_dist, int64_t* out_idx, int mem, void* stream);
+/* mem = SQ_MEM_DEVICE_ASYNC: the call enqueues its kernels and returns without waiting for them; `queries`
+ * are read in the order of `stream`.  The results of call i are final -- certified, uncertified queries redone,
+ * complete in out_dist / out_idx -- when the NEXT call on the handle (another search, sq_dense_sync,
+ * sq_dense_append, sq_dense_destroy) returns; until then the call's `queries`, `out_dist` and `out_idx` must
+ * stay valid and untouched (so consecutive asynchronous calls alternate between two output buffers).  The device
+ * never idles between calls, and with option "dense_async_streams" = 2 (default) consecutive calls run on two
+ * internal streams so that the short kernels ending call i overlap those starting call i + 1.  sq_get_stats
+ * reports the last FINISHED call.  sq_dense_sync finishes every call in flight. */
+int sq_dense_sync(sq_handle_t h);
 int sq_dense_destroy(sq_handle_t h);
 
 /* Distances from one query to n gathered candidate rows, in the reference's

@@ -20,6 +20,7 @@ import numpy as np
 SQ_OK = 0
 SQ_MEM_HOST = 0
 SQ_MEM_DEVICE = 1
+SQ_MEM_DEVICE_ASYNC = 2
 SQ_METRIC_L2 = 0
 SQ_METRIC_COSINE = 1
 SQ_DTYPE_F32 = 0
@@ -37,7 +38,7 @@ EXPORTS = (
     "sq_set_option", "sq_get_stats", "sq_itq_hash",
     "sq_itq_model_create", "sq_itq_model_hash", "sq_itq_model_destroy",
     "sq_hamming_create", "sq_hamming_search", "sq_hamming_destroy",
-    "sq_dense_create", "sq_dense_append", "sq_dense_search", "sq_dense_destroy",
+    "sq_dense_create", "sq_dense_append", "sq_dense_search", "sq_dense_sync", "sq_dense_destroy",
     "sq_dense_distances", "sq_merge_topk", "sq_merge_topk_strided",
     "sq_rows_create", "sq_rows_append", "sq_rows_rerank", "sq_rows_destroy",
     "sq_itqfit_create", "sq_itqfit_set_mean", "sq_itqfit_cov", "sq_itqfit_project", "sq_itqfit_iterate",
@@ -84,6 +85,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_dense_create.argtypes = [c_vp, c_i64, c_int, c_int, c_int, c_i64, ctypes.POINTER(c_i64)]
     lib.sq_dense_append.argtypes = [c_i64, c_vp, c_i64, c_int]
     lib.sq_dense_search.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]
+    lib.sq_dense_sync.argtypes = [c_i64]
     lib.sq_dense_destroy.argtypes = [c_i64]
     lib.sq_dense_distances.argtypes = [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_int, c_vp]
     lib.sq_merge_topk.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]
@@ -401,6 +403,18 @@ class DenseIndex(_Handle):
                "sq_dense_search")
 
 
+    def search_device_async(self, q_ptr: int, nq: int, k: int, out_dist_ptr: int, out_idx_ptr: int, stream: int = 0) -> None:
+        """``SQ_MEM_DEVICE_ASYNC``: enqueue and return.  The results are final when the next call on this index
+        (another search, :meth:`sync`, ``append``, ``close``) returns; alternate between two output buffers."""
+        _check(load().sq_dense_search(self.handle, _ptr(q_ptr), int(nq), int(k), _ptr(out_dist_ptr),
+                                      _ptr(out_idx_ptr), SQ_MEM_DEVICE_ASYNC, ctypes.c_void_p(stream or None)),
+               "sq_dense_search")
+
+    def sync(self) -> None:
+        """Finish every asynchronous search in flight (``sq_dense_sync``)."""
+        _check(load().sq_dense_sync(self.handle), "sq_dense_sync")
+
+
 def dense_distances(query: np.ndarray, rows: np.ndarray, metric: int = SQ_METRIC_L2) -> np.ndarray:
     """Reference-arithmetic distances from ``query`` to each of ``rows`` (host
     arrays).  Computed in float32 when both operands are float32, otherwise in
@@ -443,12 +457,14 @@ def merge_topk(dist: np.ndarray, idx: np.ndarray, k_out: int) -> Tuple[np.ndarra
 def merge_topk_gathered(buf: np.ndarray, nshards: int, nq: int, k_in: int, k_out: int,
                         dist_dtype) -> Tuple[np.ndarray, np.ndarray]:
     """Host merge straight from the receive buffer of ONE all-gather: ``buf`` is a C-contiguous
-    uint8 array of ``nshards`` blocks, each ``[ids int64 nq*k_in][dist nq*k_in]``."""
+    uint8 array of ``nshards`` blocks, each ``[ids int64 nq*k_in][dist nq*k_in]`` padded to a multiple of 8 bytes
+    (``distributed.packed_block_bytes``)."""
     dist_dtype = np.dtype(dist_dtype)
     dt = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int32): 2}[dist_dtype]
-    per = nq * k_in * (8 + dist_dtype.itemsize)
+    per = (nq * k_in * (8 + dist_dtype.itemsize) + 7) // 8 * 8    # blocks padded to 8 bytes: id blocks stay aligned
     if buf.dtype != np.uint8 or not buf.flags.c_contiguous or buf.size != nshards * per:
-        raise ValueError("buf must be a contiguous uint8 array of nshards * nq * k_in * (8 + dist size) bytes")
+        raise ValueError("buf must be a contiguous uint8 array of nshards blocks of nq * k_in * (8 + dist size) "
+                         "bytes, each rounded up to a multiple of 8")
     od = np.empty((nq, k_out), dtype=dist_dtype)
     oi = np.empty((nq, k_out), dtype=np.int64)
     base = buf.ctypes.data

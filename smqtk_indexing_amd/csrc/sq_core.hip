@@ -89,6 +89,7 @@ extern "C" int sq_set_option(const char* name, int64_t value) {
     else if (n == "spin_wait_us") g_opt.spin_wait_us = (int)value;
     else if (n == "dense_rerank_segments") g_opt.dense_rerank_segments = (int)value;
     else if (n == "dense_qplanes") g_opt.dense_qplanes = (int)value;
+    else if (n == "dense_async_streams") g_opt.dense_async_streams = (int)value;
     else return fail(SQ_ERR_INVALID, "sq_set_option: unknown option '%s'", name);
     return SQ_OK;
 }
@@ -112,13 +113,18 @@ extern "C" int sq_get_stats(sq_handle_t hid, sq_stats_t* out) {
 // -- extended past k_out to the whole tie group of the last distance -- is put in id order (a
 // no-op test when shards hold increasing id ranges) and the list is cut to k_out.
 // dshard / ishard: distance between consecutive shards' [nq][k_in] blocks, in BYTES
+// (every NaN, whatever its sign or payload, gets ONE key just below an exhausted list's: NaN distances rank after
+// all numbers, as on a single GPU -- x86 0/0 and numpy produce the sign-bit-set quiet NaN)
+static constexpr uint64_t kMergeNaN = ~0ull - 1;
 static inline uint64_t merge_key(float v) {
+    if (v != v) return kMergeNaN;
     if (v == 0.0f) v = 0.0f;  // -0 and +0 are one distance
     uint32_t b;
     std::memcpy(&b, &v, 4);
     return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
 }
 static inline uint64_t merge_key(double v) {
+    if (v != v) return kMergeNaN;
     if (v == 0.0) v = 0.0;
     uint64_t b;
     std::memcpy(&b, &v, 8);

@@ -31,6 +31,39 @@
 
 namespace sq {
 
+// Per-call workspace.  A synchronous search uses slot 0; asynchronous searches (SQ_MEM_DEVICE_ASYNC)
+// alternate between the two slots so that the kernels of call i + 1 are enqueued -- and, with the slots'
+// own streams, partly run -- while call i is still on the device; the status words of call i are read when
+// call i + 1 has been enqueued (dense_resolve).
+struct DenseCall {
+    bool pending = false;
+    const float* q = nullptr;
+    int nq = 0, k = 0, nq_pad = 0;
+    void* out_dist = nullptr;
+    long long* out_idx = nullptr;
+    hipStream_t st = nullptr;     // the stream the call's kernels were enqueued on
+    bool small = false, all_fallback = false, prof = false, use_event = false;
+    sq_stats_t stats{};
+};
+struct DenseSlot {
+    DevBuf q_scaled, q_al, qn2, thr, wave_out, wave_cnt, cnt, keys, sample, out_keys, cos_nq, oflag;
+    HostPinned status_host;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_in = nullptr, ev_done = nullptr;
+    hipStream_t own = nullptr;    // internal stream of the slot (asynchronous calls with "dense_async_streams" = 2)
+    DenseCall call;
+    void release() {
+        for (DevBuf* b : {&q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt, &keys, &sample, &out_keys, &cos_nq, &oflag})
+            b->release();
+        status_host.release();
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e), e = nullptr;
+        if (ev_in) (void)hipEventDestroy(ev_in), ev_in = nullptr;
+        if (ev_done) (void)hipEventDestroy(ev_done), ev_done = nullptr;
+        if (own) (void)hipStreamDestroy(own), own = nullptr;
+    }
+};
+
 struct DenseHandle : HandleBase {
     const float* db = nullptr;  // device [n][ld], the caller's float32 rows (borrowed or owned)
     DevBuf owned;
@@ -38,24 +71,24 @@ struct DenseHandle : HandleBase {
     DevBuf norms;               // float32 |x - c|^2 [n_pad] (cosine: of the rows themselves)
     DevBuf center;              // float32 c [d_pad]: column means (L2), the filter's origin
     DevBuf cos_nx;              // float64 |x|^2 [n] in the reference order (cosine re-rank)
-    DevBuf cos_nq;              // float64 |q|^2 [nq] of the current call (cosine)
     long long n = 0, n_pad = 0;
     int d = 0, d_pad = 0;
     long long ld = 0;
     int metric = SQ_METRIC_L2;
     long long id_base = 0;
     double xn2_max = 0.0;       // max squared row norm (error bound of the L2 filter)
-    // workspace
     DevBuf norms1;  // L2: |x|^2 (1 - alpha) for one query plane (`norms`: two planes)
-    DevBuf q_dev, q_scaled, q_al, qn2, thr, wave_out, wave_cnt, cnt, keys, sample, out_keys, out_dist_dev,
-        out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch;
-    HostPinned status_host;
+    DenseSlot slot[2];
+    unsigned long long async_calls = 0;  // asynchronous calls so far (slot = parity)
+    // workspace shared by all calls: host-memory staging, the exact path (runs synchronously), index build
+    DevBuf q_dev, out_dist_dev, out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch, fb_cnt;
     PinnedStage stage;
     ~DenseHandle() override {
-        for (DevBuf* b : {&owned, &scan, &norms, &norms1, &center, &cos_nx, &cos_nq, &q_dev, &q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt,
-                          &keys, &sample, &out_keys, &out_dist_dev, &out_idx_dev, &big_keys, &fb_sample, &fb_keys, &fb_out, &scratch})
+        for (DevBuf* b : {&owned, &scan, &norms, &norms1, &center, &cos_nx, &q_dev, &out_dist_dev, &out_idx_dev, &big_keys,
+                          &fb_sample, &fb_keys, &fb_out, &scratch, &fb_cnt})
             b->release();
-        status_host.release();
+        slot[0].release();
+        slot[1].release();
         stage.release();
     }
 };
@@ -174,8 +207,28 @@ static int scan_query_tiles(int d_pad, int nqt) {
     return want;
 }
 
-static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, void* out_dist, long long* out_idx,
-                               hipStream_t st) {
+// Wait for an event the way stream_wait waits for a stream (poll, then block).
+static hipError_t event_wait(hipEvent_t ev) {
+    const long long budget_us = g_opt.spin_wait_us;
+    if (budget_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int i = 0; i < 64; ++i) {
+                const hipError_t e = hipEventQuery(ev);
+                if (e != hipErrorNotReady) return e;
+            }
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > budget_us)
+                break;
+        }
+    }
+    return hipEventSynchronize(ev);
+}
+
+// Enqueue one search (nq <= kDenseQueryChunk queries) on `st` with the workspace of slot `s`; nothing is
+// waited for.  dense_resolve() finishes the call: it waits for the kernels, reads the status words and
+// sends uncertified queries down the exact path.
+static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, int k, void* out_dist, long long* out_idx,
+                         hipStream_t st, bool use_event) {
     const long long n = h->n;
     const int d = h->d, d_pad = h->d_pad;
     const int kk = (int)(k < n ? k : n);
@@ -184,7 +237,6 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     const size_t key_bytes = cosine ? sizeof(K128) : sizeof(u64);
     u32 cap = g_opt.candidate_cap > 0 ? (u32)g_opt.candidate_cap : 65536u;
     if (cap < (u32)(4 * kk)) cap = (u32)(4 * kk);
-    const bool force_fb = g_opt.force_fallback != 0;
     const bool small = n <= (long long)cap;
     const bool scan_ok = h->scan.p != nullptr && !small;
     const int qt = scan_query_tiles(d_pad, (nq + TILE_ROWS - 1) / TILE_ROWS);  // query tiles per wave
@@ -194,28 +246,37 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     const int group_q = qt * TILE_ROWS;                                           // queries per scan workgroup
     const int nqt = (nq + group_q - 1) / group_q;                                 // groups of qt query tiles
     const int nq_pad = nqt * group_q;
-    h->stats = sq_stats_t{};
+    DenseCall& c = s.call;
+    c = DenseCall{};
+    c.q = q;
+    c.nq = nq;
+    c.k = k;
+    c.nq_pad = nq_pad;
+    c.out_dist = out_dist;
+    c.out_idx = out_idx;
+    c.st = st;
+    c.prof = prof;
+    c.small = small;
+    c.use_event = use_event;
     if (prof) {
-        for (auto& e : h->ev)
+        for (auto& e : s.ev)
             if (!e) SQ_HIP(hipEventCreate(&e));
-        SQ_HIP(hipEventRecord(h->ev[0], st));
-        SQ_HIP(hipEventRecord(h->ev[1], st));
-        SQ_HIP(hipEventRecord(h->ev[2], st));
+        SQ_HIP(hipEventRecord(s.ev[0], st));
     }
-    SQ_TRY(h->cnt.reserve((size_t)nq_pad * 4));
-    SQ_TRY(h->thr.reserve((size_t)nq_pad * 4));
-    SQ_TRY(h->qn2.reserve((size_t)nq_pad * 8));
-    SQ_TRY(h->q_scaled.reserve((size_t)nq_pad * d_pad * 4));
-    SQ_TRY(h->out_keys.reserve((size_t)nq * k * key_bytes));
-    SQ_TRY(h->status_host.reserve((size_t)(nq_pad + nq) * 4));
-    u32* cnt = h->cnt.as<u32>();
-    float* thr = h->thr.as<float>();
-    double* qn2 = h->qn2.as<double>();
-    uint4* qs = h->q_scaled.as<uint4>();
+    SQ_TRY(s.cnt.reserve((size_t)nq_pad * 4));
+    SQ_TRY(s.thr.reserve((size_t)nq_pad * 4));
+    SQ_TRY(s.qn2.reserve((size_t)nq_pad * 8));
+    SQ_TRY(s.q_scaled.reserve((size_t)nq_pad * d_pad * 4));
+    SQ_TRY(s.out_keys.reserve((size_t)nq * k * key_bytes));
+    SQ_TRY(s.status_host.reserve((size_t)(nq_pad + nq) * 4));
+    SQ_TRY(s.oflag.reserve(64));
+    u32* cnt = s.cnt.as<u32>();
+    float* thr = s.thr.as<float>();
+    double* qn2 = s.qn2.as<double>();
+    uint4* qs = s.q_scaled.as<uint4>();
     // per-query candidate counts and status words land in pinned host memory straight from the
     // finalisation (no copy launch): [cnt (nq_pad) | status (nq)]
-    u32* hs_raw = reinterpret_cast<u32*>(h->status_host.p);
-    u32* hs = hs_raw + nq_pad;
+    u32* hs_raw = reinterpret_cast<u32*>(s.status_host.p);
     u32* hs_raw_dev = nullptr;
     SQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs_raw_dev), hs_raw, 0));
     u32* hs_dev = hs_raw_dev + nq_pad;
@@ -228,36 +289,35 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     const double eps_b = dense_eps_b(d_pad);
     const size_t l2_lds = (size_t)((d + 3) / 4 * 4) * 4;
     if (cosine) {
-        SQ_TRY(h->cos_nq.reserve((size_t)nq * 8));
-        hipLaunchKernelGGL(dense_cos_qnorm_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, q, nq, d, h->cos_nq.as<double>());
+        SQ_TRY(s.cos_nq.reserve((size_t)nq * 8));
+        hipLaunchKernelGGL(dense_cos_qnorm_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, q, nq, d, s.cos_nq.as<double>());
     }
     const double* cnx = h->cos_nx.as<double>();
-    const double* cnq = h->cos_nq.as<double>();
+    const double* cnq = s.cos_nq.as<double>();
 
     const long long key_stride = small ? n : (long long)cap;
-    bool all_fallback = false;
     if (small) {
         // every row is a candidate: exact keys for all rows, no scan
-        SQ_TRY(h->keys.reserve((size_t)nq * key_stride * key_bytes));
+        SQ_TRY(s.keys.reserve((size_t)nq * key_stride * key_bytes));
         hipLaunchKernelGGL(fill_u32_kernel, dim3((nq_pad + 255) / 256), dim3(256), 0, st, cnt, (long long)nq_pad, (u32)n);
         const unsigned gx = (unsigned)((n + 255) / 256);
-        if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
+        if (prof) SQ_HIP(hipEventRecord(s.ev[1], st));
         if (cosine)
             hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, nq), dim3(256), 0, st, h->db, h->ld, d, q, nullptr, cnt,
-                               (u32)n, n, 0ll, h->keys.as<K128>(), key_stride, cnx, cnq, nullptr, 0);
+                               (u32)n, n, 0ll, s.keys.as<K128>(), key_stride, cnx, cnq, nullptr, 0);
         else
             hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, nq), dim3(256), l2_lds, st, h->db, h->ld, d, q, nullptr,
-                               cnt, (u32)n, n, 0ll, h->keys.as<u64>(), key_stride, nullptr, 0);
-        if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
-        h->stats.scan_launches = 1;
-        h->stats.bytes_scanned = n * (long long)d * 4;
+                               cnt, (u32)n, n, 0ll, s.keys.as<u64>(), key_stride, nullptr, 0);
+        if (prof) SQ_HIP(hipEventRecord(s.ev[2], st));
+        c.stats.scan_launches = 1;
+        c.stats.bytes_scanned = n * (long long)d * 4;
         if (cosine) {
-            SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, (u32)n, key_stride, k, nq, h->out_keys.as<K128>(),
+            SQ_TRY(select_launch_t<K128>(s.keys.as<K128>(), cnt, (u32)n, key_stride, k, nq, s.out_keys.as<K128>(),
                                          DenseFinalizeCos{cnt, (u32)n, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx,
                                                           hs_dev, hs_raw_dev, nullptr, 0},
                                          st));
         } else {
-            SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, (u32)n, key_stride, k, nq, h->out_keys.as<u64>(),
+            SQ_TRY(select_launch_t<u64>(s.keys.as<u64>(), cnt, (u32)n, key_stride, k, nq, s.out_keys.as<u64>(),
                                         DenseFinalizeL2{cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0,
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, nullptr, 0},
                                         st));
@@ -281,8 +341,8 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         while (stride > 1 && (n_tiles / stride) * 2 < 8ll * kk) stride >>= 1;
         const long long ns_tiles = (n_tiles + stride - 1) / stride;
         const long long ns = ns_tiles * 2;  // one sample (a 16-row group minimum) per lane half per tile
-        SQ_TRY(h->sample.reserve((size_t)nq_pad * ns * 4));
-        SQ_TRY(h->keys.reserve((size_t)nq * key_stride * key_bytes));
+        SQ_TRY(s.sample.reserve((size_t)nq_pad * ns * 4));
+        SQ_TRY(s.keys.reserve((size_t)nq * key_stride * key_bytes));
         const int cus = cu_count(h->device);
         int nrb = g_opt.dense_blocks > 0 ? g_opt.dense_blocks : cus;
         nrb = (nrb + 7) / 8 * 8;
@@ -291,12 +351,12 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         const long long n_waves = (long long)nrb * nqt * wv;
         const u32 wave_cap = 2048;
         const int ldq = (d + 3) / 4 * 4;
-        SQ_TRY(h->wave_out.reserve((size_t)n_waves * wave_cap * 8));
-        SQ_TRY(h->wave_cnt.reserve((size_t)n_waves * 8));
-        SQ_TRY(h->q_al.reserve((size_t)nq * ldq * 4));
-        u32* oflag = h->scratch.as<u32>() + 16;
+        SQ_TRY(s.wave_out.reserve((size_t)n_waves * wave_cap * 8));
+        SQ_TRY(s.wave_cnt.reserve((size_t)n_waves * 8));
+        SQ_TRY(s.q_al.reserve((size_t)nq * ldq * 4));
+        u32* oflag = s.oflag.as<u32>();
         hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, q, nq, d, d_pad, h->metric, qs,
-                           qn2, thr, cnt, oflag, h->q_al.as<float>(), ldq, h->center.p ? h->center.as<float>() : nullptr);
+                           qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq, h->center.p ? h->center.as<float>() : nullptr);
         DenseScanArgs a{};
         a.scan = h->scan.as<uint4>();
         a.norms = cosine ? nullptr : (qp == 1 ? h->norms1.as<float>() : h->norms.as<float>());  // n' of this plane count
@@ -304,10 +364,10 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         a.n_tiles = n_tiles;
         a.qs = qs;
         a.thr = thr;
-        a.wave_out = h->wave_out.as<uint2>();
-        a.wave_cnt = h->wave_cnt.as<u32>();
+        a.wave_out = s.wave_out.as<uint2>();
+        a.wave_cnt = s.wave_cnt.as<u32>();
         a.wave_cap = wave_cap;
-        a.sample_out = h->sample.as<float>();
+        a.sample_out = s.sample.as<float>();
         a.ns = ns;
         a.nqt = nqt;
         a.debug = g_opt.dense_debug;
@@ -323,11 +383,11 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         a.tile_step = 1;
         a.n_sel = n_tiles;
         a.nrb = nrb;
-        if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
+        if (prof) SQ_HIP(hipEventRecord(s.ev[1], st));
         SQ_TRY(scan_launch<false>(a, d_pad, qt, qp, st));
-        if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
-        h->stats.scan_launches = 2;
-        h->stats.bytes_scanned = h->n_pad * ((long long)d_pad * 2 + (cosine ? 0 : 4));
+        if (prof) SQ_HIP(hipEventRecord(s.ev[2], st));
+        c.stats.scan_launches = 2;
+        c.stats.bytes_scanned = h->n_pad * ((long long)d_pad * 2 + (cosine ? 0 : 4));
         // exact re-rank of the survivors (wave segments -> per-query keys), select, certify
         // A re-rank workgroup takes `wpb` survivor segments of one scan workgroup (its waves share the query
         // group), 128 threads per segment.  Many small workgroups win: the kernel is a chain of dependent
@@ -340,33 +400,73 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         const size_t rr_lds = (qt == 1 && ldq <= 156) ? (size_t)32 * (ldq + 4) * 4 : 0;  // the query tile in LDS (rerank_block)
         const unsigned gxr = (unsigned)((n_waves + wpb - 1) / wpb);
         if (cosine) {
-            hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
-                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, h->keys.as<K128>(), cnt,
+            hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, s.q_al.as<float>(),
+                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<K128>(), cnt,
                                cap, oflag, cnx, cnq, g_opt.dense_debug);
-            SQ_TRY(select_launch_t<K128>(h->keys.as<K128>(), cnt, cap, key_stride, k, nq, h->out_keys.as<K128>(),
+            SQ_TRY(select_launch_t<K128>(s.keys.as<K128>(), cnt, cap, key_stride, k, nq, s.out_keys.as<K128>(),
                                          DenseFinalizeCos{cnt, cap, kk, h->id_base, thr, eps_a + eps_b, 1, (double*)out_dist,
                                                           out_idx, hs_dev, hs_raw_dev, oflag, 0},
                                          st));
         } else {
-            hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, h->q_al.as<float>(),
-                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, h->keys.as<u64>(), cnt,
+            hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, s.q_al.as<float>(),
+                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<u64>(), cnt,
                                cap, oflag, g_opt.dense_debug);
-            SQ_TRY(select_launch_t<u64>(h->keys.as<u64>(), cnt, cap, key_stride, k, nq, h->out_keys.as<u64>(),
+            SQ_TRY(select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(),
                                         DenseFinalizeL2{cnt, cap, kk, h->id_base, thr, qn2, 0.5 * eps_a + eps_b, 1,
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0},
                                         st));
         }
     } else {
-        all_fallback = true;  // rows wider than the MFMA scan covers: exact path for every query
+        c.all_fallback = true;  // rows wider than the MFMA scan covers: exact path for every query
     }
-    if (prof) SQ_HIP(hipEventRecord(h->ev[3], st));
+    if (prof) SQ_HIP(hipEventRecord(s.ev[3], st));
+    if (use_event) {
+        if (!s.ev_done) SQ_HIP(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+        SQ_HIP(hipEventRecord(s.ev_done, st));
+    }
+    c.pending = true;
+    return SQ_OK;
+}
+
+// Finish the call enqueued on slot `s`: wait for its kernels, collect the statistics, and redo every query the
+// filter could not certify on the exact path (synchronously, on the call's stream).  h->stats = this call's.
+static int dense_resolve(DenseHandle* h, DenseSlot& s) {
+    DenseCall& c = s.call;
+    if (!c.pending) return SQ_OK;
+    c.pending = false;
+    const long long n = h->n;
+    const int d = h->d;
+    const int nq = c.nq, k = c.k;
+    const int kk = (int)(k < n ? k : n);
+    const bool cosine = h->metric == SQ_METRIC_COSINE;
+    const size_t key_bytes = cosine ? sizeof(K128) : sizeof(u64);
+    u32 cap = g_opt.candidate_cap > 0 ? (u32)g_opt.candidate_cap : 65536u;
+    if (cap < (u32)(4 * kk)) cap = (u32)(4 * kk);
+    const bool force_fb = g_opt.force_fallback != 0;
+    const bool small = c.small, all_fallback = c.all_fallback;
+    hipStream_t st = c.st;
+    const float* q = c.q;
+    void* out_dist = c.out_dist;
+    long long* out_idx = c.out_idx;
+    u32* cnt = s.cnt.as<u32>();
+    float* thr = s.thr.as<float>();
+    double* qn2 = s.qn2.as<double>();
+    const double* cnx = h->cos_nx.as<double>();
+    const double* cnq = s.cos_nq.as<double>();
+    u32* hs_raw = reinterpret_cast<u32*>(s.status_host.p);
+    u32* hs = hs_raw + c.nq_pad;
+    u32* hs_raw_dev = nullptr;
+    SQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs_raw_dev), hs_raw, 0));
+    u32* hs_dev = hs_raw_dev + c.nq_pad;
+    const size_t l2_lds = (size_t)((d + 3) / 4 * 4) * 4;
+    h->stats = c.stats;
     if (!all_fallback) {
-        SQ_HIP(stream_wait(st));  // counts and status words are in hs_raw / hs now
+        SQ_HIP(c.use_event ? event_wait(s.ev_done) : stream_wait(st));  // counts and status words are in hs_raw / hs now
         SQ_HIP(hipGetLastError());
-        if (prof) {
+        if (c.prof) {
             float t1 = 0, t2 = 0;
-            SQ_HIP(hipEventElapsedTime(&t1, h->ev[1], h->ev[2]));
-            SQ_HIP(hipEventElapsedTime(&t2, h->ev[0], h->ev[3]));
+            SQ_HIP(hipEventElapsedTime(&t1, s.ev[1], s.ev[2]));
+            SQ_HIP(hipEventElapsedTime(&t2, s.ev[0], s.ev[3]));
             h->stats.scan_ms = t1;
             h->stats.total_ms = t2;
         }
@@ -384,17 +484,22 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
     std::vector<int> todo;
     for (int qi = 0; qi < nq; ++qi)
         if (all_fallback || (!small && (hs[qi] != 0 || force_fb))) todo.push_back(qi);
+    if (todo.empty()) return SQ_OK;
     // group size: the key arrays of a group stay under 4 GB; rows beyond the group kernel's depth go one by one
     int gmax = (int)std::min<long long>(EXACT_GROUP, std::max<long long>(1, (4ll << 30) / (n * (long long)key_bytes)));
     if (d > (128 << EXACT_GROUP_DEPTH) || (g_opt.dense_debug & 256)) gmax = 1;    // debug 256: measurement, one query per pass
     const size_t grp_lds = (size_t)EXACT_GROUP * ((d + 3) / 4 * 4) * 4;
     const bool grp_ok = grp_lds <= 160 * 1024 - 256 && d <= (128 << EXACT_GROUP_DEPTH);
-    if (grp_ok && !todo.empty()) {
+    if (grp_ok) {
         SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_exact_group_kernel<false, u64>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)grp_lds));
         SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_exact_group_kernel<true, K128>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)grp_lds));
     }
+    // the exact path keeps its own per-query counters: the slot's belong to a call that may still be in flight
+    // when another asynchronous call's queries are redone
+    SQ_TRY(h->fb_cnt.reserve((size_t)(nq + 64) * 4));
+    u32* full_cnt = h->fb_cnt.as<u32>();
     for (size_t t0 = 0; t0 < todo.size(); t0 += (size_t)gmax) {
         const int gn = (int)std::min<size_t>((size_t)gmax, todo.size() - t0);
         ExactGroup grp{};
@@ -425,11 +530,11 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
             const int qi = grp.idx[0];
             if (cosine)
                 hipLaunchKernelGGL(dense_exact_cos_kernel, dim3(gx, 1), dim3(256), 0, st, h->db, h->ld, d,
-                                   q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<K128>(), n, cnx,
+                                   q + (long long)qi * d, nullptr, full_cnt + qi, (u32)n, n, 0ll, h->big_keys.as<K128>(), n, cnx,
                                    cnq + qi, fb_sample, (int)fb_stride);
             else
                 hipLaunchKernelGGL(dense_exact_l2_kernel, dim3(gx, 1), dim3(256), l2_lds, st, h->db, h->ld, d,
-                                   q + (long long)qi * d, nullptr, cnt + qi, (u32)n, n, 0ll, h->big_keys.as<u64>(), n,
+                                   q + (long long)qi * d, nullptr, full_cnt + qi, (u32)n, n, 0ll, h->big_keys.as<u64>(), n,
                                    fb_sample, (int)fb_stride);
         }
         h->stats.scan_launches++;
@@ -464,27 +569,40 @@ static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, vo
         for (int g = 0; g < gn; ++g) {
             if (done[g]) continue;
             const int qi = grp.idx[g];
-            hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, cnt + qi, 1ll, (u32)n);
+            hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, full_cnt + qi, 1ll, (u32)n);
+            SQ_TRY(h->fb_out.reserve((size_t)k * key_bytes));
             if (cosine) {
-                SQ_TRY(select_launch_t<K128>(h->big_keys.as<K128>() + (long long)g * n, cnt + qi, (u32)n, n, k, 1,
-                                             h->out_keys.as<K128>() + (long long)qi * k,
-                                             DenseFinalizeCos{cnt, (u32)n, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx,
+                SQ_TRY(select_launch_t<K128>(h->big_keys.as<K128>() + (long long)g * n, full_cnt + qi, (u32)n, n, k, 1,
+                                             h->fb_out.as<K128>(),
+                                             DenseFinalizeCos{full_cnt, (u32)n, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx,
                                                               hs_dev, nullptr, nullptr, qi},
                                              st));
             } else {
-                SQ_TRY(select_launch_t<u64>(h->big_keys.as<u64>() + (long long)g * n, cnt + qi, (u32)n, n, k, 1,
-                                            h->out_keys.as<u64>() + (long long)qi * k,
-                                            DenseFinalizeL2{cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0,
+                SQ_TRY(select_launch_t<u64>(h->big_keys.as<u64>() + (long long)g * n, full_cnt + qi, (u32)n, n, k, 1,
+                                            h->fb_out.as<u64>(),
+                                            DenseFinalizeL2{full_cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0,
                                                             (float*)out_dist, out_idx, hs_dev, nullptr, nullptr, qi},
                                             st));
             }
         }
     }
-    if (h->stats.fallback_queries) {
-        SQ_HIP(hipStreamSynchronize(st));
-        SQ_HIP(hipGetLastError());
-    }
+    SQ_HIP(hipStreamSynchronize(st));
+    SQ_HIP(hipGetLastError());
     return SQ_OK;
+}
+
+// Finish every asynchronous call still in flight, oldest first.
+static int dense_sync_all(DenseHandle* h) {
+    const int newest = (int)((h->async_calls + 1) & 1);  // slot of the most recent asynchronous call
+    SQ_TRY(dense_resolve(h, h->slot[newest ^ 1]));
+    SQ_TRY(dense_resolve(h, h->slot[newest]));
+    return SQ_OK;
+}
+
+static int dense_search_device(DenseHandle* h, const float* q, int nq, int k, void* out_dist, long long* out_idx,
+                               hipStream_t st) {
+    SQ_TRY(dense_enqueue(h, h->slot[0], q, nq, k, out_dist, out_idx, st, false));
+    return dense_resolve(h, h->slot[0]);
 }
 
 // Large batches run in chunks so that the per-query workspace (candidate key lists of `cap` keys, the
@@ -681,6 +799,8 @@ extern "C" int sq_dense_append(sq_handle_t hid, const float* rows, int64_t n_add
     if (!rows || n_add <= 0) return fail(SQ_ERR_INVALID, "sq_dense_append: bad argument");
     std::lock_guard<std::mutex> l(h->mu);
     if (!h->owned.p) return fail(SQ_ERR_UNSUPPORTED, "sq_dense_append: the index borrows the caller's device matrix");
+    SQ_HIP(hipSetDevice(h->device));
+    SQ_TRY(dense_sync_all(h));
     const long long n_old = h->n, n_new = n_old + n_add;
     if (n_new >= (1ll << 32)) return fail(SQ_ERR_UNSUPPORTED, "sq_dense_append: more than 2^32-1 rows per shard");
     SQ_HIP(hipSetDevice(h->device));
@@ -713,7 +833,28 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
     SQ_HIP(hipSetDevice(h->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t dsz = h->metric == SQ_METRIC_COSINE ? 8 : 4;
-    if (mem == SQ_MEM_DEVICE)
+    if (mem == SQ_MEM_DEVICE_ASYNC && nq <= kDenseQueryChunk) {
+        // Call i is enqueued before call i - 1 is waited for: the device always has the next call's kernels
+        // queued behind the running ones, and the host reads a call's status words (and redoes what the filter
+        // could not certify) one call later.  With "dense_async_streams" = 2 the two slots run on streams of
+        // their own, ordered behind the caller's stream by an event, so the small kernels at the end of call
+        // i - 1 (re-rank, select) and at the start of call i (query prep, sample pass, threshold) overlap.
+        DenseSlot& s = h->slot[h->async_calls & 1];
+        SQ_TRY(dense_resolve(h, s));  // (the call two back; normally resolved during the previous call)
+        hipStream_t run = st;
+        if (g_opt.dense_async_streams == 2) {
+            if (!s.own) SQ_HIP(hipStreamCreateWithFlags(&s.own, hipStreamNonBlocking));
+            if (!s.ev_in) SQ_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+            SQ_HIP(hipEventRecord(s.ev_in, st));        // the caller's earlier work on `stream` (the queries) comes first
+            SQ_HIP(hipStreamWaitEvent(s.own, s.ev_in, 0));
+            run = s.own;
+        }
+        SQ_TRY(dense_enqueue(h, s, queries, nq, k, out_dist, reinterpret_cast<long long*>(out_idx), run, true));
+        h->async_calls++;
+        return dense_resolve(h, h->slot[h->async_calls & 1]);  // the previous call: its results are final on return
+    }
+    SQ_TRY(dense_sync_all(h));
+    if (mem != SQ_MEM_HOST)
         return dense_search_chunked(h, queries, nq, k, out_dist, reinterpret_cast<long long*>(out_idx), st);
     const size_t qb = (size_t)nq * h->d * 4;
     SQ_TRY(h->q_dev.reserve(qb));
@@ -729,10 +870,23 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
     return SQ_OK;
 }
 
+extern "C" int sq_dense_sync(sq_handle_t hid) {
+    auto* h = static_cast<DenseHandle*>(lookup_handle(hid, H_DENSE));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_dense_sync: unknown handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    SQ_HIP(hipSetDevice(h->device));
+    return dense_sync_all(h);
+}
+
 extern "C" int sq_dense_destroy(sq_handle_t hid) {
-    auto* h = remove_handle(hid, H_DENSE);
-    if (!h) return fail(SQ_ERR_INVALID, "sq_dense_destroy: unknown handle");
+    auto* hb = remove_handle(hid, H_DENSE);
+    if (!hb) return fail(SQ_ERR_INVALID, "sq_dense_destroy: unknown handle");
+    auto* h = static_cast<DenseHandle*>(hb);
     (void)hipSetDevice(h->device);
+    {
+        std::lock_guard<std::mutex> lock(h->mu);
+        (void)dense_sync_all(h);  // nothing of this handle is left on the device when its buffers go
+    }
     delete h;
     return SQ_OK;
 }

@@ -11,6 +11,7 @@ there is no reference interface to mirror here; the per-shard search is the C
 ABI (``sq_dense_search`` / ``sq_hamming_search`` with ``id_base`` = first row
 of the shard) and the merge is ``sq_merge_topk``.
 """
+import time
 from typing import Callable, Optional, Tuple
 
 import numpy as np
@@ -23,11 +24,21 @@ def shard_range(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     return r0, min(r0 + per, n_total)
 
 
-def allgather_merge(local_dist, local_idx, k: int, group=None, merge_on: Optional[int] = None):
+def packed_block_bytes(nq: int, k_in: int, dist_itemsize: int) -> int:
+    """Bytes of one shard's block ``[ids int64 nq*k_in][dist nq*k_in]`` in a packed all-gather buffer, rounded
+    up to 8 so that every shard's id block stays 8-byte aligned (float32 / int32 distances with odd nq*k_in)."""
+    return (int(nq) * int(k_in) * (8 + int(dist_itemsize)) + 7) // 8 * 8
+
+
+def allgather_merge(local_dist, local_idx, k: int, group=None, merge_on: Optional[int] = None,
+                    packed: Optional[bool] = None):
     """All-gather every rank's ``[nq, k_in]`` top-k lists and merge them.
 
     ``local_dist`` / ``local_idx`` are torch tensors on the rank's device (CUDA
     tensors go over RCCL, CPU tensors over gloo).  Ids must already be global.
+    ``packed`` (default: on for CUDA tensors): ONE collective of a byte buffer per rank,
+    ``[ids int64 nq*k_in][dist nq*k_in]``, merged in place from the receive buffer
+    (``sq_merge_topk_strided``); otherwise two plain all-gathers.
     Returns ``(dist [nq,k], idx [nq,k])`` numpy arrays on every rank, or only on
     rank ``merge_on`` (others get ``None``) when given.
     """
@@ -38,14 +49,15 @@ def allgather_merge(local_dist, local_idx, k: int, group=None, merge_on: Optiona
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     nq, k_in = int(local_dist.shape[0]), int(local_dist.shape[1])
-    if local_dist.is_cuda:
-        # one collective: [ids int64 nq*k_in][dist nq*k_in] per rank in a byte buffer; the merge reads the
-        # host copy of the receive buffer in place (sq_merge_topk_strided)
+    if packed is None:
+        packed = bool(local_dist.is_cuda)
+    if packed:
         esz = local_dist.element_size()
-        send = torch.empty(nq * k_in * (8 + esz), dtype=torch.uint8, device=local_dist.device)
+        per = packed_block_bytes(nq, k_in, esz)
+        send = torch.zeros(per, dtype=torch.uint8, device=local_dist.device)
         send[: nq * k_in * 8].view(torch.int64).view(nq, k_in).copy_(local_idx)
-        send[nq * k_in * 8:].view(local_dist.dtype).view(nq, k_in).copy_(local_dist)
-        recv = torch.empty((world, send.numel()), dtype=torch.uint8, device=local_dist.device)
+        send[nq * k_in * 8: nq * k_in * (8 + esz)].view(local_dist.dtype).view(nq, k_in).copy_(local_dist)
+        recv = torch.empty(world * per, dtype=torch.uint8, device=local_dist.device)   # 1-D: gloo wants it flat
         dist.all_gather_into_tensor(recv, send, group=group)
         if merge_on is not None and rank != merge_on:
             return None
@@ -58,7 +70,7 @@ def allgather_merge(local_dist, local_idx, k: int, group=None, merge_on: Optiona
     dist.all_gather(list(gi.unbind(0)), local_idx.contiguous(), group=group)
     if merge_on is not None and rank != merge_on:
         return None
-    return _lib.merge_topk(gd.numpy(), gi.numpy(), int(k))
+    return _lib.merge_topk(gd.cpu().numpy(), gi.cpu().numpy(), int(k))
 
 
 class ShardedIndex:
@@ -69,13 +81,14 @@ class ShardedIndex:
     :func:`dense_shard` / :func:`hamming_shard` from the HIP index.
     """
 
-    def __init__(self, local_search: Callable, group=None):
+    def __init__(self, local_search: Callable, group=None, packed: Optional[bool] = None):
         self.local_search = local_search
         self.group = group
+        self.packed = packed
 
     def search(self, queries, k: int, merge_on: Optional[int] = None):
         d, i = self.local_search(queries, k)
-        return allgather_merge(d, i, k, self.group, merge_on)
+        return allgather_merge(d, i, k, self.group, merge_on, self.packed)
 
 
 def dense_shard(db_shard, row0: int, metric: int = 0, group=None) -> ShardedIndex:
@@ -339,85 +352,143 @@ class PipelinedMerger:
         self._thread.join()
 
 
+class HipSearcher:
+    """Adapter of a ``_lib.DenseIndex`` / ``_lib.HammingIndex`` for :class:`PipelinedShardedSearch`.
+
+    ``search_into(q, k, out_d, out_i)`` writes the shard's top-k for the query batch into the two device tensors.
+    ``lag`` says when that answer is final: 0 -- when ``search_into`` returns (the synchronous C ABI call);
+    1 -- when the NEXT ``search_into`` (or ``finish``) returns: ``sq_dense_search`` with ``SQ_MEM_DEVICE_ASYNC``,
+    which keeps the device busy across calls (include/smqtk_hip.h)."""
+
+    def __init__(self, index, stream_handle: int = 0, use_async: bool = False):
+        self.index, self.stream = index, int(stream_handle)
+        self.lag = 1 if (use_async and hasattr(index, "search_device_async")) else 0
+
+    def search_into(self, queries, k: int, out_d, out_i) -> None:
+        fn = self.index.search_device_async if self.lag else self.index.search_device
+        fn(queries.data_ptr(), int(queries.shape[0]), int(k), out_d.data_ptr(), out_i.data_ptr(), self.stream)
+
+    def finish(self) -> None:
+        if self.lag:
+            self.index.sync()
+
+
 class PipelinedShardedSearch:
     """Batches through a sharded index with the collective and the merge off the critical path.
 
-    ``submit(queries)`` runs the local search of batch i on the pipeline's own compute stream (the C ABI call
-    returns when the shard's answer is in the send buffer), starts the all-gather of batch i asynchronously
-    (RCCL's stream) and, on the merging rank, the copy of the gathered buffer to pinned host memory on torch's
-    current stream -- both run under the search of batch i + 1 -- then hands batch i - 1's host buffer to the
-    merge thread (:class:`PipelinedMerger`) and returns the merged result of batch i - 2 (``None`` for the
-    first two calls and on the other ranks).  ``flush()`` returns the results still in flight, oldest first.
-    Two send / receive / host buffers alternate; every reuse is ordered behind the previous user.
-    ``index``: ``_lib.DenseIndex`` or ``_lib.HammingIndex`` over the rank's shard (ids already global).
+    ``submit(queries)`` runs the local search of batch i (``searcher.search_into``: see :class:`HipSearcher`),
+    then -- for the newest batch b = i - lag whose shard answer is final -- starts the all-gather asynchronously
+    (RCCL's stream / gloo's thread) and, on the merging rank, the copy of the gathered buffer to pinned host memory
+    on torch's current stream; both run under the search of the next batch.  It then hands batch b - 1's host
+    buffer to the merge thread (:class:`PipelinedMerger`) and returns the merged result of batch b - 2 (``None``
+    while the pipeline fills, and on the other ranks).  ``flush()`` finishes the searches and returns the results
+    still in flight, oldest first.  Two send / receive / host buffers alternate; every reuse is ordered behind the
+    previous user.  CPU tensors (gloo) take the same path without streams or pinned copies: the CPU tests drive
+    it with an oracle-backed searcher.
+    ``searcher``: an object with ``lag``, ``search_into`` and ``finish`` (or a ``_lib`` index: wrapped in a
+    synchronous :class:`HipSearcher` on a compute stream of the pipeline's own).
     """
 
-    def __init__(self, index, nq: int, k: int, dist_dtype, group=None, merge_on: int = 0, device=None):
+    def __init__(self, searcher, nq: int, k: int, dist_dtype, group=None, merge_on: int = 0, device=None,
+                 use_async: bool = False):
         import torch
         import torch.distributed as dist
-        self.index, self.nq, self.k, self.group = index, int(nq), int(k), group
+        self.nq, self.k, self.group = int(nq), int(k), group
         self.world, self.rank, self.merge_on = dist.get_world_size(group), dist.get_rank(group), merge_on
-        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device(device)
+        self.cuda = dev.type == "cuda"
+        if not hasattr(searcher, "search_into"):
+            # a _lib index: its searches get a stream of their own; collectives and copies stay on the current stream
+            self.compute = torch.cuda.Stream(device=dev)
+            searcher = HipSearcher(searcher, self.compute.cuda_stream, use_async)
+        self.searcher = searcher
+        self.lag = int(searcher.lag)
         esz = torch.empty(0, dtype=dist_dtype).element_size()
         self.np_dt = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32}[dist_dtype]
-        per = self.nq * self.k * (8 + esz)
-        self.send = [torch.empty(per, dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.out_i = [s[: self.nq * self.k * 8].view(torch.int64).view(self.nq, self.k) for s in self.send]
-        self.out_d = [s[self.nq * self.k * 8:].view(dist_dtype).view(self.nq, self.k) for s in self.send]
-        self._ptr_d = [t.data_ptr() for t in self.out_d]
-        self._ptr_i = [t.data_ptr() for t in self.out_i]
-        self.recv = [torch.empty((self.world, per), dtype=torch.uint8, device=dev) for _ in range(2)]
+        per = packed_block_bytes(self.nq, self.k, esz)
+        nk = self.nq * self.k
+        self.send = [torch.zeros(per, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.out_i = [s[: nk * 8].view(torch.int64).view(self.nq, self.k) for s in self.send]
+        self.out_d = [s[nk * 8: nk * (8 + esz)].view(dist_dtype).view(self.nq, self.k) for s in self.send]
+        self.recv = [torch.empty(self.world * per, dtype=torch.uint8, device=dev) for _ in range(2)]   # 1-D: gloo wants it flat
         self.work = [None, None]
-        self.i = 0
-        self.compute = torch.cuda.Stream(device=dev)     # the searches; collectives and copies stay on the current stream
-        self._compute_handle = self.compute.cuda_stream
+        self.i = 0                 # batches submitted
+        self.gathered = 0          # batches whose all-gather has been started
         self.merging = self.rank == merge_on
         if self.merging:
-            self.host = [torch.empty((self.world, per), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+            if self.cuda:
+                self.host = [torch.empty(self.world * per, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+                self.copied = [torch.cuda.Event(), torch.cuda.Event()]   # host[j] holds the gathered buffer of its batch
+            else:
+                self.host = self.recv
             self.host_np = [h.numpy().reshape(-1) for h in self.host]
-            self.copied = [torch.cuda.Event(), torch.cuda.Event()]   # host[j] holds the gathered buffer of its batch
             self.copy_pending = [False, False]
             self.ticket = [None, None]                                # merge reading host[j]
             self.merger = PipelinedMerger()
 
+    def _wait_work(self, j: int) -> None:
+        w = self.work[j]
+        if w is not None:
+            if self.cuda:
+                while not w.is_completed():   # finished long ago in the steady state -- make it formal
+                    time.sleep(0)             # (yields the GIL: the merge thread may be waiting for it)
+            else:
+                w.wait()
+            self.work[j] = None
+
     def _merge_ready(self, j: int) -> None:
         """Batch in buffer j: its host copy is complete -> to the merge thread."""
         if self.copy_pending[j]:
-            ev = self.copied[j]
-            while not ev.query():
-                pass
+            if self.cuda:
+                ev = self.copied[j]
+                while not ev.query():
+                    time.sleep(0)
+            else:
+                self._wait_work(j)
             self.copy_pending[j] = False
             self.ticket[j] = self.merger.submit(self.host_np[j], self.world, self.nq, self.k, self.k, self.np_dt)
 
-    def submit(self, queries):
+    def _gather_next(self):
+        """Start the all-gather of the oldest batch not yet gathered (its send buffer is final) and move the
+        batches behind it one stage on; returns the merged result that left the pipeline, if any."""
         import torch.distributed as dist
-        j = self.i & 1
-        self.i += 1
-        w = self.work[j]
-        if w is not None:
-            # batch i - 2's all-gather read send[j] and wrote recv[j]; it finished long ago -- make it formal
-            while not w.is_completed():
-                pass
-            self.work[j] = None
-        self.index.search_device(queries.data_ptr(), self.nq, self.k, self._ptr_d[j], self._ptr_i[j], self._compute_handle)
+        j = self.gathered & 1
+        self.gathered += 1
         ready = None
         if self.merging and self.ticket[j] is not None:
-            ready = self.merger.result(self.ticket[j])     # batch i - 2: merged under the search that just returned
+            ready = self.merger.result(self.ticket[j])     # two batches back: merged under the searches since
             self.ticket[j] = None
-        # the search call returned: send[j] is complete on the device (the call waits for its stream)
         self.work[j] = w = dist.all_gather_into_tensor(self.recv[j], self.send[j], group=self.group, async_op=True)
         if self.merging:
-            w.wait()                                       # orders the current stream (not the host) behind the gather
-            self.host[j].copy_(self.recv[j], non_blocking=True)
-            self.copied[j].record()
+            if self.cuda:
+                w.wait()                                   # orders the current stream (not the host) behind the gather
+                self.host[j].copy_(self.recv[j], non_blocking=True)
+                self.copied[j].record()
             self.copy_pending[j] = True
-            self._merge_ready(j ^ 1)                       # batch i - 1: gathered and copied under this search
+            self._merge_ready(j ^ 1)                       # the batch before: gathered and copied meanwhile
         return ready
+
+    def submit(self, queries):
+        j = self.i & 1
+        self.i += 1
+        self._wait_work(j)       # the all-gather two batches back read send[j] and wrote recv[j]
+        self.searcher.search_into(queries, self.k, self.out_d[j], self.out_i[j])
+        # batches up to i - lag are final in their send buffers now
+        if self.i - self.lag > self.gathered:
+            return self._gather_next()
+        return None
 
     def flush(self):
         out = []
+        self.searcher.finish()
+        while self.gathered < self.i:
+            r = self._gather_next()
+            if r is not None:
+                out.append(r)
         if self.merging:
-            last = (self.i - 1) & 1 if self.i else 0
+            last = (self.gathered - 1) & 1 if self.gathered else 0
             for j in (last ^ 1, last):                     # oldest first
                 self._merge_ready(j)
             for j in (last ^ 1, last):
@@ -425,9 +496,7 @@ class PipelinedShardedSearch:
                     out.append(self.merger.result(self.ticket[j]))
                     self.ticket[j] = None
         for j in range(2):
-            if self.work[j] is not None:
-                self.work[j].wait()
-                self.work[j] = None
+            self._wait_work(j)
         return out
 
     def close(self) -> None:

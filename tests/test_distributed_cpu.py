@@ -157,6 +157,132 @@ def test_sharded_search_gloo_world2(tmp_path, kind):
     assert (tmp_path / f"ok_{kind}").exists()
 
 
+class _OracleSearcher:
+    """Shard searcher for PipelinedShardedSearch backed by the oracle.  ``lag`` = 1 imitates
+    sq_dense_search(SQ_MEM_DEVICE_ASYNC): a call's answer only appears in its output tensors when the NEXT call
+    (or finish()) returns -- so the test fails if the pipeline gathers a send buffer too early."""
+
+    def __init__(self, db, r0, lag):
+        self.db, self.r0, self.lag = db, r0, lag
+        self.pending = None
+
+    def _run(self, job):
+        import torch
+        q, k, out_d, out_i = job
+        for j, qv in enumerate(q.numpy()):
+            dd, ii = O.dense_topk(self.db, qv, k)
+            out_d[j].fill_(float("inf"))
+            out_i[j].fill_(-1)
+            out_d[j, :len(dd)] = torch.from_numpy(dd)
+            out_i[j, :len(ii)] = torch.from_numpy(ii + self.r0)
+
+    def search_into(self, queries, k, out_d, out_i):
+        job = (queries.clone(), k, out_d, out_i)
+        if not self.lag:
+            self._run(job)
+            return
+        out_d.fill_(-1.0)              # garbage until the call is "finished"
+        out_i.fill_(-7)
+        if self.pending is not None:
+            self._run(self.pending)
+        self.pending = job
+
+    def finish(self):
+        if self.pending is not None:
+            self._run(self.pending)
+            self.pending = None
+
+
+def _pipeline_worker(rank: int, world: int, port: int, lag: int, out_dir: str) -> None:
+    import torch
+    import torch.distributed as dist
+    from smqtk_indexing_amd.distributed import PipelinedShardedSearch, ShardedIndex, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(99)
+    nq, k, d = 3, 7, 24                                   # nq * k odd: the packed blocks need their 8-byte padding
+    db = rng.standard_normal((2001, d)).astype(np.float32)
+    db[1500] = db[20]                                      # a tie across the two shards
+    batches = [rng.standard_normal((nq, d)).astype(np.float32) for _ in range(5)]
+    batches[1][0] = db[20]
+    r0, r1 = shard_range(db.shape[0], world, rank)
+    pipe = PipelinedShardedSearch(_OracleSearcher(db[r0:r1], r0, lag), nq, k, torch.float32, merge_on=0, device="cpu")
+    got = []
+    for i, q in enumerate(batches):
+        r = pipe.submit(torch.from_numpy(q))
+        if rank == 0:
+            assert (r is None) == (i < 2 + lag), (i, lag)
+        else:
+            assert r is None
+        if r is not None:
+            got.append(r)
+    got += pipe.flush()
+    assert pipe.flush() == []
+    # the packed single-buffer branch of allgather_merge, on CPU tensors
+    s = _OracleSearcher(db[r0:r1], r0, 0)
+    od, oi = torch.empty((nq, k), dtype=torch.float32), torch.empty((nq, k), dtype=torch.int64)
+
+    def local(queries, kk):
+        s.search_into(queries, kk, od, oi)
+        return od, oi
+    packed = ShardedIndex(local, packed=True).search(torch.from_numpy(batches[1]), k, merge_on=0)
+    if rank == 0:
+        assert len(got) == len(batches)
+        for q, (dd, ii) in zip(batches, got):
+            for j in range(nq):
+                rd, ri = O.dense_topk(db, q[j], k)        # the oracle over the WHOLE database
+                np.testing.assert_array_equal(ii[j], ri)
+                np.testing.assert_array_equal(dd[j].view(np.uint32), rd.view(np.uint32))
+        np.testing.assert_array_equal(packed[1], got[1][1])
+        np.testing.assert_array_equal(packed[0], got[1][0])
+        open(os.path.join(out_dir, "ok_pipe"), "w").write("ok")
+    else:
+        assert got == [] and packed is None
+    pipe.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lag", [0, 1])
+def test_pipelined_sharded_search_and_packed_gather_gloo_world2(tmp_path, lag):
+    """Two ranks through PipelinedShardedSearch (blocking and asynchronous-style searches) and through the packed
+    single-buffer branch of allgather_merge, checked against the oracle over the whole database."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(2, port, lag, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok_pipe").exists()
+
+
+def test_merge_gathered_padded_blocks_and_nan_order():
+    """Host only: the strided merge over blocks padded to 8 bytes (odd nq*k, float32), and NaN distances of either
+    sign rank after every number (the single-GPU contract: test_cosine_zero_vectors_give_nan_ranked_last)."""
+    from smqtk_indexing_amd import _lib
+    from smqtk_indexing_amd.distributed import packed_block_bytes
+    nq, k = 1, 3
+    per = packed_block_bytes(nq, k, 4)
+    assert per == 40 and per % 8 == 0
+    neg_nan = np.array([0xFFC00000], dtype=np.uint32).view(np.float32)[0]     # what x86 0/0 gives
+    pos_nan = np.float32("nan")
+    shards = [(np.array([0.1, 0.2, neg_nan], np.float32), np.array([5, 6, 7], np.int64)),
+              (np.array([0.15, 0.3, 0.4], np.float32), np.array([10, 11, 12], np.int64)),
+              (np.array([0.35, pos_nan, pos_nan], np.float32), np.array([20, 21, 22], np.int64))]
+    buf = np.zeros(3 * per, dtype=np.uint8)
+    for s, (dd, ii) in enumerate(shards):
+        buf[s * per: s * per + 24] = ii.view(np.uint8)
+        buf[s * per + 24: s * per + 36] = dd.view(np.uint8)
+    od, oi = _lib.merge_topk_gathered(buf, 3, nq, k, 9, np.float32)
+    assert oi[0, :6].tolist() == [5, 10, 6, 11, 20, 12]
+    np.testing.assert_array_equal(od[0, :6], np.array([0.1, 0.15, 0.2, 0.3, 0.35, 0.4], np.float32))
+    assert np.isnan(od[0, 6:]).all() and sorted(oi[0, 6:].tolist()) == [7, 21, 22]
+    d3 = np.stack([s[0] for s in shards])[:, None, :].astype(np.float64)
+    d3[0, 0, 2] = np.array([0xFFF8000000000000], dtype=np.uint64).view(np.float64)[0]
+    i3 = np.stack([s[1] for s in shards])[:, None, :]
+    od, oi = _lib.merge_topk(d3, i3, 4)
+    assert oi[0].tolist() == [5, 10, 6, 11]                # -nan no longer displaces 0.3
+
+
 def test_shard_range_covers_rows():
     from smqtk_indexing_amd.distributed import shard_range
     for n in (1, 7, 8, 10_000_000, 100_000_001):

@@ -21,6 +21,7 @@ def _reset_options():
     for name in ("candidate_cap", "sample_stride", "force_fallback", "profile", "dense_stages", "dense_blocks", "dense_qt",
                  "itq_exact", "hamming_no_permute", "dense_no_center", "dense_qplanes"):
         _lib.set_option(name, 0)
+    _lib.set_option("dense_async_streams", 2)
 
 
 # ------------------------------------------------------------------- Hamming
@@ -353,6 +354,53 @@ def test_dense_uncertifiable_data_takes_exact_path():
     idx = _dense_check(db, qs[:, :96].copy() if qs.shape[1] >= 96 else rng.standard_normal((2, 96)).astype(np.float32),
                        10, "euclidean")
     assert idx.stats()["fallback_queries"] == 2
+
+
+@pytest.mark.parametrize("streams", [1, 2])
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_dense_async_calls_equal_blocking_calls(metric, streams):
+    """SQ_MEM_DEVICE_ASYNC: calls are enqueued back to back and finished one call later (status words read, uncertified
+    queries redone); every call's answer must be the blocking call's, including calls whose queries take the exact
+    path, calls of a different batch size in between, and the call still in flight at sq_dense_sync / destroy."""
+    import torch
+    _lib.set_option("dense_async_streams", streams)
+    rng = np.random.default_rng(41)
+    n, d, k = 150_000, 96, 20
+    dbh = rng.standard_normal((n, d)).astype(np.float32)
+    dbh[5000:5400] = dbh[17]                       # a tie group larger than k: candidate ties
+    dev = torch.device("cuda", 0)
+    db = torch.from_numpy(dbh).to(dev)
+    m = _lib.SQ_METRIC_COSINE if metric == "cosine" else _lib.SQ_METRIC_L2
+    ddt = torch.float64 if metric == "cosine" else torch.float32
+    idx = _lib.DenseIndex(db.data_ptr(), n=n, d=d, metric=m, device_ptr=True, id_base=7, keepalive=db)
+    stream = torch.cuda.current_stream().cuda_stream
+    sizes = [5, 33, 5, 70, 1, 5, 5]
+    qs = [rng.standard_normal((b, d)).astype(np.float32) for b in sizes]
+    qs[2][0] = dbh[17]
+    want = [idx.search(q, k) for q in qs]
+    qd = [torch.from_numpy(q).to(dev) for q in qs]
+    od = [torch.empty((b, k), dtype=ddt, device=dev) for b in sizes]
+    oi = [torch.empty((b, k), dtype=torch.int64, device=dev) for b in sizes]
+    for j, q in enumerate(qd):
+        if j == 4:
+            _lib.set_option("force_fallback", 1)   # calls FINISHED while this is on (3 and 4) are redone on the exact path
+        idx.search_device_async(q.data_ptr(), sizes[j], k, od[j].data_ptr(), oi[j].data_ptr(), stream)
+        if j == 5:
+            assert idx.stats()["fallback_queries"] == 1   # call 4 (one query) was finished by this call
+            _lib.set_option("force_fallback", 0)
+        if j >= 1:                                 # the previous call is final now
+            np.testing.assert_array_equal(oi[j - 1].cpu().numpy(), want[j - 1][1])
+            np.testing.assert_array_equal(od[j - 1].cpu().numpy(), want[j - 1][0])
+    idx.sync()
+    np.testing.assert_array_equal(oi[-1].cpu().numpy(), want[-1][1])
+    np.testing.assert_array_equal(od[-1].cpu().numpy(), want[-1][0])
+    # a blocking call after asynchronous ones, and destroy with a call in flight
+    d2, i2 = idx.search(qs[1], k)
+    np.testing.assert_array_equal(i2, want[1][1])
+    idx.search_device_async(qd[0].data_ptr(), sizes[0], k, od[0].data_ptr(), oi[0].data_ptr(), stream)
+    idx.close()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(oi[0].cpu().numpy(), want[0][1])
 
 
 def test_dense_wide_rows_exact_path():

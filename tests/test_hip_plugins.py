@@ -501,16 +501,17 @@ def test_bruteforce_update_appends_on_the_device():
     assert idx.nn(q, 1)[0][0].uuid() == 7
 
 
-def test_pipelined_sharded_search_rccl_world1():
+@pytest.mark.parametrize("use_async", [False, True])
+def test_pipelined_sharded_search_rccl_world1(use_async):
     """PipelinedShardedSearch: the all-gather and the host merge of a batch run under the next batch's
-    search; results come back two submits later, in order, and equal the direct search."""
+    search; results come back two (asynchronous searches: three) submits later, in order, and equal the direct search."""
     import os
     import torch
     import torch.distributed as dist
     from smqtk_indexing_amd.distributed import PipelinedShardedSearch
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = "29521"
+    os.environ["MASTER_PORT"] = "29522" if use_async else "29521"
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -520,11 +521,12 @@ def test_pipelined_sharded_search_rccl_world1():
         index = _lib.DenseIndex(db.data_ptr(), n=db.shape[0], d=64, device_ptr=True, id_base=500, keepalive=db)
         nq, k = 7, 15
         batches = [torch.from_numpy(rng.standard_normal((nq, 64)).astype(np.float32)).to(dev) for _ in range(6)]
-        pipe = PipelinedShardedSearch(index, nq, k, torch.float32, device=dev)
+        pipe = PipelinedShardedSearch(index, nq, k, torch.float32, device=dev, use_async=use_async)
+        assert pipe.lag == (1 if use_async else 0)
         got = []
         for i, q in enumerate(batches):
             r = pipe.submit(q)
-            assert (r is None) == (i < 2)
+            assert (r is None) == (i < 2 + pipe.lag)
             if r is not None:
                 got.append(r)
         got += pipe.flush()
