@@ -44,7 +44,10 @@ static constexpr int MAX_DPAD = 512;
 // --------------------------------------------------------------- bf16 split
 __device__ __forceinline__ u32 bf16_bits_rn(float x) {
     u32 u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
+    // NaN stays NaN: the integer rounding below would carry a NaN with a full mantissa into the sign bit
+    // (0x7FFFFFFF -> -0.0, a finite-looking value; MI355X_MICROARCH.md pitfalls).  +-inf round to themselves.
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x0040u;
+    u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even
     return u >> 16;
 }
 __device__ __forceinline__ void bf16_split(float x, u32& hi, u32& lo) {
@@ -65,7 +68,12 @@ static __global__ __launch_bounds__(256) void dense_colsum_kernel(const float* _
     const long long r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
     for (int k = threadIdx.x; k < d; k += 256) {
         double acc = 0.0;
-        for (long long r = r0; r < r1; ++r) acc += (double)db[r * ld + k];
+        for (long long r = r0; r < r1; ++r) {
+            // non-finite elements are left out: one NaN / inf row must not turn the filter's origin (and with it
+            // every filter score) into NaN -- such a row can never be a candidate anyway
+            const float v = db[r * ld + k];
+            if (fabsf(v) < __builtin_inff()) acc += (double)v;
+        }
         atomicAdd(&colsum[k], acc);
     }
 }
@@ -160,6 +168,7 @@ static __global__ __launch_bounds__(256) void dense_rowstats_kernel(const float*
     // address: 14 ms of a 17 ms index build)
     __shared__ float s_max[4];
     float m = row < n ? (float)(acc * (1.0 + 1e-6)) : 0.f;
+    if (!(m < __builtin_inff())) m = 0.f;  // rows with non-finite elements never pass the filter: not part of the bound
     for (int o = 8; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
     __syncthreads();

@@ -39,6 +39,16 @@ DENSE_CASES = {
 }
 DENSE_KMAX = 100
 
+# SURVEY 8(c) G5 at its specified size: 20 k x 128, float32 AND float64, uniform and normal, 32 queries, the
+# reference's order for k = 100 (k = 1 and 10 are its prefixes).  tag -> (n, d, nq, seed, distribution, dtype,
+# cosine queries): separate fixture g5b_dense_nn_20k.npz.
+DENSE_BIG_CASES = {
+    "uni20k": (20000, 128, 32, 35, "uniform", "float32", 8),
+    "nrm20k": (20000, 128, 32, 36, "normal", "float32", 8),
+    "nrm20k_f64": (20000, 128, 32, 37, "normal", "float64", 8),
+    "uni20k_f64": (20000, 128, 32, 38, "uniform", "float64", 8),
+}
+
 # tag -> (n, d, bits, seed, metric, n values)
 LSH_CASES = {
     "rand_euclid": (1000, 64, 16, 41, "euclidean", (1, 10, 1000)),
@@ -99,6 +109,30 @@ def dense_inputs(n: int, d: int, nq: int, seed: int, dist: str, dtype: str):
         db[7] = db[3]                              # exact duplicate rows: a tie
         qs[0] = db[11]                             # a self query: distance 0
     return db, qs
+
+
+def lsh_scenario_random_euclidean():
+    """The data of TestLshIndexAlgorithms._random_euclidean (tests/impls/nn_index/test_lsh.py:754-813):
+    numpy's legacy generator seeded with RANDOM_SEED = 0, 1000 x 256 uniform rows drawn one by one, then the
+    random query drawn AFTER the functor was trained (the training draws from the same global generator, so the
+    fixture stores that query).  Returns (db, near-duplicate query of row 0)."""
+    st = np.random.RandomState(0)          # == np.random.seed(0) followed by np.random.rand(dim) per row
+    db = np.vstack([st.rand(256) for _ in range(1000)])
+    v = db[0].copy()
+    v_min = max(v.min(), 0.1)
+    v[0] += v_min
+    v[255] -= v_min
+    return db, v
+
+
+def lsh_scenario_known_ordered(order_seed: int = 0):
+    """TestLshIndexAlgorithms._known_ordered_euclidean (test_lsh.py:934-966): rows (j, 2j), j < 1000, build order
+    shuffled by python's `random` (seeded here; the test leaves it unseeded).  Returns (uuids in build order, rows)."""
+    import random
+    uu = list(range(1000))
+    random.Random(order_seed).shuffle(uu)
+    rows = np.array([[j, 2 * j] for j in uu], dtype=float)
+    return uu, rows
 
 
 def lsh_inputs(n: int, d: int, seed: int):

@@ -175,6 +175,129 @@ def main() -> None:
             g5[f"{tag}_{metric}_dist"] = np.stack(dists)
     np.savez_compressed(os.path.join(HERE, "g5_dense_nn.npz"), **g5)
 
+    # ------------------------------------- G5b dense kNN at SURVEY 8(c)'s size, float32 and float64
+    g5b = {}
+    for tag, (n, d, nq, seed, dist, dt, nq_cos) in GI.DENSE_BIG_CASES.items():
+        db, qs = GI.dense_inputs(n, d, nq, seed, dist, dt)
+        g5b[f"{tag}_sha_db"] = sha(db)
+        g5b[f"{tag}_sha_q"] = sha(qs)
+        for metric, fn in (("euclidean", rmetrics.euclidean_distance), ("cosine", rmetrics.cosine_distance)):
+            nq_m = nq if metric == "euclidean" else nq_cos
+            idxs, dists = [], []
+            for q in qs[:nq_m]:
+                dd = np.array([fn(q, r) for r in db])      # lsh.py:475-476, 511: one call per row, query first
+                if metric == "euclidean":
+                    assert dd.dtype == db.dtype            # dtype preserving (metrics.py:73-86)
+                order = sorted(range(n), key=lambda i: dd[i])[:GI.DENSE_KMAX]   # stable (lsh.py:513)
+                idxs.append(np.array(order, dtype=np.int64))
+                dists.append(dd[order])
+            g5b[f"{tag}_{metric}_idx"] = np.stack(idxs)
+            g5b[f"{tag}_{metric}_dist"] = np.stack(dists)
+    np.savez_compressed(os.path.join(HERE, "g5b_dense_nn_20k.npz"), **g5b)
+
+    # ---------------- G6b the three TestLshIndexAlgorithms scenarios (test_lsh.py:754-979), reference outputs
+    g6b = {}
+
+    def run_queries(index, queries):
+        out = {}
+        for name, vec, nn in queries:
+            r, dist = index.nn(C.DescriptorMemoryElement(("q", name)).set_vector(vec), nn)
+            out[name] = (np.array([e.uuid() for e in r], dtype=np.int64), np.asarray(dist, dtype=np.float64))
+        return out
+
+    for hi_tag in ("none", "linear"):
+        # (1) random euclidean: 1000 x 256, 32-bit ITQ (seed 0)
+        np.random.seed(0)
+        db, near0 = GI.lsh_scenario_random_euclidean()
+        td = []
+        for j in range(1000):
+            td.append(C.DescriptorMemoryElement(j).set_vector(np.random.rand(256)))
+        assert np.array_equal(np.vstack([e.vector() for e in td]), db)
+        ftor = ItqFunctor(bit_length=32, random_seed=0)
+        ftor.fit(td)
+        index = LSHNearestNeighborIndex(ftor, C.MemoryDescriptorSet(), C.MemoryKeyValueStore(),
+                                        hash_index=LinearHashIndex() if hi_tag == "linear" else None,
+                                        distance_method="euclidean")
+        index.build_index(td)
+        qrand = np.random.rand(256)                        # drawn where the test draws it
+        res = run_queries(index, [("self255_n1", db[255], 1), ("near0_n1", near0, 1), ("rand_n10", qrand, 10),
+                                  ("rand_n1000", qrand, 1000)])
+        assert res["self255_n1"][0][0] == 255 and res["near0_n1"][0][0] == 0
+        pre = f"rand_{hi_tag}_"
+        g6b[pre + "mean"], g6b[pre + "rot"] = ftor.mean_vec, np.real(ftor.rotation)
+        g6b[pre + "qrand"] = qrand
+        g6b[pre + "count"] = np.array(index.count())
+        g6b[pre + "ncodes"] = np.array(len(list(index.hash2uuids_kvstore.keys())))
+        for name, (u, dv) in res.items():
+            g6b[pre + name + "_uuids"], g6b[pre + name + "_dist"] = u, dv
+
+        # (2) unit vectors, 5-bit ITQ
+        unit = [C.DescriptorMemoryElement(i).set_vector(np.eye(5)[i]) for i in range(5)]
+        ftor = ItqFunctor(bit_length=5, random_seed=0)
+        ftor.fit(unit)
+        index = LSHNearestNeighborIndex(ftor, C.MemoryDescriptorSet(), C.MemoryKeyValueStore(),
+                                        hash_index=LinearHashIndex() if hi_tag == "linear" else None,
+                                        distance_method="euclidean")
+        index.build_index(unit)
+        res = run_queries(index, [("zero_n5", np.zeros(5), 5), ("e3_n1", np.eye(5)[3], 1), ("e3_n5", np.eye(5)[3], 5)])
+        assert (res["zero_n5"][1] == 1.0).all() and res["e3_n1"][0][0] == 3 and res["e3_n1"][1][0] == 0.0
+        pre = f"unit_{hi_tag}_"
+        g6b[pre + "mean"], g6b[pre + "rot"] = ftor.mean_vec, np.real(ftor.rotation)
+        for name, (u, dv) in res.items():
+            g6b[pre + name + "_uuids"], g6b[pre + name + "_dist"] = u, dv
+
+        # (3) known order: (j, 2j), 1-bit ITQ
+        uu, rows = GI.lsh_scenario_known_ordered()
+        elems = [C.DescriptorMemoryElement(u).set_vector(r) for u, r in zip(uu, rows)]
+        ftor = ItqFunctor(bit_length=1, random_seed=0)
+        ftor.fit(elems)
+        index = LSHNearestNeighborIndex(ftor, C.MemoryDescriptorSet(), C.MemoryKeyValueStore(),
+                                        hash_index=LinearHashIndex() if hi_tag == "linear" else None,
+                                        distance_method="euclidean")
+        index.build_index(elems)
+        res = run_queries(index, [("origin_n5", np.zeros(2), 5), ("origin_n1000", np.zeros(2), 1000)])
+        assert res["origin_n5"][0].tolist() == [0, 1, 2, 3, 4]
+        assert res["origin_n1000"][0].tolist() == list(range(1000))
+        pre = f"ord_{hi_tag}_"
+        g6b[pre + "mean"], g6b[pre + "rot"] = ftor.mean_vec, np.real(ftor.rotation)
+        for name, (u, dv) in res.items():
+            g6b[pre + name + "_uuids"], g6b[pre + name + "_dist"] = u, dv
+    np.savez_compressed(os.path.join(HERE, "g6b_lsh_scenarios.npz"), **g6b)
+
+    # ------------- G8 cache bytes WRITTEN BY THE REFERENCE (itq.py:222-237 save_model, linear.py:133-142 save_cache)
+    g8 = {}
+    x, _ = GI.lsh_inputs(300, 24, 8)
+    for dt in (np.float64, np.float32):
+        mc, rc = C.DataMemoryElement(), C.DataMemoryElement()
+        f = ItqFunctor(mean_vec_cache=mc, rotation_cache=rc, bit_length=12, random_seed=2, itq_iterations=5)
+        f.fit([C.DescriptorMemoryElement(i).set_vector(v) for i, v in enumerate(x.astype(dt))])
+        assert not mc.is_empty() and not rc.is_empty()
+        tag = np.dtype(dt).name
+        g8[f"itq_{tag}_mean_bytes"] = np.frombuffer(mc.get_bytes(), dtype=np.uint8)
+        g8[f"itq_{tag}_rot_bytes"] = np.frombuffer(rc.get_bytes(), dtype=np.uint8)
+        g8[f"itq_{tag}_mean"], g8[f"itq_{tag}_rot"] = f.mean_vec, np.real(f.rotation)
+        probe = x[:40].astype(dt)
+        g8[f"itq_{tag}_probe_codes"] = np.vstack([f.get_hash(r) for r in probe])
+    for bits, tag in ((20, "b20"), (62, "b62"), (64, "b64")):
+        ce = C.DataMemoryElement()
+        idx = LinearHashIndex(cache_element=ce)
+        hv = rng.random((500, bits)) > 0.5
+        if bits == 64:
+            hv[0, 0] = True                                # at least one code >= 2**63 ...
+            hv[1, 0] = False                               # ... and one below: numpy infers float64 (lossy upstream)
+        idx.build_index(hv)
+        g8[f"lin_{tag}_cache_bytes"] = np.frombuffer(ce.get_bytes(), dtype=np.uint8)
+        g8[f"lin_{tag}_codes"] = np.unique(O.pack_bits_msb(hv), axis=0)
+        arr = np.load(__import__("io").BytesIO(ce.get_bytes()))
+        g8[f"lin_{tag}_cache_dtype"] = np.array(str(arr.dtype))
+        if bits < 64:
+            q = hv[3]
+            rows, dists = LinearHashIndex(cache_element=ce).nn(q, 7)      # a reference index re-loaded from those bytes
+            g8[f"lin_{tag}_q"] = q
+            g8[f"lin_{tag}_nn_dist"] = np.asarray(dists, dtype=np.float64)
+            g8[f"lin_{tag}_nn_codes"] = O.pack_bits_msb(rows)
+    np.savez_compressed(os.path.join(HERE, "g8_reference_caches.npz"), **g8)
+
     # ------------------------------------------------------ G6 LSH end to end
     g6 = {}
     for tag, (n, d, bits, seed, metric, ns) in GI.LSH_CASES.items():

@@ -604,3 +604,115 @@ def test_itq_resident_model_equals_one_shot_hash(norm, mean_dt):
     model.close()
     with pytest.raises(_lib.HipError):
         model.hash(x[:1])
+
+
+# ------------------------------------------- parity holes named by the round-1 review
+@pytest.mark.parametrize("bits", [512, 1024])
+def test_hamming_wide_codes(golden, bits):
+    """512- and 1024-bit codes (the reference pins 1024-bit hamming_distance: tests/utils/test_metrics.py:85-104).
+    Index = the 1000 `a` codes of fixture g2 plus random ones; the distance from b[j] to a[j] must be the REFERENCE's
+    d[j], and the whole top-k must equal the oracle's (small index: exact keys; large index: the streaming scan)."""
+    g = golden("g2_hamming.npz")
+    w = bits // 64
+    rng = np.random.default_rng(bits)
+    if bits == 1024:
+        a, b, dref = g["a_1024"], g["b_1024"], g["d_1024"]
+    else:   # the first / last 8 words of the 1024-bit pairs are 512-bit pairs; their reference distance by popcount
+        a = np.ascontiguousarray(g["a_1024"][:, :8])
+        b = np.ascontiguousarray(g["b_1024"][:, :8])
+        dref = O.popcount_u64(a ^ b).sum(axis=1).astype(np.int32)
+    for extra in (0, 120_000):
+        codes = np.unique(np.vstack([a, rng.integers(0, 2 ** 64, size=(extra, w), dtype=np.uint64)]), axis=0)
+        row_of = {c.tobytes(): i for i, c in enumerate(codes)}
+        idx = _hamming_check(codes, b[:6], 50)
+        dd, ii = idx.search(b[:40], codes.shape[0] if extra == 0 else 100)
+        if extra == 0:
+            for j in range(40):          # every code is returned: find a[j] among b[j]'s results
+                at = np.nonzero(ii[j] == row_of[a[j].tobytes()])[0]
+                assert len(at) == 1 and dd[j, at[0]] == dref[j]
+        # a near-duplicate of an indexed code is its own nearest neighbour at distance 1
+        q = codes[[5, 17]].copy()
+        q[:, w - 1] ^= np.uint64(1)
+        d1, i1 = idx.search(q, 3)
+        assert d1[:, 0].tolist() == [1, 1] and i1[:, 0].tolist() == [5, 17]
+
+
+@pytest.mark.parametrize("tag", list(GI.DENSE_BIG_CASES))
+def test_dense_golden_20k(golden, tag):
+    """Fixture G5 at SURVEY 8(c)'s size (20 k x 128, 32 queries), float32 AND float64 descriptors, against the
+    REFERENCE's per-row distances + stable sort.  float32 rows: sq_dense_search (ids and float32 distances bit
+    identical).  float64 rows: the descriptor matrix resident as float64 (sq_rows_*: the LSH re-rank stage, the
+    only float64 consumer) with every row a candidate, and sq_dense_distances."""
+    g = golden("g5b_dense_nn_20k.npz")
+    n, d, nq, seed, dist, dt, nq_cos = GI.DENSE_BIG_CASES[tag]
+    db, qs = GI.dense_inputs(n, d, nq, seed, dist, dt)
+    ridx, rdist = g[f"{tag}_euclidean_idx"], g[f"{tag}_euclidean_dist"]
+    cidx, cdist = g[f"{tag}_cosine_idx"], g[f"{tag}_cosine_dist"]
+    if dt == "float32":
+        for cap in (0, 2048):                                     # exact keys for all rows / the MFMA scan path
+            _lib.set_option("candidate_cap", cap)
+            idx = _lib.DenseIndex(db)
+            dd, ii = idx.search(qs, 100)
+            np.testing.assert_array_equal(ii, ridx)
+            np.testing.assert_array_equal(dd.view(np.uint32), rdist.view(np.uint32))
+            assert (cap == 0) == (idx.stats()["scan_launches"] == 1)
+            for k in (1, 10):
+                np.testing.assert_array_equal(idx.search(qs, k)[1], ridx[:, :k])
+            idx.close()
+            ic = _lib.DenseIndex(db, metric=_lib.SQ_METRIC_COSINE)
+            dd, ii = ic.search(qs[:nq_cos], 100)
+            np.testing.assert_allclose(dd, cdist, rtol=1e-9, atol=1e-12)
+            ic.close()
+    else:
+        m = _lib.RowMatrix(db)
+        cand = np.tile(np.arange(n, dtype=np.int64), nq)
+        off = np.arange(nq + 1, dtype=np.int64) * n
+        dd, pos = m.rerank(qs, _lib.SQ_METRIC_L2, cand, off, 100)
+        assert dd.dtype == np.float64
+        np.testing.assert_array_equal(pos, ridx)
+        np.testing.assert_array_equal(dd.view(np.uint64), rdist.view(np.uint64))    # float64, bit identical
+        dd, pos = m.rerank(qs[:nq_cos], _lib.SQ_METRIC_COSINE, cand[: nq_cos * n], off[: nq_cos + 1], 100)
+        np.testing.assert_allclose(dd, cdist, rtol=1e-9, atol=1e-12)
+        m.close()
+        full = _lib.dense_distances(qs[3], db, _lib.SQ_METRIC_L2)
+        np.testing.assert_array_equal(full[ridx[3]].view(np.uint64), rdist[3].view(np.uint64))
+
+
+@pytest.mark.parametrize("n", [900, 150_000])
+def test_dense_non_finite_rows(n):
+    """Rows holding NaN / +-inf elements.  numpy's distance to such a row is NaN or +inf; the stable sort ranks
+    +inf after every number and NaN after that.  n = 150 000 goes through the bf16 scan (the scan copy of a
+    non-finite row must never look like a small finite score), n = 900 through the exact keys."""
+    rng = np.random.default_rng(77)
+    d = 64
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    bad = rng.choice(n, size=60, replace=False)
+    for j, r in enumerate(bad):
+        db[r, rng.integers(0, d)] = [np.nan, np.inf, -np.inf][j % 3]
+        if j % 7 == 0:
+            db[r, :] = np.nan
+    db[bad[1], :2] = [np.inf, -np.inf]
+    qs = rng.standard_normal((5, d)).astype(np.float32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        idx = _lib.DenseIndex(db)
+        for k in (10, 100):
+            dd, ii = idx.search(qs, k)
+            for qi, q in enumerate(qs):
+                rd, ri = O.dense_topk(db, q, k)
+                assert np.isfinite(rd).all()
+                np.testing.assert_array_equal(ii[qi], ri)
+                np.testing.assert_array_equal(dd[qi].view(np.uint32), rd.view(np.uint32))
+        if n <= 1000:
+            # k = n: the +inf and NaN rows come last, +inf before NaN, each group in row order
+            dd, ii = idx.search(qs[:2], n)
+            for qi in range(2):
+                rd, ri = O.dense_topk(db, qs[qi], n)
+                fin = np.isfinite(rd)
+                np.testing.assert_array_equal(ii[qi][fin], ri[fin])
+                assert set(ii[qi][~fin].tolist()) == set(ri[~fin].tolist())
+                assert np.isinf(dd[qi][~fin]).sum() == np.isinf(rd[~fin]).sum()
+        # a query with a non-finite element: every distance is NaN / inf; nothing may crash or hang
+        qbad = qs[:1].copy()
+        qbad[0, 3] = np.nan
+        dd, ii = idx.search(qbad, 5)
+        assert not np.isfinite(dd).any()

@@ -572,3 +572,65 @@ def test_lsh_update_appends_to_the_device_mirror(hash_index):
             assert da == db and [e.uuid() for e in ra] == [e.uuid() for e in rb]
     grown.update_index([DescriptorMemoryElement(5).set_vector(x[5] + 1.0)])     # replaces uuid 5
     assert grown._mirror is None
+
+
+# ----------------------------------------- reference scenarios and reference-written caches (fixtures g6b, g8)
+@pytest.mark.parametrize("hi_tag", ["none", "linear"])
+def test_lsh_reference_scenarios(golden, hi_tag):
+    """The three TestLshIndexAlgorithms scenarios (tests/impls/nn_index/test_lsh.py:754-979) with the models the
+    REFERENCE fitted and the results it returned: the HIP index must return admissible results with the reference's
+    distances (which Hamming-tied codes enter at rank n is set-order dependent upstream), the identical answer when
+    n covers every code, and pass the scenarios' own assertions."""
+    from tests.test_oracle_golden import _check_lsh_admissible, _lsh_state, lsh_scenarios
+    g = golden("g6b_lsh_scenarios.npz")
+    for name, uuids, rows, (mean, rot), queries in lsh_scenarios(g, hi_tag):
+        f = HipItqFunctor(bit_length=rot.shape[1])
+        f.mean_vec, f.rotation = mean, rot
+        index = HipLSHNearestNeighborIndex(f, MemoryDescriptorSet(), MemoryKeyValueStore(),
+                                           HipLinearHashIndex() if hi_tag == "linear" else None,
+                                           distance_method="euclidean")
+        index.build_index([DescriptorMemoryElement(u).set_vector(r) for u, r in zip(uuids, rows)])
+        uniq, buckets = _lsh_state(rows, mean, rot)
+        row_of = {u: r for r, u in enumerate(uuids)}
+        for qname, qv, nn in queries:
+            r, dists = index.nn(DescriptorMemoryElement("q").set_vector(qv), nn)
+            r_uu, r_dist = g[f"{name}_{hi_tag}_{qname}_uuids"], g[f"{name}_{hi_tag}_{qname}_dist"]
+            got_rows = np.array([row_of[e.uuid()] for e in r])
+            _check_lsh_admissible(qv, nn, mean, rot, uniq, buckets, rows, "euclidean", got_rows, np.asarray(dists))
+            if nn >= uniq.shape[0]:
+                np.testing.assert_allclose(dists, r_dist, rtol=1e-12)
+                dd = np.asarray(dists)
+                if (dd[1:] != dd[:-1]).all():
+                    assert [e.uuid() for e in r] == r_uu.tolist()
+            if qname in ("self255_n1", "near0_n1", "e3_n1", "origin_n5"):
+                assert [e.uuid() for e in r] == r_uu.tolist() and list(dists) == r_dist.tolist()
+            if qname == "zero_n5":
+                assert list(dists) == [1.0] * 5
+        if name == "rand":
+            assert index.count() == int(g[f"rand_{hi_tag}_count"])
+
+
+def test_reference_written_caches_on_device(golden):
+    """Fixture g8: model / cache bytes written by the reference's ItqFunctor.save_model (itq.py:222-237) and
+    LinearHashIndex.save_cache (linear.py:133-142) are loaded by the HIP classes, which then answer as the reference."""
+    g = golden("g8_reference_caches.npz")
+    x, _ = GI.lsh_inputs(300, 24, 8)
+    for tag in ("float64", "float32"):
+        f = HipItqFunctor(mean_vec_cache=DataMemoryElement(g[f"itq_{tag}_mean_bytes"].tobytes()),
+                          rotation_cache=DataMemoryElement(g[f"itq_{tag}_rot_bytes"].tobytes()), bit_length=12)
+        probe = x[:40].astype(tag)
+        np.testing.assert_array_equal(f.get_hash(probe), g[f"itq_{tag}_probe_codes"])
+        np.testing.assert_array_equal(np.vstack([f.get_hash(r) for r in probe]), g[f"itq_{tag}_probe_codes"])
+    for tag in ("b20", "b62"):
+        bits = int(tag[1:])
+        idx = HipLinearHashIndex(cache_element=DataMemoryElement(g[f"lin_{tag}_cache_bytes"].tobytes()))
+        rows, dists = idx.nn(g[f"lin_{tag}_q"], 7)
+        np.testing.assert_allclose(dists, g[f"lin_{tag}_nn_dist"], rtol=0, atol=1e-15)
+        codes = g[f"lin_{tag}_codes"]
+        full = O.popcount_u64(codes ^ O.pack_bits_msb(g[f"lin_{tag}_q"][None])[0][None, :]).sum(axis=1)
+        lut = {O.packed_to_int(r): i for i, r in enumerate(codes)}
+        O.assert_topk_equivalent(np.rint(g[f"lin_{tag}_nn_dist"] * bits).astype(np.int32),
+                                 np.array([lut[O.packed_to_int(r)] for r in g[f"lin_{tag}_nn_codes"]]),
+                                 np.rint(np.asarray(dists) * bits).astype(np.int32),
+                                 np.array([lut[O.packed_to_int(r)] for r in O.pack_bits_msb(rows)]),
+                                 all_dist_of=lambda r: full[r])

@@ -267,3 +267,109 @@ def test_scipy_cosine_order():
         if abs(c) > 1:
             c = math.copysign(1, c)
         assert cdist(u[None], v[None], "cosine")[0, 0] == 1.0 - c
+
+
+# --------------------------- G5b dense kNN at SURVEY 8(c)'s size (20 k x 128, float32 AND float64, 32 queries)
+@pytest.mark.parametrize("tag", list(GI.DENSE_BIG_CASES))
+def test_dense_nn_golden_20k(golden, tag):
+    g = golden("g5b_dense_nn_20k.npz")
+    n, d, nq, seed, dist, dt, nq_cos = GI.DENSE_BIG_CASES[tag]
+    db, qs = GI.dense_inputs(n, d, nq, seed, dist, dt)
+    assert sha(db) == str(g[f"{tag}_sha_db"]) and sha(qs) == str(g[f"{tag}_sha_q"])
+    ridx, rdist = g[f"{tag}_euclidean_idx"], g[f"{tag}_euclidean_dist"]
+    assert ridx.shape == (32, 100) and rdist.dtype == np.dtype(dt)          # metrics.py:73-86 keeps the dtype
+    for qi in range(nq):
+        gd, gi = O.dense_topk(db, qs[qi], 100, "euclidean")
+        assert gd.dtype == np.dtype(dt)
+        np.testing.assert_array_equal(gd, rdist[qi])                         # bit identical, float32 and float64
+        np.testing.assert_array_equal(gi, ridx[qi])
+        for k in (1, 10):                                                    # k = 1, 10 are prefixes of the same sort
+            np.testing.assert_array_equal(O.dense_topk(db, qs[qi], k, "euclidean")[1], ridx[qi][:k])
+    ridx, rdist = g[f"{tag}_cosine_idx"], g[f"{tag}_cosine_dist"]
+    for qi in range(nq_cos):
+        gd, gi = O.dense_topk(db, qs[qi], 100, "cosine")
+        np.testing.assert_allclose(gd, rdist[qi], rtol=1e-9, atol=1e-9)      # batched vs per-row cdist
+        full = O.dense_distances(db, qs[qi], "cosine")
+        assert (np.abs(full[gi] - full[ridx[qi]]) < 1e-9).all()
+
+
+# ----------------- G6b the three TestLshIndexAlgorithms scenarios (test_lsh.py:754-979), reference outputs
+def lsh_scenarios(g, hi_tag):
+    """(name, uuids in row order, rows, model, [(query name, vector, n)]) of the three scenarios."""
+    db, near0 = GI.lsh_scenario_random_euclidean()
+    pre = f"rand_{hi_tag}_"
+    qrand = g[pre + "qrand"]
+    yield ("rand", list(range(1000)), db, (g[pre + "mean"], g[pre + "rot"]),
+           [("self255_n1", db[255], 1), ("near0_n1", near0, 1), ("rand_n10", qrand, 10), ("rand_n1000", qrand, 1000)])
+    pre = f"unit_{hi_tag}_"
+    yield ("unit", list(range(5)), np.eye(5), (g[pre + "mean"], g[pre + "rot"]),
+           [("zero_n5", np.zeros(5), 5), ("e3_n1", np.eye(5)[3], 1), ("e3_n5", np.eye(5)[3], 5)])
+    uu, rows = GI.lsh_scenario_known_ordered()
+    pre = f"ord_{hi_tag}_"
+    yield ("ord", uu, rows, (g[pre + "mean"], g[pre + "rot"]),
+           [("origin_n5", np.zeros(2), 5), ("origin_n1000", np.zeros(2), 1000)])
+
+
+@pytest.mark.parametrize("hi_tag", ["none", "linear"])
+def test_lsh_reference_scenarios_golden(golden, hi_tag):
+    g = golden("g6b_lsh_scenarios.npz")
+    for name, uuids, rows, (mean, rot), queries in lsh_scenarios(g, hi_tag):
+        uniq, buckets = _lsh_state(rows, mean, rot)
+        ua = np.asarray(uuids)
+        row_of = {u: r for r, u in enumerate(uuids)}
+        for qname, qv, nn in queries:
+            r_uu, r_dist = g[f"{name}_{hi_tag}_{qname}_uuids"], g[f"{name}_{hi_tag}_{qname}_dist"]
+            ids, dist = O.lsh_nn(qv, nn, mean, rot, None, uniq, buckets, rows, "euclidean")
+            r_rows = np.array([row_of[int(u)] for u in r_uu])
+            _check_lsh_admissible(qv, nn, mean, rot, uniq, buckets, rows, "euclidean", r_rows, r_dist)
+            _check_lsh_admissible(qv, nn, mean, rot, uniq, buckets, rows, "euclidean", ids, dist)
+            if nn >= uniq.shape[0]:
+                # n covers every code: exact brute force over all rows, order fully determined up to distance ties
+                np.testing.assert_allclose(dist, r_dist, rtol=1e-12)
+                if (dist[1:] != dist[:-1]).all():
+                    np.testing.assert_array_equal(ua[ids], r_uu)
+        if name == "rand":
+            assert uniq.shape[0] == int(g[f"rand_{hi_tag}_ncodes"]) and len(rows) == int(g[f"rand_{hi_tag}_count"])
+    # the scenario assertions themselves (test_lsh.py:783-813, 856-876, 953-966)
+    assert g[f"rand_{hi_tag}_self255_n1_uuids"][0] == 255 and g[f"rand_{hi_tag}_near0_n1_uuids"][0] == 0
+    assert (np.diff(g[f"rand_{hi_tag}_rand_n1000_dist"]) > 0).all()
+    assert (g[f"unit_{hi_tag}_zero_n5_dist"] == 1.0).all() and g[f"unit_{hi_tag}_e3_n5_dist"][0] == 0.0
+    assert g[f"ord_{hi_tag}_origin_n1000_uuids"].tolist() == list(range(1000))
+
+
+# --------------- G8 cache bytes written by the reference (itq.py:222-237 save_model, linear.py:133-142 save_cache)
+def test_reference_written_caches_load(golden):
+    """Host side only (no kernel call): HipItqFunctor / HipLinearHashIndex read the bytes the reference wrote."""
+    from smqtk_indexing_amd._compat import DataMemoryElement
+    from smqtk_indexing_amd.impls.hash_index.hip_linear import HipLinearHashIndex
+    from smqtk_indexing_amd.impls.lsh_functor.hip_itq import HipItqFunctor
+    g = golden("g8_reference_caches.npz")
+    for tag in ("float64", "float32"):
+        f = HipItqFunctor(mean_vec_cache=DataMemoryElement(g[f"itq_{tag}_mean_bytes"].tobytes()),
+                          rotation_cache=DataMemoryElement(g[f"itq_{tag}_rot_bytes"].tobytes()), bit_length=12)
+        assert f.has_model() and f.mean_vec.dtype == np.dtype(tag)
+        np.testing.assert_array_equal(f.mean_vec, g[f"itq_{tag}_mean"])
+        np.testing.assert_array_equal(np.real(f.rotation), g[f"itq_{tag}_rot"])
+        x, _ = GI.lsh_inputs(300, 24, 8)
+        probe = x[:40].astype(tag)
+        got = np.vstack([O.itq_get_hash(r, f.mean_vec, np.real(f.rotation)) for r in probe])
+        np.testing.assert_array_equal(got, g[f"itq_{tag}_probe_codes"])
+        # and the bytes this build writes are the bytes the reference wrote (numpy.save of the same arrays)
+        m2, r2 = DataMemoryElement(), DataMemoryElement()
+        f.mean_vec_cache_elem, f.rotation_cache_elem = m2, r2
+        f.save_model()
+        assert m2.get_bytes() == g[f"itq_{tag}_mean_bytes"].tobytes()
+    for tag in ("b20", "b62"):
+        assert str(g[f"lin_{tag}_cache_dtype"]) == "int64"
+        idx = HipLinearHashIndex(cache_element=DataMemoryElement(g[f"lin_{tag}_cache_bytes"].tobytes()))
+        np.testing.assert_array_equal(idx.codes_packed(), g[f"lin_{tag}_codes"])
+        assert idx.count() == g[f"lin_{tag}_codes"].shape[0]
+        bits = int(tag[1:])
+        rows, dist = O.linear_hash_nn_reference(set(O.packed_to_int(c) for c in idx.codes_packed()), g[f"lin_{tag}_q"], 7)
+        np.testing.assert_allclose(dist, g[f"lin_{tag}_nn_dist"])
+        assert bits == len(g[f"lin_{tag}_q"])
+    # codes at and above 2**63 next to smaller ones: numpy.save(tuple(ints)) stores FLOAT64 (lossy upstream, SURVEY 8f
+    # rank 2); that cache is refused rather than loaded as corrupted codes
+    assert str(g["lin_b64_cache_dtype"]) == "float64"
+    with pytest.raises(ValueError):
+        HipLinearHashIndex(cache_element=DataMemoryElement(g["lin_b64_cache_bytes"].tobytes()))
