@@ -30,7 +30,8 @@ SQ_NORM_L2 = 2
 SQ_MAX_K = 16384
 
 LIB_NAME = "libsmqtk_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# SMQTK_HIP_LIBRARY: another build of the same library (measurement: kernel variants side by side)
+LIB_PATH = os.environ.get("SMQTK_HIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 # every symbol include/smqtk_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (

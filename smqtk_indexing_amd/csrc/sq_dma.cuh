@@ -65,4 +65,29 @@ __device__ __forceinline__ void wait_units_in_flight(int units) {
         wait_vmcnt<0>();
 }
 
+// A store the counted waits know about: exactly one VMEM instruction under the current exec mask.
+__device__ __forceinline__ void store_u64_counted(u64* p, u64 v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
+// Allow `units` younger DMA units (PER instructions each) and the stores of `epis` younger tile epilogues
+// (S store instructions each) to stay outstanding: vmcnt is one in-order queue for a wave's loads and stores.
+template <int PER, int S, int EMAX, int U, int E>
+__device__ __forceinline__ void wait_ops_rec(int units, int epis) {
+    if (units == U && epis == E) {
+        wait_vmcnt<(U * PER + E * S < 63 ? U * PER + E * S : 63)>();
+        return;
+    }
+    if constexpr (E > 0)
+        wait_ops_rec<PER, S, EMAX, U, E - 1>(units, epis);
+    else if constexpr (U > 0)
+        wait_ops_rec<PER, S, EMAX, U - 1, EMAX>(units, epis);
+    else
+        wait_vmcnt<0>();  // anything unexpected: drain
+}
+template <int NSTAGE, int PER, int S>
+__device__ __forceinline__ void wait_ops_in_flight(int units, int epis) {
+    wait_ops_rec<PER, S, NSTAGE, NSTAGE - 1, NSTAGE>(units, epis);
+}
+
 }  // namespace sq

@@ -246,7 +246,10 @@ typedef double f64x2_t __attribute__((ext_vector_type(2)));
 // sign in place.  (A whole-row float64 MFMA recompute of the ~4 % of rows owning such a bit cost
 // 0.31 ms at 10 M x 128 -> 64 bits -- 64x the flops needed; one or eight lanes per entry cost as much:
 // every 16-byte piece of a row then pulls its own cache line through L2.)
-static constexpr int ITQ_FIX_PARTS = 4;
+#ifndef SQ_ITQ_FIX_PARTS
+#define SQ_ITQ_FIX_PARTS 4
+#endif
+static constexpr int ITQ_FIX_PARTS = SQ_ITQ_FIX_PARTS;
 static __global__ __launch_bounds__(256) void itq_fix_bits_kernel(ItqArgs a, const u64* __restrict__ seg,
                                                                   const u32* __restrict__ seg_cnt, long long seg_cap,
                                                                   const double* __restrict__ rt64) {
@@ -409,10 +412,13 @@ static ItqFastGeom itq_fast_geometry(int d, int words) {
     if (d % 64 != 0 || d > 256 || words > 2) return g;
     g.ku = d / 64;
     g.ct = words * 2;
-    g.breg = g.ku * g.ct <= 4;  // R fragments fit in registers: eight waves, LDS is all rings
+    // R's hi fragments in registers (lo planes in LDS), eight waves -- unless four column tiles of accumulators are
+    // live as well (64-d -> 128 bits): that spilled, and a scratch reload in the loop drains the DMA ring
+    g.breg = g.ku * g.ct <= 4 && g.ct <= 2;
     g.waves = g.breg ? ITQF_WAVES_BREG : ITQF_WAVES_LDSB;
     const int dp = (d + 127) / 128 * 128;
-    const size_t fixed = g.breg ? 0 : (size_t)g.ct * 32 * dp * 4;
+    // LDS copy of R: both bfloat16 planes, or only the lo planes when the hi fragments live in registers
+    const size_t fixed = (size_t)g.ct * 32 * dp * (g.breg ? 2 : 4);
     for (int ns = g.breg ? 2 : 4; ns >= 2; --ns) {
         const size_t lds = fixed + (size_t)g.waves * ns * ITQF_UNIT_BYTES;
         if (lds <= 160 * 1024) {
@@ -429,7 +435,6 @@ static int itq_fast_dispatch(const ItqFastArgs& fa, const ItqFastGeom& g, hipStr
     if (g.breg) {
         switch (g.ku * 10 + g.ct) {
             case 12: return itq_fast_launch_t<8, 2, 1, 2, NORMED, true>(fa, g.lds, st);
-            case 14: return itq_fast_launch_t<8, 2, 1, 4, NORMED, true>(fa, g.lds, st);
             default: return itq_fast_launch_t<8, 2, 2, 2, NORMED, true>(fa, g.lds, st);  // 22
         }
     }
@@ -439,6 +444,7 @@ static int itq_fast_dispatch(const ItqFastArgs& fa, const ItqFastGeom& g, hipStr
         if (g.stages == 3) return itq_fast_launch_t<4, 3, KUv, CTv, NORMED, false>(fa, g.lds, st);             \
         return itq_fast_launch_t<4, 2, KUv, CTv, NORMED, false>(fa, g.lds, st);
     switch (g.ku * 10 + g.ct) {
+        SQ_ITQF_CASE(1, 4)
         SQ_ITQF_CASE(2, 4)
         SQ_ITQF_CASE(3, 2)
         SQ_ITQF_CASE(3, 4)
@@ -485,6 +491,7 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
     const size_t o_img = take((size_t)pc * ((a.d + 127) / 128 * 128) * 4);
     const bool l2 = a.norm == SQ_NORM_L2;
     const size_t o_seg = take((size_t)nwaves * seg_cap * 8), o_cnt = take((size_t)nwaves * 4);
+    const size_t o_dummy = take((size_t)nwaves * 8);
     const size_t o_rt = take((size_t)pc * a.d * 8);
     keep_pool_memory(device);
     unsigned char* base = nullptr;
@@ -515,6 +522,7 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
     fa.bits = a.bits;
     fa.seg = reinterpret_cast<u64*>(base + o_seg);
     fa.seg_cnt = reinterpret_cast<u32*>(base + o_cnt);
+    fa.seg_dummy = reinterpret_cast<u64*>(base + o_dummy);
     fa.seg_cap = seg_cap;
     fa.n_tiles = n_tiles;
     fa.nrb = nrb;

@@ -38,6 +38,31 @@ static constexpr int ITQF_WAVES_LDSB = 4;  // waves when the R fragments come fr
 static constexpr int ITQF_WAVES_BREG = 8;  // waves when they live in registers
 static constexpr int ITQF_MAX_CT = 4;                           // up to 128 padded hash bits
 
+// Ballot words into the lanes of their rows.  d0[lane_a] = a0, d0[lane_b] = b0, d1[lane_a] = a1, d1[lane_b] = b1 (the
+// values are wave-uniform SGPRs -- the two halves of two ballots -- the other lanes keep what they hold): four
+// v_writelane_b32 with immediate lane numbers.  gfx950 needs two wait states between a VALU instruction that writes
+// an SGPR (the v_cmp behind a ballot) and a VALU instruction that reads it; hipcc pads that for its own code but not
+// inside an asm string, so the block starts with its own s_nop 1.  (Without it the first v_writelane read the
+// PREVIOUS ballot: wrong codes on the GPU, caught by test_itq_10m_x_128_codes_equal_float64_torch.)
+__device__ __forceinline__ void write_lanes_2x2(u32& d0, u32& d1, u32 a0, u32 b0, u32 a1, u32 b1, int lane_a, int lane_b) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_writelane_b32 %0, %2, %6\n\t"
+        "v_writelane_b32 %0, %3, %7\n\t"
+        "v_writelane_b32 %1, %4, %6\n\t"
+        "v_writelane_b32 %1, %5, %7"
+        : "+v"(d0), "+v"(d1)
+        : "s"(a0), "s"(b0), "s"(a1), "s"(b1), "n"(lane_a), "n"(lane_b));
+}
+__device__ __forceinline__ void write_lanes_1x2(u32& d0, u32 a0, u32 b0, int lane_a, int lane_b) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_writelane_b32 %0, %1, %3\n\t"
+        "v_writelane_b32 %0, %2, %4"
+        : "+v"(d0)
+        : "s"(a0), "s"(b0), "n"(lane_a), "n"(lane_b));
+}
+
 struct ItqFastArgs {
     const float* x;        // [n][d] float32 rows, d % 64 == 0, 16-byte aligned
     long long n;
@@ -51,6 +76,7 @@ struct ItqFastArgs {
     int words, pad, bits;  // pad = words*64 - bits leading zero columns
     u64* seg;              // [waves of the launch][seg_cap] undecided (row | column tile << 30) << 32 | 32-column mask
     u32* seg_cnt;          // [waves of the launch]
+    u64* seg_dummy;        // [waves of the launch] sink of the always-issued entry store (see STORES_PER_TILE)
     long long seg_cap;
     long long n_tiles;
     int nrb;               // workgroups
@@ -140,8 +166,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
     constexpr int DP = (D + 127) / 128 * 128;  // plane stride of the R image
     constexpr int PC = CT * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: [R image: PC * 2 planes * DP*2 bytes (not BREG)][rings]
-    constexpr u32 r_bytes = BREG ? 0u : (u32)PC * 2u * DP * 2u;
+    // LDS: [R image][rings].  Not BREG: both bfloat16 planes of every column, PC * 2 * DP*2 bytes, as in global
+    // memory.  BREG: only the LO planes, PC * DP*2 bytes (16 KB at d = 128 -> 64 bits); the HI fragments live in
+    // registers.  (Both planes in registers -- 128 VGPRs at KU * CT = 4 -- left the compiler 9 registers short at
+    // two waves per SIMD, and the scratch reload it then placed in the loop waits vmcnt(0): the DMA ring drained
+    // once per tile, 38 % of the wave cycles parked on it.)
+    constexpr u32 r_bytes = BREG ? (u32)PC * DP * 2u : (u32)PC * 2u * DP * 2u;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u32 lds_base = (u32)(uintptr_t)smem;
@@ -153,17 +183,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
     auto b_off = [&](int ks, int pc) {
         return (u32)pc * 2u * (DP * 2) + (u32)(ks >> 3) * 256u + (u32)(((2 * (ks & 7) + h) ^ (pc & 15)) * 16);
     };
-    itq_bf16x8 breg[BREG ? KU * 4 : 1][CT][2];
+    // BREG: offset of the LO fragment inside the LDS copy of the lo planes ([pc][DP*2 bytes])
+    auto blo_off = [&](int ks, int pc) {
+        return (u32)pc * (DP * 2) + (u32)(ks >> 3) * 256u + (u32)(((2 * (ks & 7) + h) ^ (pc & 15)) * 16);
+    };
+    itq_bf16x8 breg[BREG ? KU * 4 : 1][CT];   // BREG: the HI fragments of every k-step
     if constexpr (BREG) {
         const unsigned char* img = reinterpret_cast<const unsigned char*>(a.rimage);
 #pragma unroll
         for (int ks = 0; ks < KU * 4; ++ks)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const u32 o = b_off(ks, ct * 32 + r31);
-                breg[ks][ct][0] = *reinterpret_cast<const itq_bf16x8*>(img + o);
-                breg[ks][ct][1] = *reinterpret_cast<const itq_bf16x8*>(img + o + DP * 2);
-            }
+            for (int ct = 0; ct < CT; ++ct) breg[ks][ct] = *reinterpret_cast<const itq_bf16x8*>(img + b_off(ks, ct * 32 + r31));
+        // lo planes -> LDS: 16-byte chunk i of the copy = chunk (i % cpp) of column (i / cpp)'s second plane
+        constexpr u32 cpp = DP * 2 / 16;  // chunks per plane
+        const uint4* src = a.rimage;
+        for (u32 i = threadIdx.x; i < r_bytes / 16; i += WAVES * 64)
+            reinterpret_cast<uint4*>(smem)[i] = src[(i / cpp) * (2 * cpp) + cpp + (i % cpp)];
+        __syncthreads();
     } else {
         const uint4* src = a.rimage;
         for (u32 i = threadIdx.x; i < r_bytes / 16; i += WAVES * 64) reinterpret_cast<uint4*>(smem)[i] = src[i];
@@ -176,8 +212,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
     const long long total_units = my_tiles * KU;
     u64* myseg = a.seg + wave_id * a.seg_cap;
 
-    // lane L < 32 finalises row L of a tile: accumulator register my_i of lane half my_h holds it
-    const int my_i = (r31 & 3) | ((r31 >> 3) << 2), my_h = (r31 >> 2) & 1;
+    // lane L < 32 finalises row L of a tile (the sign / undecided words are dropped into it with v_writelane)
 
     float cnorm[CT], cb[CT], cberr[CT];
     bool cvalid[CT];
@@ -187,6 +222,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
         cnorm[ct] = a.colnorm[pc] * a.eps_rel;
         cb[ct] = a.cb32[pc];
         cberr[ct] = a.cberr[pc];
+        // the accumulators start from -c_b without normalisation: c_b takes part in the float32 accumulation
+        if constexpr (!NORMED) cberr[ct] += fabsf(cb[ct]) * ((3.f * D + 2.f) * 5.9604644775390625e-08f * 1.0001f);
         cvalid[ct] = pc >= a.pad;
         // complete before the DMA ring starts (see sq_dense_scan.cuh)
         asm volatile("" : "+v"(cnorm[ct]), "+v"(cb[ct]), "+v"(cberr[ct]));
@@ -195,7 +232,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
 #pragma unroll
         for (int ks = 0; ks < KU * 4; ++ks)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(breg[ks][ct][0]), "+v"(breg[ks][ct][1]));
+            for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(breg[ks][ct]));
     }
 
     u32 voff[8];
@@ -205,11 +242,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
         voff[j] = (u32)(r * (D * 4) + (((lane & 15) ^ (r & 15)) * 16));
     }
 
+    // The wave's own stores (codes, undecided-bit entries) sit in the same in-order vmcnt queue as its DMA loads.
+    // A wait that only counted the younger UNITS (vmcnt(8 * units)) also waited for the first loads of the next
+    // unit whenever stores had been issued after it -- i.e. after every tile.  Every tile therefore issues a FIXED
+    // number of store instructions (STORES_PER_TILE, from inline asm: a compiler-visible store could be split or
+    // merged) and the waits allow them: vmcnt(8 * younger units + STORES_PER_TILE * younger tile epilogues).
+    constexpr int STORES_PER_TILE = CT / 2 + CT;
+    int epi_total = 0;          // tile epilogues so far
+    int epi_at[NSTAGE];         // epi_total when the unit now in ring slot s was issued
     long long iss_tile = wave_id;
     int iss_kc = 0, iss_slot = 0;
     long long issued = 0;
     auto issue_next = [&]() {
         if (issued >= total_units) return;
+#pragma unroll
+        for (int sl2 = 0; sl2 < NSTAGE; ++sl2)
+            if (iss_slot == sl2) epi_at[sl2] = epi_total;
         long long row0 = iss_tile * 32;
         // the last tile may reach past the matrix: pull it back (rows are re-done, the results of
         // rows >= n are never stored) so that no DMA leaves the allocation
@@ -227,12 +275,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
     };
     for (int p = 0; p < NSTAGE; ++p) issue_next();
 
-    auto read_b = [&](int ks, itq_bf16x8 (&bf)[CT][2]) {  // not BREG
+    auto read_b = [&](int ks, itq_bf16x8 (&bf)[CT][2]) {  // fragments of k-step ks from LDS (BREG: the lo plane only)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            const unsigned char* col = smem + b_off(ks, ct * 32 + r31);
-            bf[ct][0] = *reinterpret_cast<const itq_bf16x8*>(col);
-            bf[ct][1] = *reinterpret_cast<const itq_bf16x8*>(col + DP * 2);
+            if constexpr (BREG) {
+                bf[ct][1] = *reinterpret_cast<const itq_bf16x8*>(smem + blo_off(ks, ct * 32 + r31));
+            } else {
+                const unsigned char* col = smem + b_off(ks, ct * 32 + r31);
+                bf[ct][0] = *reinterpret_cast<const itq_bf16x8*>(col);
+                bf[ct][1] = *reinterpret_cast<const itq_bf16x8*>(col + DP * 2);
+            }
         }
     };
 
@@ -243,60 +295,82 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
         long long row0 = tile * 32;
         const long long shift = row0 + 32 > a.n ? row0 + 32 - a.n : 0;  // rows the DMA window moved back
         row0 -= shift;
+        // without normalisation the accumulators start from -c_b, so that they END as z~ = x . R_b - c_b and the
+        // epilogue has no arithmetic left (the float32 accumulation error on c_b is part of cberr_eff)
         itq_f32x16 acc[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[ct][i] = NORMED ? 0.f : -cb[ct];
         float sumsq = 0.f;
 #pragma unroll
         for (int kc = 0; kc < KU; ++kc) {
-            // unit `consumed` must have landed; younger units may stay in flight
-            wait_units_in_flight<NSTAGE, 8>((int)(issued - consumed - 1));
+            // unit `consumed` must have landed; younger units and the stores of younger epilogues may stay in flight
+            {
+                int epi_young = 0;
+#pragma unroll
+                for (int sl2 = 0; sl2 < NSTAGE; ++sl2)
+                    if (rd_slot == sl2) epi_young = epi_total - epi_at[sl2];
+                wait_ops_in_flight<NSTAGE, 8, STORES_PER_TILE>((int)(issued - consumed - 1), epi_young);
+            }
             const unsigned char* sl = ring_ptr + rd_slot * ITQF_UNIT_BYTES;
-            itq_f32x4 xa[4][2];
+            // The 32 rows x 64 floats of the unit reach the registers in two halves (k-steps 0-1, then 2-3): all four
+            // k-steps at once need 32 registers next to the 128 of the R fragments and the 32 accumulators, and the
+            // compiler then spilled -- a scratch reload inside the loop makes it wait vmcnt(0), which drains the DMA
+            // ring once per tile (38 % of the wave cycles parked, profiles/r02_itq_pmc_before.json).  The slot is
+            // handed back to the DMA after the second half has been read.
+            itq_f32x4 xa[2][2];
             itq_bf16x8 bcur[CT][2], bnxt[CT][2];
+            read_b(kc * 4, bnxt);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    xa[s][e] = *reinterpret_cast<const itq_f32x4*>(sl + r31 * 256 + (((4 * s + 2 * h + e) ^ (r31 & 15)) * 16));
-            if constexpr (!BREG) read_b(kc * 4, bnxt);
-            // the slot is free once its values are in registers
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            ++consumed;
-            if (++rd_slot == NSTAGE) rd_slot = 0;
-            issue_next();
+                for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if constexpr (!BREG) {
+                    for (int e = 0; e < 2; ++e)
+                        xa[s2][e] = *reinterpret_cast<const itq_f32x4*>(
+                            sl + r31 * 256 + (((4 * (2 * half + s2) + 2 * h + e) ^ (r31 & 15)) * 16));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (half == 1) {  // the slot is free once its values are in registers
+                    ++consumed;
+                    if (++rd_slot == NSTAGE) rd_slot = 0;
+                    issue_next();
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int s = 2 * half + s2;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
-                        bcur[ct][0] = bnxt[ct][0];
+                        if constexpr (!BREG) bcur[ct][0] = bnxt[ct][0];
                         bcur[ct][1] = bnxt[ct][1];
                     }
                     if (s < 3) read_b(kc * 4 + s + 1, bnxt);  // the next k-step's fragments under this one's arithmetic
-                }
-                itq_bf16x8 uh, ul;
+                    itq_bf16x8 uh, ul;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float u = j < 4 ? xa[s][0][j] : xa[s][1][j - 4];
-                    sumsq = __fmaf_rn(u, u, sumsq);
-                    const __bf16 hi = (__bf16)u;
-                    uh[j] = hi;
-                    ul[j] = (__bf16)(u - (float)hi);
-                }
+                    for (int j = 0; j < 8; ++j) {
+                        const float u = j < 4 ? xa[s2][0][j] : xa[s2][1][j - 4];
+                        sumsq = __fmaf_rn(u, u, sumsq);
+                        const __bf16 hi = (__bf16)u;
+                        uh[j] = hi;
+                        ul[j] = (__bf16)(u - (float)hi);
+                    }
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const itq_bf16x8 bh = BREG ? breg[BREG ? kc * 4 + s : 0][ct][0] : bcur[ct][0];
-                    const itq_bf16x8 bl = BREG ? breg[BREG ? kc * 4 + s : 0][ct][1] : bcur[ct][1];
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, bh, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, bl, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, bh, acc[ct], 0, 0, 0);
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const itq_bf16x8 bh = BREG ? breg[BREG ? kc * 4 + s : 0][ct] : bcur[ct][0];
+                        const itq_bf16x8 bl = bcur[ct][1];
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, bh, acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, bl, acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, bh, acc[ct], 0, 0, 0);
+                    }
                 }
             }
         }
-        // ---- tile complete: x . R for 32 rows x PC columns (lane = column, register i = row (i&3)+8(i>>2)+4h)
+        // ---- tile complete: x . R (- c_b) for 32 rows x PC columns (lane = column, register i = row (i&3)+8(i>>2)+4h)
+        // The epilogue is the expensive part of a tile in instructions (the kernel is issue bound, PMC: 43 % of the
+        // wave cycles issuing, 36 % stalled on issue), so it does the least it can: per (register, column tile) ONE
+        // compare whose ballot is the sign word of two rows, dropped into the lanes of those rows with two
+        // v_writelane, and a running minimum of |z~|; the per-row words of undecided bits are only built for a
+        // column tile whose minimum says some bit is undecided (or when a row holds a non-finite value).
         sumsq += __shfl_xor(sumsq, 32);  // both halves of row r31
         float rowscale = 1.f, U = 1.f;
         if constexpr (NORMED) {
@@ -307,46 +381,74 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
             for (int o = 16; o > 0; o >>= 1) umax = fmaxf(umax, __shfl_xor(umax, o));
             U = sqrtf(umax) * 1.0001f;  // the largest |x| of the tile
         }
+        const bool bad_rows = __ballot(!(sumsq < __builtin_inff())) != 0ull;  // NaN / inf in a row: every bit to float64
         u32 half_word[CT], unc_mask[CT];  // this lane's row: sign bits and undecided columns of every column tile
+        float mabs[CT], eps[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            half_word[ct] = unc_mask[ct] = 0u;
+            mabs[ct] = __builtin_inff();
+            eps[ct] = cnorm[ct] * U + cberr[ct];  // cnorm carries eps_rel
+        }
+        auto zval = [&](int ct, int i, float rs) {
+            if constexpr (NORMED) return __fmaf_rn(acc[ct][i], rs, -cb[ct]);
+            return acc[ct][i];
+        };
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+            const int row_a = (i & 3) + 8 * (i >> 2);  // row of lane half 0; half 1 holds row_a + 4
             float rs = 1.f;
-            if constexpr (NORMED) rs = __shfl(rowscale, (i & 3) + 8 * (i >> 2) + 4 * h);
+            if constexpr (NORMED) rs = __shfl(rowscale, row_a + 4 * h);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                if (i == 0) half_word[ct] = unc_mask[ct] = 0;
-                const float eps = cnorm[ct] * U + cberr[ct];  // cnorm carries eps_rel
-                const float z = acc[ct][i] * rs - cb[ct];
-                const u64 pos = __ballot(z >= 0.f);
-                const u64 unc = __ballot(cvalid[ct] && !(fabsf(z) > eps));
-                if (i == my_i) {  // this lane's row sits in register i of lane half my_h
-                    half_word[ct] = __brev(my_h ? (u32)(pos >> 32) : (u32)pos);  // column 0 -> most significant
-                    unc_mask[ct] = my_h ? (u32)(unc >> 32) : (u32)unc;                  // bit c = column c of the tile
+            for (int ct = 0; ct < CT; ct += 2) {  // CT is 2 or 4: two column tiles per write block
+                const float z0 = zval(ct, i, rs), z1 = zval(ct + 1, i, rs);
+                const u64 pos0 = __ballot(z0 >= 0.f), pos1 = __ballot(z1 >= 0.f);
+                mabs[ct] = fminf(mabs[ct], fabsf(z0));  // (a NaN is skipped here: bad_rows covers it)
+                mabs[ct + 1] = fminf(mabs[ct + 1], fabsf(z1));
+                write_lanes_2x2(half_word[ct], half_word[ct + 1], (u32)pos0, (u32)(pos0 >> 32), (u32)pos1, (u32)(pos1 >> 32),
+                                row_a, row_a + 4);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            half_word[ct] = __brev(half_word[ct]);  // column 0 -> most significant
+            if (bad_rows || __ballot(cvalid[ct] && !(mabs[ct] > eps[ct])) != 0ull) {  // wave-uniform, one tile in ~4 per column tile
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row_a = (i & 3) + 8 * (i >> 2);
+                    float rs = 1.f;
+                    if constexpr (NORMED) rs = __shfl(rowscale, row_a + 4 * h);
+                    const float z = zval(ct, i, rs);
+                    const u64 unc = __ballot(cvalid[ct] && !(fabsf(z) > eps[ct]));
+                    write_lanes_1x2(unc_mask[ct], (u32)unc, (u32)(unc >> 32), row_a, row_a + 4);  // bit c = column c of the tile
                 }
             }
         }
         const long long row = row0 + r31;
         const bool mine = lane < 32 && r31 >= (int)shift && row < a.n;  // rows below `shift` belong to the previous tile
+        // (at least one lane is `mine` in every tile: exactly CT / 2 store instructions)
         if (mine) {
 #pragma unroll
             for (int w = 0; w < CT / 2; ++w) {
                 u64 v = ((u64)half_word[2 * w] << 32) | (u64)half_word[2 * w + 1];
                 if (w == 0 && a.pad > 0) v &= (~0ull) >> a.pad;
-                a.out[row * a.words + w] = v;
+                store_u64_counted(a.out + row * a.words + w, v);
             }
         }
         // undecided bits: one entry per (row, column tile) that has any, for the float64 evaluation of
-        // exactly those bits (itq_fix_bits_kernel)
+        // exactly those bits (itq_fix_bits_kernel).  Lane 63 (never `mine`) writes a dummy word so that the
+        // instruction is issued in every tile: exactly CT store instructions.
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const bool need = mine && unc_mask[ct] != 0;
             const u64 nb = __ballot(need);
-            if (need) {
-                const u32 p = wcount + __builtin_amdgcn_mbcnt_hi((u32)(nb >> 32), __builtin_amdgcn_mbcnt_lo((u32)nb, 0u));
-                myseg[p] = ((u64)((u32)row | ((u32)ct << 30)) << 32) | (u64)unc_mask[ct];
-            }
+            const u32 p = wcount + __builtin_amdgcn_mbcnt_hi((u32)(nb >> 32), __builtin_amdgcn_mbcnt_lo((u32)nb, 0u));
+            if (need || lane == 63)
+                store_u64_counted(need ? myseg + p : a.seg_dummy + wave_id,
+                                  ((u64)((u32)row | ((u32)ct << 30)) << 32) | (u64)unc_mask[ct]);
             wcount += (u32)__popcll(nb);
         }
+        ++epi_total;
     }
     if (lane == 0) a.seg_cnt[wave_id] = wcount;
 }

@@ -323,3 +323,41 @@ def test_lsh_config_roundtrip():
     assert isinstance(j.hash_index, HipLinearHashIndex) and j.lsh_functor.bit_length == 4
     c["hash_index"] = None
     assert HipLSHNearestNeighborIndex.from_config(c).hash_index is None
+
+
+def test_entry_points_name_importable_plugin_modules():
+    """pyproject.toml registers the HIP implementations the way the reference registers its own
+    (entry-point group "smqtk_plugins", name -> module: reference pyproject.toml:71-82); every listed module
+    imports and holds a concrete subclass of one of the three interfaces, and the SMQTK_PLUGIN_PATH route
+    (the other discovery mechanism of smqtk_core's Pluggable) finds the same classes."""
+    import importlib
+    import os
+    import tomli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "pyproject.toml"), "rb") as f:
+        cfg = tomli.load(f)
+    eps = cfg["project"]["entry-points"]["smqtk_plugins"]
+    assert len(eps) == 4
+    found = {}
+    for name, module in eps.items():
+        assert name == module
+        mod = importlib.import_module(module)
+        impls = [c for c in vars(mod).values() if isinstance(c, type) and c.__module__ == module
+                 and issubclass(c, (NearestNeighborsIndex, HashIndex, LshFunctor))]
+        assert len(impls) == 1, (module, impls)
+        found[module] = impls[0]
+    assert set(found.values()) == {HipLinearHashIndex, HipItqFunctor, HipBruteForceNearestNeighborsIndex,
+                                   HipLSHNearestNeighborIndex}
+    old = os.environ.get("SMQTK_PLUGIN_PATH")
+    os.environ["SMQTK_PLUGIN_PATH"] = ":".join(eps.values())
+    try:
+        assert HipLinearHashIndex in HashIndex.get_impls()
+        assert HipItqFunctor in LshFunctor.get_impls()
+        assert {HipBruteForceNearestNeighborsIndex, HipLSHNearestNeighborIndex} <= set(NearestNeighborsIndex.get_impls())
+    finally:
+        if old is None:
+            del os.environ["SMQTK_PLUGIN_PATH"]
+        else:
+            os.environ["SMQTK_PLUGIN_PATH"] = old
+    for pkg in cfg["tool"]["setuptools"]["packages"]:
+        importlib.import_module(pkg)
