@@ -476,6 +476,7 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 // float32 rows through the filter; the rows it cannot decide through the float64 kernel.
 static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st, int device) {
     const int pc = a.words * 64;
+    const bool l2 = a.norm == SQ_NORM_L2;
     const long long n_tiles = (a.n + 31) / 32;
     const int nrb = cu_count(device);
     const long long nwaves = (long long)nrb * g.waves;
@@ -488,8 +489,8 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
         return at;
     };
     const size_t o_cn = take((size_t)pc * 4), o_cb = take((size_t)pc * 4), o_cbe = take((size_t)pc * 4);
+    const size_t o_cabs = take((size_t)pc * 4);
     const size_t o_img = take((size_t)pc * ((a.d + 127) / 128 * 128) * 4);
-    const bool l2 = a.norm == SQ_NORM_L2;
     const size_t o_seg = take((size_t)nwaves * seg_cap * 8), o_cnt = take((size_t)nwaves * 4);
     const size_t o_dummy = take((size_t)nwaves * 8);
     const size_t o_rt = take((size_t)pc * a.d * 8);
@@ -500,10 +501,16 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
         (void)hipFreeAsync(base, st);
         return rc;
     };
+    // relative error of x . R_b per unit |x||R_b| (sq_itq_fast.cuh): 2^-20 (x: two round-toward-zero float16 planes)
+    // + 2^-21 (the dropped x_lo R_lo) + 3d * 2^-24 (float32 accumulation of 3d products) + 2^-20 (the float32 scale /
+    // subtract, the reference's float32 x/|x|) [+ 2^-18: float32 |x|^2, normalize=2].  R's own residual is measured
+    // by the prep kernel and added to the column's coefficient.
+    const double eps_rel = ((9.5367431640625e-07 + 4.76837158203125e-07) * 1.001 + 3.0 * a.d * 5.9604644775390625e-08 +
+                            9.5367431640625e-07 + (l2 ? 3.814697265625e-06 : 0.0)) * 1.001;
     hipLaunchKernelGGL(itq_fast_prep_kernel, dim3((unsigned)pc), dim3(256), 0, st, a.mean, a.rot, a.d, a.bits, a.pad,
                        reinterpret_cast<unsigned short*>(base + o_img), reinterpret_cast<float*>(base + o_cn),
                        reinterpret_cast<float*>(base + o_cb), reinterpret_cast<float*>(base + o_cbe),
-                       reinterpret_cast<double*>(base + o_rt));
+                       reinterpret_cast<double*>(base + o_rt), eps_rel, reinterpret_cast<float*>(base + o_cabs));
     ItqFastArgs fa{};
     fa.x = reinterpret_cast<const float*>(a.x);
     fa.n = a.n;
@@ -512,10 +519,7 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
     fa.colnorm = reinterpret_cast<const float*>(base + o_cn);
     fa.cb32 = reinterpret_cast<const float*>(base + o_cb);
     fa.cberr = reinterpret_cast<const float*>(base + o_cbe);
-    // 3 * 2^-16 (the dropped pieces of the bf16 splits) + 3d * 2^-24 (float32 accumulation) + 2^-20 (the float32
-    // scale / subtract, the reference's float32 x/|x|) [+ 2^-18: float32 |x|^2, normalize=2]; sq_itq_fast.cuh
-    fa.eps_rel = (float)((3.0 * 1.52587890625e-05 * 1.001 + 3.0 * a.d * 5.9604644775390625e-08 + 9.5367431640625e-07 +
-                          (l2 ? 3.814697265625e-06 : 0.0)) * 1.001);
+    fa.cabs = reinterpret_cast<const float*>(base + o_cabs);
     fa.out = a.out;
     fa.words = a.words;
     fa.pad = a.pad;

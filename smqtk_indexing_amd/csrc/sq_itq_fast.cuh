@@ -1,5 +1,5 @@
-// ITQ hash codes at the HBM rate: a certified bf16x3 filter in front of the
-// float64 kernel (sq_itq.hip).
+// ITQ hash codes at the HBM rate: a certified half-precision filter (f16x3) in
+// front of the float64 kernel (sq_itq.hip).
 //
 // ItqFunctor.get_hash (smqtk_indexing/impls/lsh_functor/itq.py:389-408) only
 // keeps the SIGN of z = (v - mean) . R, v = x or x/|x|, but evaluates z in
@@ -7,23 +7,43 @@
 // bits: 3.9 ms) under a 0.85 ms HBM floor.  The sign of z is known as soon as
 // |z~| exceeds the error bound of a cheaper evaluation z~, so this kernel
 // streams the float32 rows once (the dense scan's LDS-DMA ring), splits x and R
-// into bfloat16 pairs, evaluates x_hi R_hi + x_hi R_lo + x_lo R_hi on
-// v_mfma_f32_32x32x16_bf16 and finishes with z~ = (x . R_b) s - c_b, where
-// s = 1/|x| (normalize=2, |x| from the same pass) or 1 and c_b = mean . R_b is a
-// float64 product rounded once.  Bits with |z~| > eps(row, column) are final;
-// the others (one in ~2500) are listed as (row, column tile, mask) entries and
-// evaluated in float64 one bit at a time (itq_fix_bits_kernel, sq_itq.hip), so
-// every code is exactly what the float64 evaluation gives.
+// into float16 pairs (x = x_hi + x_lo + dx), evaluates
+// x_hi R_hi + x_hi R_lo + x_lo R_hi on v_mfma_f32_32x32x16_f16 and finishes with
+// z~ = (x . R_b) s - c_b, where s = 1/|x| (normalize=2, |x| from the same pass)
+// or 1 and c_b = mean . R_b is a float64 product rounded once.  Bits with
+// |z~| > eps(tile, column) are final; the others are listed as (row, column
+// tile, mask) entries and evaluated in float64 one bit at a time
+// (itq_fix_bits_kernel, sq_itq.hip), so every code is exactly what the float64
+// evaluation gives.
 //
-// Error bound.  x = x_hi + x_lo + dx, |dx_k| <= 2^-16 |x_k| and
-// the same for R (after its float32 rounding); the dropped x_lo R_lo is
-// <= 2^-16 |x_k||R_kb|; the float32 accumulation of 3d terms adds
-// <= 3d 2^-24 sum |x_k||R_kb|; Cauchy-Schwarz over k gives
-//   |x . R_b - (x . R_b)~| <= (3 * 2^-16 + 3d 2^-24) |x| |R_b|.
-// normalize=2: the reference's v_k = fl32(x_k / fl32|x|) is within 2^-21 |x_k|/|x|
-// of x_k/|x|, and s is within 2^-18 (float32 sum of squares); scaled to the unit
-// row that is (3 * 2^-16 + 3d 2^-24 + 2^-20 + 2^-18) |R_b|.  c_b: its float32
-// rounding and float64 summation error, from the prep kernel (cberr).
+// Why float16 planes (round 1 used bfloat16).  The kernel is bound by vector
+// instruction issue, not by the matrix cores (PMC, profiles/r02_itq_pmc_*.json:
+// the DMA skeleton alone streams the matrix in 0.85 ms, removing every MFMA
+// changes nothing).  A bfloat16 split costs 3 vector instructions per element
+// (convert, widen the high part back, subtract, convert); with float16 the
+// residual x - x_hi is ONE v_fma_mix_f32 reading the packed half directly:
+// 2 per element (v_cvt_pkrtz_f16_f32 for two highs, two v_fma_mix_f32,
+// v_cvt_pkrtz_f16_f32 for two lows).  And 11 + 11 significand bits leave
+// 2^-20 |x_k| behind instead of 2^-16: the error bound is then mostly the
+// float32 accumulation, 2.8x fewer bits stay undecided.  The price is range:
+// see "Range" below.
+//
+// Error bound, per column b, all terms through Cauchy-Schwarz:
+//   x:  round-toward-zero to float16 twice: |dx_k| < 2^-20 |x_k| + 2^-24
+//       (the absolute part: float16 subnormals) -> 2^-20 |x||R_b| + 2^-24 |R_b|_1
+//   R:  its two planes are fixed, so the prep kernel measures the residual
+//       exactly: |x| * |R_b - R_hi,b - R_lo,b|_2   (`rres`, part of colnorm)
+//   dropped x_lo R_lo: |x_lo| <= 2^-10 |x| (+ abs), |R_lo,b| <= 2^-11 |R_b|: 2^-21 |x||R_b|
+//   float32 accumulation of 3d products: 3d 2^-24 |x||R_b|
+//   the reference's float32 x/|x| and the float32 scale / subtract here: 2^-20;
+//   normalize=2: s within 2^-18 (float32 sum of squares)
+//   c_b: its float32 rounding and float64 summation error (cberr); without
+//   normalisation c_b also rides through the float32 accumulation.
+// Range.  |x_k| >= 65504 would saturate a plane silently, so a tile whose
+// largest |x|^2 is not below 1e9 sends all its bits to the float64 kernel
+// (as does a NaN / inf, through the NaN-safe undecided test); values below
+// 2^-14 lose relative precision to the absolute term above: data of tiny
+// scale (|x| << 1e-2) stays correct but leaves more bits to float64.
 #pragma once
 #include "sq_dma.cuh"
 
@@ -31,7 +51,8 @@ namespace sq {
 
 typedef float itq_f32x4 __attribute__((ext_vector_type(4)));
 typedef float itq_f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 itq_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 itq_f16x8 __attribute__((ext_vector_type(8)));
+typedef u32 itq_u32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int ITQF_UNIT_BYTES = 32 * 256;                // 32 rows x 64 floats
 static constexpr int ITQF_WAVES_LDSB = 4;  // waves when the R fragments come from LDS
@@ -63,15 +84,38 @@ __device__ __forceinline__ void write_lanes_1x2(u32& d0, u32 a0, u32 b0, int lan
         : "s"(a0), "s"(b0), "n"(lane_a), "n"(lane_b));
 }
 
+// (x0, x1) -> packed float16 highs (round toward zero) and packed float16 lows of the exact residuals:
+// 4 vector instructions for two elements.  v_fma_mix_f32 reads the packed half directly: lo = hi * -1.0 + x.
+#ifndef SQ_ITQ_MIX
+#define SQ_ITQ_MIX 1
+#endif
+#ifndef SQ_ITQ_GRAM
+#define SQ_ITQ_GRAM 1
+#endif
+__device__ __forceinline__ void split_f16_pair(float x0, float x1, u32& hi, u32& lo) {
+    hi = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    float l0, l1;
+#if SQ_ITQ_MIX
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(x1));
+#else
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t hv = __builtin_bit_cast(h2_t, hi);
+    l0 = x0 - (float)hv[0];
+    l1 = x1 - (float)hv[1];
+#endif
+    lo = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+}
+
 struct ItqFastArgs {
     const float* x;        // [n][d] float32 rows, d % 64 == 0, 16-byte aligned
     long long n;
     int d;
     const uint4* rimage;   // image of R: [pc columns][2 planes][dp*2 bytes], dp = d rounded up to 128; chunks swizzled by column & 15
-    const float* colnorm;  // [pc] |R_b|_2 rounded up; pad columns 0
+    const float* colnorm;  // [pc] eps_rel |R_b|_2 + |R_b - R_hi,b - R_lo,b|_2, rounded up: times |x|; pad columns 0
+    const float* cabs;     // [pc] 2^-24 |R_b|_1: the absolute (float16 subnormal) part of the x split
     const float* cb32;     // [pc] mean . R_b in float32 (normalize=2 form)
     const float* cberr;    // [pc] bound of what cb32 and the float32 division leave out
-    float eps_rel;         // 3 * 2^-16 + 3d * 2^-24 + 2^-20 (+ 2^-18 for normalize=2): times |R_b| |x|
     u64* out;              // [n][words]
     int words, pad, bits;  // pad = words*64 - bits leading zero columns
     u64* seg;              // [waves of the launch][seg_cap] undecided (row | column tile << 30) << 32 | 32-column mask
@@ -93,13 +137,18 @@ static __global__ __launch_bounds__(256) void itq_fast_prep_kernel(const double*
                                                                     float* __restrict__ colnorm,
                                                                     float* __restrict__ cb32,
                                                                     float* __restrict__ cberr,
-                                                                    double* __restrict__ rt64) {
+                                                                    double* __restrict__ rt64, double eps_rel,
+                                                                    float* __restrict__ cabs_out) {
     const int pc = blockIdx.x;
     const int b = pc - pad;
     __shared__ double red[256];
     __shared__ double red2[256];
     __shared__ double red3[256];
-    double acc = 0.0, cacc = 0.0, cabs = 0.0, macc = 0.0;
+    __shared__ double red4[256];
+    __shared__ int s_big;
+    if (threadIdx.x == 0) s_big = 0;
+    __syncthreads();
+    double acc = 0.0, cacc = 0.0, cabs = 0.0, macc = 0.0, rres = 0.0, rl1 = 0.0;
     for (int k = threadIdx.x; k < d; k += 256) {
         const double r = b >= 0 ? rot[(long long)k * bits + b] : 0.0;
         rt64[(long long)pc * d + k] = r;  // column-major float64 copy: the per-bit float64 evaluation reads whole columns
@@ -108,8 +157,12 @@ static __global__ __launch_bounds__(256) void itq_fast_prep_kernel(const double*
         cabs += fabs(mean[k] * r);
         macc += mean[k] * mean[k];
         const float rf = (float)r;
-        const __bf16 hi = (__bf16)rf;
-        const __bf16 lo = (__bf16)(rf - (float)hi);
+        const _Float16 hi = (_Float16)rf;                 // round to nearest
+        const _Float16 lo = (_Float16)(rf - (float)hi);
+        const double dr = r - (double)(float)hi - (double)(float)lo;   // what the two planes leave of R (exact)
+        rres += dr * dr;
+        rl1 += fabs(r);
+        if (!(fabs(r) < 60000.0)) s_big = 1;              // beyond float16: the column decides nothing
         // element k of column pc: 256-byte segment k/128, chunk 2*((k%128)/16) + ((k%16)/8), swizzled
         const int seg = k >> 7, kk = k & 127;
         const int chunk = ((2 * (kk >> 4) + ((kk >> 3) & 1)) ^ (pc & 15));
@@ -126,9 +179,22 @@ static __global__ __launch_bounds__(256) void itq_fast_prep_kernel(const double*
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) colnorm[pc] = (float)(sqrt(red[0]) * (1.0 + 1e-6));
-    __syncthreads();
     const double rnorm = sqrt(red[0]);
+    __syncthreads();
+    red[threadIdx.x] = rres;
+    red4[threadIdx.x] = rl1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            red[threadIdx.x] += red[threadIdx.x + o];
+            red4[threadIdx.x] += red4[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        colnorm[pc] = s_big ? __builtin_inff() : (float)((rnorm * eps_rel + sqrt(red[0])) * (1.0 + 1e-6));
+        cabs_out[pc] = (float)(red4[0] * 5.9604644775390625e-08 * (1.0 + 1e-6));
+    }
     __syncthreads();
     red[threadIdx.x] = cacc;
     red2[threadIdx.x] = cabs;
@@ -187,13 +253,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
     auto blo_off = [&](int ks, int pc) {
         return (u32)pc * (DP * 2) + (u32)(ks >> 3) * 256u + (u32)(((2 * (ks & 7) + h) ^ (pc & 15)) * 16);
     };
-    itq_bf16x8 breg[BREG ? KU * 4 : 1][CT];   // BREG: the HI fragments of every k-step
+    itq_f16x8 breg[BREG ? KU * 4 : 1][CT];   // BREG: the HI fragments of every k-step
     if constexpr (BREG) {
         const unsigned char* img = reinterpret_cast<const unsigned char*>(a.rimage);
 #pragma unroll
         for (int ks = 0; ks < KU * 4; ++ks)
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) breg[ks][ct] = *reinterpret_cast<const itq_bf16x8*>(img + b_off(ks, ct * 32 + r31));
+            for (int ct = 0; ct < CT; ++ct) breg[ks][ct] = *reinterpret_cast<const itq_f16x8*>(img + b_off(ks, ct * 32 + r31));
         // lo planes -> LDS: 16-byte chunk i of the copy = chunk (i % cpp) of column (i / cpp)'s second plane
         constexpr u32 cpp = DP * 2 / 16;  // chunks per plane
         const uint4* src = a.rimage;
@@ -214,19 +280,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
 
     // lane L < 32 finalises row L of a tile (the sign / undecided words are dropped into it with v_writelane)
 
-    float cnorm[CT], cb[CT], cberr[CT];
-    bool cvalid[CT];
+    float cnorm[CT], cb[CT], cberr[CT], cabs[CT];
+    u64 valid_lanes[CT];  // ballot of the lanes whose column is a real hash bit (not padding)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int pc = ct * 32 + r31;
-        cnorm[ct] = a.colnorm[pc] * a.eps_rel;
+        cnorm[ct] = a.colnorm[pc];  // relative part of the bound: times |x| (prep kernel)
         cb[ct] = a.cb32[pc];
         cberr[ct] = a.cberr[pc];
-        // the accumulators start from -c_b without normalisation: c_b takes part in the float32 accumulation
-        if constexpr (!NORMED) cberr[ct] += fabsf(cb[ct]) * ((3.f * D + 2.f) * 5.9604644775390625e-08f * 1.0001f);
-        cvalid[ct] = pc >= a.pad;
+        cabs[ct] = a.cabs[pc];
+        // the accumulators start from -c_b without normalisation: c_b takes part in the float32 accumulation,
+        // and the absolute part of the split's error is not scaled by a row's 1/|x|
+        if constexpr (!NORMED) cberr[ct] += fabsf(cb[ct]) * ((3.f * D + 2.f) * 5.9604644775390625e-08f * 1.0001f) + cabs[ct];
+        valid_lanes[ct] = __ballot(pc >= a.pad);
         // complete before the DMA ring starts (see sq_dense_scan.cuh)
-        asm volatile("" : "+v"(cnorm[ct]), "+v"(cb[ct]), "+v"(cberr[ct]));
+        asm volatile("" : "+v"(cnorm[ct]), "+v"(cb[ct]), "+v"(cberr[ct]), "+v"(cabs[ct]));
     }
     if constexpr (BREG) {
 #pragma unroll
@@ -275,15 +343,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
     };
     for (int p = 0; p < NSTAGE; ++p) issue_next();
 
-    auto read_b = [&](int ks, itq_bf16x8 (&bf)[CT][2]) {  // fragments of k-step ks from LDS (BREG: the lo plane only)
+    auto read_b = [&](int ks, itq_f16x8 (&bf)[CT][2]) {  // fragments of k-step ks from LDS (BREG: the lo plane only)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             if constexpr (BREG) {
-                bf[ct][1] = *reinterpret_cast<const itq_bf16x8*>(smem + blo_off(ks, ct * 32 + r31));
+                bf[ct][1] = *reinterpret_cast<const itq_f16x8*>(smem + blo_off(ks, ct * 32 + r31));
             } else {
                 const unsigned char* col = smem + b_off(ks, ct * 32 + r31);
-                bf[ct][0] = *reinterpret_cast<const itq_bf16x8*>(col);
-                bf[ct][1] = *reinterpret_cast<const itq_bf16x8*>(col + DP * 2);
+                bf[ct][0] = *reinterpret_cast<const itq_f16x8*>(col);
+                bf[ct][1] = *reinterpret_cast<const itq_f16x8*>(col + DP * 2);
             }
         }
     };
@@ -302,7 +370,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ct][i] = NORMED ? 0.f : -cb[ct];
+        // |x|^2 per row: normalize=2 needs every row's own (float32 sum of squares, as round 1); without
+        // normalisation only the LARGEST |x| of the tile enters the bound, and the matrix cores give it for free:
+        // G = X_hi X_hi^T (one more MFMA per k-step, A and B are the same registers) has the squared norms on its
+        // diagonal and nothing larger anywhere (Cauchy-Schwarz), so max |G| over the accumulator IS max |x_hi|^2 --
+        // 8 v_max3 + a wave reduction per tile instead of a multiply-add per element.
         float sumsq = 0.f;
+        itq_f32x16 gram;
+        if constexpr (!NORMED && SQ_ITQ_GRAM) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gram[i] = 0.f;
+        }
 #pragma unroll
         for (int kc = 0; kc < KU; ++kc) {
             // unit `consumed` must have landed; younger units and the stores of younger epilogues may stay in flight
@@ -320,7 +398,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
             // ring once per tile (38 % of the wave cycles parked, profiles/r02_itq_pmc_before.json).  The slot is
             // handed back to the DMA after the second half has been read.
             itq_f32x4 xa[2][2];
-            itq_bf16x8 bcur[CT][2], bnxt[CT][2];
+            itq_f16x8 bcur[CT][2], bnxt[CT][2];
             read_b(kc * 4, bnxt);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -345,22 +423,29 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
                         bcur[ct][1] = bnxt[ct][1];
                     }
                     if (s < 3) read_b(kc * 4 + s + 1, bnxt);  // the next k-step's fragments under this one's arithmetic
-                    itq_bf16x8 uh, ul;
+                    itq_u32x4 uhw, ulw;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float u = j < 4 ? xa[s2][0][j] : xa[s2][1][j - 4];
-                        sumsq = __fmaf_rn(u, u, sumsq);
-                        const __bf16 hi = (__bf16)u;
-                        uh[j] = hi;
-                        ul[j] = (__bf16)(u - (float)hi);
+                    for (int j = 0; j < 8; j += 2) {
+                        const float u0 = j < 4 ? xa[s2][0][j] : xa[s2][1][j - 4];
+                        const float u1 = j < 4 ? xa[s2][0][j + 1] : xa[s2][1][j - 3];
+                        if constexpr (NORMED || !SQ_ITQ_GRAM) {
+                            sumsq = __fmaf_rn(u0, u0, sumsq);
+                            sumsq = __fmaf_rn(u1, u1, sumsq);
+                        }
+                        u32 hw, lw;
+                        split_f16_pair(u0, u1, hw, lw);
+                        uhw[j >> 1] = hw;
+                        ulw[j >> 1] = lw;
                     }
+                    const itq_f16x8 uh = __builtin_bit_cast(itq_f16x8, uhw), ul = __builtin_bit_cast(itq_f16x8, ulw);
+                    if constexpr (!NORMED && SQ_ITQ_GRAM) gram = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, uh, gram, 0, 0, 0);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
-                        const itq_bf16x8 bh = BREG ? breg[BREG ? kc * 4 + s : 0][ct] : bcur[ct][0];
-                        const itq_bf16x8 bl = bcur[ct][1];
-                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul, bh, acc[ct], 0, 0, 0);
-                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, bl, acc[ct], 0, 0, 0);
-                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh, bh, acc[ct], 0, 0, 0);
+                        const itq_f16x8 bh = BREG ? breg[BREG ? kc * 4 + s : 0][ct] : bcur[ct][0];
+                        const itq_f16x8 bl = bcur[ct][1];
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, bh, acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, bl, acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, bh, acc[ct], 0, 0, 0);
                     }
                 }
             }
@@ -369,26 +454,46 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
         // The epilogue is the expensive part of a tile in instructions (the kernel is issue bound, PMC: 43 % of the
         // wave cycles issuing, 36 % stalled on issue), so it does the least it can: per (register, column tile) ONE
         // compare whose ballot is the sign word of two rows, dropped into the lanes of those rows with two
-        // v_writelane, and a running minimum of |z~|; the per-row words of undecided bits are only built for a
-        // column tile whose minimum says some bit is undecided (or when a row holds a non-finite value).
-        sumsq += __shfl_xor(sumsq, 32);  // both halves of row r31
-        float rowscale = 1.f, U = 1.f;
+        // v_writelane, and one compare + scalar OR for "some |z~| of this column is within eps"; the per-row words
+        // of undecided bits are only built for a column tile in which that happened (or in a saturating tile).
+        float rowscale = 1.f, U = 1.f, big;
         if constexpr (NORMED) {
+            sumsq += __shfl_xor(sumsq, 32);  // both halves of row r31
             rowscale = sumsq > 0.f ? 1.0f / sqrtf(sumsq) : 0.f;  // zero row: z~ = -mean.R_b
-        } else {
-            float umax = sumsq;
+            big = sumsq;
+            // the absolute part of the split's error meets the LARGEST 1/|x| of the tile
+            float rsmax = rowscale;
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) umax = fmaxf(umax, __shfl_xor(umax, o));
-            U = sqrtf(umax) * 1.0001f;  // the largest |x| of the tile
+            for (int o = 16; o > 0; o >>= 1) rsmax = fmaxf(rsmax, __shfl_xor(rsmax, o));
+            U = rsmax;
+        } else if constexpr (!SQ_ITQ_GRAM) {
+            sumsq += __shfl_xor(sumsq, 32);
+            float g = sumsq;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) g = fmaxf(g, __shfl_xor(g, o));
+            big = g;
+            U = sqrtf(g) * 1.0001f;
+        } else {
+            float g = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) g = __builtin_fmaxf(g, __builtin_fmaxf(fabsf(gram[i]), fabsf(gram[i + 1])));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) g = fmaxf(g, __shfl_xor(g, o));
+            big = g;
+            // |x| <= (|x_hi| + 2^-24 sqrt(d)) / (1 - 2^-10), G in float32
+            U = (sqrtf(g) + 1e-6f) * 1.002f;
         }
-        const bool bad_rows = __ballot(!(sumsq < __builtin_inff())) != 0ull;  // NaN / inf in a row: every bit to float64
+        // a plane saturates silently from |x_k| = 65504 on: such a tile (and one holding an inf) decides nothing here.
+        // (A NaN row is not seen by the maxima above; its z~ are NaN and the undecided test below is NaN-safe.)
+        const bool bad_rows = __ballot(!(big < 1e9f)) != 0ull;
         u32 half_word[CT], unc_mask[CT];  // this lane's row: sign bits and undecided columns of every column tile
-        float mabs[CT], eps[CT];
+        float eps[CT];
+        u64 unc_any[CT];                  // lanes (columns) that saw |z~| <= eps or a NaN in some row of the tile
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             half_word[ct] = unc_mask[ct] = 0u;
-            mabs[ct] = __builtin_inff();
-            eps[ct] = cnorm[ct] * U + cberr[ct];  // cnorm carries eps_rel
+            unc_any[ct] = 0ull;
+            eps[ct] = NORMED ? cnorm[ct] + cberr[ct] + cabs[ct] * U : cnorm[ct] * U + cberr[ct];
         }
         auto zval = [&](int ct, int i, float rs) {
             if constexpr (NORMED) return __fmaf_rn(acc[ct][i], rs, -cb[ct]);
@@ -403,8 +508,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
             for (int ct = 0; ct < CT; ct += 2) {  // CT is 2 or 4: two column tiles per write block
                 const float z0 = zval(ct, i, rs), z1 = zval(ct + 1, i, rs);
                 const u64 pos0 = __ballot(z0 >= 0.f), pos1 = __ballot(z1 >= 0.f);
-                mabs[ct] = fminf(mabs[ct], fabsf(z0));  // (a NaN is skipped here: bad_rows covers it)
-                mabs[ct + 1] = fminf(mabs[ct + 1], fabsf(z1));
+                unc_any[ct] |= __ballot(!(fabsf(z0) > eps[ct]));          // one compare + one scalar OR; true for a NaN
+                unc_any[ct + 1] |= __ballot(!(fabsf(z1) > eps[ct + 1]));
                 write_lanes_2x2(half_word[ct], half_word[ct + 1], (u32)pos0, (u32)(pos0 >> 32), (u32)pos1, (u32)(pos1 >> 32),
                                 row_a, row_a + 4);
             }
@@ -412,14 +517,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             half_word[ct] = __brev(half_word[ct]);  // column 0 -> most significant
-            if (bad_rows || __ballot(cvalid[ct] && !(mabs[ct] > eps[ct])) != 0ull) {  // wave-uniform, one tile in ~4 per column tile
+            if (bad_rows || (unc_any[ct] & valid_lanes[ct]) != 0ull) {  // wave-uniform
+                const bool cval = (valid_lanes[ct] >> lane) & 1ull;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row_a = (i & 3) + 8 * (i >> 2);
                     float rs = 1.f;
                     if constexpr (NORMED) rs = __shfl(rowscale, row_a + 4 * h);
                     const float z = zval(ct, i, rs);
-                    const u64 unc = __ballot(cvalid[ct] && !(fabsf(z) > eps[ct]));
+                    const u64 unc = __ballot(cval && (bad_rows || !(fabsf(z) > eps[ct])));
                     write_lanes_1x2(unc_mask[ct], (u32)unc, (u32)(unc >> 32), row_a, row_a + 4);  // bit c = column c of the tile
                 }
             }
