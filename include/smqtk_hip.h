@@ -145,6 +145,18 @@ int sq_hamming_create(const uint64_t* codes, int64_t n, int words, int mem,
  * out_idx int64 [nq][k]. */
 int sq_hamming_search(sq_handle_t h, const uint64_t* queries, int nq, int k,
                       int32_t* out_dist, int64_t* out_idx, int mem, void* stream);
+/* Incremental mutation of an index that owns its device copy (created from host memory, or from a device array of
+ * at least 4096 codes, which is copied): what LinearHashIndex._update_index / _remove_from_index do with a set
+ * union / difference (impls/hash_index/linear.py:167-204), without re-uploading the whole code array.  Row ids are
+ * ranks in the caller's sorted order of unique codes, so the caller says where things rank:
+ *   append: new_codes [m][words] (host memory), ascending, none of them in the index; insert_pos[m] (host) =
+ *           number of codes currently in the index that are smaller than new code j (ascending).  Afterwards the
+ *           ids are the ranks in the merged order.
+ *   remove: ranks[m] (host), strictly ascending current row ids that leave; the remaining codes close ranks.
+ * Only the m new codes / m ranks cross PCIe; the device appends physically (or fills the holes from the tail) and
+ * keeps an explicit rank per code (4 bytes, read for survivors only).  SQ_ERR_UNSUPPORTED for a borrowed array. */
+int sq_hamming_append(sq_handle_t h, const uint64_t* new_codes, int64_t m, const int64_t* insert_pos);
+int sq_hamming_remove(sq_handle_t h, const int64_t* ranks, int64_t m);
 int sq_hamming_destroy(sq_handle_t h);
 
 /* ----------------------------------------------------------------- dense

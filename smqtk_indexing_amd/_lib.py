@@ -38,7 +38,7 @@ EXPORTS = (
     "sq_last_error", "sq_version", "sq_device_count", "sq_device_name",
     "sq_set_option", "sq_get_stats", "sq_itq_hash",
     "sq_itq_model_create", "sq_itq_model_hash", "sq_itq_model_destroy",
-    "sq_hamming_create", "sq_hamming_search", "sq_hamming_destroy",
+    "sq_hamming_create", "sq_hamming_search", "sq_hamming_append", "sq_hamming_remove", "sq_hamming_destroy",
     "sq_dense_create", "sq_dense_append", "sq_dense_search", "sq_dense_sync", "sq_dense_destroy",
     "sq_dense_distances", "sq_merge_topk", "sq_merge_topk_strided",
     "sq_rows_create", "sq_rows_append", "sq_rows_rerank", "sq_rows_destroy",
@@ -82,6 +82,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_itq_model_destroy.argtypes = [c_i64]
     lib.sq_hamming_create.argtypes = [c_vp, c_i64, c_int, c_int, c_i64, ctypes.POINTER(c_i64)]
     lib.sq_hamming_search.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]
+    lib.sq_hamming_append.argtypes = [c_i64, c_vp, c_i64, c_vp]
+    lib.sq_hamming_remove.argtypes = [c_i64, c_vp, c_i64]
     lib.sq_hamming_destroy.argtypes = [c_i64]
     lib.sq_dense_create.argtypes = [c_vp, c_i64, c_int, c_int, c_int, c_i64, ctypes.POINTER(c_i64)]
     lib.sq_dense_append.argtypes = [c_i64, c_vp, c_i64, c_int]
@@ -335,6 +337,26 @@ class HammingIndex(_Handle):
         _check(load().sq_hamming_search(self.handle, _ptr(q), nq, int(k), _ptr(dist), _ptr(idx), SQ_MEM_HOST, None),
                "sq_hamming_search")
         return dist, idx
+
+    def append(self, new_codes: np.ndarray, insert_pos: np.ndarray) -> None:
+        """``sq_hamming_append``: ``new_codes`` ``uint64[m, words]`` ascending and not in the index, ``insert_pos[m]``
+        = number of indexed codes smaller than each; row ids become the ranks in the merged order."""
+        c = _host(new_codes, np.uint64)
+        pos = _host(insert_pos, np.int64).reshape(-1)
+        if c.ndim != 2 or c.shape[1] != self.words or pos.shape[0] != c.shape[0]:
+            raise ValueError("new_codes must be uint64[m, words] with one insert position each")
+        if c.shape[0] == 0:
+            return
+        _check(load().sq_hamming_append(self.handle, _ptr(c), int(c.shape[0]), _ptr(pos)), "sq_hamming_append")
+        self.n += int(c.shape[0])
+
+    def remove(self, ranks: np.ndarray) -> None:
+        """``sq_hamming_remove``: strictly ascending current row ids that leave the index."""
+        r = _host(ranks, np.int64).reshape(-1)
+        if r.shape[0] == 0:
+            return
+        _check(load().sq_hamming_remove(self.handle, _ptr(r), int(r.shape[0])), "sq_hamming_remove")
+        self.n -= int(r.shape[0])
 
     def search_device(self, q_ptr: int, nq: int, k: int, out_dist_ptr: int, out_idx_ptr: int, stream: int = 0) -> None:
         _check(load().sq_hamming_search(self.handle, _ptr(q_ptr), int(nq), int(k), _ptr(out_dist_ptr),

@@ -12,13 +12,16 @@
 // atomics, a prefix-sum compaction per query and `select_topk_kernel` over the
 // few survivors.  Small arrays and overflowing queries take the all-keys path.
 // Integer-exact.  DESIGN.md section 4.3.
+#include <algorithm>
+
 #include "sq_select.cuh"
 
 namespace sq {
 
-// (row * mul) mod n: see orig_row
+// (row * mul) mod n, or -- once the index has been appended to / removed from -- an explicit table: see orig_row
 struct RowPerm {
     u64 mul, inv;
+    const u32* rank;  // non-null: physical row p holds the code of sorted rank rank[p]
 };
 
 struct HammingHandle : HandleBase {
@@ -27,13 +30,17 @@ struct HammingHandle : HandleBase {
     long long n = 0;
     int words = 0;
     long long id_base = 0;
-    RowPerm pmul{1, 0};  // physical row p holds caller row (p * pmul.mul) mod n
+    RowPerm pmul{1, 0, nullptr};  // physical row p holds caller row (p * pmul.mul) mod n (or pmul.rank[p])
+    DevBuf rank;                  // u32[n] explicit ranks, after the first append / remove
+    DevBuf mut_tmp;               // scratch of the mutation kernels
     // workspace
     DevBuf q_dev, keys, cnt, hist, thr, out_keys, status, out_dist_dev, out_idx_dev, big_keys, seg, bcnt;
     HostPinned status_host;
     PinnedStage stage;
     ~HammingHandle() override {
         owned.release();
+        rank.release();
+        mut_tmp.release();
         q_dev.release();
         keys.release();
         cnt.release();
@@ -63,6 +70,7 @@ struct HammingHandle : HandleBase {
 // (row * mul) mod n without a 64-bit division: Barrett with inv = floor((2^64 - 1) / n); the
 // quotient estimate is at most 2 short.
 __device__ __forceinline__ u32 orig_row(long long row, RowPerm pm, long long n) {
+    if (pm.rank) return pm.rank[row];
     if (pm.mul == 1ull) return (u32)row;
     const u64 x = (u64)row * pm.mul;
     u64 r = x - __umul64hi(x, pm.inv) * (u64)n;
@@ -643,6 +651,103 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
     return SQ_OK;
 }
 
+// ------------------------------------------------------------------ mutations
+// LinearHashIndex.update_index / remove_from_index are a set union / difference on the host
+// (impls/hash_index/linear.py:167-204).  The device copy follows without a re-upload of the whole array: the
+// caller -- who owns the sorted order, row id = rank of the code -- says where the new codes rank
+// (sq_hamming_append) or which ranks leave (sq_hamming_remove); new codes are appended physically, removed ones are
+// filled from the tail, and an explicit rank table (u32 per code, read for survivors only) replaces the
+// arithmetic permutation.
+static __global__ void hamming_rank_init_kernel(u32* __restrict__ rank, long long n, RowPerm pm) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) rank[p] = orig_row(p, pm, n);
+}
+// pos[j] ascending = number of OLD codes smaller than new code j: old rank r moves up by #{j : pos[j] <= r};
+// new code j (they arrive sorted) gets rank pos[j] + j
+static __global__ void hamming_rank_insert_kernel(u32* __restrict__ rank, long long n_old, const long long* __restrict__ pos,
+                                                  long long m) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_old) {
+        const long long r = rank[p];
+        long long lo = 0, hi = m;  // first j with pos[j] > r
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (pos[mid] <= r) lo = mid + 1; else hi = mid;
+        }
+        rank[p] = (u32)(r + lo);
+    } else if (p < n_old + m) {
+        const long long j = p - n_old;
+        rank[p] = (u32)(pos[j] + j);
+    }
+}
+__device__ __forceinline__ long long lower_bound_ll(const long long* __restrict__ a, long long m, long long v) {
+    long long lo = 0, hi = m;  // first j with a[j] >= v
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// rr ascending = ranks that leave.  Dead rows in the head [0, n - m) become holes, live rows in the tail
+// [n - m, n) movers: there are as many of one as of the other.  cnt[0] holes, cnt[1] movers.
+static __global__ void hamming_remove_mark_kernel(const u32* __restrict__ rank, long long n, const long long* __restrict__ rr,
+                                                  long long m, u32* __restrict__ holes, u32* __restrict__ movers,
+                                                  u32* __restrict__ cnt) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const long long r = rank[p];
+    const long long j = lower_bound_ll(rr, m, r);
+    const bool dead = j < m && rr[j] == r;
+    if (p < n - m) {
+        if (dead) holes[atomicAdd(&cnt[0], 1u)] = (u32)p;
+    } else if (!dead) {
+        movers[atomicAdd(&cnt[1], 1u)] = (u32)p;
+    }
+}
+static __global__ void hamming_remove_move_kernel(u64* __restrict__ codes, u32* __restrict__ rank, int W,
+                                                  const u32* __restrict__ holes, const u32* __restrict__ movers,
+                                                  const u32* __restrict__ cnt) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt[0] || i >= cnt[1]) return;
+    const long long dst = holes[i], src = movers[i];
+    for (int w = 0; w < W; ++w) codes[dst * W + w] = codes[src * W + w];
+    rank[dst] = rank[src];
+}
+static __global__ void hamming_rank_remove_kernel(u32* __restrict__ rank, long long n_new, const long long* __restrict__ rr,
+                                                  long long m) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_new) return;
+    const long long r = rank[p];
+    rank[p] = (u32)(r - lower_bound_ll(rr, m, r));  // ranks below r that left
+}
+
+// room for `bytes` in b with its first `used` bytes kept (grown by half again at least)
+static int hamming_grow_keep(DevBuf& b, size_t used, size_t need) {
+    if (need <= b.cap) return SQ_OK;
+    DevBuf nb;
+    SQ_TRY(nb.reserve(std::max(need, used + used / 2)));
+    if (used && b.p && hipMemcpy(nb.p, b.p, used, hipMemcpyDeviceToDevice) != hipSuccess) {
+        nb.release();
+        return fail(SQ_ERR_HIP, "device copy failed while growing the code array");
+    }
+    b.release();
+    b = nb;
+    return SQ_OK;
+}
+
+static int hamming_materialise_rank(HammingHandle* h, long long rows_needed) {
+    if (!h->rank.p) {
+        SQ_TRY(h->rank.reserve((size_t)std::max(rows_needed, h->n) * 4));
+        hipLaunchKernelGGL(hamming_rank_init_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, 0, h->rank.as<u32>(),
+                           h->n, h->pmul);
+        SQ_HIP(hipDeviceSynchronize());
+    } else {
+        SQ_TRY(hamming_grow_keep(h->rank, (size_t)h->n * 4, (size_t)rows_needed * 4));
+    }
+    h->pmul.rank = h->rank.as<u32>();
+    return SQ_OK;
+}
+
 }  // namespace sq
 
 using namespace sq;
@@ -676,7 +781,7 @@ extern "C" int sq_hamming_create(const uint64_t* codes, int64_t n, int words, in
             };
             while (mul < 2 || gcd(mul, (u64)n) != 1) ++mul;
         }
-        h->pmul = RowPerm{mul, ~0ull / (u64)n};
+        h->pmul = RowPerm{mul, ~0ull / (u64)n, nullptr};
         const size_t bytes = (size_t)n * words * 8;
         const u64* src = reinterpret_cast<const u64*>(codes);
         DevBuf staged;
@@ -737,6 +842,64 @@ extern "C" int sq_hamming_search(sq_handle_t hid, const uint64_t* queries, int n
     SQ_HIP(h->stage.out(out_idx, h->out_idx_dev.p, (size_t)nq * k * 8, st));
     SQ_HIP(stream_wait(st));
     h->stage.finish();
+    return SQ_OK;
+}
+
+extern "C" int sq_hamming_append(sq_handle_t hid, const uint64_t* new_codes, int64_t m, const int64_t* insert_pos) {
+    auto* h = static_cast<HammingHandle*>(lookup_handle(hid, H_HAMMING));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_hamming_append: unknown handle");
+    if (!new_codes || !insert_pos || m <= 0) return fail(SQ_ERR_INVALID, "sq_hamming_append: bad argument");
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->owned.p) return fail(SQ_ERR_UNSUPPORTED, "sq_hamming_append: the index borrows the caller's device array");
+    const long long n_old = h->n, n_new = n_old + m;
+    if (n_new >= (1ll << 32)) return fail(SQ_ERR_UNSUPPORTED, "sq_hamming_append: more than 2^32-1 codes per shard");
+    for (int64_t j = 0; j < m; ++j)
+        if (insert_pos[j] < 0 || insert_pos[j] > n_old || (j && insert_pos[j] < insert_pos[j - 1]))
+            return fail(SQ_ERR_INVALID, "sq_hamming_append: insert positions must be ascending and within [0, n]");
+    SQ_HIP(hipSetDevice(h->device));
+    const int W = h->words;
+    SQ_TRY(hamming_grow_keep(h->owned, (size_t)n_old * W * 8, (size_t)n_new * W * 8));
+    h->codes = h->owned.as<u64>();
+    SQ_TRY(hamming_materialise_rank(h, n_new));
+    SQ_TRY(h->mut_tmp.reserve((size_t)m * 8));
+    SQ_HIP(hipMemcpy(h->owned.as<u64>() + n_old * W, new_codes, (size_t)m * W * 8, hipMemcpyHostToDevice));
+    SQ_HIP(hipMemcpy(h->mut_tmp.p, insert_pos, (size_t)m * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(hamming_rank_insert_kernel, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, 0, h->rank.as<u32>(),
+                       n_old, h->mut_tmp.as<long long>(), (long long)m);
+    SQ_HIP(hipDeviceSynchronize());
+    h->n = n_new;
+    return SQ_OK;
+}
+
+extern "C" int sq_hamming_remove(sq_handle_t hid, const int64_t* ranks, int64_t m) {
+    auto* h = static_cast<HammingHandle*>(lookup_handle(hid, H_HAMMING));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_hamming_remove: unknown handle");
+    if (!ranks || m <= 0) return fail(SQ_ERR_INVALID, "sq_hamming_remove: bad argument");
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->owned.p) return fail(SQ_ERR_UNSUPPORTED, "sq_hamming_remove: the index borrows the caller's device array");
+    const long long n = h->n;
+    if (m >= n) return fail(SQ_ERR_INVALID, "sq_hamming_remove: cannot remove every code (destroy the index instead)");
+    for (int64_t j = 0; j < m; ++j)
+        if (ranks[j] < 0 || ranks[j] >= n || (j && ranks[j] <= ranks[j - 1]))
+            return fail(SQ_ERR_INVALID, "sq_hamming_remove: ranks must be strictly ascending and below n");
+    SQ_HIP(hipSetDevice(h->device));
+    SQ_TRY(hamming_materialise_rank(h, n));
+    // scratch: [ranks i64 m][holes u32 m][movers u32 m][cnt u32 2]
+    SQ_TRY(h->mut_tmp.reserve((size_t)m * 16 + 64));
+    long long* rr = h->mut_tmp.as<long long>();
+    u32* holes = reinterpret_cast<u32*>(rr + m);
+    u32* movers = holes + m;
+    u32* cnt = movers + m;
+    SQ_HIP(hipMemcpy(rr, ranks, (size_t)m * 8, hipMemcpyHostToDevice));
+    SQ_HIP(hipMemset(cnt, 0, 8));
+    hipLaunchKernelGGL(hamming_remove_mark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, h->rank.as<u32>(), n, rr,
+                       (long long)m, holes, movers, cnt);
+    hipLaunchKernelGGL(hamming_remove_move_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, h->owned.as<u64>(),
+                       h->rank.as<u32>(), h->words, holes, movers, cnt);
+    hipLaunchKernelGGL(hamming_rank_remove_kernel, dim3((unsigned)((n - m + 255) / 256)), dim3(256), 0, 0, h->rank.as<u32>(),
+                       n - m, rr, (long long)m);
+    SQ_HIP(hipDeviceSynchronize());
+    h->n = n - m;
     return SQ_OK;
 }
 

@@ -160,23 +160,60 @@ class HipLinearHashIndex(HashIndex):
             self._set(_unique_rows(packed))
             self.save_cache()
 
+    @staticmethod
+    def _locate(cur: np.ndarray, other: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """For sorted unique ``cur`` ``[n, W]`` and sorted unique ``other`` ``[m, W]``: (merged sorted unique rows,
+        position of every ``other`` row in ``merged``, mask of the ``other`` rows that are in ``cur``)."""
+        merged, inv = np.unique(np.vstack([cur, other]), axis=0, return_inverse=True)
+        inv = np.asarray(inv).reshape(-1)
+        at = inv[cur.shape[0]:]
+        present = np.zeros(merged.shape[0], dtype=bool)
+        present[inv[:cur.shape[0]]] = True
+        return merged, at, present[at]
+
     def _update_index(self, hashes: Iterable[np.ndarray]) -> None:
         with self._model_lock:
             cur, new = self._align(self._pack(hashes))
-            self._set(_unique_rows(np.vstack([cur, new])))
+            new = _unique_rows(new)
+            merged, at, known = self._locate(cur, new)
+            dev = self._dev
+            if (dev is not None and cur.shape[0] and cur.shape[1] == self._codes.shape[1] == dev.words
+                    and (~known).sum() <= cur.shape[0]):
+                # only the codes that are really new travel to the device (sq_hamming_append), with the number of
+                # indexed codes below each: linear.py:167-182 is a set union, not a rebuild
+                fresh = np.ascontiguousarray(new[~known])
+                pos = at[~known] - np.arange(fresh.shape[0], dtype=np.int64)
+                self._codes = merged
+                if fresh.shape[0]:
+                    try:
+                        dev.append(fresh, pos)
+                    except _lib.HipError:
+                        self._set(merged)      # (a borrowed device array cannot grow: re-upload at the next query)
+            else:
+                self._set(merged)
             self.save_cache()
 
     def _remove_from_index(self, hashes: Iterable[np.ndarray]) -> None:
         with self._model_lock:
             cur, rem = self._align(self._pack(hashes))
-            have = set(packed_to_ints(cur)) if cur.shape[0] else set()
-            rem_ints = packed_to_ints(_unique_rows(rem))
-            for v in rem_ints:
-                if v not in have:
-                    raise KeyError(v)
-            drop = set(rem_ints)
-            keep = np.array([v not in drop for v in packed_to_ints(cur)], dtype=bool)
-            self._set(np.ascontiguousarray(cur[keep]))
+            rem = _unique_rows(rem)
+            merged, at, known = self._locate(cur, rem)
+            if not known.all():                                  # KeyError before anything changes (linear.py:197-203)
+                raise KeyError(packed_to_ints(rem[~known][:1])[0])
+            ranks = at.astype(np.int64)                          # every removed code is in cur: merged == cur
+            keep = np.ones(cur.shape[0], dtype=bool)
+            keep[ranks] = False
+            left = np.ascontiguousarray(cur[keep])
+            dev = self._dev
+            if (dev is not None and left.shape[0] and cur.shape[1] == self._codes.shape[1] == dev.words
+                    and ranks.shape[0] <= left.shape[0]):
+                self._codes = left
+                try:
+                    dev.remove(ranks)                            # sq_hamming_remove: the ranks, not the array, cross PCIe
+                except _lib.HipError:
+                    self._set(left)
+            else:
+                self._set(left)
             self.save_cache()
 
     def nn_packed(self, queries: np.ndarray, n: int) -> Tuple[np.ndarray, np.ndarray]:

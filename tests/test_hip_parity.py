@@ -716,3 +716,55 @@ def test_dense_non_finite_rows(n):
         qbad[0, 3] = np.nan
         dd, ii = idx.search(qbad, 5)
         assert not np.isfinite(dd).any()
+
+
+@pytest.mark.parametrize("bits", [64, 200, 512])
+def test_hamming_append_remove_equals_a_fresh_index(bits):
+    """sq_hamming_append / sq_hamming_remove: the device copy follows a set union / difference
+    (linear.py:167-204) with only the new codes / the leaving ranks uploaded; after every mutation the index answers
+    exactly like one created from the resulting sorted code array (ids = ranks in that array)."""
+    rng = np.random.default_rng(bits)
+    w = (bits + 63) // 64
+    pool = rng.integers(0, 2 ** 64, size=(60_000, w), dtype=np.uint64)
+    pad = w * 64 - bits
+    if pad:
+        pool[:, 0] &= np.uint64((1 << (64 - pad)) - 1)
+    pool = np.unique(pool, axis=0)
+    perm = rng.permutation(pool.shape[0])
+    cur = np.unique(pool[perm[:30_000]], axis=0)
+    qs = np.ascontiguousarray(pool[perm[100:110]])
+    qs[5:, w - 1] ^= np.uint64(5)
+    idx = _lib.HammingIndex(cur)
+
+    def check(k=60):
+        assert idx.n == cur.shape[0]
+        d, i = idx.search(qs, k)
+        for qi, q in enumerate(qs):
+            rd, ri = O.hamming_topk(cur, q, k)
+            np.testing.assert_array_equal(d[qi], rd)
+            np.testing.assert_array_equal(i[qi], ri)
+
+    check()
+    steps = [("add", perm[30_000:30_700]), ("del", perm[:5000:7]), ("add", perm[30_700:52_000]), ("del", perm[40_000:41_000]),
+             ("del", perm[20_000:29_000]), ("add", perm[52_000:52_003])]
+    for op, sel in steps:
+        other = np.unique(pool[sel], axis=0)
+        merged, inv = np.unique(np.vstack([cur, other]), axis=0, return_inverse=True)
+        at = np.asarray(inv).reshape(-1)[cur.shape[0]:]
+        if op == "add":
+            assert merged.shape[0] == cur.shape[0] + other.shape[0]           # all new
+            idx.append(other, at - np.arange(other.shape[0]))
+            cur = merged
+        else:
+            assert merged.shape[0] == cur.shape[0]                            # all present
+            idx.remove(at)
+            keep = np.ones(cur.shape[0], dtype=bool)
+            keep[at] = False
+            cur = np.ascontiguousarray(cur[keep])
+        check()
+    with pytest.raises(_lib.HipError):
+        idx.remove(np.array([3, 3]))                                          # not strictly ascending: nothing changes
+    with pytest.raises(_lib.HipError):
+        idx.append(cur[:2], np.array([5, 1]))
+    check(k=1)
+    idx.close()

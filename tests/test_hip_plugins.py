@@ -634,3 +634,34 @@ def test_reference_written_caches_on_device(golden):
                                  np.rint(np.asarray(dists) * bits).astype(np.int32),
                                  np.array([lut[O.packed_to_int(r)] for r in O.pack_bits_msb(rows)]),
                                  all_dist_of=lambda r: full[r])
+
+
+def test_linear_update_remove_keep_the_device_copy():
+    """HipLinearHashIndex.update_index / remove_from_index with a live device index: the device copy is mutated in
+    place (sq_hamming_append / sq_hamming_remove), never re-uploaded, and answers like a freshly built index."""
+    rng = np.random.default_rng(44)
+    bits = 96
+    hv = rng.random((9000, bits)) > 0.5
+    a = HipLinearHashIndex()
+    a.build_index(hv[:5000])
+    q = hv[77]
+    a.nn(q, 5)                                   # creates the device copy
+    dev = a._dev
+    assert dev is not None
+    a.update_index(hv[5000:8000])
+    a.update_index(hv[4990:5010])                # mostly known codes: only the new ones are appended
+    assert a._dev is dev and dev.n == a.count()
+    with pytest.raises(KeyError):
+        a.remove_from_index([hv[8500]])          # unknown code: nothing changes
+    assert a._dev is dev and dev.n == a.count()
+    a.remove_from_index(hv[100:900])
+    assert a._dev is dev and dev.n == a.count()
+    b = HipLinearHashIndex()
+    b.build_index(np.vstack([hv[:100], hv[900:8000]]))
+    assert a.count() == b.count()
+    for qv in (hv[77], hv[6000], hv[8999], ~hv[3]):
+        for n in (1, 40, 700):
+            ra, da = a.nn(qv, n)
+            rb, db = b.nn(qv, n)
+            assert da == db
+            np.testing.assert_array_equal(ra, rb)

@@ -351,9 +351,13 @@ def test_entry_points_name_importable_plugin_modules():
     old = os.environ.get("SMQTK_PLUGIN_PATH")
     os.environ["SMQTK_PLUGIN_PATH"] = ":".join(eps.values())
     try:
-        assert HipLinearHashIndex in HashIndex.get_impls()
-        assert HipItqFunctor in LshFunctor.get_impls()
-        assert {HipBruteForceNearestNeighborsIndex, HipLSHNearestNeighborIndex} <= set(NearestNeighborsIndex.get_impls())
+        # get_impls() lists USABLE implementations only (smqtk_core's Pluggable): with libsmqtk_hip.so and a GPU the
+        # four classes are discovered; without, is_usable() is False (it must not raise) and they are filtered out
+        usable = _lib.usable()
+        assert all(c.is_usable() == usable for c in found.values())
+        assert (HipLinearHashIndex in HashIndex.get_impls()) == usable
+        assert (HipItqFunctor in LshFunctor.get_impls()) == usable
+        assert ({HipBruteForceNearestNeighborsIndex, HipLSHNearestNeighborIndex} <= set(NearestNeighborsIndex.get_impls())) == usable
     finally:
         if old is None:
             del os.environ["SMQTK_PLUGIN_PATH"]
