@@ -60,10 +60,19 @@ extern "C" {
 #define SQ_DTYPE_F32 0
 #define SQ_DTYPE_F64 1
 
-#define SQ_NORM_NONE (-1) /* ItqFunctor(normalize=None) */
-#define SQ_NORM_L2 2      /* ItqFunctor(normalize=2)    */
+/* ItqFunctor(normalize=...) (impls/lsh_functor/itq.py:172-191: numpy.linalg.norm(v, ord, axis, keepdims), zero
+ * norms replaced by 1, v / norm in v's dtype).  These orders are evaluated on the device in numpy's own arithmetic;
+ * any other order numpy accepts (general p) is normalised by the caller with numpy itself and hashed with
+ * SQ_NORM_NONE (HipItqFunctor does that): its |x|**p needs libm's pow exactly as numpy calls it. */
+#define SQ_NORM_NONE (-1)        /* normalize=None                 */
+#define SQ_NORM_L0 0             /* normalize=0: count of non-zeros */
+#define SQ_NORM_L1 1             /* normalize=1                    */
+#define SQ_NORM_L2 2             /* normalize=2                    */
+#define SQ_NORM_INF 1000         /* normalize=numpy.inf            */
+#define SQ_NORM_NEG_INF (-1000)  /* normalize=-numpy.inf           */
 
-#define SQ_MAX_K 16384    /* largest k one search call returns per query */
+#define SQ_MAX_K 16384    /* k up to here is answered by the one-workgroup select; larger k (the reference has no
+                           * limit on n) is answered too, by a full device sort of the candidate keys: slower */
 
 typedef int64_t sq_handle_t;
 

@@ -26,7 +26,11 @@ SQ_METRIC_COSINE = 1
 SQ_DTYPE_F32 = 0
 SQ_DTYPE_F64 = 1
 SQ_NORM_NONE = -1
+SQ_NORM_L0 = 0
+SQ_NORM_L1 = 1
 SQ_NORM_L2 = 2
+SQ_NORM_INF = 1000
+SQ_NORM_NEG_INF = -1000
 SQ_MAX_K = 16384
 
 LIB_NAME = "libsmqtk_hip.so"

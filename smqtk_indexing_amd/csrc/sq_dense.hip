@@ -98,11 +98,18 @@ static constexpr int kSelectLdsKeys64 = 16384;
 static constexpr int kSelectLdsKeys128 = 7168;
 
 // select + the finalisation post-op (keys -> distances / ids, certification, status) in one launch
+static DevBuf g_dense_sort_scratch[64];  // per device: scratch of the any-k sorted select (rare path; under the handle lock + synchronous use)
+
 template <class K, class Post>
 static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out,
                            const Post& post, hipStream_t st) {
     static bool attr_set = false;
     const int lds_keys = sizeof(K) == 8 ? kSelectLdsKeys64 : kSelectLdsKeys128;
+    if (k > lds_keys) {  // beyond the one-workgroup select: full sort (sq_select.cuh, "any-k sorted select")
+        int dev = 0;
+        SQ_HIP(hipGetDevice(&dev));
+        return sort_select_large<K, Post>(keys, cnt, cap, stride, k, nq, out, g_dense_sort_scratch[dev & 63], post, st);
+    }
     const size_t lds = (size_t)(lds_keys + SELECT_SORT_MAX) * sizeof(K);
     if (!attr_set) {
         SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<K, Post>),
@@ -238,7 +245,9 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
     u32 cap = g_opt.candidate_cap > 0 ? (u32)g_opt.candidate_cap : 65536u;
     if (cap < (u32)(4 * kk)) cap = (u32)(4 * kk);
     const bool small = n <= (long long)cap;
-    const bool scan_ok = h->scan.p != nullptr && !small;
+    // k beyond the one-workgroup select (16384; cosine 7168): every query takes the exact path, whose select sorts
+    // (the reference has no limit on n: lsh.py:513-518)
+    const bool scan_ok = h->scan.p != nullptr && !small && kk <= (cosine ? kSelectLdsKeys128 : kSelectLdsKeys64);
     const int qt = scan_query_tiles(d_pad, (nq + TILE_ROWS - 1) / TILE_ROWS);  // query tiles per wave
     // query planes: the multi-tile configuration is MFMA bound, so it drops q_lo (half the MFMAs, twice the
     // product bound: ~1.4x more rows pass the filter) unless asked otherwise
@@ -826,9 +835,6 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
     auto* h = static_cast<DenseHandle*>(lookup_handle(hid, H_DENSE));
     if (!h) return fail(SQ_ERR_INVALID, "sq_dense_search: unknown handle");
     if (!queries || !out_dist || !out_idx || nq <= 0 || k <= 0) return fail(SQ_ERR_INVALID, "sq_dense_search: bad argument");
-    if (k > SQ_MAX_K) return fail(SQ_ERR_UNSUPPORTED, "sq_dense_search: k=%d exceeds SQ_MAX_K=%d", k, SQ_MAX_K);
-    if (h->metric == SQ_METRIC_COSINE && k > kSelectLdsKeys128)
-        return fail(SQ_ERR_UNSUPPORTED, "sq_dense_search: cosine k=%d exceeds %d", k, kSelectLdsKeys128);
     std::lock_guard<std::mutex> lock(h->mu);
     SQ_HIP(hipSetDevice(h->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

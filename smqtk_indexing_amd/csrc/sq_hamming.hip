@@ -33,6 +33,7 @@ struct HammingHandle : HandleBase {
     RowPerm pmul{1, 0, nullptr};  // physical row p holds caller row (p * pmul.mul) mod n (or pmul.rank[p])
     DevBuf rank;                  // u32[n] explicit ranks, after the first append / remove
     DevBuf mut_tmp;               // scratch of the mutation kernels
+    DevBuf sort_tmp;              // scratch of the any-k sorted select (k > 16384)
     // workspace
     DevBuf q_dev, keys, cnt, hist, thr, out_keys, status, out_dist_dev, out_idx_dev, big_keys, seg, bcnt;
     HostPinned status_host;
@@ -41,6 +42,7 @@ struct HammingHandle : HandleBase {
         owned.release();
         rank.release();
         mut_tmp.release();
+        sort_tmp.release();
         q_dev.release();
         keys.release();
         cnt.release();
@@ -503,8 +505,10 @@ static void hist_dispatch(const HammingHandle* h, const u64* qs, int nq, int bit
 static constexpr int kSelectLdsKeys64 = 16384;  // 128 KiB of LDS for the candidate keys
 
 static int select_launch(const u64* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, u64* out,
-                         hipStream_t st) {
+                         hipStream_t st, DevBuf& sort_scratch) {
     static bool attr_set = false;
+    if (k > kSelectLdsKeys64)  // linear.py:235-238 has no limit on n: the any-k sorted select (sq_select.cuh)
+        return sort_select_large<u64, SelectNoPost>(keys, cnt, cap, stride, k, nq, out, sort_scratch, SelectNoPost(), st);
     const size_t lds = (size_t)(kSelectLdsKeys64 + SELECT_SORT_MAX) * sizeof(u64);
     if (!attr_set) {
         SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<u64>),
@@ -555,7 +559,7 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
         h->stats.scan_launches = 1;
         h->stats.bytes_scanned = n * W * 8;
-        SQ_TRY(select_launch(keys, cnt, (u32)n, key_stride, k, nq, okeys, st));
+        SQ_TRY(select_launch(keys, cnt, (u32)n, key_stride, k, nq, okeys, st, h->sort_tmp));
         hipLaunchKernelGGL(hamming_finalize_kernel, dim3(nq), dim3(256), 0, st, okeys, cnt, (u32)n, nq, k, h->id_base,
                            out_dist, out_idx, status, kk, hs_dev, nq, 0);
     } else {
@@ -612,7 +616,7 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
         h->stats.scan_launches = 1;
         h->stats.bytes_scanned = n * W * 8;
-        SQ_TRY(select_launch(keys, cnt, cap, key_stride, k, nq, okeys, st));
+        SQ_TRY(select_launch(keys, cnt, cap, key_stride, k, nq, okeys, st, h->sort_tmp));
         hipLaunchKernelGGL(hamming_finalize_kernel, dim3(nq), dim3(256), 0, st, okeys, cnt, cap, nq, k, h->id_base,
                            out_dist, out_idx, status, kk, hs_dev, nq, 0);
     }
@@ -637,7 +641,7 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
             u64* bk = h->big_keys.as<u64>();
             hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, cnt + q, 1ll, (u32)(n > 0xffffffffll ? 0xffffffffu : n));
             scan_dispatch(h, qs + (long long)q * W, 1, thr, bk, cnt + q, (u32)n, n, /*mode*/ 1, st);
-            SQ_TRY(select_launch(bk, cnt + q, (u32)n, n, k, 1, okeys + (long long)q * k, st));
+            SQ_TRY(select_launch(bk, cnt + q, (u32)n, n, k, 1, okeys + (long long)q * k, st, h->sort_tmp));
             hipLaunchKernelGGL(hamming_finalize_kernel, dim3(1), dim3(256), 0, st, okeys + (long long)q * k, cnt + q,
                                (u32)n, 1, k, h->id_base, out_dist + (long long)q * k, out_idx + (long long)q * k,
                                status + q, kk, nullptr, 0, 0);
@@ -822,7 +826,6 @@ extern "C" int sq_hamming_search(sq_handle_t hid, const uint64_t* queries, int n
     if (!h) return fail(SQ_ERR_INVALID, "sq_hamming_search: unknown handle");
     if (!queries || !out_dist || !out_idx || nq <= 0 || k <= 0)
         return fail(SQ_ERR_INVALID, "sq_hamming_search: bad argument");
-    if (k > SQ_MAX_K) return fail(SQ_ERR_UNSUPPORTED, "sq_hamming_search: k=%d exceeds SQ_MAX_K=%d", k, SQ_MAX_K);
     std::lock_guard<std::mutex> lock(h->mu);
     SQ_HIP(hipSetDevice(h->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

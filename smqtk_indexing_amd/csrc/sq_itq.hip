@@ -31,7 +31,7 @@ struct ItqArgs {
     int bits;
     int words;          // W = ceil(bits/64)
     int pad;            // W*64 - bits leading zero columns
-    int norm;           // SQ_NORM_NONE / SQ_NORM_L2
+    int norm;           // SQ_NORM_NONE / SQ_NORM_L2 / _L1 / _L0 / _INF / _NEG_INF
     u64* out;           // [n][W]
     int dk;             // k rows of R staged per chunk (multiple of 16)
     int nchunks;
@@ -61,13 +61,19 @@ __device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(
 __device__ __forceinline__ float sqrt_rn(float a) { return (float)sqrt((double)a); }
 __device__ __forceinline__ double sqrt_rn(double a) { return sqrt(a); }
 
-// Row L2 norms in numpy's arithmetic (itq.py:185: np.linalg.norm(v, 2, axis, keepdims)):
-// pairwise float sum of squares in x's dtype, correctly rounded sqrt, 0 -> 1.
-// 8 lanes per row.  Kept out of the MFMA kernel so that one stays within 256
+// Row norms in numpy's arithmetic (itq.py:185: np.linalg.norm(v, ord, axis, keepdims), numpy/linalg/linalg.py):
+//   ord 2:    sqrt(add.reduce(x * x))      pairwise float sum in x's dtype, correctly rounded sqrt
+//   ord 1:    add.reduce(abs(x))           the same pairwise sum of |x|
+//   ord 0:    (x != 0).astype(dtype).sum() (exact: small integers)
+//   ord inf:  abs(x).max()     ord -inf: abs(x).min()      (a NaN wins, as in numpy's maximum / minimum)
+// and 0 -> 1 (itq.py:187).  8 lanes per row.  Kept out of the MFMA kernel so that one stays within 256
 // VGPRs (two workgroups per CU) without spilling.
+__device__ __forceinline__ float abs_t(float v) { return fabsf(v); }
+__device__ __forceinline__ double abs_t(double v) { return fabs(v); }
 template <class T>
 __global__ __launch_bounds__(256) void itq_norms_kernel(const T* __restrict__ X, long long n_all, int d, T* __restrict__ nrm,
-                                                        const u32* __restrict__ list, const u32* __restrict__ list_total) {
+                                                        const u32* __restrict__ list, const u32* __restrict__ list_total,
+                                                        int ord) {
     const int j8 = threadIdx.x & 7;
     const long long stride = (long long)gridDim.x * 32;
     const long long n = list ? (long long)*list_total : n_all;  // listed rows only (sq_itq_fast.cuh), or all
@@ -77,9 +83,32 @@ __global__ __launch_bounds__(256) void itq_norms_kernel(const T* __restrict__ X,
         row = live ? row : n - 1;
         if (list) row = (long long)list[row];
         const T* xr = X + row * d;
-        auto term = [xr](int i) { return mul_rn(xr[i], xr[i]); };
-        T s = np_pairwise_sum<T>(term, d, j8);
-        T nv = sqrt_rn(s);
+        T nv;
+        if (ord == SQ_NORM_INF || ord == SQ_NORM_NEG_INF) {
+            const bool mx = ord == SQ_NORM_INF;
+            T m = abs_t(xr[j8 < d ? j8 : 0]);
+            bool nan = m != m;
+            for (int i = j8 + 8; i < d; i += 8) {
+                const T v = abs_t(xr[i]);
+                nan |= v != v;
+                m = mx ? (v > m ? v : m) : (v < m ? v : m);
+            }
+            for (int o = 1; o < 8; o <<= 1) {
+                const T v = __shfl_xor(m, o);
+                nan |= (bool)__shfl_xor((int)nan, o);
+                m = mx ? (v > m ? v : m) : (v < m ? v : m);
+            }
+            nv = nan ? (T)__builtin_nanf("") : m;
+        } else if (ord == SQ_NORM_L1) {
+            auto term = [xr](int i) { return abs_t(xr[i]); };
+            nv = np_pairwise_sum<T>(term, d, j8);
+        } else if (ord == SQ_NORM_L0) {
+            auto term = [xr](int i) { return xr[i] != (T)0 ? (T)1 : (T)0; };
+            nv = np_pairwise_sum<T>(term, d, j8);
+        } else {
+            auto term = [xr](int i) { return mul_rn(xr[i], xr[i]); };
+            nv = sqrt_rn(np_pairwise_sum<T>(term, d, j8));
+        }
         if (nv == (T)0) nv = (T)1;
         if (live && j8 == 0) nrm[row] = nv;
     }
@@ -136,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void itq_hash_kernel(ItqArgs a) {
             row = row < nrows ? row : nrows - 1;
             if (a.list) row = (long long)a.list[row];
             xrow[rt] = X + row * a.d;
-            nrm_l[rt] = a.norm == SQ_NORM_L2 ? reinterpret_cast<const T*>(a.nrm)[row] : (T)1;
+            nrm_l[rt] = a.nrm ? reinterpret_cast<const T*>(a.nrm)[row] : (T)1;
         }
         for (int chunk = 0; chunk < a.nchunks; ++chunk) {
             if (a.nchunks > 1) {
@@ -166,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void itq_hash_kernel(ItqArgs a) {
                         double v = 0.0;
                         if (k < a.d) {
                             T xv = xq[j];
-                            if (a.norm == SQ_NORM_L2) xv = div_rn(xv, nrm_l[rt]);
+                            if (a.nrm) xv = div_rn(xv, nrm_l[rt]);
                             if constexpr (sizeof(T) == 4) {
                                 if (a.sub32)
                                     v = (double)__fsub_rn(xv, (float)s_mean[k]);  // s_mean[k] is a float32 value
@@ -455,20 +484,41 @@ static int itq_fast_dispatch(const ItqFastArgs& fa, const ItqFastGeom& g, hipStr
 #undef SQ_ITQF_CASE
 }
 
-// Keep the stream-ordered pool's memory across calls: by default it is handed back at every synchronisation
-// and each call would pay for fresh allocations (~100 MB for a 10 M-row hash call).
-static void keep_pool_memory(int device) {
+// Stream-ordered scratch from a pool of the library's OWN (one per device).  The pool keeps up to kPoolKeepBytes
+// across synchronisations, so small latency-bound calls (one query vector: ~100 KB) never pay for a fresh
+// allocation, while the scratch of a bulk call (gigabytes for a 10 M-row hash from host memory) goes back to the
+// driver at the next synchronisation instead of staying reserved for the life of the process.  (Round 1 raised the
+// release threshold of the process-wide DEFAULT pool to "never": a global setting other users of that pool saw,
+// and memory that hipMalloc-based buffers and torch's allocator could no longer get.)
+static constexpr uint64_t kPoolKeepBytes = 256ull << 20;
+static hipMemPool_t scratch_pool(int device) {
     static std::mutex mu;
-    static bool kept[64] = {};
+    static hipMemPool_t pools[64] = {};
+    static bool tried[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
     std::lock_guard<std::mutex> l(mu);
-    if (device >= 0 && device < 64 && !kept[device]) {
-        hipMemPool_t pool;
-        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-            uint64_t keep = ~0ull;
+    if (!tried[device]) {
+        tried[device] = true;
+        hipMemPoolProps props{};
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = device;
+        hipMemPool_t pool = nullptr;
+        if (hipMemPoolCreate(&pool, &props) == hipSuccess) {
+            uint64_t keep = kPoolKeepBytes;
             (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            pools[device] = pool;
+        } else {
+            (void)hipGetLastError();
         }
-        kept[device] = true;
     }
+    return pools[device];
+}
+static hipError_t scratch_alloc(void** p, size_t bytes, hipStream_t st, int device) {
+    hipMemPool_t pool = scratch_pool(device);
+    if (pool) return hipMallocFromPoolAsync(p, bytes, pool, st);
+    return hipMallocAsync(p, bytes, st);  // (no private pool: the default one, with its default threshold)
 }
 
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -494,9 +544,8 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
     const size_t o_seg = take((size_t)nwaves * seg_cap * 8), o_cnt = take((size_t)nwaves * 4);
     const size_t o_dummy = take((size_t)nwaves * 8);
     const size_t o_rt = take((size_t)pc * a.d * 8);
-    keep_pool_memory(device);
     unsigned char* base = nullptr;
-    SQ_HIP(hipMallocAsync(reinterpret_cast<void**>(&base), off, st));
+    SQ_HIP(scratch_alloc(reinterpret_cast<void**>(&base), off, st, device));
     auto done = [&](int rc) {
         (void)hipFreeAsync(base, st);
         return rc;
@@ -545,15 +594,15 @@ static int itq_launch(const ItqArgs& a0, hipStream_t st, int device) {
     if constexpr (sizeof(T) == 4) {
         const ItqFastGeom g = itq_fast_geometry(a.d, a.words);
         if (g.stages >= 2 && a.n >= 32 && a.n < (1ll << 30) && (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 &&
-            !g_opt.itq_exact)
+            !g_opt.itq_exact && (a.norm == SQ_NORM_NONE || a.norm == SQ_NORM_L2))  // (the other orders: float64 kernel)
             return itq_fast_path(a, g, st, device);
     }
     void* nrm = nullptr;
-    if (a.norm == SQ_NORM_L2) {  // stream-ordered scratch: [n] norms in x's dtype
-        SQ_HIP(hipMallocAsync(&nrm, (size_t)a.n * sizeof(T), st));
+    if (a.norm != SQ_NORM_NONE) {  // stream-ordered scratch: [n] norms in x's dtype
+        SQ_HIP(scratch_alloc(&nrm, (size_t)a.n * sizeof(T), st, device));
         long long gx = std::min<long long>((a.n + 31) / 32, 16ll * cu_count(device));
         hipLaunchKernelGGL((itq_norms_kernel<T>), dim3((unsigned)gx), dim3(256), 0, st, reinterpret_cast<const T*>(a.x),
-                           a.n, a.d, reinterpret_cast<T*>(nrm), (const u32*)nullptr, (const u32*)nullptr);
+                           a.n, a.d, reinterpret_cast<T*>(nrm), (const u32*)nullptr, (const u32*)nullptr, a.norm);
         a.nrm = nrm;
     }
     int rc;
@@ -562,6 +611,11 @@ static int itq_launch(const ItqArgs& a0, hipStream_t st, int device) {
     else rc = itq_launch_t<T, 16>(a, st, device);
     if (nrm) (void)hipFreeAsync(nrm, st);
     return rc;
+}
+
+static bool itq_norm_supported(int ord) {
+    return ord == SQ_NORM_NONE || ord == SQ_NORM_L2 || ord == SQ_NORM_L1 || ord == SQ_NORM_L0 || ord == SQ_NORM_INF ||
+           ord == SQ_NORM_NEG_INF;
 }
 
 }  // namespace sq
@@ -575,8 +629,8 @@ extern "C" int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d, const d
     if (x_dtype != SQ_DTYPE_F32 && x_dtype != SQ_DTYPE_F64) return fail(SQ_ERR_INVALID, "sq_itq_hash: unknown dtype %d", x_dtype);
     if (mean_dtype != SQ_DTYPE_F32 && mean_dtype != SQ_DTYPE_F64)
         return fail(SQ_ERR_INVALID, "sq_itq_hash: unknown mean dtype %d", mean_dtype);
-    if (norm_ord != SQ_NORM_NONE && norm_ord != SQ_NORM_L2)
-        return fail(SQ_ERR_UNSUPPORTED, "sq_itq_hash: normalize=%d not supported on the device (None or 2)", norm_ord);
+    if (!itq_norm_supported(norm_ord))
+        return fail(SQ_ERR_UNSUPPORTED, "sq_itq_hash: normalize code %d not supported on the device", norm_ord);
     int device = 0;
     SQ_HIP(hipGetDevice(&device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -598,14 +652,13 @@ extern "C" int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d, const d
         a.out = reinterpret_cast<u64*>(out_codes);
         return x_dtype == SQ_DTYPE_F32 ? itq_launch<float>(a, st, device) : itq_launch<double>(a, st, device);
     }
-    // Host buffers: ONE stream-ordered allocation for rows | mean | rotation | codes (the pool keeps the memory
-    // across calls).  Four hipMalloc / hipFree pairs per call made hashing one query vector -- what every
+    // Host buffers: ONE stream-ordered allocation for rows | mean | rotation | codes (the library's pool keeps up to
+    // 256 MB across calls).  Four hipMalloc / hipFree pairs per call made hashing one query vector -- what every
     // LSHNearestNeighborIndex.nn does first -- cost 94 us.
-    keep_pool_memory(device);
     const size_t o_x = 0, o_m = align256(o_x + (size_t)n * d * esz), o_r = align256(o_m + (size_t)d * 8);
     const size_t o_out = align256(o_r + (size_t)d * bits * 8), total = o_out + (size_t)n * words * 8;
     unsigned char* base = nullptr;
-    SQ_HIP(hipMallocAsync(reinterpret_cast<void**>(&base), total, st));
+    SQ_HIP(scratch_alloc(reinterpret_cast<void**>(&base), total, st, device));
     auto done = [&](int code) {
         (void)hipFreeAsync(base, st);
         return code;
@@ -647,8 +700,8 @@ extern "C" int sq_itq_model_create(const double* mean, int mean_dtype, const dou
     if (!mean || !rotation || !out || d <= 0 || bits <= 0) return fail(SQ_ERR_INVALID, "sq_itq_model_create: bad argument");
     if (mean_dtype != SQ_DTYPE_F32 && mean_dtype != SQ_DTYPE_F64)
         return fail(SQ_ERR_INVALID, "sq_itq_model_create: unknown mean dtype %d", mean_dtype);
-    if (norm_ord != SQ_NORM_NONE && norm_ord != SQ_NORM_L2)
-        return fail(SQ_ERR_UNSUPPORTED, "sq_itq_model_create: normalize=%d not supported on the device (None or 2)", norm_ord);
+    if (!itq_norm_supported(norm_ord))
+        return fail(SQ_ERR_UNSUPPORTED, "sq_itq_model_create: normalize code %d not supported on the device", norm_ord);
     auto* h = new ItqModelHandle();
     h->kind = H_ITQ;
     h->d = d;

@@ -21,11 +21,11 @@ struct RowsHandle : HandleBase {
     int dtype = SQ_DTYPE_F32;
     long long n = 0;
     int d = 0;
-    DevBuf q_dev, cand_dev, off_dev, cnt_dev, keys, out_keys, out_dist, out_pos;
+    DevBuf q_dev, cand_dev, off_dev, cnt_dev, keys, out_keys, out_dist, out_pos, sort_tmp;
     PinnedStage stage;
     ~RowsHandle() override {
         stage.release();
-        for (DevBuf* b : {&owned, &q_dev, &cand_dev, &off_dev, &cnt_dev, &keys, &out_keys, &out_dist, &out_pos}) b->release();
+        for (DevBuf* b : {&owned, &q_dev, &cand_dev, &off_dev, &cnt_dev, &keys, &out_keys, &out_dist, &out_pos, &sort_tmp}) b->release();
     }
 };
 
@@ -112,9 +112,12 @@ __global__ void rows_finalize_kernel(const K* __restrict__ sorted, const u32* __
 }
 
 template <class K>
-static int rows_select(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out, hipStream_t st) {
+static int rows_select(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out, hipStream_t st,
+                       DevBuf& sort_scratch) {
     static bool attr_set = false;
     const int lds_keys = sizeof(K) == 8 ? 16384 : 7168;
+    if (k > lds_keys)  // lsh.py:513-518 slices whatever n is asked: the any-k sorted select (sq_select.cuh)
+        return sort_select_large<K, SelectNoPost>(keys, cnt, cap, stride, k, nq, out, sort_scratch, SelectNoPost(), st);
     const size_t lds = (size_t)(lds_keys + SELECT_SORT_MAX) * sizeof(K);
     if (!attr_set) {
         SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<K>),
@@ -133,7 +136,7 @@ static int rows_rerank_t(RowsHandle* h, int nq, int metric, long long maxc, int 
     hipLaunchKernelGGL((rows_rerank_keys_kernel<T, K>), dim3(gx, nq), dim3(256), 0, st,
                        reinterpret_cast<const T*>(h->rows), h->n, h->d, h->q_dev.as<T>(), metric,
                        h->cand_dev.as<long long>(), h->off_dev.as<long long>(), maxc, h->keys.as<K>(), h->cnt_dev.as<u32>());
-    SQ_TRY(rows_select<K>(h->keys.as<K>(), h->cnt_dev.as<u32>(), (u32)maxc, maxc, k, nq, h->out_keys.as<K>(), st));
+    SQ_TRY(rows_select<K>(h->keys.as<K>(), h->cnt_dev.as<u32>(), (u32)maxc, maxc, k, nq, h->out_keys.as<K>(), st, h->sort_tmp));
     hipLaunchKernelGGL((rows_finalize_kernel<K>), dim3(nq), dim3(256), 0, st, h->out_keys.as<K>(), h->cnt_dev.as<u32>(), k,
                        h->out_dist.p, h->out_pos.as<long long>());
     SQ_HIP(hipGetLastError());
@@ -209,10 +212,8 @@ extern "C" int sq_rows_rerank(sq_handle_t hid, const void* queries, int nq, int 
     if (!queries || !cand_rows || !cand_offsets || !out_dist || !out_pos || nq <= 0 || k <= 0)
         return fail(SQ_ERR_INVALID, "sq_rows_rerank: bad argument");
     if (metric != SQ_METRIC_L2 && metric != SQ_METRIC_COSINE) return fail(SQ_ERR_INVALID, "sq_rows_rerank: unknown metric");
-    if (k > SQ_MAX_K) return fail(SQ_ERR_UNSUPPORTED, "sq_rows_rerank: k=%d exceeds SQ_MAX_K=%d", k, SQ_MAX_K);
     const bool f32 = h->dtype == SQ_DTYPE_F32;
     const bool k64 = f32 && metric == SQ_METRIC_L2;  // float32 distances, 64-bit keys
-    if (!k64 && k > 7168) return fail(SQ_ERR_UNSUPPORTED, "sq_rows_rerank: k=%d exceeds 7168 for float64 distances", k);
     long long maxc = 0;
     const long long total = cand_offsets[nq];
     for (int q = 0; q < nq; ++q) {

@@ -280,6 +280,90 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const K* __restrict__
     post(q, dst, k);
 }
 
+// ------------------------------------------------------- any-k sorted select
+// The one-workgroup select above needs k <= its LDS capacity (16384 64-bit keys, 7168 128-bit keys).  The reference
+// has no such limit (linear.py:235-238 and lsh.py:513-518 slice whatever n is asked), so larger k takes this path:
+// every query's list (cnt[q] keys, clamped to cap, the rest padding) is sorted completely -- an LDS bitonic sort of
+// chunks, then log2(P / chunk) passes of merge-by-ranking (every key finds its place in the merged run with one
+// binary search in the sibling run: fully parallel, no data-dependent control flow between threads), ping-pong
+// between two scratch buffers of nq * P keys -- and the first k keys are the answer.  O(P log P) per query with
+// P = cap rounded up to a power of two: a rare path, built to be correct and simple rather than fast.
+template <class K>
+struct SortLarge {
+    static constexpr int CH = sizeof(K) == 8 ? 4096 : 2048;  // keys per LDS chunk (32 KB)
+};
+
+template <class K>
+__global__ __launch_bounds__(1024) void sortl_chunk_kernel(const K* __restrict__ keys, const u32* __restrict__ cnt, u32 cap,
+                                                            long long stride, K* __restrict__ dst, long long P) {
+    constexpr int CH = SortLarge<K>::CH;
+    __shared__ K sk[CH];
+    const int q = blockIdx.y;
+    const long long base = (long long)blockIdx.x * CH;
+    const u32 craw = cnt[q];
+    const long long M = craw < cap ? craw : cap;
+    for (int i = threadIdx.x; i < CH; i += blockDim.x)
+        sk[i] = base + i < M ? keys[(long long)q * stride + base + i] : KeyOps<K>::maxv();
+    bitonic_sort_lds<K>(sk, CH);
+    for (int i = threadIdx.x; i < CH; i += blockDim.x) dst[(long long)q * P + base + i] = sk[i];
+}
+
+// runs of `run` sorted keys -> runs of 2 * run.  Real keys are unique; padding keys (all equal, the maximum) keep
+// distinct places because the left run counts the right keys BELOW and the right run the left keys AT OR BELOW.
+template <class K>
+__global__ __launch_bounds__(256) void sortl_merge_kernel(const K* __restrict__ src, K* __restrict__ dst, long long P,
+                                                           long long run) {
+    const int q = blockIdx.y;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P) return;
+    const long long pair = e / (2 * run), within = e - pair * 2 * run;
+    const K* a = src + (long long)q * P + pair * 2 * run;
+    const bool left = within < run;
+    const long long i = left ? within : within - run;
+    const K key = a[within];
+    const K* other = left ? a + run : a;
+    long long lo = 0, hi = run;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        const bool go_right = left ? KeyOps<K>::less(other[mid], key) : !KeyOps<K>::less(key, other[mid]);
+        if (go_right) lo = mid + 1; else hi = mid;
+    }
+    dst[(long long)q * P + pair * 2 * run + i + lo] = key;
+}
+
+template <class K, class Post>
+__global__ __launch_bounds__(1024) void sortl_finish_kernel(const K* __restrict__ sorted, long long P, int k,
+                                                             K* __restrict__ out, Post post) {
+    const int q = blockIdx.x;
+    K* dst = out + (long long)q * k;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) dst[i] = i < P ? sorted[(long long)q * P + i] : KeyOps<K>::maxv();
+    __syncthreads();
+    post(q, dst, k);
+}
+
+// keys: [nq][stride], cnt[q] valid (clamped to cap); out: [nq][k]; scratch grows to 2 * nq * P keys.
+template <class K, class Post>
+static int sort_select_large(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out,
+                             DevBuf& scratch, const Post& post, hipStream_t st) {
+    constexpr int CH = SortLarge<K>::CH;
+    long long P = CH;
+    while (P < (long long)cap) P <<= 1;
+    SQ_TRY(scratch.reserve((size_t)2 * nq * P * sizeof(K)));
+    K* a = scratch.as<K>();
+    K* b = a + (size_t)nq * P;
+    hipLaunchKernelGGL((sortl_chunk_kernel<K>), dim3((unsigned)(P / CH), (unsigned)nq), dim3(1024), 0, st, keys, cnt, cap, stride,
+                       a, P);
+    for (long long run = CH; run < P; run <<= 1) {
+        hipLaunchKernelGGL((sortl_merge_kernel<K>), dim3((unsigned)((P + 255) / 256), (unsigned)nq), dim3(256), 0, st, a, b, P, run);
+        K* t = a;
+        a = b;
+        b = t;
+    }
+    hipLaunchKernelGGL((sortl_finish_kernel<K, Post>), dim3((unsigned)nq), dim3(1024), 0, st, a, P, k, out, post);
+    SQ_HIP(hipGetLastError());
+    return SQ_OK;
+}
+
 // ------------------------------------------------------------ block helpers
 __device__ __forceinline__ float wave_min(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));

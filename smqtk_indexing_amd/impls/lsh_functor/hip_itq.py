@@ -69,11 +69,8 @@ class HipItqFunctor(LshFunctor):
         self.normalize = normalize
         self.random_seed = random_seed
         if normalize is not None:
-            # same validation the reference performs (itq.py:162-164) ...
-            np.linalg.norm(np.random.rand(8), normalize, 0, keepdims=True)
-            # ... and the device kernel implements the L2 case only
-            if float(normalize) != 2.0:
-                raise ValueError("HipItqFunctor supports normalize=None or 2 on the device, got %r" % (normalize,))
+            # the validation the reference performs (itq.py:162-164): whatever numpy.linalg.norm accepts for a vector
+            self._norm_vector(np.random.rand(8))
         self.mean_vec: Optional[np.ndarray] = None
         self.rotation: Optional[np.ndarray] = None
         self.load_model()
@@ -110,8 +107,22 @@ class HipItqFunctor(LshFunctor):
                 np.save(buf, arr)
                 elem.set_bytes(buf.getvalue())
 
+    # normalize values whose row norm the device evaluates in numpy's own arithmetic (include/smqtk_hip.h); any other
+    # order numpy accepts (a general p: |x|**p through libm's pow) is normalised here by numpy itself, exactly as the
+    # reference does (itq.py:185-188), and the normalised rows are hashed with SQ_NORM_NONE
+    _DEVICE_NORMS = {2.0: _lib.SQ_NORM_L2, 1.0: _lib.SQ_NORM_L1, 0.0: _lib.SQ_NORM_L0,
+                     float("inf"): _lib.SQ_NORM_INF, float("-inf"): _lib.SQ_NORM_NEG_INF}
+
+    def _norm_on_host(self) -> bool:
+        return self.normalize is not None and self._norm_ord() == _lib.SQ_NORM_NONE
+
     def _norm_ord(self) -> int:
-        return _lib.SQ_NORM_NONE if self.normalize is None else _lib.SQ_NORM_L2
+        if self.normalize is None:
+            return _lib.SQ_NORM_NONE
+        try:
+            return self._DEVICE_NORMS.get(float(self.normalize), _lib.SQ_NORM_NONE)
+        except (TypeError, ValueError):
+            return _lib.SQ_NORM_NONE
 
     def _norm_vector(self, v: np.ndarray) -> np.ndarray:
         """Host normalisation used by ``fit`` only (itq.py:172-191)."""
@@ -134,12 +145,19 @@ class HipItqFunctor(LshFunctor):
             raise ValueError("expected an [n, d] matrix")
         if x.dtype != np.float32:
             x = x.astype(np.float64)       # ints / float16 etc. upcast like numpy would
+        if self._norm_on_host():
+            x = np.ascontiguousarray(self._norm_vector(x), dtype=x.dtype)
         return self._device_model().hash(x)
 
     def _device_model(self) -> "_lib.ItqModel":
         """The model resident on the device (sq_itq_model_*), rebuilt when mean_vec / rotation / normalize change
         (they are plain attributes, as in the reference, so identity and norm are what can be checked)."""
-        key = (id(self.mean_vec), id(self.rotation), self._norm_ord())
+        # the model arrays are plain attributes, as in the reference: an in-place edit keeps their identity, so the
+        # key carries a digest of their content as well (d * bits * 8 bytes: microseconds)
+        import hashlib
+        digest = hashlib.blake2b(np.ascontiguousarray(self.mean_vec).tobytes() +
+                                 np.ascontiguousarray(np.real(self.rotation)).tobytes(), digest_size=16).digest()
+        key = (id(self.mean_vec), id(self.rotation), self._norm_ord(), digest)
         cached = getattr(self, "_model_cache", None)
         if cached is None or cached[0] != key:
             if cached is not None:
@@ -183,7 +201,12 @@ class HipItqFunctor(LshFunctor):
         B^T V.  The d x d eigen-decomposition and the bits x bits SVDs are numpy's, as in the
         reference.  Descriptors up to 128-d, codes up to 128 bits."""
         nbits = self.bit_length
-        fit = _lib.ItqFit(x_in, self._norm_ord())
+        norm_ord = self._norm_ord()
+        if norm_ord not in (_lib.SQ_NORM_NONE, _lib.SQ_NORM_L2) or self._norm_on_host():
+            # the training products know normalize=None / 2; every other order is applied by numpy first
+            x_in = np.ascontiguousarray(self._norm_vector(x_in))
+            norm_ord = _lib.SQ_NORM_NONE
+        fit = _lib.ItqFit(x_in, norm_ord)
         try:
             # np.mean keeps the descriptors' dtype; the model (and everything derived below) uses that value
             mean_vec = fit.mean.astype(x_in.dtype if x_in.dtype in (np.float32, np.float64) else np.float64)

@@ -173,7 +173,10 @@ def test_argument_validation_through_the_raw_abi():
     assert lib.sq_rows_destroy(12345) != 0 and lib.sq_dense_destroy(12345) != 0 and lib.sq_hamming_destroy(12345) != 0
     m = np.zeros(8)
     assert lib.sq_itq_hash(x.ctypes.data, 0, 4, 8, m.ctypes.data, 1, m.ctypes.data, 0, -1, x.ctypes.data, 0, null) != 0  # bits <= 0
-    assert lib.sq_itq_hash(x.ctypes.data, 0, 4, 8, m.ctypes.data, 1, m.ctypes.data, 4, 1, x.ctypes.data, 0, null) != 0   # normalize=1
+    assert lib.sq_itq_hash(x.ctypes.data, 0, 4, 8, m.ctypes.data, 1, m.ctypes.data, 4, 7, x.ctypes.data, 0, null) != 0   # no such normalize code
     assert b"normalize" in lib.sq_last_error()
+    assert lib.sq_hamming_append(12345, x.ctypes.data, 1, x.ctypes.data) != 0 and lib.sq_hamming_remove(12345, x.ctypes.data, 1) != 0
+    assert b"sq_hamming_remove: unknown handle" in lib.sq_last_error()
+    assert lib.sq_dense_sync(12345) != 0
     st = _lib.SqStats()
     assert lib.sq_get_stats(12345, ctypes.byref(st)) != 0

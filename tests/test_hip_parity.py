@@ -768,3 +768,38 @@ def test_hamming_append_remove_equals_a_fresh_index(bits):
         idx.append(cur[:2], np.array([5, 1]))
     check(k=1)
     idx.close()
+
+
+def test_k_beyond_the_one_workgroup_select():
+    """The reference slices whatever n is asked (linear.py:235-238, lsh.py:513-518): no cap on k.  k above the
+    one-workgroup select's capacity (16384 keys; 7168 for float64 / cosine keys) is answered by a full device sort
+    (sq_select.cuh, sort_select_large) -- same canonical order, checked against the oracle."""
+    rng = np.random.default_rng(61)
+    db = rng.standard_normal((90_000, 32)).astype(np.float32)
+    db[500:520] = db[3]                                       # ties
+    qs = rng.standard_normal((3, 32)).astype(np.float32)
+    _dense_check(db, qs, 20_000, "euclidean")                 # scan-sized matrix, exact path + sort
+    _dense_check(db, qs[:2], 90_000, "euclidean")             # k = n
+    _dense_check(db[:30_000], qs, 17_000, "euclidean")        # small matrix (every row a candidate) + sort
+    _dense_check(db, qs[:2], 8_000, "cosine")
+    _dense_check(db[:20_000], qs[:2], 20_000, "cosine")
+    codes = np.unique(rng.integers(0, 2 ** 64, size=(80_000, 2), dtype=np.uint64), axis=0)
+    hq = rng.integers(0, 2 ** 64, size=(3, 2), dtype=np.uint64)
+    _hamming_check(codes, hq, 20_000)
+    _hamming_check(codes[:30_000], hq, 30_000)
+    for dt, kbig in ((np.float32, 18_000), (np.float64, 9_000)):
+        rows = rng.standard_normal((40_000, 24)).astype(dt)
+        m = _lib.RowMatrix(rows)
+        cand = rng.permutation(40_000)[:25_000].astype(np.int64)
+        off = np.array([0, 25_000], dtype=np.int64)
+        q = rng.standard_normal((1, 24)).astype(dt)
+        for metric, name in ((_lib.SQ_METRIC_L2, "euclidean"), (_lib.SQ_METRIC_COSINE, "cosine")):
+            dist, pos = m.rerank(q, metric, cand, off, kbig)
+            full = O.dense_distances(rows[cand], q[0], name)
+            order = np.argsort(full, kind="stable")[:kbig]
+            np.testing.assert_array_equal(pos[0], order)
+            if name == "euclidean":
+                np.testing.assert_array_equal(dist[0], full[order])
+            else:
+                np.testing.assert_allclose(dist[0], full[order], rtol=1e-12, atol=1e-15)
+        m.close()

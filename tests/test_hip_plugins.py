@@ -156,6 +156,34 @@ def test_itq_functor_matches_reference_golden(golden):
         np.testing.assert_array_equal(O.pack_bits_msb(one[None])[0], got[5])
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("norm", [1, 0, np.inf, -np.inf, 3, 0.5])
+def test_itq_every_normalize_order(norm, dt):
+    """ItqFunctor accepts any order numpy.linalg.norm takes for a vector (itq.py:172-191).  1, 0 and +-inf are
+    evaluated on the device in numpy's arithmetic (row norms in the rows' dtype, 0 -> 1, element-wise division);
+    a general p is normalised by numpy on the host and hashed on the device.  Codes = the oracle's."""
+    rng = np.random.default_rng(31)
+    n, d, bits = 3000, 128, 64
+    x = (rng.standard_normal((n, d)) * 2).astype(dt)
+    x[::9, ::3] = 0.0                      # zeros: ord 0 / -inf see them
+    x[5] = 0.0                             # a zero row: norm replaced by 1
+    mean = (rng.standard_normal(d) * 0.01).astype(np.float64)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    rot = np.ascontiguousarray(q[:, :bits])
+    f = HipItqFunctor(bit_length=bits, normalize=norm)
+    f.mean_vec, f.rotation = mean, rot
+    got = f.get_hash(x)
+    z = O.itq_z(x, mean, rot, norm)
+    ref = z >= 0
+    bad = (got != ref).any(axis=1)
+    assert bad.sum() == 0 or np.abs(z[bad]).min(axis=1).max() < 1e-9 * np.abs(z).max()
+    one = f.get_hash(x[17])
+    np.testing.assert_array_equal(one, got[17])
+    if norm in (1, np.inf):                # the packed C ABI call with the order code
+        code = _lib.SQ_NORM_L1 if norm == 1 else _lib.SQ_NORM_INF
+        np.testing.assert_array_equal(_lib.itq_hash(x, mean, rot, code), O.pack_bits_msb(got))
+
+
 # ------------------------------------------- HipBruteForceNearestNeighborsIndex
 def test_bruteforce_known_answers():
     # tests/impls/nn_index/test_faiss.py:443-515 (the reference's exact-index KATs)
@@ -665,3 +693,29 @@ def test_linear_update_remove_keep_the_device_copy():
             rb, db = b.nn(qv, n)
             assert da == db
             np.testing.assert_array_equal(ra, rb)
+
+
+def test_plugins_answer_large_n():
+    """nn(d, n) with n far above the kernels' one-workgroup select: the plugin classes answer like the reference
+    would (every descriptor / code, ascending), they do not raise."""
+    rng = np.random.default_rng(71)
+    x = rng.standard_normal((20_000, 16)).astype(np.float32)
+    bf = HipBruteForceNearestNeighborsIndex()
+    bf.build_index(_elems(x))
+    r, d = bf.nn(DescriptorMemoryElement("q").set_vector(x[5]), 19_000)
+    assert len(r) == 19_000 and r[0].uuid() == 5 and (np.diff(d) >= 0).all()
+    rd, ri = O.dense_topk(x, x[5], 19_000)
+    assert [e.uuid() for e in r[:50]] == ri[:50].tolist() and [e.uuid() for e in r[-50:]] == ri[-50:].tolist()
+    hv = rng.random((40_000, 40)) > 0.5
+    hi = HipLinearHashIndex()
+    hi.build_index(hv)
+    codes, dists = hi.nn(hv[3], 25_000)
+    assert len(codes) == min(25_000, hi.count()) and dists[0] == 0.0 and (np.diff(dists) >= 0).all()
+    f = HipItqFunctor(bit_length=12, itq_iterations=3, random_seed=0)
+    f.fit(_elems(x[:2000]))
+    for metric in ("euclidean", "cosine"):
+        lsh = HipLSHNearestNeighborIndex(f, MemoryDescriptorSet(), MemoryKeyValueStore(), HipLinearHashIndex(),
+                                         distance_method=metric)
+        lsh.build_index(_elems(x))
+        r, d = lsh.nn(DescriptorMemoryElement("q").set_vector(x[9]), 20_000)      # n covers every code: everything
+        assert len(r) == 20_000 and r[0].uuid() == 9 and (np.diff(d) >= 0).all()

@@ -193,10 +193,18 @@ def test_itq_functor_config_model_and_errors():
     f.mean_vec = np.zeros(4)
     with pytest.raises(Exception, match="rotation matrix is none"):
         f.get_hash(np.zeros(4))
-    with pytest.raises(ValueError):
-        HipItqFunctor(normalize=1)
+    # every order numpy.linalg.norm accepts for a vector is accepted, like the reference (itq.py:162-164, 172-191) ...
+    for ordv, code in ((1, _lib.SQ_NORM_L1), (2, _lib.SQ_NORM_L2), (0, _lib.SQ_NORM_L0), (np.inf, _lib.SQ_NORM_INF),
+                       (-np.inf, _lib.SQ_NORM_NEG_INF), (3, _lib.SQ_NORM_NONE), (0.5, _lib.SQ_NORM_NONE)):
+        fn = HipItqFunctor(normalize=ordv)
+        assert fn._norm_ord() == code and fn._norm_on_host() == (ordv in (3, 0.5))
+        v = np.array([[3., -4., 0.], [0., 0., 0.]])
+        np.testing.assert_array_equal(fn._norm_vector(v), O.itq_norm_vector(v, ordv))
+    # ... and what numpy rejects is rejected in the constructor
     with pytest.raises(ValueError):
         HipItqFunctor(normalize="foobar")
+    with pytest.raises(ValueError):
+        HipItqFunctor(normalize="fro")
     m, r = DataMemoryElement(), DataMemoryElement()
     g = HipItqFunctor(m, r, bit_length=3, itq_iterations=7, normalize=2, random_seed=4)
     g.mean_vec, g.rotation = np.arange(3.), np.eye(3)
