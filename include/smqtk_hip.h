@@ -166,6 +166,7 @@ int sq_hamming_search(sq_handle_t h, const uint64_t* queries, int nq, int k,
  * keeps an explicit rank per code (4 bytes, read for survivors only).  SQ_ERR_UNSUPPORTED for a borrowed array. */
 int sq_hamming_append(sq_handle_t h, const uint64_t* new_codes, int64_t m, const int64_t* insert_pos);
 int sq_hamming_remove(sq_handle_t h, const int64_t* ranks, int64_t m);
+int sq_hamming_info(sq_handle_t h, int64_t* out_n, int* out_words); /* codes held, 64-bit words per code */
 int sq_hamming_destroy(sq_handle_t h);
 
 /* ----------------------------------------------------------------- dense
@@ -245,6 +246,22 @@ int sq_rows_append(sq_handle_t h, const void* rows, int64_t n_add, int mem);
 int sq_rows_rerank(sq_handle_t h, const void* queries, int nq, int metric,
                    const int64_t* cand_rows, const int64_t* cand_offsets, int k,
                    void* out_dist, int64_t* out_pos, void* stream);
+/* The whole query path of LSHNearestNeighborIndex._nn (impls/nn_index/lsh.py:452-519) for a batch, on the device:
+ * hash the query descriptors (ItqFunctor.get_hash, lsh.py:473) -> the n nearest hash codes (HashIndex.nn,
+ * lsh.py:480-487) -> bucket expansion through the hash -> uuids store (lsh.py:489-501) -> distance per candidate row,
+ * stable sort, first n (lsh.py:505-519).  Nothing but the queries goes up and the winners come down; between the
+ * stages only two integers (candidates in total, longest list) visit the host.
+ *   sq_rows_set_buckets: the store as a CSR map over the row matrix: csr_off[n_codes + 1] (code id -> first entry),
+ *       csr_rows[n] (row numbers, bucket by bucket, row order inside a bucket); code id = row id of `hamming`
+ *       (rank of the code in the sorted unique codes).  Host arrays are copied, device arrays borrowed.
+ *   sq_lsh_query: queries [nq][d] in the rows' dtype; `itq` a resident model (sq_itq_model_create) whose codes have
+ *       the width of `hamming`'s; n_codes_wanted = the n of HashIndex.nn; k_out = results per query.
+ *       out_dist: float32[nq][k_out] for float32 rows with SQ_METRIC_L2, else float64[nq][k_out] (+inf padding);
+ *       out_rows: int64[nq][k_out] row numbers of the winners (-1 padding).  Order: (distance, position in the
+ *       candidate list) = the reference's stable sort.  mem: where queries / outputs live. */
+int sq_rows_set_buckets(sq_handle_t rows, const int64_t* csr_off, int64_t n_codes, const int64_t* csr_rows, int mem);
+int sq_lsh_query(sq_handle_t rows, sq_handle_t hamming, sq_handle_t itq, const void* queries, int nq,
+                 int n_codes_wanted, int metric, int k_out, void* out_dist, int64_t* out_rows, int mem, void* stream);
 int sq_rows_destroy(sq_handle_t h);
 
 /* ----------------------------------------------------------------- merge

@@ -42,10 +42,10 @@ EXPORTS = (
     "sq_last_error", "sq_version", "sq_device_count", "sq_device_name",
     "sq_set_option", "sq_get_stats", "sq_itq_hash",
     "sq_itq_model_create", "sq_itq_model_hash", "sq_itq_model_destroy",
-    "sq_hamming_create", "sq_hamming_search", "sq_hamming_append", "sq_hamming_remove", "sq_hamming_destroy",
+    "sq_hamming_create", "sq_hamming_search", "sq_hamming_append", "sq_hamming_remove", "sq_hamming_info", "sq_hamming_destroy",
     "sq_dense_create", "sq_dense_append", "sq_dense_search", "sq_dense_sync", "sq_dense_destroy",
     "sq_dense_distances", "sq_merge_topk", "sq_merge_topk_strided",
-    "sq_rows_create", "sq_rows_append", "sq_rows_rerank", "sq_rows_destroy",
+    "sq_rows_create", "sq_rows_append", "sq_rows_rerank", "sq_rows_set_buckets", "sq_lsh_query", "sq_rows_destroy",
     "sq_itqfit_create", "sq_itqfit_set_mean", "sq_itqfit_cov", "sq_itqfit_project", "sq_itqfit_iterate",
     "sq_itqfit_destroy",
 )
@@ -100,6 +100,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_rows_create.argtypes = [c_vp, c_int, c_i64, c_int, c_int, ctypes.POINTER(c_i64)]
     lib.sq_rows_append.argtypes = [c_i64, c_vp, c_i64, c_int]
     lib.sq_rows_rerank.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]
+    lib.sq_rows_set_buckets.argtypes = [c_i64, c_vp, c_i64, c_vp, c_int]
+    lib.sq_lsh_query.argtypes = [c_i64, c_i64, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]
+    lib.sq_hamming_info.argtypes = [c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]
     lib.sq_rows_destroy.argtypes = [c_i64]
     lib.sq_itqfit_create.argtypes = [c_vp, c_int, c_i64, c_int, c_int, c_int, c_vp, ctypes.POINTER(c_i64)]
     lib.sq_itqfit_set_mean.argtypes = [c_i64, c_vp]
@@ -504,17 +507,62 @@ class RowMatrix:
     """Descriptor rows resident on the device for the LSH re-rank stage
     (``sq_rows_*``; lsh.py:499-519).  ``rows``: ``[n, d]`` float32 or float64."""
 
-    def __init__(self, rows: np.ndarray):
-        rows = np.asarray(rows)
-        if rows.ndim != 2 or rows.dtype not in (np.float32, np.float64):
-            raise ValueError("rows must be a [n, d] float32 or float64 matrix")
-        rows = np.ascontiguousarray(rows)
-        self.dtype = rows.dtype
-        self.n, self.d = int(rows.shape[0]), int(rows.shape[1])
+    def __init__(self, rows, n: Optional[int] = None, d: Optional[int] = None, dtype=None, device_ptr: bool = False,
+                 keepalive=None):
+        if device_ptr:      # a device matrix [n, d] of `dtype`, borrowed (kept alive by `keepalive`)
+            assert n is not None and d is not None and dtype is not None
+            self.dtype = np.dtype(dtype)
+            self.n, self.d = int(n), int(d)
+            ptr, mem = _ptr(rows), SQ_MEM_DEVICE
+            self._keepalive = keepalive
+        else:
+            rows = np.asarray(rows)
+            if rows.ndim != 2 or rows.dtype not in (np.float32, np.float64):
+                raise ValueError("rows must be a [n, d] float32 or float64 matrix")
+            rows = np.ascontiguousarray(rows)
+            self.dtype = rows.dtype
+            self.n, self.d = int(rows.shape[0]), int(rows.shape[1])
+            ptr, mem = _ptr(rows), SQ_MEM_HOST
         h = ctypes.c_int64(0)
-        _check(load().sq_rows_create(_ptr(rows), SQ_DTYPE_F32 if rows.dtype == np.float32 else SQ_DTYPE_F64,
-                                     self.n, self.d, SQ_MEM_HOST, ctypes.byref(h)), "sq_rows_create")
+        _check(load().sq_rows_create(ptr, SQ_DTYPE_F32 if self.dtype == np.float32 else SQ_DTYPE_F64,
+                                     self.n, self.d, mem, ctypes.byref(h)), "sq_rows_create")
         self._h: Optional[int] = h.value
+
+    def set_buckets(self, csr_off, csr_rows, n_codes: Optional[int] = None, device_ptr: bool = False, keepalive=None) -> None:
+        """The hash -> rows store as a CSR map (``sq_rows_set_buckets``): ``csr_off[n_codes + 1]``, ``csr_rows[n]``."""
+        if device_ptr:
+            assert n_codes is not None
+            self._csr_keepalive = keepalive
+            _check(load().sq_rows_set_buckets(self._h, _ptr(csr_off), int(n_codes), _ptr(csr_rows), SQ_MEM_DEVICE),
+                   "sq_rows_set_buckets")
+            return
+        off = _host(np.asarray(csr_off), np.int64).reshape(-1)
+        rows = _host(np.asarray(csr_rows), np.int64).reshape(-1)
+        if rows.shape[0] != self.n:
+            raise ValueError("csr_rows must list every row once")
+        _check(load().sq_rows_set_buckets(self._h, _ptr(off), int(off.shape[0] - 1), _ptr(rows), SQ_MEM_HOST),
+               "sq_rows_set_buckets")
+
+    def lsh_query(self, hamming: "HammingIndex", itq: "ItqModel", queries: np.ndarray, n_codes: int, metric: int,
+                  k: int) -> Tuple[np.ndarray, np.ndarray]:
+        """``sq_lsh_query``: hash -> nearest ``n_codes`` codes -> bucket expansion -> exact re-rank, all on the device.
+        Returns (dist ``[nq, k]``, rows ``[nq, k]``; -1 / +inf padding)."""
+        q = _host(np.asarray(queries), self.dtype)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError("queries must be [nq, d]")
+        nq = q.shape[0]
+        k64 = self.dtype == np.float32 and metric == SQ_METRIC_L2
+        dist = np.empty((nq, k), dtype=np.float32 if k64 else np.float64)
+        rows = np.empty((nq, k), dtype=np.int64)
+        _check(load().sq_lsh_query(self._h, hamming.handle, itq.handle, _ptr(q), nq, int(n_codes), int(metric), int(k),
+                                   _ptr(dist), _ptr(rows), SQ_MEM_HOST, None), "sq_lsh_query")
+        return dist, rows
+
+    def lsh_query_device(self, hamming: "HammingIndex", itq: "ItqModel", q_ptr: int, nq: int, n_codes: int, metric: int,
+                         k: int, out_dist_ptr: int, out_rows_ptr: int, stream: int = 0) -> None:
+        _check(load().sq_lsh_query(self._h, hamming.handle, itq.handle, _ptr(q_ptr), int(nq), int(n_codes), int(metric),
+                                   int(k), _ptr(out_dist_ptr), _ptr(out_rows_ptr), SQ_MEM_DEVICE,
+                                   ctypes.c_void_p(stream or None)), "sq_lsh_query")
 
     def append(self, rows: np.ndarray) -> None:
         """Rows ``[m, d]`` of the matrix's dtype behind the resident ones (``sq_rows_append``)."""

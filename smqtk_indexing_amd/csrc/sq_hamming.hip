@@ -527,6 +527,9 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
     const int kk = (int)(k < n ? k : n);
     const bool prof = g_opt.profile != 0;
     u32 cap = g_opt.candidate_cap > 0 ? (u32)g_opt.candidate_cap : 65536u;
+    // room for the tie group at the threshold distance (integer distances: the codes AT the threshold can outnumber
+    // those below it several times)
+    if (g_opt.candidate_cap <= 0 && cap < (u32)std::min<long long>(16ll * kk, 1ll << 30)) cap = (u32)std::min<long long>(16ll * kk, 1ll << 30);
     if (cap < (u32)(2 * kk)) cap = (u32)(2 * kk);
     const bool small = n <= (long long)cap;
     h->stats = sq_stats_t{};
@@ -568,6 +571,11 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         const long long per_block = 256ll * (W == 1 ? 4 : W == 2 ? 2 : 1);
         const long long blocks_all = (n + per_block - 1) / per_block;
         while (step > 1 && (blocks_all / step) * per_block < 64ll * kk) step >>= 1;
+        // the threshold admits ~step * k codes (k of them in the 1/step sample) times the tie expansion: keep that
+        // inside the candidate lists.  (At the default step of 64 every query with k >= ~500 overflowed its list
+        // and took the exact path: 18 ms per query at 10 M codes, found by bench.py --workload lsh_c3.)
+        if (g_opt.sample_stride <= 0)
+            while (step > 1 && (long long)step * kk * 8 > (long long)cap) step >>= 1;
         SQ_TRY(h->hist.reserve((size_t)nq * (bits + 1) * 4));
         u32* hist = h->hist.as<u32>();
         SQ_HIP(hipMemsetAsync(hist, 0, (size_t)nq * (bits + 1) * 4, st));
@@ -903,6 +911,15 @@ extern "C" int sq_hamming_remove(sq_handle_t hid, const int64_t* ranks, int64_t 
                        n - m, rr, (long long)m);
     SQ_HIP(hipDeviceSynchronize());
     h->n = n - m;
+    return SQ_OK;
+}
+
+extern "C" int sq_hamming_info(sq_handle_t hid, int64_t* out_n, int* out_words) {
+    auto* h = static_cast<HammingHandle*>(lookup_handle(hid, H_HAMMING));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_hamming_info: unknown handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (out_n) *out_n = h->n;
+    if (out_words) *out_words = h->words;
     return SQ_OK;
 }
 

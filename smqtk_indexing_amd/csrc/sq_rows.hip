@@ -9,6 +9,7 @@
 // distances in the reference's arithmetic (the code of sq_dense_distances) and
 // returns the k smallest in (distance, position in the candidate list) order,
 // which is exactly the order a stable sort over the candidate list produces.
+#include <algorithm>
 #include <vector>
 
 #include "sq_dense_exact.cuh"
@@ -22,10 +23,19 @@ struct RowsHandle : HandleBase {
     long long n = 0;
     int d = 0;
     DevBuf q_dev, cand_dev, off_dev, cnt_dev, keys, out_keys, out_dist, out_pos, sort_tmp;
+    // bucket map of the LSH index (sq_rows_set_buckets): code id -> rows, CSR; and the scratch of sq_lsh_query
+    const long long* csr_off = nullptr;   // device [n_codes + 1]
+    const long long* csr_rows = nullptr;  // device [n]
+    long long n_codes = 0;
+    DevBuf csr_off_owned, csr_rows_owned, codes_dev, ham_dist, ham_idx, pre_dev, out_rows;
+    HostPinned totals_host;               // [total candidates, largest list]
     PinnedStage stage;
     ~RowsHandle() override {
         stage.release();
-        for (DevBuf* b : {&owned, &q_dev, &cand_dev, &off_dev, &cnt_dev, &keys, &out_keys, &out_dist, &out_pos, &sort_tmp}) b->release();
+        totals_host.release();
+        for (DevBuf* b : {&owned, &q_dev, &cand_dev, &off_dev, &cnt_dev, &keys, &out_keys, &out_dist, &out_pos, &sort_tmp,
+                          &csr_off_owned, &csr_rows_owned, &codes_dev, &ham_dist, &ham_idx, &pre_dev, &out_rows})
+            b->release();
     }
 };
 
@@ -108,6 +118,97 @@ __global__ void rows_finalize_kernel(const K* __restrict__ sorted, const u32* __
             reinterpret_cast<double*>(out_dist)[(long long)q * k + i] = ok ? unordered_f64(key.hi) : (double)__builtin_inff();
             out_pos[(long long)q * k + i] = ok ? (long long)key.lo : -1ll;
         }
+    }
+}
+
+// ------------------------------------------------------------------ bucket expansion on the device
+// LSHNearestNeighborIndex._nn, lsh.py:489-501: every near hash code is looked up in the hash -> uuids store and the
+// buckets are concatenated in the order of the codes.  Here the store is a CSR map (code id -> rows) resident on
+// the device and the nearest code ids arrive straight from the Hamming search (device memory): a query's candidate
+// list is built without the ids ever visiting the host.
+// (1) per query: bucket sizes of its m code ids (-1 = none), exclusive prefix (pre[q][j]) and total (tot[q]).
+static __global__ __launch_bounds__(256) void lsh_bucket_sizes_kernel(const long long* __restrict__ ids, int m,
+                                                                       const long long* __restrict__ csr_off, long long n_codes,
+                                                                       long long* __restrict__ pre, long long* __restrict__ tot) {
+    const int q = blockIdx.x;
+    __shared__ long long s_wave[4];
+    __shared__ long long s_run;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j0 = 0; j0 < m; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        long long len = 0;
+        if (j < m) {
+            const long long id = ids[(long long)q * m + j];
+            if (id >= 0 && id < n_codes) len = csr_off[id + 1] - csr_off[id];
+        }
+        long long inc = len;  // inclusive scan inside the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_wave[wv] = inc;
+        __syncthreads();
+        long long base = s_run;
+        for (int w = 0; w < wv; ++w) base += s_wave[w];
+        if (j < m) pre[(long long)q * m + j] = base + inc - len;
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tot[q] = s_run;
+}
+// (2) offsets of the queries' lists and the two numbers the host needs to size the re-rank: [total, largest list]
+static __global__ void lsh_offsets_kernel(const long long* __restrict__ tot, int nq, long long* __restrict__ off,
+                                          long long* __restrict__ totals_host) {
+    if (blockIdx.x || threadIdx.x) return;
+    long long run = 0, mx = 0;
+    for (int q = 0; q < nq; ++q) {
+        off[q] = run;
+        run += tot[q];
+        mx = tot[q] > mx ? tot[q] : mx;
+    }
+    off[nq] = run;
+    totals_host[0] = run;
+    totals_host[1] = mx;
+}
+// (3) the candidate lists: bucket j of query q starts at off[q] + pre[q][j]; rows of a bucket in row order
+static __global__ __launch_bounds__(256) void lsh_fill_candidates_kernel(const long long* __restrict__ ids, int m,
+                                                                          const long long* __restrict__ csr_off,
+                                                                          const long long* __restrict__ csr_rows, long long n_codes,
+                                                                          const long long* __restrict__ pre,
+                                                                          const long long* __restrict__ off,
+                                                                          long long* __restrict__ cand) {
+    const int q = blockIdx.y;
+    const int j = blockIdx.x * 32 + (threadIdx.x >> 3);  // eight lanes per bucket
+    if (j >= m) return;
+    const long long id = ids[(long long)q * m + j];
+    if (id < 0 || id >= n_codes) return;
+    const long long b0 = csr_off[id], len = csr_off[id + 1] - b0;
+    long long* dst = cand + off[q] + pre[(long long)q * m + j];
+    for (long long t = threadIdx.x & 7; t < len; t += 8) dst[t] = csr_rows[b0 + t];
+}
+// winners: positions in the candidate list -> row numbers
+template <class K>
+__global__ void lsh_finalize_kernel(const K* __restrict__ sorted, const u32* __restrict__ cnt, int k_sel, int k_out,
+                                    const long long* __restrict__ cand, const long long* __restrict__ off,
+                                    void* __restrict__ out_dist, long long* __restrict__ out_rows) {
+    const int q = blockIdx.x;
+    const u32 c = cnt[q];
+    for (int i = threadIdx.x; i < k_out; i += blockDim.x) {
+        const bool ok = i < k_sel && (u32)i < c;
+        long long row = -1;
+        if constexpr (sizeof(K) == 8) {
+            const K key = ok ? sorted[(long long)q * k_sel + i] : 0ull;
+            reinterpret_cast<float*>(out_dist)[(long long)q * k_out + i] = ok ? unordered_f32((u32)(key >> 32)) : __builtin_inff();
+            if (ok) row = cand[off[q] + (long long)(key & 0xffffffffull)];
+        } else {
+            const K key = ok ? sorted[(long long)q * k_sel + i] : K128{0ull, 0ull};
+            reinterpret_cast<double*>(out_dist)[(long long)q * k_out + i] = ok ? unordered_f64(key.hi) : (double)__builtin_inff();
+            if (ok) row = cand[off[q] + (long long)key.lo];
+        }
+        out_rows[(long long)q * k_out + i] = row;
     }
 }
 
@@ -256,6 +357,135 @@ extern "C" int sq_rows_rerank(sq_handle_t hid, const void* queries, int nq, int 
     SQ_HIP(h->stage.out(out_pos, h->out_pos.p, (size_t)nq * k * 8, st));
     SQ_HIP(stream_wait(st));
     h->stage.finish();
+    return SQ_OK;
+}
+
+extern "C" int sq_rows_set_buckets(sq_handle_t hid, const int64_t* csr_off, int64_t n_codes, const int64_t* csr_rows, int mem) {
+    auto* h = static_cast<RowsHandle*>(lookup_handle(hid, H_ROWS));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_rows_set_buckets: unknown handle");
+    if (!csr_off || !csr_rows || n_codes <= 0) return fail(SQ_ERR_INVALID, "sq_rows_set_buckets: bad argument");
+    std::lock_guard<std::mutex> lock(h->mu);
+    SQ_HIP(hipSetDevice(h->device));
+    if (mem == SQ_MEM_DEVICE) {
+        h->csr_off = reinterpret_cast<const long long*>(csr_off);
+        h->csr_rows = reinterpret_cast<const long long*>(csr_rows);
+    } else {
+        if (csr_off[0] != 0 || csr_off[n_codes] != h->n)
+            return fail(SQ_ERR_INVALID, "sq_rows_set_buckets: offsets must start at 0 and end at the row count");
+        SQ_TRY(h->csr_off_owned.reserve((size_t)(n_codes + 1) * 8));
+        SQ_TRY(h->csr_rows_owned.reserve((size_t)h->n * 8));
+        SQ_HIP(hipMemcpy(h->csr_off_owned.p, csr_off, (size_t)(n_codes + 1) * 8, hipMemcpyHostToDevice));
+        SQ_HIP(hipMemcpy(h->csr_rows_owned.p, csr_rows, (size_t)h->n * 8, hipMemcpyHostToDevice));
+        h->csr_off = h->csr_off_owned.as<long long>();
+        h->csr_rows = h->csr_rows_owned.as<long long>();
+    }
+    h->n_codes = n_codes;
+    return SQ_OK;
+}
+
+namespace sq {
+template <class T, class K>
+static int lsh_rerank_t(RowsHandle* h, int nq, int metric, long long maxc, int k_sel, int k_out, void* out_dist_dev,
+                        long long* out_rows_dev, hipStream_t st) {
+    SQ_TRY(h->keys.reserve((size_t)nq * maxc * sizeof(K)));
+    SQ_TRY(h->out_keys.reserve((size_t)nq * k_sel * sizeof(K)));
+    const unsigned gx = (unsigned)((maxc + 31) / 32);
+    hipLaunchKernelGGL((rows_rerank_keys_kernel<T, K>), dim3(gx, nq), dim3(256), 0, st,
+                       reinterpret_cast<const T*>(h->rows), h->n, h->d, h->q_dev.as<T>(), metric,
+                       h->cand_dev.as<long long>(), h->off_dev.as<long long>(), maxc, h->keys.as<K>(), h->cnt_dev.as<u32>());
+    SQ_TRY(rows_select<K>(h->keys.as<K>(), h->cnt_dev.as<u32>(), (u32)maxc, maxc, k_sel, nq, h->out_keys.as<K>(), st, h->sort_tmp));
+    hipLaunchKernelGGL((lsh_finalize_kernel<K>), dim3(nq), dim3(256), 0, st, h->out_keys.as<K>(), h->cnt_dev.as<u32>(), k_sel,
+                       k_out, h->cand_dev.as<long long>(), h->off_dev.as<long long>(), out_dist_dev, out_rows_dev);
+    SQ_HIP(hipGetLastError());
+    return SQ_OK;
+}
+}  // namespace sq
+
+extern "C" int sq_hamming_info(sq_handle_t h, int64_t* out_n, int* out_words);
+
+extern "C" int sq_lsh_query(sq_handle_t rows_h, sq_handle_t hamming_h, sq_handle_t itq_h, const void* queries, int nq,
+                            int n_codes_wanted, int metric, int k_out, void* out_dist, int64_t* out_rows, int mem,
+                            void* stream) {
+    auto* h = static_cast<RowsHandle*>(lookup_handle(rows_h, H_ROWS));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_lsh_query: unknown row matrix handle");
+    if (!queries || !out_dist || !out_rows || nq <= 0 || n_codes_wanted <= 0 || k_out <= 0)
+        return fail(SQ_ERR_INVALID, "sq_lsh_query: bad argument");
+    if (metric != SQ_METRIC_L2 && metric != SQ_METRIC_COSINE) return fail(SQ_ERR_INVALID, "sq_lsh_query: unknown metric");
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->csr_off) return fail(SQ_ERR_INVALID, "sq_lsh_query: no bucket map (sq_rows_set_buckets)");
+    int64_t ham_n = 0;
+    int words = 0;
+    SQ_TRY(sq_hamming_info(hamming_h, &ham_n, &words));
+    if (ham_n != h->n_codes) return fail(SQ_ERR_INVALID, "sq_lsh_query: the hash index holds %lld codes, the bucket map %lld",
+                                         (long long)ham_n, h->n_codes);
+    SQ_HIP(hipSetDevice(h->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool f32 = h->dtype == SQ_DTYPE_F32;
+    const bool k64 = f32 && metric == SQ_METRIC_L2;
+    const size_t esz = f32 ? 4 : 8, dsz = k64 ? 4 : 8;
+    const int m = (int)std::min<long long>(n_codes_wanted, ham_n);  // nearest codes per query
+    const void* q_dev = queries;
+    if (mem != SQ_MEM_DEVICE) {
+        SQ_TRY(h->q_dev.reserve((size_t)nq * h->d * esz));
+        SQ_TRY(h->stage.begin((size_t)nq * h->d * esz + (size_t)nq * k_out * (dsz + 8)));
+        SQ_HIP(h->stage.in(h->q_dev.p, queries, (size_t)nq * h->d * esz, st));
+        q_dev = h->q_dev.p;
+    } else {
+        // the re-rank kernels read the queries from q_dev: borrow the caller's buffer for this call
+        SQ_TRY(h->q_dev.reserve((size_t)nq * h->d * esz));
+        SQ_HIP(hipMemcpyAsync(h->q_dev.p, queries, (size_t)nq * h->d * esz, hipMemcpyDeviceToDevice, st));
+        q_dev = h->q_dev.p;
+    }
+    // hash (lsh.py:473), nearest codes (lsh.py:480-487): device to device
+    SQ_TRY(h->codes_dev.reserve((size_t)nq * words * 8));
+    SQ_TRY(h->ham_dist.reserve((size_t)nq * m * 4));
+    SQ_TRY(h->ham_idx.reserve((size_t)nq * m * 8));
+    SQ_TRY(sq_itq_model_hash(itq_h, q_dev, h->dtype, nq, h->codes_dev.as<uint64_t>(), SQ_MEM_DEVICE, st));
+    SQ_TRY(sq_hamming_search(hamming_h, h->codes_dev.as<uint64_t>(), nq, m, h->ham_dist.as<int32_t>(), h->ham_idx.as<int64_t>(),
+                             SQ_MEM_DEVICE, st));
+    // bucket expansion (lsh.py:489-501) on the device; only [total, largest list] comes back
+    SQ_TRY(h->pre_dev.reserve((size_t)nq * m * 8 + (size_t)nq * 8));
+    SQ_TRY(h->off_dev.reserve((size_t)(nq + 1) * 8));
+    SQ_TRY(h->cnt_dev.reserve((size_t)nq * 4));
+    SQ_TRY(h->totals_host.reserve(16));
+    long long* pre = h->pre_dev.as<long long>();
+    long long* tot = pre + (size_t)nq * m;
+    long long* th = reinterpret_cast<long long*>(h->totals_host.p);
+    long long* th_dev = nullptr;
+    SQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&th_dev), th, 0));
+    hipLaunchKernelGGL(lsh_bucket_sizes_kernel, dim3(nq), dim3(256), 0, st, h->ham_idx.as<long long>(), m, h->csr_off, h->n_codes,
+                       pre, tot);
+    hipLaunchKernelGGL(lsh_offsets_kernel, dim3(1), dim3(1), 0, st, tot, nq, h->off_dev.as<long long>(), th_dev);
+    SQ_HIP(stream_wait(st));
+    const long long total = th[0], maxc = th[1];
+    if (maxc >= (1ll << 32)) return fail(SQ_ERR_UNSUPPORTED, "sq_lsh_query: more than 2^32-1 candidates for one query");
+    void* od = out_dist;
+    long long* orow = reinterpret_cast<long long*>(out_rows);
+    if (mem != SQ_MEM_DEVICE) {
+        SQ_TRY(h->out_dist.reserve((size_t)nq * k_out * dsz));
+        SQ_TRY(h->out_rows.reserve((size_t)nq * k_out * 8));
+        od = h->out_dist.p;
+        orow = h->out_rows.as<long long>();
+    }
+    SQ_TRY(h->cand_dev.reserve((size_t)(total > 0 ? total : 1) * 8));
+    const long long mc = maxc > 0 ? maxc : 1;
+    hipLaunchKernelGGL(lsh_fill_candidates_kernel, dim3((unsigned)((m + 31) / 32), nq), dim3(256), 0, st, h->ham_idx.as<long long>(),
+                       m, h->csr_off, h->csr_rows, h->n_codes, pre, h->off_dev.as<long long>(), h->cand_dev.as<long long>());
+    const int k_sel = (int)std::min<long long>(k_out, mc);
+    int rc;
+    if (k64)
+        rc = lsh_rerank_t<float, u64>(h, nq, metric, mc, k_sel, k_out, od, orow, st);
+    else if (f32)
+        rc = lsh_rerank_t<float, K128>(h, nq, metric, mc, k_sel, k_out, od, orow, st);
+    else
+        rc = lsh_rerank_t<double, K128>(h, nq, metric, mc, k_sel, k_out, od, orow, st);
+    if (rc != SQ_OK) return rc;
+    if (mem != SQ_MEM_DEVICE) {
+        SQ_HIP(h->stage.out(out_dist, od, (size_t)nq * k_out * dsz, st));
+        SQ_HIP(h->stage.out(out_rows, orow, (size_t)nq * k_out * 8, st));
+        SQ_HIP(stream_wait(st));
+        h->stage.finish();
+    }
     return SQ_OK;
 }
 

@@ -69,6 +69,7 @@ class _DeviceMirror:
         order = np.argsort(inverse, kind="stable")               # rows grouped by code id, row order inside a bucket
         self.csr_rows = order.astype(np.int64)
         self.csr_off = np.searchsorted(inverse[order], np.arange(codes.shape[0] + 1)).astype(np.int64)
+        self.rows.set_buckets(self.csr_off, self.csr_rows)       # the bucket map next to the rows (sq_lsh_query)
         self.own_index: Optional[HipLinearHashIndex] = None      # for hash_index=None
         self.checked_codes: Optional[np.ndarray] = None          # hash_index code array last compared with self.codes
         self.checked_ok = False
@@ -143,7 +144,8 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
         self.device_rerank = bool(device_rerank)
         self._mirror: Optional[_DeviceMirror] = None
         self._mirror_tried = False
-        self._count_cache: Optional[Tuple[int, int]] = None
+        self._count_cache: Optional[Tuple[Tuple[int, int], int]] = None
+        self._mirror_key: Optional[Tuple[int, int]] = None
         self.lsh_functor = lsh_functor
         self.descriptor_set = descriptor_set
         self.hash_index = hash_index
@@ -181,12 +183,50 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
         hv = np.vstack([np.asarray(self.lsh_functor.get_hash(v)).astype(bool) for v in vectors])
         return hv, packed_to_ints(pack_bits_msb(hv))
 
+    @staticmethod
+    def _buckets(uids: List[Hashable], keys: List[int]) -> Dict[int, Set[Hashable]]:
+        """hash code -> set of uuids for descriptors (uids) with integer codes (keys): one python step per BUCKET
+        (argsort + run boundaries), not per descriptor as lsh.py:316-323 walks them."""
+        if not uids:
+            return {}
+        try:
+            ka = np.asarray(keys, dtype=np.uint64)                    # codes up to 64 bits: sortable as machine words
+        except OverflowError:
+            ka = None
+        if ka is None or ka.dtype != np.uint64:
+            out: Dict[int, Set[Hashable]] = collections.defaultdict(set)
+            for u, key in zip(uids, keys):
+                out[key].add(u)
+            return dict(out)
+        order = np.argsort(ka, kind="stable")
+        sk = ka[order]
+        starts = np.flatnonzero(np.concatenate(([True], sk[1:] != sk[:-1])))
+        ends = np.append(starts[1:], len(sk))
+        ol = order.tolist()
+        return {int(sk[a]): {uids[i] for i in ol[a:b]} for a, b in zip(starts.tolist(), ends.tolist())}
+
     # ---------------------------------------------------------- device mirror
     def _drop_mirror(self) -> None:
         if self._mirror is not None:
             self._mirror.close()
         self._mirror = None
         self._mirror_tried = False
+        self._mirror_key = None
+
+    def _state_key(self) -> Tuple[int, int]:
+        """A cheap version of the two stores this index reads: (hash codes in the key-value store, descriptors in the
+        set).  The caches below (bucket-size sum, device mirror) are only valid for the state they were built from;
+        stores shared with another writer (a database-backed DescriptorSet / KeyValueStore) change underneath, and
+        every change this key sees drops the caches.  A change it cannot see -- a uuid moving between existing
+        buckets of a shared store with both counts unchanged -- needs an explicit :meth:`refresh`."""
+        return len(self.hash2uuids_kvstore), int(self.descriptor_set.count())
+
+    def refresh(self) -> None:
+        """Forget everything cached from the stores (device mirror, bucket-size sum): the next query re-reads them.
+        Call after the descriptor set or the key-value store was modified by someone other than this index."""
+        with self._model_lock:
+            self._drop_mirror()
+            self._count_cache = None
 
     def _set_mirror(self, elems: List[DescriptorElement], vectors: List[np.ndarray], hv: np.ndarray) -> None:
         """(Re)build the device mirror from descriptors in row order, their vectors and bool codes."""
@@ -203,8 +243,11 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
         if mat.ndim != 2 or mat.dtype not in (np.float32, np.float64):
             return
         self._mirror = _DeviceMirror([d.uuid() for d in elems], mat, pack_bits_msb(np.asarray(hv).astype(bool)))
+        self._mirror_key = self._state_key()
 
     def _ensure_mirror(self) -> Optional[_DeviceMirror]:
+        if self._mirror is not None and self._mirror_key != self._state_key():
+            self._drop_mirror()            # the stores changed underneath (another writer): rebuild from them
         if self._mirror is None and not self._mirror_tried and self.device_rerank:
             elems = list(self.descriptor_set)
             if elems:
@@ -240,6 +283,20 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
         hi = self._mirror_hash_index(m)
         if hi is None:
             return None
+        f = self.lsh_functor
+        if (hasattr(f, "_device_model") and hasattr(f, "_norm_on_host") and not f._norm_on_host() and f.has_model()
+                and words_for_bits(f.rotation.shape[1]) == m.codes.shape[1] and f.rotation.shape[0] == m.rows.d):
+            # the whole query path in one device call (sq_lsh_query): hash -> nearest codes -> bucket expansion ->
+            # exact re-rank; only the queries go up and the n winners per query come down (lsh.py:473-519)
+            k = int(min(n, m.rows.n))
+            dist, rows = m.rows.lsh_query(hi._device(), f._device_model(), vectors, n, self._metric, k)
+            out = []
+            for qi in range(vectors.shape[0]):
+                good = rows[qi] >= 0
+                uuids = [m.uuids[int(r)] for r in rows[qi][good]]
+                descrs = tuple(self.descriptor_set.get_many_descriptors(uuids))
+                out.append((descrs, tuple(float(x) for x in dist[qi][good])))
+            return out
         if hasattr(self.lsh_functor, "get_hash_packed"):
             qp = self.lsh_functor.get_hash_packed(vectors)      # packed codes straight from the device  # type: ignore[attr-defined]
         else:
@@ -293,9 +350,9 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
         # NearestNeighborsIndex.nn calls count() per query; here the sum is cached and recomputed only
         # after this index mutated the store or the store's key count changed underneath it.
         with self._model_lock:
-            nkeys = len(self.hash2uuids_kvstore)
-            if self._count_cache is None or self._count_cache[0] != nkeys:
-                self._count_cache = (nkeys, sum(len(s) for s in self.hash2uuids_kvstore.values()))
+            key = self._state_key()
+            if self._count_cache is None or self._count_cache[0] != key:
+                self._count_cache = (key, sum(len(s) for s in self.hash2uuids_kvstore.values()))
             return self._count_cache[1]
 
     def _build_index(self, descriptors: Iterable[DescriptorElement]) -> None:
@@ -307,10 +364,7 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
             elems = list(self.descriptor_set)
             vectors = [d.vector() for d in elems]
             hv, keys = self._hash_many(vectors)
-            update: Dict[Hashable, Set[Hashable]] = collections.defaultdict(set)
-            for d, key in zip(elems, keys):
-                update[key].add(d.uuid())
-            self.hash2uuids_kvstore.add_many(update)
+            self.hash2uuids_kvstore.add_many(self._buckets([d.uuid() for d in elems], keys))
             self._count_cache = None
             if self.hash_index is not None:
                 self.hash_index.build_index(hv)
@@ -326,11 +380,9 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
             self.descriptor_set.add_many_descriptors(elems)
             vectors = [d.vector() for d in elems]
             hv, keys = self._hash_many(vectors)
-            update: Dict[Hashable, Set[Hashable]] = {}
-            for d, key in zip(elems, keys):
-                if key not in update:
-                    update[key] = self.hash2uuids_kvstore.get(key, set())
-                update[key] |= {d.uuid()}
+            update: Dict[Hashable, Set[Hashable]] = self._buckets(uids, keys)
+            for key in update:                                       # union with what the store holds (lsh.py:364-378)
+                update[key] |= self.hash2uuids_kvstore.get(key, set())
             self.hash2uuids_kvstore.add_many(update)
             self._count_cache = None
             if self.hash_index is not None:
@@ -344,6 +396,7 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
                         # only the new descriptors are uploaded (sq_rows_append); lsh.py:364-378 likewise touches
                         # only the new descriptors' buckets
                         m.append(uids, mat, pack_bits_msb(np.asarray(hv).astype(bool)))
+                        self._mirror_key = self._state_key()
                         appended = True
                 except ValueError:
                     appended = False

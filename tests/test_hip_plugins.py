@@ -719,3 +719,46 @@ def test_plugins_answer_large_n():
         lsh.build_index(_elems(x))
         r, d = lsh.nn(DescriptorMemoryElement("q").set_vector(x[9]), 20_000)      # n covers every code: everything
         assert len(r) == 20_000 and r[0].uuid() == 9 and (np.diff(d) >= 0).all()
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_lsh_query_composite_matches_oracle(dt, metric):
+    """sq_lsh_query: hash -> nearest codes -> bucket expansion -> exact re-rank in one device call, against the
+    oracle's restatement of lsh.py:452-519 (the same canonical code order, so rows AND distances must agree)."""
+    rng = np.random.default_rng(83)
+    n, d, bits = 6000, 40, 9                                    # 9 bits: ~500 buckets of ~12 rows
+    db = rng.standard_normal((n, d)).astype(dt)
+    db[100] = db[7]
+    mean = db[:500].mean(axis=0).astype(np.float64)
+    q_, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    rot = np.ascontiguousarray(q_[:, :bits])
+    packed = _lib.itq_hash(db, mean, rot)
+    uniq, inv = np.unique(packed, axis=0, return_inverse=True)
+    inv = np.asarray(inv).reshape(-1)
+    order = np.argsort(inv, kind="stable").astype(np.int64)
+    off = np.searchsorted(inv[order], np.arange(uniq.shape[0] + 1)).astype(np.int64)
+    buckets = [order[off[u]:off[u + 1]].tolist() for u in range(uniq.shape[0])]
+    hidx = _lib.HammingIndex(uniq)
+    rows = _lib.RowMatrix(db)
+    rows.set_buckets(off, order)
+    model = _lib.ItqModel(mean, rot)
+    m = _lib.SQ_METRIC_L2 if metric == "euclidean" else _lib.SQ_METRIC_COSINE
+    qs = rng.standard_normal((5, d)).astype(dt)
+    qs[0] = db[7]
+    for ncodes in (1, 7, 60, 10_000):
+        k = min(ncodes, n) if ncodes < 100 else 300
+        dist, got = rows.lsh_query(hidx, model, qs, ncodes, m, k)
+        for qi, q in enumerate(qs):
+            ids, rd = O.lsh_nn(q, ncodes, mean, rot, None, uniq, buckets, db, metric)   # the n nearest codes, top n rows
+            ids, rd = ids[:k], rd[:k]
+            kk = len(ids)
+            np.testing.assert_array_equal(got[qi, :kk], ids)
+            assert (got[qi, kk:] == -1).all()
+            if metric == "euclidean":
+                np.testing.assert_array_equal(dist[qi, :kk], rd.astype(dist.dtype))
+            else:
+                np.testing.assert_allclose(dist[qi, :kk], rd, rtol=1e-12, atol=1e-15)
+    rows.close()
+    hidx.close()
+    model.close()

@@ -373,3 +373,32 @@ def test_entry_points_name_importable_plugin_modules():
             os.environ["SMQTK_PLUGIN_PATH"] = old
     for pkg in cfg["tool"]["setuptools"]["packages"]:
         importlib.import_module(pkg)
+
+
+def test_lsh_bucket_construction_and_refresh():
+    """hash2uuids built one step per bucket (not per descriptor) equals the per-descriptor walk of lsh.py:316-323;
+    codes wider than 64 bits take the plain walk.  refresh() / the store-version key drop the caches when the
+    stores changed underneath the index."""
+    rng = np.random.default_rng(3)
+    keys = [int(x) for x in rng.integers(0, 50, size=400)] + [2 ** 64 - 1, 2 ** 63]
+    uids = [f"u{i}" for i in range(len(keys))]
+    want = {}
+    for u, key in zip(uids, keys):
+        want.setdefault(key, set()).add(u)
+    assert HipLSHNearestNeighborIndex._buckets(uids, keys) == want
+    wide = keys[:20] + [2 ** 70 + 3, 2 ** 70 + 3]
+    got = HipLSHNearestNeighborIndex._buckets(uids[:22], wide)
+    assert got[2 ** 70 + 3] == {"u20", "u21"} and sum(map(len, got.values())) == 22
+    assert HipLSHNearestNeighborIndex._buckets([], []) == {}
+    f = HipItqFunctor(bit_length=2)
+    f.mean_vec, f.rotation = np.zeros(3), np.eye(3)[:, :2]
+    idx = HipLSHNearestNeighborIndex(f, MemoryDescriptorSet(), MemoryKeyValueStore(), None, distance_method="euclidean")
+    idx.hash2uuids_kvstore.add_many({1: {"a", "b"}, 2: {"c"}})
+    idx.descriptor_set.add_many_descriptors([DescriptorMemoryElement(u).set_vector(np.ones(3)) for u in "abc"])
+    assert idx.count() == 3
+    idx.hash2uuids_kvstore.add_many({3: {"d"}})                # another writer: a new bucket -> the key changes
+    assert idx.count() == 4
+    idx.hash2uuids_kvstore.add_many({1: {"a", "b", "e"}})      # same number of buckets, same descriptor count:
+    assert idx.count() == 4                                     # not visible to the cheap key ...
+    idx.refresh()
+    assert idx.count() == 5                                     # ... refresh() re-reads the stores
