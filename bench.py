@@ -220,6 +220,18 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         elapsed = float(t.item())
     n_stats = len(scan_ms)
     head_scan_ms = float(np.mean(scan_ms)) if scan_ms else 0.0
+    # the same kernel without anything running beside it (blocking calls, after the timed region): in the pipelined
+    # steps above the scan of one call shares the device with the short kernels of its neighbours, so its bracketed
+    # duration there is longer than its own streaming time
+    alone_ms = None
+    if use_async and not use_dist:
+        od1 = torch.empty((nq, k), dtype=ddt, device=dev)
+        oi1 = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        al = []
+        for _ in range(12):
+            index.search_device(queries.data_ptr(), nq, k, od1.data_ptr(), oi1.data_ptr(), stream)
+            al.append(index.stats()["scan_ms"])
+        alone_ms = float(np.mean(al[2:]))
     head_cands = float(np.mean(cands)) / nq if cands else None
     head_fb = int(np.sum(fallbacks)) if fallbacks else 0
 
@@ -392,6 +404,11 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 "traffic": None,
                 "traffic_replayed": replay,
                 "kernel": "dense_scan_kernel (full pass)", "kernel_ms": head_scan_ms,
+                "kernel_ms_note": "mean hipEvent-bracketed duration of the full-pass launches INSIDE the timed region; with pipelined "
+                                  "calls the scan shares the device with the neighbouring calls' short kernels (and runs on 3/4 of the "
+                                  "CUs to leave them room), so this is longer than the kernel alone: kernel_ms_unoverlapped",
+                "kernel_ms_unoverlapped": alone_ms,
+                "frac_unoverlapped": streamed / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if alone_ms else None,
                 "bytes_definition": "achieved/frac: bytes the kernel streams per launch = n_pad*(2*d_pad + 4) (bf16 scan copy + f32 norms)",
                 "streamed_bytes_per_launch": streamed,
                 "bytes_per_row": d_pad * 2 + (0 if cosine else 4),

@@ -353,7 +353,13 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         SQ_TRY(s.sample.reserve((size_t)nq_pad * ns * 4));
         SQ_TRY(s.keys.reserve((size_t)nq * key_stride * key_bytes));
         const int cus = cu_count(h->device);
-        int nrb = g_opt.dense_blocks > 0 ? g_opt.dense_blocks : cus;
+        // One scan workgroup per CU fills the chip -- and leaves nothing for the other call slot's short kernels
+        // (re-rank, select of the previous call; query prep, sample pass, threshold of the next), whose workgroups
+        // need LDS of their own.  When the two slots run on their own streams the scan takes three quarters of
+        // the CUs: alone it is as fast (HBM bound: 0.433 ms on 160 workgroups against 0.439 on 256 at 10 M x 128),
+        // and the pipelined step drops from 0.50 to 0.46 ms (tools/step_sweep.py dense_blocks=...).
+        // (one query tile per wave only: the multi-tile configurations are MFMA bound and want every CU)
+        int nrb = g_opt.dense_blocks > 0 ? g_opt.dense_blocks : (use_event && g_opt.dense_async_streams == 2 && qt == 1 ? cus * 3 / 4 : cus);
         nrb = (nrb + 7) / 8 * 8;
         const int wv = scan_geometry(d_pad, qt, qp).waves;
         // survivors leave the scan as per-wave segments; the re-rank kernel turns them into per-query key lists
@@ -849,11 +855,16 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
         SQ_TRY(dense_resolve(h, s));  // (the call two back; normally resolved during the previous call)
         hipStream_t run = st;
         if (g_opt.dense_async_streams == 2) {
-            if (!s.own) SQ_HIP(hipStreamCreateWithFlags(&s.own, hipStreamNonBlocking));
+            // One query tile per wave (HBM bound): the two slots alternate between two streams, so neighbouring
+            // calls overlap.  Larger batches (MFMA bound, and kept cheap in HBM traffic by all workgroups of an XCD
+            // walking the same rows) must not run two scans at once -- two scans at different rows evict each
+            // other's rows from L2 (256 queries: 1.17 -> 1.68 ms per call): they share slot 0's stream.
+            DenseSlot& owner = scan_query_tiles(h->d_pad, (nq + TILE_ROWS - 1) / TILE_ROWS) == 1 ? s : h->slot[0];
+            if (!owner.own) SQ_HIP(hipStreamCreateWithFlags(&owner.own, hipStreamNonBlocking));
             if (!s.ev_in) SQ_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
             SQ_HIP(hipEventRecord(s.ev_in, st));        // the caller's earlier work on `stream` (the queries) comes first
-            SQ_HIP(hipStreamWaitEvent(s.own, s.ev_in, 0));
-            run = s.own;
+            SQ_HIP(hipStreamWaitEvent(owner.own, s.ev_in, 0));
+            run = owner.own;
         }
         SQ_TRY(dense_enqueue(h, s, queries, nq, k, out_dist, reinterpret_cast<long long*>(out_idx), run, true));
         h->async_calls++;
