@@ -123,7 +123,7 @@ int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d,
  * The O(n) products of ItqFunctor.fit (impls/lsh_functor/itq.py:291-387) and
  * _find_itq_rotation (itq.py:239-289) with the descriptor matrix resident on
  * the device; the d x d eigen-decomposition and the b x b SVD per iteration stay
- * with the caller (numpy, as in the reference).  d <= 128, bits <= 128.
+ * with the caller (numpy, as in the reference).  d <= 512, bits <= 256 (the outputs are tiled 128 x 128).
  *   create:   x [n][d] of dtype; norm_ord as sq_itq_hash; out_mean[d] = column
  *             means of norm(x) (itq.py:330)
  *   set_mean: the mean values the model keeps (numpy stores them in x's dtype)

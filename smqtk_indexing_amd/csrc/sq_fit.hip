@@ -78,22 +78,28 @@ __global__ __launch_bounds__(256) void fit_colsum_kernel(const T* __restrict__ x
     }
 }
 
-// out[P][Q] += sum over the workgroup's rows of a_row (x) b_row.  The rows of the two operands are
-// staged in LDS (RB rows at a time); a thread owns a TP x TQ register tile of the output.
+// out[P][Q] += sum over the workgroup's rows of a_row (x) b_row.  The output is cut into tiles of GT x GT
+// (grid.y x grid.z), one workgroup per (row slab, tile): the slices of the two operands' rows that a tile needs are
+// staged in LDS (RB rows at a time); a thread owns a TP x TQ register tile of the output tile (256 threads x 8 x 8 =
+// 128 x 128).  Round 1 had one tile, i.e. P, Q <= 128; tiling covers 512-wide descriptors (BASELINE config 4, the
+// reference's own 256-d test) and 256-bit codes.
 //   MODE 0: a = b = norm(x) - mean                (covariance; P = Q = d)
 //   MODE 1: a = sign bits of the row's code as +-1, b = v   (ITQ iteration; P = Q = bits)
+static constexpr int FIT_GT = 128;
 template <class T, int MODE, int TP, int TQ>
 __global__ __launch_bounds__(256) void fit_gram_kernel(const T* __restrict__ x, const double* __restrict__ nrm,
                                                         const double* __restrict__ mean, const double* __restrict__ v,
                                                         const u64* __restrict__ codes, int words, long long n, int P, int Q,
                                                         long long rows_per_block, double* __restrict__ out) {
     constexpr int RB = 16;
-    extern __shared__ double s_ab[];  // [RB][P] then [RB][Q] (MODE 0: one copy, P == Q)
+    const int pb = blockIdx.y * FIT_GT, qb = blockIdx.z * FIT_GT;                 // this workgroup's output tile
+    const int PW = P - pb < FIT_GT ? P - pb : FIT_GT, QW = Q - qb < FIT_GT ? Q - qb : FIT_GT;   // its extent
+    extern __shared__ double s_ab[];  // [RB][PW] then [RB][QW]
     double* s_a = s_ab;
-    double* s_b = MODE == 0 ? s_ab : s_ab + RB * P;
-    const int tq = threadIdx.x % ((Q + TQ - 1) / TQ), tp = threadIdx.x / ((Q + TQ - 1) / TQ);
+    double* s_b = s_ab + RB * FIT_GT;
+    const int tq = threadIdx.x % ((QW + TQ - 1) / TQ), tp = threadIdx.x / ((QW + TQ - 1) / TQ);
     const int p0 = tp * TP, q0 = tq * TQ;
-    const bool live = p0 < P && q0 < Q;
+    const bool live = p0 < PW && q0 < QW;
     double acc[TP][TQ];
 #pragma unroll
     for (int i = 0; i < TP; ++i)
@@ -105,22 +111,26 @@ __global__ __launch_bounds__(256) void fit_gram_kernel(const T* __restrict__ x, 
         const int nr = (int)std::min<long long>(RB, r1 - rb);
         __syncthreads();
         if (MODE == 0) {
-            for (int e = threadIdx.x; e < RB * P; e += 256) {
-                const int r = e / P, k = e - r * P;
-                s_a[e] = r < nr ? fit_elem(x, rb + r, P, k, nrm) - mean[k] : 0.0;
+            for (int e = threadIdx.x; e < RB * PW; e += 256) {
+                const int r = e / PW, k = e - r * PW;
+                s_a[e] = r < nr ? fit_elem(x, rb + r, P, pb + k, nrm) - mean[pb + k] : 0.0;
+            }
+            for (int e = threadIdx.x; e < RB * QW; e += 256) {
+                const int r = e / QW, k = e - r * QW;
+                s_b[e] = r < nr ? fit_elem(x, rb + r, Q, qb + k, nrm) - mean[qb + k] : 0.0;
             }
         } else {
-            for (int e = threadIdx.x; e < RB * P; e += 256) {
-                const int r = e / P, k = e - r * P;
-                // bit k of the row's code, MSB first in right-aligned words (sq_itq_hash layout)
-                const int pos = words * 64 - P + k;
+            for (int e = threadIdx.x; e < RB * PW; e += 256) {
+                const int r = e / PW, k = e - r * PW;
+                // bit pb + k of the row's code, MSB first in right-aligned words (sq_itq_hash layout)
+                const int pos = words * 64 - P + pb + k;
                 double val = 0.0;
                 if (r < nr) val = ((codes[(rb + r) * words + (pos >> 6)] >> (63 - (pos & 63))) & 1ull) ? 1.0 : -1.0;
                 s_a[e] = val;
             }
-            for (int e = threadIdx.x; e < RB * Q; e += 256) {
-                const int r = e / Q, k = e - r * Q;
-                s_b[e] = r < nr ? v[(rb + r) * Q + k] : 0.0;
+            for (int e = threadIdx.x; e < RB * QW; e += 256) {
+                const int r = e / QW, k = e - r * QW;
+                s_b[e] = r < nr ? v[(rb + r) * Q + qb + k] : 0.0;
             }
         }
         __syncthreads();
@@ -128,9 +138,9 @@ __global__ __launch_bounds__(256) void fit_gram_kernel(const T* __restrict__ x, 
             for (int r = 0; r < RB; ++r) {
                 double av[TP], bv[TQ];
 #pragma unroll
-                for (int i = 0; i < TP; ++i) av[i] = p0 + i < P ? s_a[r * P + p0 + i] : 0.0;
+                for (int i = 0; i < TP; ++i) av[i] = p0 + i < PW ? s_a[r * PW + p0 + i] : 0.0;
 #pragma unroll
-                for (int j = 0; j < TQ; ++j) bv[j] = q0 + j < Q ? s_b[r * Q + q0 + j] : 0.0;
+                for (int j = 0; j < TQ; ++j) bv[j] = q0 + j < QW ? s_b[r * QW + q0 + j] : 0.0;
 #pragma unroll
                 for (int i = 0; i < TP; ++i)
 #pragma unroll
@@ -143,51 +153,77 @@ __global__ __launch_bounds__(256) void fit_gram_kernel(const T* __restrict__ x, 
         for (int i = 0; i < TP; ++i)
 #pragma unroll
             for (int j = 0; j < TQ; ++j)
-                if (p0 + i < P && q0 + j < Q) atomicAdd(&out[(long long)(p0 + i) * Q + q0 + j], acc[i][j]);
+                if (p0 + i < PW && q0 + j < QW) atomicAdd(&out[(long long)(pb + p0 + i) * Q + qb + q0 + j], acc[i][j]);
     }
 }
 
-// v[row][0..b) = (norm(x_row) - mean) . pc, pc [d][b] in LDS; 32 rows per workgroup pass, a thread owns
-// one row and b/8 columns.
+// v[row][c0..c0+bc) = (norm(x_row) - mean) . pc[:, c0..c0+bc): the columns of pc go through LDS a chunk at a time
+// (grid.y = chunk: [d][bc] doubles), the rows 32 at a time in k-slices of FIT_KC elements ([32][FIT_KC] doubles); a thread
+// owns one row and up to 16 of the chunk's columns (bc <= 128), accumulated in registers across the k-slices.
+static constexpr int FIT_KC = 128;
 template <class T>
 __global__ __launch_bounds__(256) void fit_project_kernel(const T* __restrict__ x, const double* __restrict__ nrm,
                                                            const double* __restrict__ mean, const double* __restrict__ pc,
-                                                           long long n, int d, int b, double* __restrict__ v) {
-    extern __shared__ double s_pc[];  // [d][b] then [32][d]
-    double* s_x = s_pc + (size_t)d * b;
-    for (int e = threadIdx.x; e < d * b; e += 256) s_pc[e] = pc[e];
+                                                           long long n, int d, int b, int bc, double* __restrict__ v) {
+    extern __shared__ double s_pc[];  // [d][bc] then [32][FIT_KC]
+    double* s_x = s_pc + (size_t)d * bc;
+    const int c0 = blockIdx.y * bc;
+    const int cw = b - c0 < bc ? b - c0 : bc;
+    for (int e = threadIdx.x; e < d * cw; e += 256) {
+        const int k = e / cw, j = e - k * cw;
+        s_pc[k * bc + j] = pc[(long long)k * b + c0 + j];
+    }
     const int r = threadIdx.x >> 3, c8 = threadIdx.x & 7;
     for (long long rb = (long long)blockIdx.x * 32; rb < n; rb += (long long)gridDim.x * 32) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < 32 * d; e += 256) {
-            const int rr = e / d, k = e - rr * d;
-            s_x[e] = rb + rr < n ? fit_elem(x, rb + rr, d, k, nrm) - mean[k] : 0.0;
+        double acc[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = 0.0;
+        for (int k0 = 0; k0 < d; k0 += FIT_KC) {
+            const int kw = d - k0 < FIT_KC ? d - k0 : FIT_KC;
+            __syncthreads();
+            for (int e = threadIdx.x; e < 32 * kw; e += 256) {
+                const int rr = e / kw, k = e - rr * kw;
+                s_x[rr * FIT_KC + k] = rb + rr < n ? fit_elem(x, rb + rr, d, k0 + k, nrm) - mean[k0 + k] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = c8 + 8 * t;
+                if (j < cw) {
+                    double a = acc[t];
+                    for (int k = 0; k < kw; ++k) a = fma(s_x[r * FIT_KC + k], s_pc[(k0 + k) * bc + j], a);
+                    acc[t] = a;
+                }
+            }
         }
-        __syncthreads();
-        for (int j = c8; j < b; j += 8) {
-            double acc = 0.0;
-            for (int k = 0; k < d; ++k) acc = fma(s_x[r * d + k], s_pc[k * b + j], acc);
-            if (rb + r < n) v[(rb + r) * b + j] = acc;
+        if (rb + r < n) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = c8 + 8 * t;
+                if (j < cw) v[(rb + r) * b + c0 + j] = acc[t];
+            }
         }
     }
 }
+
+static constexpr int FIT_MAX_D = 512, FIT_MAX_BITS = 256;
 
 template <class T>
 static int fit_gram_cov(FitHandle* h, double* out_dev) {
     const int d = h->d;
     const long long rpb = 2048;
     const unsigned grid = (unsigned)((h->n + rpb - 1) / rpb);
-    const size_t lds = (size_t)16 * d * 8;
+    const unsigned tiles = (unsigned)((d + FIT_GT - 1) / FIT_GT);
+    const size_t lds = (size_t)2 * 16 * FIT_GT * 8;
     const double* nrm = h->norm == SQ_NORM_L2 ? h->nrm.as<double>() : nullptr;
-    // thread tiles: 256 threads x (TP x TQ) >= d x d
+    if (d > FIT_MAX_D) return fail(SQ_ERR_UNSUPPORTED, "sq_itqfit: d=%d above %d", d, FIT_MAX_D);
+    // thread tiles: 256 threads x (TP x TQ) cover an output tile (4 x 4 when the whole output is <= 64 x 64)
     if (d <= 64)
-        hipLaunchKernelGGL((fit_gram_kernel<T, 0, 4, 4>), dim3(grid), dim3(256), lds, 0, (const T*)h->x, nrm, h->mean.as<double>(),
-                           nullptr, nullptr, 0, h->n, d, d, rpb, out_dev);
-    else if (d <= 128)
-        hipLaunchKernelGGL((fit_gram_kernel<T, 0, 8, 8>), dim3(grid), dim3(256), lds, 0, (const T*)h->x, nrm, h->mean.as<double>(),
-                           nullptr, nullptr, 0, h->n, d, d, rpb, out_dev);
+        hipLaunchKernelGGL((fit_gram_kernel<T, 0, 4, 4>), dim3(grid, tiles, tiles), dim3(256), lds, 0, (const T*)h->x, nrm,
+                           h->mean.as<double>(), nullptr, nullptr, 0, h->n, d, d, rpb, out_dev);
     else
-        return fail(SQ_ERR_UNSUPPORTED, "sq_itqfit: d=%d above 128 (covariance tile)", d);
+        hipLaunchKernelGGL((fit_gram_kernel<T, 0, 8, 8>), dim3(grid, tiles, tiles), dim3(256), lds, 0, (const T*)h->x, nrm,
+                           h->mean.as<double>(), nullptr, nullptr, 0, h->n, d, d, rpb, out_dev);
     SQ_HIP(hipGetLastError());
     return SQ_OK;
 }
@@ -205,7 +241,7 @@ extern "C" int sq_itqfit_create(const void* x, int dtype, int64_t n, int d, int 
     if (dtype != SQ_DTYPE_F32 && dtype != SQ_DTYPE_F64) return fail(SQ_ERR_INVALID, "sq_itqfit_create: unknown dtype %d", dtype);
     if (norm_ord != SQ_NORM_NONE && norm_ord != SQ_NORM_L2)
         return fail(SQ_ERR_UNSUPPORTED, "sq_itqfit_create: normalize=%d not supported on the device (None or 2)", norm_ord);
-    if (d > 128) return fail(SQ_ERR_UNSUPPORTED, "sq_itqfit_create: d=%d above 128", d);
+    if (d > FIT_MAX_D) return fail(SQ_ERR_UNSUPPORTED, "sq_itqfit_create: d=%d above %d", d, FIT_MAX_D);
     auto* h = new FitHandle();
     h->kind = H_FIT;
     h->dtype = dtype;
@@ -229,7 +265,7 @@ extern "C" int sq_itqfit_create(const void* x, int dtype, int64_t n, int d, int 
     }
     int rc;
     if ((rc = h->mean.reserve((size_t)d * 8)) != SQ_OK) return bail(rc);
-    if ((rc = h->acc.reserve((size_t)128 * 128 * 8)) != SQ_OK) return bail(rc);
+    if ((rc = h->acc.reserve((size_t)std::max(d * d, FIT_MAX_BITS * FIT_MAX_BITS) * 8)) != SQ_OK) return bail(rc);
     if (norm_ord == SQ_NORM_L2) {
         if ((rc = h->nrm.reserve((size_t)n * 8)) != SQ_OK) return bail(rc);
         const unsigned g = (unsigned)((n + 31) / 32);
@@ -283,7 +319,8 @@ extern "C" int sq_itqfit_cov(sq_handle_t hid, double* out_cov) {
 
 extern "C" int sq_itqfit_project(sq_handle_t hid, const double* pc, int bits) {
     auto* h = static_cast<FitHandle*>(lookup_handle(hid, H_FIT));
-    if (!h || !pc || bits <= 0 || bits > 128) return fail(SQ_ERR_INVALID, "sq_itqfit_project: bad argument (1 <= bits <= 128)");
+    if (!h || !pc || bits <= 0 || bits > FIT_MAX_BITS)
+        return fail(SQ_ERR_INVALID, "sq_itqfit_project: bad argument (1 <= bits <= %d)", FIT_MAX_BITS);
     std::lock_guard<std::mutex> lock(h->mu);
     SQ_HIP(hipSetDevice(h->device));
     const int d = h->d;
@@ -291,20 +328,25 @@ extern "C" int sq_itqfit_project(sq_handle_t hid, const double* pc, int bits) {
     SQ_TRY(h->v.reserve((size_t)h->n * bits * 8));
     SQ_TRY(h->small.reserve((size_t)std::max(d, bits) * bits * 8));
     SQ_HIP(hipMemcpy(h->small.p, pc, (size_t)d * bits * 8, hipMemcpyHostToDevice));
-    const size_t lds = ((size_t)d * bits + (size_t)32 * d) * 8;
-    if (lds > 160 * 1024) return fail(SQ_ERR_UNSUPPORTED, "sq_itqfit_project: d=%d bits=%d exceed the LDS", d, bits);
+    // columns of pc per pass: as many as fit the LDS beside the 32 staged rows (multiples of 8)
+    int bc = (int)((150 * 1024 / 8 - 32 * FIT_KC) / d) / 8 * 8;
+    if (bc > 128) bc = 128;
+    if (bc > (bits + 7) / 8 * 8) bc = (bits + 7) / 8 * 8;
+    if (bc < 8) return fail(SQ_ERR_UNSUPPORTED, "sq_itqfit_project: d=%d exceeds the LDS", d);
+    const size_t lds = ((size_t)d * bc + (size_t)32 * FIT_KC) * 8;
+    const unsigned chunks = (unsigned)((bits + bc - 1) / bc);
     const double* nrm = h->norm == SQ_NORM_L2 ? h->nrm.as<double>() : nullptr;
     const unsigned g = (unsigned)std::min<long long>((h->n + 31) / 32, 4ll * cu_count(h->device));
     if (h->dtype == SQ_DTYPE_F32) {
         SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_project_kernel<float>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((fit_project_kernel<float>), dim3(g), dim3(256), lds, 0, (const float*)h->x, nrm, h->mean.as<double>(),
-                           h->small.as<double>(), h->n, d, bits, h->v.as<double>());
+        hipLaunchKernelGGL((fit_project_kernel<float>), dim3(g, chunks), dim3(256), lds, 0, (const float*)h->x, nrm,
+                           h->mean.as<double>(), h->small.as<double>(), h->n, d, bits, bc, h->v.as<double>());
     } else {
         SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fit_project_kernel<double>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((fit_project_kernel<double>), dim3(g), dim3(256), lds, 0, (const double*)h->x, nrm, h->mean.as<double>(),
-                           h->small.as<double>(), h->n, d, bits, h->v.as<double>());
+        hipLaunchKernelGGL((fit_project_kernel<double>), dim3(g, chunks), dim3(256), lds, 0, (const double*)h->x, nrm,
+                           h->mean.as<double>(), h->small.as<double>(), h->n, d, bits, bc, h->v.as<double>());
     }
     SQ_HIP(hipDeviceSynchronize());
     return SQ_OK;
@@ -332,13 +374,14 @@ extern "C" int sq_itqfit_iterate(sq_handle_t hid, const double* r, double* out_c
     if (rc != SQ_OK) return done(rc);
     const long long rpb = 2048;
     const unsigned grid = (unsigned)((h->n + rpb - 1) / rpb);
-    const size_t lds = (size_t)2 * 16 * b * 8;
+    const size_t lds = (size_t)2 * 16 * FIT_GT * 8;
+    const unsigned tiles = (unsigned)((b + FIT_GT - 1) / FIT_GT);
     if (b <= 64)
-        hipLaunchKernelGGL((fit_gram_kernel<double, 1, 4, 4>), dim3(grid), dim3(256), lds, 0, nullptr, nullptr, nullptr,
-                           h->v.as<double>(), codes.as<u64>(), words, h->n, b, b, rpb, h->acc.as<double>());
+        hipLaunchKernelGGL((fit_gram_kernel<double, 1, 4, 4>), dim3(grid, tiles, tiles), dim3(256), lds, 0, nullptr, nullptr,
+                           nullptr, h->v.as<double>(), codes.as<u64>(), words, h->n, b, b, rpb, h->acc.as<double>());
     else
-        hipLaunchKernelGGL((fit_gram_kernel<double, 1, 8, 8>), dim3(grid), dim3(256), lds, 0, nullptr, nullptr, nullptr,
-                           h->v.as<double>(), codes.as<u64>(), words, h->n, b, b, rpb, h->acc.as<double>());
+        hipLaunchKernelGGL((fit_gram_kernel<double, 1, 8, 8>), dim3(grid, tiles, tiles), dim3(256), lds, 0, nullptr, nullptr,
+                           nullptr, h->v.as<double>(), codes.as<u64>(), words, h->n, b, b, rpb, h->acc.as<double>());
     if (hipMemcpy(out_c, h->acc.p, (size_t)b * b * 8, hipMemcpyDeviceToHost) != hipSuccess)
         return done(fail(SQ_ERR_HIP, "sq_itqfit_iterate: failed: %s", hipGetErrorString(hipGetLastError())));
     return done(SQ_OK);

@@ -199,7 +199,7 @@ class HipItqFunctor(LshFunctor):
         """(mean_vec, rotation) with the O(n) work of itq.py:330-362 and 271-275 on the device
         (``sq_itqfit_*``): mean, covariance, PCA projection and, per ITQ iteration, sign(V R) and
         B^T V.  The d x d eigen-decomposition and the bits x bits SVDs are numpy's, as in the
-        reference.  Descriptors up to 128-d, codes up to 128 bits."""
+        reference.  Descriptors up to 512-d, codes up to 256 bits."""
         nbits = self.bit_length
         norm_ord = self._norm_ord()
         if norm_ord not in (_lib.SQ_NORM_NONE, _lib.SQ_NORM_L2) or self._norm_on_host():
@@ -229,7 +229,7 @@ class HipItqFunctor(LshFunctor):
     def fit(self, descriptors: Iterable[DescriptorElement], use_multiprocessing: bool = True) -> np.ndarray:
         """Train mean vector and rotation from descriptors, then return the training set's codes
         (bool ``[n, bits]``, computed on the GPU).  With ``fit_on_device`` (default) the products
-        over the n descriptors run on the device when they fit its kernels (d <= 128, <= 128 bits,
+        over the n descriptors run on the device when they fit its kernels (d <= 512, <= 256 bits,
         a real-valued PCA basis); otherwise, and always for the small dense linear algebra, numpy."""
         if self.has_model():
             raise RuntimeError("Model components have already been loaded.")
@@ -240,7 +240,7 @@ class HipItqFunctor(LshFunctor):
                              "smaller than requested due to PCA decomposition "
                              "result being bound by number of features.")
         x_in = np.asarray([d.vector() for d in descr])
-        if (self.fit_on_device and x_in.ndim == 2 and x_in.shape[1] <= 128 and self.bit_length <= 128
+        if (self.fit_on_device and x_in.ndim == 2 and x_in.shape[1] <= 512 and self.bit_length <= 256
                 and x_in.shape[0] > 1 and _lib.usable()):
             self.mean_vec, self.rotation = self._fit_device(x_in)
         else:

@@ -96,7 +96,11 @@ def test_itq_fit_known_answer_and_cache():
 
 
 @pytest.mark.parametrize("dt,normalize,d,bits", [(np.float32, None, 128, 64), (np.float64, 2, 96, 32),
-                                                 (np.float32, 2, 40, 40), (np.float64, None, 128, 100)])
+                                                 (np.float32, 2, 40, 40), (np.float64, None, 128, 100),
+                                                 # beyond one 128 x 128 output tile: the reference's own 256-d scenario
+                                                 # (test_lsh.py:754-832) and BASELINE config 4's 512-d, up to 256 bits
+                                                 (np.float64, None, 256, 32), (np.float32, 2, 512, 256),
+                                                 (np.float32, None, 200, 130)])
 def test_itq_fit_on_device_matches_host(dt, normalize, d, bits):
     """sq_itqfit_*: mean / covariance / projection / per-iteration B^T V on the device against
     numpy on identical inputs, then the fitted model against the host fit (same seed) by its

@@ -5,7 +5,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smqtk_indexing_amd import _lib
 
-n, d, bits, iters = int(os.environ.get("N", 1_000_000)), 128, 64, 50
+n, d, bits, iters = int(os.environ.get("N", 1_000_000)), int(os.environ.get("D", 128)), int(os.environ.get("BITS", 64)), 50
 rng = np.random.default_rng(0)
 x = rng.standard_normal((n, d)).astype(np.float32)
 t0 = time.perf_counter()
