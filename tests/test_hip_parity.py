@@ -803,3 +803,32 @@ def test_k_beyond_the_one_workgroup_select():
             else:
                 np.testing.assert_allclose(dist[0], full[order], rtol=1e-12, atol=1e-15)
         m.close()
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+@pytest.mark.parametrize("nq,d", [(300, 128), (513, 100), (1024, 128)])
+def test_dense_large_batches(metric, nq, d):
+    """Batches of several hundred queries (many groups of four query tiles per scan wave, a partial last group, a
+    partial last row tile): ids and float32 distances bit-identical to the oracle, no query on the exact path."""
+    rng = np.random.default_rng(nq + d)
+    n = 200_000 + 17
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    db[5000:5050] = db[3]                              # ties
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    qs[0], qs[nq - 1] = db[3], db[n - 1]
+    m = _lib.SQ_METRIC_L2 if metric == "euclidean" else _lib.SQ_METRIC_COSINE
+    idx = _lib.DenseIndex(db, metric=m)
+    k = 20
+    dd, ii = idx.search(qs, k)
+    assert idx.stats()["fallback_queries"] == 0 and idx.stats()["scan_launches"] == 2
+    for qi in list(range(0, nq, 37)) + [nq - 1]:
+        rd, ri = O.dense_topk(db, qs[qi], k, metric)
+        if metric == "euclidean":
+            np.testing.assert_array_equal(ii[qi], ri)
+            np.testing.assert_array_equal(dd[qi].view(np.uint32), rd.view(np.uint32))
+        else:
+            np.testing.assert_allclose(dd[qi], rd, rtol=1e-12, atol=1e-15)
+            full = O.dense_distances(db, qs[qi], "cosine")
+            mism = ii[qi] != ri
+            assert not mism.any() or np.abs(full[ii[qi][mism]] - full[ri[mism]]).max() < 1e-14
+    idx.close()
