@@ -48,7 +48,9 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
         self._lock = threading.RLock()
         self._elements: List[DescriptorElement] = []
         self._row_of: Dict[Hashable, int] = {}
-        self._matrix = np.zeros((0, 0), dtype=np.float32)
+        # host copy of the float32 rows, kept as the list of blocks it arrived in: an append adds a block (no O(N)
+        # re-stacking per update); the blocks are only joined when the device copy has to be rebuilt
+        self._blocks: List[np.ndarray] = []
         self._all_f32 = True     # every indexed vector is float32: the float32 search distances are final
         self._dev: Optional[_lib.DenseIndex] = None
 
@@ -56,10 +58,21 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
         return {"distance_method": self.distance_method, "read_only": self.read_only}
 
     # ------------------------------------------------------------------ state
+    @property
+    def _matrix(self) -> np.ndarray:
+        if not self._blocks:
+            return np.zeros((0, 0), dtype=np.float32)
+        if len(self._blocks) > 1:
+            self._blocks = [np.ascontiguousarray(np.vstack(self._blocks), dtype=np.float32)]
+        return self._blocks[0]
+
+    def _dim(self) -> int:
+        return int(self._blocks[0].shape[1]) if self._blocks else 0
+
     def _set(self, elements: List[DescriptorElement], matrix: np.ndarray) -> None:
         self._elements = elements
         self._row_of = {e.uuid(): i for i, e in enumerate(elements)}
-        self._matrix = matrix
+        self._blocks = [matrix] if matrix.shape[0] else []
         self._all_f32 = all(np.asarray(e.vector()).dtype == np.float32 for e in elements)
         if self._dev is not None:
             self._dev.close()
@@ -105,7 +118,7 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
                 new[d.uuid()] = d
             add = list(new.values())
             add_m = self._to_matrix(add)
-            if self._elements and self._dev is not None and add_m.shape[1] == self._matrix.shape[1] \
+            if self._elements and self._dev is not None and add_m.shape[1] == self._dim() \
                     and not any(u in self._row_of for u in new):
                 # nothing replaced: the new rows go behind the resident matrix (sq_dense_append, what
                 # faiss.py:561-640 does with add_with_ids), no rebuild and no re-upload of the old rows
@@ -113,7 +126,7 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
                 base = len(self._elements)
                 self._elements.extend(add)
                 self._row_of.update({e.uuid(): base + i for i, e in enumerate(add)})
-                self._matrix = np.vstack([self._matrix, add_m])
+                self._blocks.append(add_m)
                 self._all_f32 = self._all_f32 and all(np.asarray(e.vector()).dtype == np.float32 for e in add)
                 return
             kept = [e for e in self._elements if e.uuid() not in new]

@@ -28,7 +28,7 @@ t0 = time.time()
 for c in range(cases):
     n = int(rng.choice([300, 5000, 70_000, 150_000, 400_000]))
     d = int(rng.choice([1, 7, 32, 64, 100, 128, 129, 200, 256, 384, 512, 700]))
-    k = int(rng.choice([1, 5, 50, 100, 600]))
+    k = int(rng.choice([1, 5, 50, 100, 600, 3000, 20000]))
     nq = int(rng.choice([1, 3, 32, 33, 70, 130]))
     metric = str(rng.choice(["euclidean", "cosine"]))
     kind = int(rng.integers(0, 5))
@@ -70,7 +70,7 @@ for c in range(cases):
 for c in range(cases // 2):
     bits = int(rng.choice([1, 7, 33, 64, 70, 128, 192, 256, 320]))
     n = int(rng.choice([50, 3000, 90_000, 300_000]))
-    k = int(rng.choice([1, 10, 100, 700]))
+    k = int(rng.choice([1, 10, 100, 700, 5000]))
     nq = int(rng.choice([1, 5, 40]))
     w = (bits + 63) // 64
     low = bool(rng.integers(0, 2))                                   # low-entropy codes: huge tie groups
@@ -93,6 +93,21 @@ for c in range(cases // 2):
             assert np.array_equal(dd[qi, :kk], rd), "hamming dist"
             assert np.array_equal(ii[qi, :kk], ri), "hamming ids"
             assert (ii[qi, kk:] == -1).all(), "hamming padding"
+        if len(codes) > 20 and rng.integers(0, 2):                  # in-place removal + re-insertion (sq_hamming_remove/append)
+            drop = np.sort(rng.choice(len(codes), size=int(rng.integers(1, min(len(codes) - 1, 500))), replace=False))
+            idx.remove(drop)
+            rest = np.delete(codes, drop, axis=0)
+            dd, ii = idx.search(qs, k)
+            rd, ri = O.hamming_topk(rest, qs[0], k)
+            assert np.array_equal(dd[0, :len(rd)], rd) and np.array_equal(ii[0, :len(rd)], ri), "hamming after remove"
+            back = codes[drop]
+            be = [tuple(int(v) for v in r) for r in rest]
+            import bisect
+            pos = np.array([bisect.bisect_left(be, tuple(int(v) for v in r)) for r in back], dtype=np.int64)
+            idx.append(back, pos)
+            dd, ii = idx.search(qs, k)
+            rd, ri = O.hamming_topk(codes, qs[0], k)
+            assert np.array_equal(dd[0, :len(rd)], rd) and np.array_equal(ii[0, :len(rd)], ri), "hamming after append"
         idx.close()
         print(f"ok   hamming {c}: n={len(codes)} bits={bits} k={k} nq={nq} low={low} fallback={st['fallback_queries']}", flush=True)
     except Exception as e:  # noqa: BLE001
@@ -103,16 +118,18 @@ for c in range(cases // 2):
 for c in range(cases // 2):
     d = int(rng.choice([3, 20, 64, 100, 128, 192, 256, 300]))
     bits = int(rng.choice([1, 8, 33, 64, 100, 128, 200]))
-    n = int(rng.choice([1, 31, 33, 1000, 40_000]))
+    n = int(rng.choice([1, 31, 33, 1000, 40_000, 300_000]))
     xdt = np.float32 if rng.integers(0, 2) else np.float64
     mdt = np.float32 if rng.integers(0, 2) else np.float64
-    norm = None if rng.integers(0, 2) else 2
+    norm = [None, None, 2, 2, 1, 0, float('inf'), float('-inf')][int(rng.integers(0, 8))]
+    code = {None: _lib.SQ_NORM_NONE, 2: _lib.SQ_NORM_L2, 1: _lib.SQ_NORM_L1, 0: _lib.SQ_NORM_L0,
+            float('inf'): _lib.SQ_NORM_INF, float('-inf'): _lib.SQ_NORM_NEG_INF}[norm]
     x = (rng.standard_normal((n, d)) * rng.lognormal(0, 1, (n, 1)) + rng.standard_normal(d)).astype(xdt)
     if n > 3: x[2] = 0
     mean = x[: max(1, n // 2)].mean(axis=0).astype(mdt)
     rot = rng.standard_normal((d, bits))
     try:
-        got = _lib.itq_hash(x, mean, rot, _lib.SQ_NORM_NONE if norm is None else _lib.SQ_NORM_L2)
+        got = _lib.itq_hash(x, mean, rot, code)
         z = O.itq_z(x, mean, rot, norm)
         ref = O.pack_bits_msb(z >= 0)
         bad = (got != ref).any(axis=1)
