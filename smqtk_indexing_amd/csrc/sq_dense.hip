@@ -78,13 +78,14 @@ struct DenseHandle : HandleBase {
     long long id_base = 0;
     double xn2_max = 0.0;       // max squared row norm (error bound of the L2 filter)
     DevBuf norms1;  // L2: |x|^2 (1 - alpha) for one query plane (`norms`: two planes)
+    DevBuf zeros;   // cosine: the 32 zero "norms" every tile of an AGPR-configuration scan starts from (norm_step 0)
     DenseSlot slot[2];
     unsigned long long async_calls = 0;  // asynchronous calls so far (slot = parity)
     // workspace shared by all calls: host-memory staging, the exact path (runs synchronously), index build
     DevBuf q_dev, out_dist_dev, out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch, fb_cnt;
     PinnedStage stage;
     ~DenseHandle() override {
-        for (DevBuf* b : {&owned, &scan, &norms, &norms1, &center, &cos_nx, &q_dev, &out_dist_dev, &out_idx_dev, &big_keys,
+        for (DevBuf* b : {&owned, &scan, &norms, &norms1, &zeros, &center, &cos_nx, &q_dev, &out_dist_dev, &out_idx_dev, &big_keys,
                           &fb_sample, &fb_keys, &fb_out, &scratch, &fb_cnt})
             b->release();
         slot[0].release();
@@ -375,6 +376,11 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         DenseScanArgs a{};
         a.scan = h->scan.as<uint4>();
         a.norms = cosine ? nullptr : (qp == 1 ? h->norms1.as<float>() : h->norms.as<float>());  // n' of this plane count
+        a.norm_step = 1;
+        if (cosine && (qt > 1 || qp == 1)) {  // the AGPR configurations always stream a norm piece
+            a.norms = h->zeros.as<float>();
+            a.norm_step = 0;
+        }
         a.n = n;
         a.n_tiles = n_tiles;
         a.qs = qs;
@@ -800,6 +806,10 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
         int rc = h->norms.reserve((size_t)h->n_pad * 4);
         if (rc == SQ_OK && metric == SQ_METRIC_L2) rc = h->norms1.reserve((size_t)h->n_pad * 4);
         if (rc == SQ_OK && metric == SQ_METRIC_COSINE) rc = h->cos_nx.reserve((size_t)n * 8);
+        if (rc == SQ_OK && metric == SQ_METRIC_COSINE) {
+            rc = h->zeros.reserve(256);
+            if (rc == SQ_OK && hipMemset(h->zeros.p, 0, 256) != hipSuccess) rc = fail(SQ_ERR_HIP, "sq_dense_create: memset failed");
+        }
         if (rc == SQ_OK && d_pad <= MAX_DPAD) rc = h->scan.reserve((size_t)h->n_pad * d_pad * 2);
         if (rc == SQ_OK) rc = dense_build_rows(h, 0);
         if (rc != SQ_OK) return bail(rc);

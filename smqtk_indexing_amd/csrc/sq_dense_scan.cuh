@@ -239,7 +239,8 @@ static __global__ __launch_bounds__(256) void dense_prep_queries_kernel(const fl
 // ------------------------------------------------------------- the scan kernel
 struct DenseScanArgs {
     const uint4* scan;      // scan copy [n_pad][d_pad/8] chunks
-    const float* norms;     // |x|^2 per row [n_pad] (L2) or nullptr (cosine)
+    const float* norms;     // |x|^2 per row [n_pad] (L2) or nullptr (cosine; the AGPR configurations get 32 zeros and norm_step 0)
+    long long norm_step;    // 1: norms[row]; 0: the same 32 entries for every tile
     long long n;            // real rows (rows >= n are padding and never emitted)
     long long n_tiles;      // ceil(n / 32)
     const uint4* qs;        // [nqt*32][d_pad/4] prepared queries
@@ -257,6 +258,7 @@ struct DenseScanArgs {
 };
 
 typedef __attribute__((address_space(3))) u32 lds_u32;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
 
 // ---- hand-placed MFMA for the multi-tile (QT > 1) configuration.
 // With QT*64 registers of query fragments a wave needs more than the 256
@@ -468,7 +470,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan) + row0 * (DPAD * 2) + iss_kc * 256;
 #pragma unroll
         for (int j = 0; j < 8; ++j) glds16(base, voff[j], dst + (u32)j * 1024);
-        if (add_norm && iss_kc == 0) glds4(a.norms + row0, voff_norm, dst + UNIT_BYTES);
+        if constexpr (AB) {
+            if (iss_kc == 0) glds4(a.norms + row0 * a.norm_step, voff_norm, dst + UNIT_BYTES);
+        } else {
+            if (add_norm && iss_kc == 0) glds4(a.norms + row0, voff_norm, dst + UNIT_BYTES);
+        }
         ++issued;
         if (++iss_kc == KU) {
             iss_kc = 0;
@@ -491,175 +497,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 ++issued;
         }
     };
-    f32x4 av_cur[8], av_nxt[8], nrm_nxt[4];
-    auto read_frags = [&](int slot_idx, bool first_of_tile) {
-        const unsigned char* sl = ring_ptr + slot_idx * SLOT_BYTES;
-        const unsigned char* arow = sl + r31 * 256;
-#pragma unroll
-        for (int g = 0; g < 8; ++g)
-            av_nxt[g] = *reinterpret_cast<const f32x4*>(arow + ((2 * g + h) ^ (r31 & 15)) * 16);
-        if (first_of_tile && add_norm) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) nrm_nxt[c] = *reinterpret_cast<const f32x4*>(sl + UNIT_BYTES + (8 * c + 4 * h) * 4);
-        }
-    };
-    for (int p = 0; p < NSTAGE; ++p) issue_next();
-
-#pragma unroll
-    for (int g = 0; g < 8; ++g) av_nxt[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) nrm_nxt[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    long long loaded = 0;  // units whose fragments have been requested from LDS
-    int rd_slot = 0, rd_kc = 0;
-    if (total_units > 0) {
-        if (nine)
-            wait_units_in_flight<NSTAGE, 9>((int)(issued - 1));
-        else
-            wait_units_in_flight<NSTAGE, 8>((int)(issued - 1));
-        if (do_math) read_frags(0, true);
-        loaded = 1;
-        rd_slot = NSTAGE > 1 ? 1 : 0;
-        rd_kc = KU > 1 ? 1 : 0;
-    }
-    for (long long sel = gw; sel < a.n_sel; sel += nwaves) {
-        f32x16 acc[QT];
-        if constexpr (AB) {
-            // ---- One wave per SIMD (or two with little else to do): nothing else hides this wave's
-            // side work, so it sits in the issue shadow of the 8*QP*QT MFMAs of a unit (an MFMA holds the
-            // vector issue for 8 of its 32 cycles): the LDS reads of the next unit's fragments behind
-            // the first MFMAs, one of the DMA instructions that refill this unit's slot behind every
-            // few MFMAs after that.  The body is specialised on (refill?, read ahead?) so the block is
-            // free of branches; the measurement-only ablations (debug 1 / 2) are not available here.
-            auto unit = [&](auto iss_c, auto rd_c, const int kc) {
-                constexpr bool ISS = decltype(iss_c)::value, RD = decltype(rd_c)::value;
-#pragma unroll
-                for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];
-                f32x16 nrm_c;
-                if (kc == 0) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) nrm_c[i] = add_norm ? nrm_nxt[i >> 2][i & 3] : 0.f;
-                }
-                asm volatile("" ::: "memory");
-                const int units_behind = (int)(issued - loaded - 1);  // younger units that may stay in flight
-                const long long irow0 = iss_sel * a.tile_step * TILE_ROWS;
-                const u32 idst = ring_base + (u32)iss_slot * SLOT_BYTES;
-                const unsigned char* ibase = reinterpret_cast<const unsigned char*>(a.scan) + irow0 * (DPAD * 2) + iss_kc * 256;
-                const bool inorm = add_norm && iss_kc == 0;
-                const bool rd_first = rd_kc == 0;
-                if (kc == 0)
-                    mfma_fence_in_c(nrm_c, av_cur);
-                else
-                    mfma_fence_in<QT>(acc, av_cur);
-                constexpr int NSLOT = 8 * QP * QT;             // one slot behind every MFMA
-                constexpr int DMA0 = NSLOT >= 16 ? 6 : 2, DSTEP = (NSLOT - DMA0 - 1) / 9 > 0 ? (NSLOT - DMA0 - 1) / 9 : 1;
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                    for (int half = 0; half < QP; ++half) {  // two planes: lo first, then hi
-#pragma unroll
-                        for (int t = 0; t < QT; ++t) {
-                            const int frag = kc * 8 * QP + (QP == 2 ? 2 * s + 1 - half : s);
-                            if (kc == 0 && s == 0 && half == 0)
-                                mfma_bf16_agpr_b_first(acc[t], av_cur[0], bq[t][frag], nrm_c);
-                            else
-                                mfma_bf16_agpr_b(acc[t], av_cur[s], bq[t][frag]);
-                            const int slot = (s * QP + half) * QT + t;
-                            if constexpr (RD) {
-                                if (slot == 1 || (NSLOT == 1)) {
-                                    if (nine)
-                                        wait_units_in_flight<NSTAGE, 9>(units_behind);
-                                    else
-                                        wait_units_in_flight<NSTAGE, 8>(units_behind);
-                                    read_frags(rd_slot, rd_first);
-                                }
-                            }
-                            if constexpr (ISS) {
-                                if (slot >= DMA0 && (slot - DMA0) % DSTEP == 0) {
-                                    const int j = (slot - DMA0) / DSTEP;
-                                    if (j < 8) glds16(ibase, voff[j], idst + (u32)j * 1024);
-                                    if (j == 8 && inorm) glds4(a.norms + irow0, voff_norm, idst + UNIT_BYTES);
-                                }
-                                // fewer slots than DMA pieces (8 MFMAs per unit): the rest goes behind the last MFMA
-                                if (slot == NSLOT - 1) {
-#pragma unroll
-                                    for (int j = (NSLOT - 1 - DMA0) / DSTEP + 1; j < 9; ++j) {
-                                        if (j < 8) glds16(ibase, voff[j], idst + (u32)j * 1024);
-                                        if (j == 8 && inorm) glds4(a.norms + irow0, voff_norm, idst + UNIT_BYTES);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-                if constexpr (RD) {
-                    ++loaded;
-                    if (++rd_slot == NSTAGE) rd_slot = 0;
-                    if (++rd_kc == KU) rd_kc = 0;
-                }
-                if constexpr (ISS) {
-                    ++issued;
-                    if (++iss_kc == KU) {
-                        iss_kc = 0;
-                        iss_sel += nwaves;
-                    }
-                    if (++iss_slot == NSTAGE) iss_slot = 0;
-                }
-                mfma_fence_out<QT>(acc);
-            };
-#pragma unroll
-            for (int kc = 0; kc < KU; ++kc) {
-                const bool rd = loaded < total_units, iss = issued < total_units;  // iss implies rd
-                if (iss)
-                    unit(std::true_type{}, std::true_type{}, kc);
-                else if (rd)
-                    unit(std::false_type{}, std::true_type{}, kc);
-                else
-                    unit(std::false_type{}, std::false_type{}, kc);
-            }
-        } else {
-#pragma unroll
-            for (int kc = 0; kc < KU; ++kc) {
-                // fragments of this unit are complete once copied (hipcc waits lgkmcnt here); its slot is free
-#pragma unroll
-                for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];
-                if (kc == 0) {
-                    // the accumulator starts from |x|^2 of the tile's rows (0 for cosine): score = |x|^2 + x.q'
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[0][i] = add_norm ? nrm_nxt[i >> 2][i & 3] : 0.f;
-                }
-                asm volatile("" ::: "memory");
-                issue_next();
-                if (loaded < total_units) {
-                    if (nine)  // younger units may stay in flight
-                        wait_units_in_flight<NSTAGE, 9>((int)(issued - loaded - 1));
-                    else
-                        wait_units_in_flight<NSTAGE, 8>((int)(issued - loaded - 1));
-                    if (do_math) read_frags(rd_slot, rd_kc == 0);
-                    ++loaded;
-                    if (++rd_slot == NSTAGE) rd_slot = 0;
-                    if (++rd_kc == KU) rd_kc = 0;
-                }
-                if (do_math) {
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, av_cur[s]);
-                        f32x4 bh, bl;
-                        if constexpr (QREG) {
-                            bh = bq[0][2 * s];
-                            bl = bq[0][2 * s + 1];
-                        } else {
-                            const unsigned char* brow = smem + (u32)r31 * DPAD * 4 + kc * 512 + ((2 * s + h) ^ (r31 & 15)) * 16;
-                            bh = *reinterpret_cast<const f32x4*>(brow);
-                            bl = *reinterpret_cast<const f32x4*>(brow + 256);
-                        }
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bl), acc[0], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bh), acc[0], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        if (!do_math) continue;
-        // ---- tile complete: scores for 32 rows x QT*32 queries (lane = query, register i = row (i&3)+8(i>>2)+4h)
+    // ---- tile complete: scores for 32 rows x QT*32 queries (lane = query, register i = row (i&3)+8(i>>2)+4h)
+    auto finish_tile = [&](const long long sel, f32x16 (&acc)[QT]) {
         const long long row0 = sel * a.tile_step * TILE_ROWS;
         const bool is_tail = row0 + TILE_ROWS > a.n;  // wave-uniform: the last, partial tile
 #pragma unroll
@@ -702,6 +541,354 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 }
                 a.sample_out[(long long)qglob * a.ns + sel * 2 + h] = ml;
             }
+        }
+    };
+
+    for (int p = 0; p < NSTAGE; ++p) issue_next();
+    long long loaded = 0;  // units whose fragments have been requested from LDS
+    int rd_slot = 0, rd_kc = 0;
+
+    if constexpr (AB && WAVES == 4) {
+        // ---- One wave per SIMD: nothing else hides this wave's side work, so it
+        // sits in the issue shadow of the 8*QP*QT MFMAs of a unit (an MFMA holds the vector issue for 8 of its 32
+        // cycles): the LDS reads of the next unit's fragments behind the first MFMAs, one of the DMA instructions
+        // that refill this unit's slot behind every few MFMAs after that.  The loop is unrolled over a group of
+        // G = lcm(NSTAGE, KU, 2) units, which makes everything about a unit but its data a compile-time constant:
+        //  * the A fragments (and the norm block that is C of a tile's first MFMAs) alternate between two register
+        //    sets -- unit u multiplies out of set u & 1 while the reads of unit u + 1 land in the other -- so no
+        //    register is copied between units;
+        //  * the ring slot (u % NSTAGE) is an immediate offset of the LDS reads and of the DMA destination: M0 is
+        //    written once per unit (slot + 4096) and the eight 1 KiB pieces use the instruction offset, which moves
+        //    the LDS and the global address alike (the per-lane global offsets carry the opposite shift);
+        //  * the body is specialised on (refill?, read ahead?), and while the ring is being refilled the number
+        //    of younger units in flight is the constant NSTAGE - 2.
+        // The norm piece is part of every tile's first unit: a cosine scan streams 32 zeros (norm_step 0) instead.
+        static_assert(NSTAGE == 2 || NSTAGE == 4, "ring depth of the AGPR configurations");
+        constexpr int G0 = NSTAGE % KU == 0 ? NSTAGE : NSTAGE * KU;  // multiple of NSTAGE (even) and of KU
+        constexpr int G = G0;
+        static_assert(G % KU == 0 && G % NSTAGE == 0 && G % 2 == 0, "group of units");
+        f32x4 fa[2][8];
+        f32x16 nrm[2];
+        // per-lane LDS addresses of the eight fragments of slot 0 and of the norm block
+        u32 la[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            la[g] = ring_base + (u32)(r31 * 256 + ((2 * g + h) ^ (r31 & 15)) * 16);
+            asm volatile("" : "+v"(la[g]));  // one register each: hipcc otherwise re-adds the wave's ring base per read
+        }
+        u32 ln = ring_base + (u32)(UNIT_BYTES + (4 * h) * 4);
+        asm volatile("" : "+v"(ln));
+        // per-lane global offsets of the eight pieces, shifted against the instruction offsets j * 1024 - 4096
+        u32 voff_s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) voff_s[j] = voff[j] + 4096u - (u32)j * 1024u;
+        auto read_ab = [&](auto par_c, auto slot_c, const bool first_of_tile) {
+            constexpr int P = decltype(par_c)::value, SL = decltype(slot_c)::value;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) fa[P][g] = *(lds_cf32x4*)(la[g] + (u32)(SL * SLOT_BYTES));
+            if (KU == 1 || first_of_tile) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 v = *(lds_cf32x4*)(ln + (u32)(SL * SLOT_BYTES + 32 * c));
+                    nrm[P][4 * c + 0] = v[0];
+                    nrm[P][4 * c + 1] = v[1];
+                    nrm[P][4 * c + 2] = v[2];
+                    nrm[P][4 * c + 3] = v[3];
+                }
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < 8; ++g) fa[0][g] = fa[1][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nrm[0][i] = nrm[1][i] = 0.f;
+        if (total_units > 0) {
+            if (KU == 1)
+                wait_units_in_flight<NSTAGE, 9>((int)(issued - 1));
+            else
+                wait_units_in_flight<NSTAGE, 8>((int)(issued - 1));
+            read_ab(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, true);
+            loaded = 1;
+            rd_kc = KU > 1 ? 1 : 0;
+        }
+        // issue cursor as running pointers (the tile of the next unit to issue)
+        const long long tile_adv = nwaves * a.tile_step * TILE_ROWS;                       // rows between a wave's tiles
+        const unsigned char* iss_ptr = reinterpret_cast<const unsigned char*>(a.scan) + iss_sel * a.tile_step * TILE_ROWS * (DPAD * 2);
+        const float* iss_nptr = a.norms + iss_sel * a.tile_step * TILE_ROWS * a.norm_step;
+        const long long iss_ptr_adv = tile_adv * (DPAD * 2), iss_nptr_adv = tile_adv * a.norm_step;
+        auto unit = [&](auto par_c, auto slot_c, auto iss_c, auto rd_c, const int kc, f32x16 (&acc)[QT]) {
+            constexpr int P = decltype(par_c)::value, SL = decltype(slot_c)::value;
+            constexpr bool ISS = decltype(iss_c)::value, RD = decltype(rd_c)::value;
+            const int units_behind = ISS ? NSTAGE - 2 : (int)(issued - loaded - 1);  // younger units that may stay in flight
+            const u32 idst = ring_base + (u32)SL * SLOT_BYTES;                       // the slot this unit leaves is refilled
+            const unsigned char* ibase = iss_ptr + iss_kc * 256;
+            const bool inorm = iss_kc == 0;
+            const bool rd_first = rd_kc == 0;
+            if (kc == 0)
+                mfma_fence_in_c(nrm[P], fa[P]);
+            else
+                mfma_fence_in<QT>(acc, fa[P]);
+            constexpr int NSLOT = 8 * QP * QT;             // one slot behind every MFMA
+            constexpr int DMA0 = NSLOT >= 16 ? 6 : 2, DSTEP = (NSLOT - DMA0 - 1) / 9 > 0 ? (NSLOT - DMA0 - 1) / 9 : 1;
+            auto dma_piece = [&](auto j_c) {
+                constexpr int J = decltype(j_c)::value;
+                if constexpr (J == 0) glds_set_m0(idst + 4096u);
+                if constexpr (J < 8) glds16_m0<J * 1024 - 4096>(ibase, voff_s[J]);
+                if constexpr (J == 8) {
+                    if (inorm) {
+                        glds_set_m0(idst + UNIT_BYTES);
+                        glds4_m0<0>(iss_nptr, voff_norm);
+                    }
+                }
+            };
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int half = 0; half < QP; ++half) {  // two planes: lo first, then hi
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        const int frag = kc * 8 * QP + (QP == 2 ? 2 * s + 1 - half : s);
+                        if (kc == 0 && s == 0 && half == 0)
+                            mfma_bf16_agpr_b_first(acc[t], fa[P][0], bq[t][frag], nrm[P]);
+                        else
+                            mfma_bf16_agpr_b(acc[t], fa[P][s], bq[t][frag]);
+                        const int slot = (s * QP + half) * QT + t;
+                        if constexpr (RD) {
+                            if (slot == 1 || (NSLOT == 1)) {
+                                if (KU == 1)
+                                    wait_units_in_flight<NSTAGE, 9>(units_behind);
+                                else
+                                    wait_units_in_flight<NSTAGE, 8>(units_behind);
+                                read_ab(std::integral_constant<int, P ^ 1>{}, std::integral_constant<int, (SL + 1) % NSTAGE>{}, rd_first);
+                            }
+                        }
+                        if constexpr (ISS) {
+                            if (slot >= DMA0 && (slot - DMA0) % DSTEP == 0) {
+                                const int j = (slot - DMA0) / DSTEP;
+                                static_for_one<9>(j, dma_piece);
+                            }
+                            // fewer slots than DMA pieces (8 MFMAs per unit): the rest goes behind the last MFMA
+                            if (slot == NSLOT - 1) {
+#pragma unroll
+                                for (int j = (NSLOT - 1 - DMA0) / DSTEP + 1; j < 9; ++j) static_for_one<9>(j, dma_piece);
+                            }
+                        }
+                    }
+                }
+            }
+            if constexpr (RD) {
+                ++loaded;
+                if (++rd_kc == KU) rd_kc = 0;
+            }
+            if constexpr (ISS) {
+                ++issued;
+                if (++iss_kc == KU) {
+                    iss_kc = 0;
+                    iss_ptr += iss_ptr_adv;
+                    iss_nptr += iss_nptr_adv;
+                }
+            }
+            mfma_fence_out<QT>(acc);
+        };
+        // G units with compile-time (register set, slot, k-unit).  STEADY: every unit of the group refills its slot
+        // (straight-line code: a three-way branch per unit makes hipcc merge the accumulators of its arms with
+        // register copies); otherwise each unit picks its variant and the group ends at a tile boundary once the
+        // tiles are done.
+        long long sel = gw;
+        f32x16 acc[QT];
+        auto group = [&](auto&& self, auto u_c, auto steady_c) -> void {
+            constexpr int U = decltype(u_c)::value;
+            constexpr bool STEADY = decltype(steady_c)::value;
+            if constexpr (U < G) {
+                constexpr int KC = U % KU;
+                constexpr std::integral_constant<int, U & 1> par{};
+                constexpr std::integral_constant<int, U % NSTAGE> sl{};
+                if constexpr (STEADY) {
+                    unit(par, sl, std::true_type{}, std::true_type{}, KC, acc);
+                } else {
+                    if (KC == 0 && sel >= a.n_sel) return;
+                    const bool rd = loaded < total_units, iss = issued < total_units;  // iss implies rd
+                    if (iss)
+                        unit(par, sl, std::true_type{}, std::true_type{}, KC, acc);
+                    else if (rd)
+                        unit(par, sl, std::false_type{}, std::true_type{}, KC, acc);
+                    else
+                        unit(par, sl, std::false_type{}, std::false_type{}, KC, acc);
+                }
+                if constexpr (KC == KU - 1) {
+                    finish_tile(sel, acc);
+                    sel += nwaves;
+                }
+                self(self, std::integral_constant<int, U + 1>{}, steady_c);
+            }
+        };
+        while (issued + G <= total_units) group(group, std::integral_constant<int, 0>{}, std::true_type{});
+        while (sel < a.n_sel) group(group, std::integral_constant<int, 0>{}, std::false_type{});
+    } else {
+        f32x4 av_cur[8], av_nxt[8], nrm_nxt[4];
+        auto read_frags = [&](int slot_idx, bool first_of_tile) {
+            const unsigned char* sl = ring_ptr + slot_idx * SLOT_BYTES;
+            const unsigned char* arow = sl + r31 * 256;
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                av_nxt[g] = *reinterpret_cast<const f32x4*>(arow + ((2 * g + h) ^ (r31 & 15)) * 16);
+            if (first_of_tile && add_norm) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) nrm_nxt[c] = *reinterpret_cast<const f32x4*>(sl + UNIT_BYTES + (8 * c + 4 * h) * 4);
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < 8; ++g) av_nxt[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) nrm_nxt[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (total_units > 0) {
+            if (nine)
+                wait_units_in_flight<NSTAGE, 9>((int)(issued - 1));
+            else
+                wait_units_in_flight<NSTAGE, 8>((int)(issued - 1));
+            if (do_math) read_frags(0, true);
+            loaded = 1;
+            rd_slot = NSTAGE > 1 ? 1 : 0;
+            rd_kc = KU > 1 ? 1 : 0;
+        }
+        for (long long sel = gw; sel < a.n_sel; sel += nwaves) {
+            f32x16 acc[QT];
+            if constexpr (AB) {
+                // ---- Two waves per SIMD, 128 + 128 registers (the two register sets of the one-wave path do not fit):
+                // the fragments of the next unit are copied into place.  As there: nothing else hides this wave's
+                // side work, so it sits in the issue shadow of the 8*QP*QT MFMAs of a unit (an MFMA holds the
+                // vector issue for 8 of its 32 cycles): the LDS reads of the next unit's fragments behind
+                // the first MFMAs, one of the DMA instructions that refill this unit's slot behind every
+                // few MFMAs after that.  The body is specialised on (refill?, read ahead?) so the block is
+                // free of branches; the measurement-only ablations (debug 1 / 2) are not available here.
+                auto unit = [&](auto iss_c, auto rd_c, const int kc) {
+                    constexpr bool ISS = decltype(iss_c)::value, RD = decltype(rd_c)::value;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];
+                    f32x16 nrm_c;
+                    if (kc == 0) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) nrm_c[i] = add_norm ? nrm_nxt[i >> 2][i & 3] : 0.f;
+                    }
+                    asm volatile("" ::: "memory");
+                    const int units_behind = (int)(issued - loaded - 1);  // younger units that may stay in flight
+                    const long long irow0 = iss_sel * a.tile_step * TILE_ROWS;
+                    const u32 idst = ring_base + (u32)iss_slot * SLOT_BYTES;
+                    const unsigned char* ibase = reinterpret_cast<const unsigned char*>(a.scan) + irow0 * (DPAD * 2) + iss_kc * 256;
+                    const bool inorm = add_norm && iss_kc == 0;
+                    const bool rd_first = rd_kc == 0;
+                    if (kc == 0)
+                        mfma_fence_in_c(nrm_c, av_cur);
+                    else
+                        mfma_fence_in<QT>(acc, av_cur);
+                    constexpr int NSLOT = 8 * QP * QT;             // one slot behind every MFMA
+                    constexpr int DMA0 = NSLOT >= 16 ? 6 : 2, DSTEP = (NSLOT - DMA0 - 1) / 9 > 0 ? (NSLOT - DMA0 - 1) / 9 : 1;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                        for (int half = 0; half < QP; ++half) {  // two planes: lo first, then hi
+#pragma unroll
+                            for (int t = 0; t < QT; ++t) {
+                                const int frag = kc * 8 * QP + (QP == 2 ? 2 * s + 1 - half : s);
+                                if (kc == 0 && s == 0 && half == 0)
+                                    mfma_bf16_agpr_b_first(acc[t], av_cur[0], bq[t][frag], nrm_c);
+                                else
+                                    mfma_bf16_agpr_b(acc[t], av_cur[s], bq[t][frag]);
+                                const int slot = (s * QP + half) * QT + t;
+                                if constexpr (RD) {
+                                    if (slot == 1 || (NSLOT == 1)) {
+                                        if (nine)
+                                            wait_units_in_flight<NSTAGE, 9>(units_behind);
+                                        else
+                                            wait_units_in_flight<NSTAGE, 8>(units_behind);
+                                        read_frags(rd_slot, rd_first);
+                                    }
+                                }
+                                if constexpr (ISS) {
+                                    if (slot >= DMA0 && (slot - DMA0) % DSTEP == 0) {
+                                        const int j = (slot - DMA0) / DSTEP;
+                                        if (j < 8) glds16(ibase, voff[j], idst + (u32)j * 1024);
+                                        if (j == 8 && inorm) glds4(a.norms + irow0 * a.norm_step, voff_norm, idst + UNIT_BYTES);
+                                    }
+                                    // fewer slots than DMA pieces (8 MFMAs per unit): the rest goes behind the last MFMA
+                                    if (slot == NSLOT - 1) {
+#pragma unroll
+                                        for (int j = (NSLOT - 1 - DMA0) / DSTEP + 1; j < 9; ++j) {
+                                            if (j < 8) glds16(ibase, voff[j], idst + (u32)j * 1024);
+                                            if (j == 8 && inorm) glds4(a.norms + irow0 * a.norm_step, voff_norm, idst + UNIT_BYTES);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if constexpr (RD) {
+                        ++loaded;
+                        if (++rd_slot == NSTAGE) rd_slot = 0;
+                        if (++rd_kc == KU) rd_kc = 0;
+                    }
+                    if constexpr (ISS) {
+                        ++issued;
+                        if (++iss_kc == KU) {
+                            iss_kc = 0;
+                            iss_sel += nwaves;
+                        }
+                        if (++iss_slot == NSTAGE) iss_slot = 0;
+                    }
+                    mfma_fence_out<QT>(acc);
+                };
+#pragma unroll
+                for (int kc = 0; kc < KU; ++kc) {
+                    const bool rd = loaded < total_units, iss = issued < total_units;  // iss implies rd
+                    if (iss)
+                        unit(std::true_type{}, std::true_type{}, kc);
+                    else if (rd)
+                        unit(std::false_type{}, std::true_type{}, kc);
+                    else
+                        unit(std::false_type{}, std::false_type{}, kc);
+                }
+            } else {
+#pragma unroll
+                for (int kc = 0; kc < KU; ++kc) {
+                    // fragments of this unit are complete once copied (hipcc waits lgkmcnt here); its slot is free
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];
+                    if (kc == 0) {
+                        // the accumulator starts from |x|^2 of the tile's rows (0 for cosine): score = |x|^2 + x.q'
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[0][i] = add_norm ? nrm_nxt[i >> 2][i & 3] : 0.f;
+                    }
+                    asm volatile("" ::: "memory");
+                    issue_next();
+                    if (loaded < total_units) {
+                        if (nine)  // younger units may stay in flight
+                            wait_units_in_flight<NSTAGE, 9>((int)(issued - loaded - 1));
+                        else
+                            wait_units_in_flight<NSTAGE, 8>((int)(issued - loaded - 1));
+                        if (do_math) read_frags(rd_slot, rd_kc == 0);
+                        ++loaded;
+                        if (++rd_slot == NSTAGE) rd_slot = 0;
+                        if (++rd_kc == KU) rd_kc = 0;
+                    }
+                    if (do_math) {
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) {
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, av_cur[s]);
+                            f32x4 bh, bl;
+                            if constexpr (QREG) {
+                                bh = bq[0][2 * s];
+                                bl = bq[0][2 * s + 1];
+                            } else {
+                                const unsigned char* brow = smem + (u32)r31 * DPAD * 4 + kc * 512 + ((2 * s + h) ^ (r31 & 15)) * 16;
+                                bh = *reinterpret_cast<const f32x4*>(brow);
+                                bl = *reinterpret_cast<const f32x4*>(brow + 256);
+                            }
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bl), acc[0], 0, 0, 0);
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bh), acc[0], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (do_math) finish_tile(sel, acc);
         }
     }
     if constexpr (!SAMPLE) {

@@ -36,6 +36,34 @@ __device__ __forceinline__ void glds4(const void* gbase_uniform, u32 voff, u32 l
         : "memory");
 }
 
+// The same copies with M0 written once for several pieces: the instruction offset OFF (-4096 .. 4095) moves the LDS
+// destination AND the global address, so a caller that wants the global address unshifted takes OFF off its per-lane
+// offset.  Used where one wave per SIMD makes scalar issue slots count (five scalar instructions per piece in the
+// self-contained form above).  Nothing else in those kernels touches M0 (gfx9 LDS instructions do not need it).
+__device__ __forceinline__ void glds_set_m0(u32 lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void glds16_m0(const void* gbase_uniform, u32 voff) {
+    static_assert(OFF >= -4096 && OFF <= 4095, "13-bit signed instruction offset");
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(gbase_uniform), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void glds4_m0(const void* gbase_uniform, u32 voff) {
+    static_assert(OFF >= -4096 && OFF <= 4095, "13-bit signed instruction offset");
+    asm volatile("global_load_lds_dword %0, %1 offset:%2" ::"v"(voff), "s"(gbase_uniform), "n"(OFF) : "memory");
+}
+// call f(integral_constant<int, j>) for the one j in [0, N) that equals the (compile-time foldable) argument
+template <int N, int J = 0, class F>
+__device__ __forceinline__ void static_for_one(int j, F&& f) {
+    if constexpr (J < N) {
+        if (j == J)
+            f(std::integral_constant<int, J>{});
+        else
+            static_for_one<N, J + 1>(j, f);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -15,7 +15,9 @@ P1=$(pick SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
 P2=$(pick SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS)
 P3=$(pick SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT)
 i=0
-for P in "$P1" "$P2" "$P3" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
+# optional cache-side passes: PMC_EXTRA="TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY;TCC_HIT TCC_MISS" (passes separated by ';')
+IFS=';' read -r -a EXTRA <<< "${PMC_EXTRA:-}"
+for P in "$P1" "$P2" "$P3" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "${EXTRA[@]}"; do
   i=$((i+1))
   [ -z "$P" ] && continue
   echo "pass $i: $P"
