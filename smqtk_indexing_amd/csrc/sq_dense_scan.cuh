@@ -199,7 +199,7 @@ static __global__ __launch_bounds__(256) void dense_prep_queries_kernel(const fl
     if (qi < nq)
         for (int i = threadIdx.x; i < ldq; i += 256) q_al[(long long)qi * ldq + i] = i < d ? q[(long long)qi * d + i] : 0.f;
     // L2 with a centre: everything the filter uses (|q'|^2, the split planes) is q' = q - c in float32
-    auto qv = [&](int i) {
+    auto qv = [&](int i) __attribute__((always_inline)) {
         const float v = q[(long long)qi * d + i];
         return center ? __fsub_rn(v, center[i]) : v;
     };
@@ -310,6 +310,72 @@ __device__ __forceinline__ void mfma_fence_out(f32x16 (&acc)[QT]) {
         asm volatile("s_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
     else
         asm volatile("s_nop 15" : "+v"(acc[0]));
+}
+// min of the 16 scores of a lane as eight VALU instructions that stay where they are written (asm volatile): the
+// skewed epilogue below places them between hand-issued MFMAs.  NaN scores lose (IEEE min), as with fminf.
+__device__ __forceinline__ float min16_pinned(const f32x16& v) {
+    float m;
+    // one statement: between separate asm statements hipcc pads every instruction with an s_nop (4 cycles each)
+    asm volatile(
+        "v_min3_f32 %0, %1, %2, %3\n\t"
+        "v_min3_f32 %0, %0, %4, %5\n\t"
+        "v_min3_f32 %0, %0, %6, %7\n\t"
+        "v_min3_f32 %0, %0, %8, %9\n\t"
+        "v_min3_f32 %0, %0, %10, %11\n\t"
+        "v_min3_f32 %0, %0, %12, %13\n\t"
+        "v_min3_f32 %0, %0, %14, %15\n\t"
+        "v_min_f32 %0, %0, %16"
+        : "=&v"(m)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+          "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    return m;
+}
+// bit i of the result = (v[i] <= thr), per lane: 16 compares into three rotating scalar pairs, each shifted into the
+// mask by an add-with-carry (mask = 2 mask + bit, rows 15 .. 0) two instructions after its compare (gfx950: a VALU
+// read of a scalar register pair needs two wait states after the VALU that wrote it).  32 instructions where hipcc's
+// compare / select / or3 sequence with its own pads comes to ~70 issue slots.
+__device__ __forceinline__ u32 le_mask16(const f32x16& v, float thr) {
+    u32 mask = 0;
+    u64 c0, c1, c2, dump;
+    asm volatile(
+        "v_cmp_le_f32_e64 %1, %5, %21\n\t"
+        "v_cmp_le_f32_e64 %2, %6, %21\n\t"
+        "v_cmp_le_f32_e64 %3, %7, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\t"
+        "v_cmp_le_f32_e64 %1, %8, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t"
+        "v_cmp_le_f32_e64 %2, %9, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t"
+        "v_cmp_le_f32_e64 %3, %10, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\t"
+        "v_cmp_le_f32_e64 %1, %11, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t"
+        "v_cmp_le_f32_e64 %2, %12, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t"
+        "v_cmp_le_f32_e64 %3, %13, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\t"
+        "v_cmp_le_f32_e64 %1, %14, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t"
+        "v_cmp_le_f32_e64 %2, %15, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t"
+        "v_cmp_le_f32_e64 %3, %16, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\t"
+        "v_cmp_le_f32_e64 %1, %17, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t"
+        "v_cmp_le_f32_e64 %2, %18, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t"
+        "v_cmp_le_f32_e64 %3, %19, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1\n\t"
+        "v_cmp_le_f32_e64 %1, %20, %21\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %2\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %3\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %0, %4, %0, %0, %1"
+        : "+v"(mask), "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(dump)
+        : "v"(v[15]), "v"(v[14]), "v"(v[13]), "v"(v[12]), "v"(v[11]), "v"(v[10]), "v"(v[9]), "v"(v[8]), "v"(v[7]),
+          "v"(v[6]), "v"(v[5]), "v"(v[4]), "v"(v[3]), "v"(v[2]), "v"(v[1]), "v"(v[0]), "v"(thr));
+    return mask;
 }
 // eight 16-byte LDS reads straight into AGPRs, complete on return
 template <int N>
@@ -464,7 +530,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     long long iss_sel = gw;
     int iss_kc = 0, iss_slot = 0;
     long long issued = 0;
-    auto issue_unit = [&]() {
+    auto issue_unit = [&]() __attribute__((always_inline)) {
         const long long row0 = iss_sel * a.tile_step * TILE_ROWS;
         const u32 dst = ring_base + (u32)iss_slot * SLOT_BYTES;
         const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan) + row0 * (DPAD * 2) + iss_kc * 256;
@@ -489,7 +555,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     //   the slot of unit u is refilled by the DMA of unit u+NSTAGE as soon as
     //   av_cur is complete.
     const bool do_dma = AB || !(a.debug & 2), do_math = AB || !(a.debug & 1);
-    auto issue_next = [&]() {
+    auto issue_next = [&]() __attribute__((always_inline)) {
         if (issued < total_units) {
             if (do_dma || issued < NSTAGE)  // ablation: the ring is filled once, then reused
                 issue_unit();
@@ -498,48 +564,82 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         }
     };
     // ---- tile complete: scores for 32 rows x QT*32 queries (lane = query, register i = row (i&3)+8(i>>2)+4h)
-    auto finish_tile = [&](const long long sel, f32x16 (&acc)[QT]) {
-        const long long row0 = sel * a.tile_step * TILE_ROWS;
-        const bool is_tail = row0 + TILE_ROWS > a.n;  // wave-uniform: the last, partial tile
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const int qglob = qglob0 + t * TILE_ROWS;
-            if constexpr (!SAMPLE) {
-                float m = acc[t][0];
-#pragma unroll
-                for (int i = 1; i < 16; ++i) m = fminf(m, acc[t][i]);
-                if (__any(m <= thr_l[t])) {
-                    // survivor mask of this lane's 16 rows (bit i <-> row row0 + (i&3) + 8(i>>2) + 4h)
-                    u32 mask = 0;
-                    if (m <= thr_l[t]) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) mask |= (acc[t][i] <= thr_l[t] ? 1u : 0u) << i;
-                        if (is_tail) mask &= tail_mask;  // drop padding rows
-                        if (a.debug & 16) mask = 0;      // ablation: survivors found but not recorded
-                    }
-                    // One entry per lane that has survivors: (row0 + 4h, mask << 16 | query within the group),
-                    // appended to this wave's own segment with a plain store.  The position comes from a
-                    // ballot (no atomic, nothing the streaming loop waits for); the re-rank expands the masks.
-                    const u64 bal = __ballot(mask != 0);
-                    if (mask) {
-                        const u32 pos = wcount + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                        if (pos < a.wave_cap) wout[pos] = make_uint2((u32)(row0 + 4 * h), (mask << 16) | (u32)(t * TILE_ROWS + r31));
-                    }
-                    wcount += (u32)__popcll(bal);
-                }
+    // finish_q: one query tile of a row tile; PIN: the minimum is computed by instructions pinned in program order
+    // the survivors of one query tile (hit: ballot of the lanes whose minimum passes): rare next to the tiles without
+    auto emit_q = [&](const long long sel, auto t_c, const f32x16& sc, const u64 hit) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+        if (hit != 0) {
+            const long long row0 = sel * a.tile_step * TILE_ROWS;
+            const bool is_tail = row0 + TILE_ROWS > a.n;  // wave-uniform: the last, partial tile
+            // survivor mask of this lane's 16 rows (bit i <-> row row0 + (i&3) + 8(i>>2) + 4h)
+            u32 mask = le_mask16(sc, thr_l[t]);  // (every lane: the lanes without a survivor get 0)
+            if (is_tail) mask &= tail_mask;       // drop padding rows
+            if (a.debug & 16) mask = 0;           // ablation: survivors found but not recorded
+            // One entry per lane that has survivors: (row0 + 4h, mask << 16 | query within the group),
+            // appended to this wave's own segment with a plain store.  The position comes from a
+            // ballot (no atomic, nothing the streaming loop waits for); the re-rank expands the masks.
+            const u64 bal = __ballot(mask != 0);
+            if (mask) {
+                const u32 pos = wcount + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                if (pos < a.wave_cap) wout[pos] = make_uint2((u32)(row0 + 4 * h), (mask << 16) | (u32)(t * TILE_ROWS + r31));
+            }
+            wcount += (u32)__popcll(bal);
+        }
+    };
+    // ---- tile complete: scores for 32 rows x QT*32 queries (lane = query, register i = row (i&3)+8(i>>2)+4h)
+    // finish_q: one query tile of a row tile; PIN: the minimum is computed by instructions pinned in program order.
+    // EMIT scan: returns the ballot of the lanes with a survivor (emit_q writes them out); SAMPLE: stores the minima.
+    auto finish_q = [&](const long long sel, auto t_c, auto pin_c, const f32x16& sc) __attribute__((always_inline)) -> u64 {
+        constexpr int t = decltype(t_c)::value;
+        constexpr bool PIN = decltype(pin_c)::value;
+#if defined(SQ_ABL) && (SQ_ABL & 4)
+        return 0;  // measurement build: no epilogue
+#endif
+        if constexpr (!SAMPLE) {
+            float m;
+            if constexpr (PIN) {
+                m = min16_pinned(sc);
             } else {
-                // the minimum score of this lane's 16 rows: the score of one actual row, hence a valid
-                // sample for an upper bound of the k-th smallest score (kth_threshold_f32_kernel)
-                float ml = __builtin_inff();
-                if (is_tail) {
+                m = sc[0];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if ((tail_mask >> i) & 1u) ml = fminf(ml, acc[t][i]);
-                } else {
+                for (int i = 1; i < 16; ++i) m = fminf(m, sc[i]);
+            }
+            return __ballot(m <= thr_l[t]);
+        } else {
+            const long long row0 = sel * a.tile_step * TILE_ROWS;
+            const bool is_tail = row0 + TILE_ROWS > a.n;  // wave-uniform: the last, partial tile
+            const int qglob = qglob0 + t * TILE_ROWS;
+            // the minimum score of this lane's 16 rows: the score of one actual row, hence a valid
+            // sample for an upper bound of the k-th smallest score (kth_threshold_f32_kernel)
+            float ml = __builtin_inff();
+            if (is_tail) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) ml = fminf(ml, acc[t][i]);
-                }
-                a.sample_out[(long long)qglob * a.ns + sel * 2 + h] = ml;
+                for (int i = 0; i < 16; ++i)
+                    if ((tail_mask >> i) & 1u) ml = fminf(ml, sc[i]);
+            } else if constexpr (PIN) {
+                ml = min16_pinned(sc);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ml = fminf(ml, sc[i]);
+            }
+            a.sample_out[(long long)qglob * a.ns + sel * 2 + h] = ml;
+            return 0;
+        }
+    };
+    auto finish_tile = [&](const long long sel, f32x16 (&acc)[QT]) __attribute__((always_inline)) {
+        u64 hit[QT];
+        hit[0] = finish_q(sel, std::integral_constant<int, 0>{}, std::false_type{}, acc[0]);
+        if constexpr (QT > 1) hit[1] = finish_q(sel, std::integral_constant<int, 1>{}, std::false_type{}, acc[1]);
+        if constexpr (QT > 2) {
+            hit[2] = finish_q(sel, std::integral_constant<int, 2>{}, std::false_type{}, acc[2]);
+            hit[3] = finish_q(sel, std::integral_constant<int, 3>{}, std::false_type{}, acc[3]);
+        }
+        if constexpr (!SAMPLE) {
+            emit_q(sel, std::integral_constant<int, 0>{}, acc[0], hit[0]);
+            if constexpr (QT > 1) emit_q(sel, std::integral_constant<int, 1>{}, acc[1], hit[1]);
+            if constexpr (QT > 2) {
+                emit_q(sel, std::integral_constant<int, 2>{}, acc[2], hit[2]);
+                emit_q(sel, std::integral_constant<int, 3>{}, acc[3], hit[3]);
             }
         }
     };
@@ -582,8 +682,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         u32 voff_s[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) voff_s[j] = voff[j] + 4096u - (u32)j * 1024u;
-        auto read_ab = [&](auto par_c, auto slot_c, const bool first_of_tile) {
+        auto read_ab = [&](auto par_c, auto slot_c, const bool first_of_tile) __attribute__((always_inline)) {
             constexpr int P = decltype(par_c)::value, SL = decltype(slot_c)::value;
+#if defined(SQ_ABL) && (SQ_ABL & 2)
+            if (loaded > 1) return;  // measurement build: the fragments of the first units are reused
+#endif
 #pragma unroll
             for (int g = 0; g < 8; ++g) fa[P][g] = *(lds_cf32x4*)(la[g] + (u32)(SL * SLOT_BYTES));
             if (KU == 1 || first_of_tile) {
@@ -615,7 +718,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         const unsigned char* iss_ptr = reinterpret_cast<const unsigned char*>(a.scan) + iss_sel * a.tile_step * TILE_ROWS * (DPAD * 2);
         const float* iss_nptr = a.norms + iss_sel * a.tile_step * TILE_ROWS * a.norm_step;
         const long long iss_ptr_adv = tile_adv * (DPAD * 2), iss_nptr_adv = tile_adv * a.norm_step;
-        auto unit = [&](auto par_c, auto slot_c, auto iss_c, auto rd_c, const int kc, f32x16 (&acc)[QT]) {
+        // SKEW (four query tiles, one k-unit): the MFMAs of a unit run as two halves -- tiles 0,1 then tiles 2,3 (the A
+        // fragments stay in registers for the whole unit, so the order is free) -- and the epilogue of a half sits
+        // between the MFMAs of the next one (tiles 0,1 of this unit under its tiles 2,3; tiles 2,3 under tiles 0,1 of
+        // the following unit): with one wave per SIMD nothing else would keep the matrix pipe busy during the ~50-100
+        // vector instructions of the four epilogues.  An epilogue starts four MFMAs (128 cycles) after the last MFMA
+        // of its accumulators, which also covers the MFMA -> VALU read hazard hipcc does not know about.
+#ifdef SQ_NO_SKEW
+        constexpr bool SKEW = false;  // measurement build
+#else
+        constexpr bool SKEW = QT == 4 && QP == 1 && KU == 1;
+#endif
+        long long prev_sel = 0;
+        bool prev_valid = false;
+        auto unit = [&](auto par_c, auto slot_c, auto iss_c, auto rd_c, const int kc, f32x16 (&acc)[QT], const long long cur_sel) __attribute__((always_inline)) {
             constexpr int P = decltype(par_c)::value, SL = decltype(slot_c)::value;
             constexpr bool ISS = decltype(iss_c)::value, RD = decltype(rd_c)::value;
             const int units_behind = ISS ? NSTAGE - 2 : (int)(issued - loaded - 1);  // younger units that may stay in flight
@@ -629,8 +745,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 mfma_fence_in<QT>(acc, fa[P]);
             constexpr int NSLOT = 8 * QP * QT;             // one slot behind every MFMA
             constexpr int DMA0 = NSLOT >= 16 ? 6 : 2, DSTEP = (NSLOT - DMA0 - 1) / 9 > 0 ? (NSLOT - DMA0 - 1) / 9 : 1;
-            auto dma_piece = [&](auto j_c) {
+            u64 hit0 = 0, hit1 = 0, hit2 = 0, hit3 = 0;
+            auto dma_piece = [&](auto j_c) __attribute__((always_inline)) {
                 constexpr int J = decltype(j_c)::value;
+#if defined(SQ_ABL) && (SQ_ABL & 1)
+                return;  // measurement build: no refill
+#endif
                 if constexpr (J == 0) glds_set_m0(idst + 4096u);
                 if constexpr (J < 8) glds16_m0<J * 1024 - 4096>(ibase, voff_s[J]);
                 if constexpr (J == 8) {
@@ -641,37 +761,55 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 }
             };
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-#pragma unroll
-                for (int half = 0; half < QP; ++half) {  // two planes: lo first, then hi
-#pragma unroll
-                    for (int t = 0; t < QT; ++t) {
-                        const int frag = kc * 8 * QP + (QP == 2 ? 2 * s + 1 - half : s);
-                        if (kc == 0 && s == 0 && half == 0)
-                            mfma_bf16_agpr_b_first(acc[t], fa[P][0], bq[t][frag], nrm[P]);
+            for (int m = 0; m < NSLOT; ++m) {
+                // MFMA m of the unit: k-step s, plane half (two planes: lo first, then hi), query tile t
+                const int s = SKEW ? (m & 15) >> 1 : m / (QP * QT);
+                const int half = SKEW ? 0 : (m / QT) % QP;
+                const int t = SKEW ? 2 * (m >> 4) + (m & 1) : m % QT;
+                const int frag = kc * 8 * QP + (QP == 2 ? 2 * s + 1 - half : s);
+                if (kc == 0 && s == 0 && half == 0)
+                    mfma_bf16_agpr_b_first(acc[t], fa[P][0], bq[t][frag], nrm[P]);
+                else
+                    mfma_bf16_agpr_b(acc[t], fa[P][s], bq[t][frag]);
+                const int slot = m;
+                if constexpr (RD) {
+                    if (slot == 1 || (NSLOT == 1)) {
+                        if (KU == 1)
+                            wait_units_in_flight<NSTAGE, 9>(units_behind);
                         else
-                            mfma_bf16_agpr_b(acc[t], fa[P][s], bq[t][frag]);
-                        const int slot = (s * QP + half) * QT + t;
-                        if constexpr (RD) {
-                            if (slot == 1 || (NSLOT == 1)) {
-                                if (KU == 1)
-                                    wait_units_in_flight<NSTAGE, 9>(units_behind);
-                                else
-                                    wait_units_in_flight<NSTAGE, 8>(units_behind);
-                                read_ab(std::integral_constant<int, P ^ 1>{}, std::integral_constant<int, (SL + 1) % NSTAGE>{}, rd_first);
-                            }
+                            wait_units_in_flight<NSTAGE, 8>(units_behind);
+                        read_ab(std::integral_constant<int, P ^ 1>{}, std::integral_constant<int, (SL + 1) % NSTAGE>{}, rd_first);
+                    }
+                }
+                if constexpr (SKEW) {
+                    // minima + ballots in the shadow of the MFMAs; the (rare) survivors are written out where the
+                    // MFMA stream has a seam anyway: before the half that overwrites their accumulators
+                    if (slot == 3 && prev_valid) hit2 = finish_q(prev_sel, std::integral_constant<int, 2>{}, std::true_type{}, acc[2]);
+                    if (slot == 9 && prev_valid) hit3 = finish_q(prev_sel, std::integral_constant<int, 3>{}, std::true_type{}, acc[3]);
+                    if (slot == 15 && prev_valid) {
+                        if constexpr (!SAMPLE) {
+                            emit_q(prev_sel, std::integral_constant<int, 2>{}, acc[2], hit2);
+                            emit_q(prev_sel, std::integral_constant<int, 3>{}, acc[3], hit3);
                         }
-                        if constexpr (ISS) {
-                            if (slot >= DMA0 && (slot - DMA0) % DSTEP == 0) {
-                                const int j = (slot - DMA0) / DSTEP;
-                                static_for_one<9>(j, dma_piece);
-                            }
-                            // fewer slots than DMA pieces (8 MFMAs per unit): the rest goes behind the last MFMA
-                            if (slot == NSLOT - 1) {
+                    }
+                    if (slot == 19) hit0 = finish_q(cur_sel, std::integral_constant<int, 0>{}, std::true_type{}, acc[0]);
+                    if (slot == 25) hit1 = finish_q(cur_sel, std::integral_constant<int, 1>{}, std::true_type{}, acc[1]);
+                    if (slot == 31) {
+                        if constexpr (!SAMPLE) {
+                            emit_q(cur_sel, std::integral_constant<int, 0>{}, acc[0], hit0);
+                            emit_q(cur_sel, std::integral_constant<int, 1>{}, acc[1], hit1);
+                        }
+                    }
+                }
+                if constexpr (ISS) {
+                    if (slot >= DMA0 && (slot - DMA0) % DSTEP == 0) {
+                        const int j = (slot - DMA0) / DSTEP;
+                        static_for_one<9>(j, dma_piece);
+                    }
+                    // fewer slots than DMA pieces (8 MFMAs per unit): the rest goes behind the last MFMA
+                    if (slot == NSLOT - 1) {
 #pragma unroll
-                                for (int j = (NSLOT - 1 - DMA0) / DSTEP + 1; j < 9; ++j) static_for_one<9>(j, dma_piece);
-                            }
-                        }
+                        for (int j = (NSLOT - 1 - DMA0) / DSTEP + 1; j < 9; ++j) static_for_one<9>(j, dma_piece);
                     }
                 }
             }
@@ -687,7 +825,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                     iss_nptr += iss_nptr_adv;
                 }
             }
-            mfma_fence_out<QT>(acc);
+            if constexpr (!SKEW) mfma_fence_out<QT>(acc);
         };
         // G units with compile-time (register set, slot, k-unit).  STEADY: every unit of the group refills its slot
         // (straight-line code: a three-way branch per unit makes hipcc merge the accumulators of its arms with
@@ -695,7 +833,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         // tiles are done.
         long long sel = gw;
         f32x16 acc[QT];
-        auto group = [&](auto&& self, auto u_c, auto steady_c) -> void {
+        auto group = [&](auto&& self, auto u_c, auto steady_c) __attribute__((always_inline)) -> void {
             constexpr int U = decltype(u_c)::value;
             constexpr bool STEADY = decltype(steady_c)::value;
             if constexpr (U < G) {
@@ -703,29 +841,49 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 constexpr std::integral_constant<int, U & 1> par{};
                 constexpr std::integral_constant<int, U % NSTAGE> sl{};
                 if constexpr (STEADY) {
-                    unit(par, sl, std::true_type{}, std::true_type{}, KC, acc);
+                    unit(par, sl, std::true_type{}, std::true_type{}, KC, acc, sel);
                 } else {
                     if (KC == 0 && sel >= a.n_sel) return;
                     const bool rd = loaded < total_units, iss = issued < total_units;  // iss implies rd
                     if (iss)
-                        unit(par, sl, std::true_type{}, std::true_type{}, KC, acc);
+                        unit(par, sl, std::true_type{}, std::true_type{}, KC, acc, sel);
                     else if (rd)
-                        unit(par, sl, std::false_type{}, std::true_type{}, KC, acc);
+                        unit(par, sl, std::false_type{}, std::true_type{}, KC, acc, sel);
                     else
-                        unit(par, sl, std::false_type{}, std::false_type{}, KC, acc);
+                        unit(par, sl, std::false_type{}, std::false_type{}, KC, acc, sel);
+                    // hipcc may merge the accumulators of the three arms with register copies: not before the MFMAs are done
+                    if constexpr (SKEW) mfma_fence_out<QT>(acc);
                 }
-                if constexpr (KC == KU - 1) {
+                if constexpr (SKEW) {
+                    prev_sel = sel;
+                    prev_valid = true;
+                    sel += nwaves;
+                } else if constexpr (KC == KU - 1) {
                     finish_tile(sel, acc);
                     sel += nwaves;
                 }
                 self(self, std::integral_constant<int, U + 1>{}, steady_c);
             }
         };
-        while (issued + G <= total_units) group(group, std::integral_constant<int, 0>{}, std::true_type{});
+        while (issued + G <= total_units) {
+            group(group, std::integral_constant<int, 0>{}, std::true_type{});
+            if constexpr (SKEW) mfma_fence_out<QT>(acc);  // (a loop-carried accumulator copy must not overtake the MFMAs)
+        }
         while (sel < a.n_sel) group(group, std::integral_constant<int, 0>{}, std::false_type{});
+        if constexpr (SKEW) {
+            if (prev_valid) {  // the last unit's tiles 2,3
+                mfma_fence_out<QT>(acc);
+                const u64 h2 = finish_q(prev_sel, std::integral_constant<int, 2>{}, std::false_type{}, acc[2]);
+                const u64 h3 = finish_q(prev_sel, std::integral_constant<int, 3>{}, std::false_type{}, acc[3]);
+                if constexpr (!SAMPLE) {
+                    emit_q(prev_sel, std::integral_constant<int, 2>{}, acc[2], h2);
+                    emit_q(prev_sel, std::integral_constant<int, 3>{}, acc[3], h3);
+                }
+            }
+        }
     } else {
         f32x4 av_cur[8], av_nxt[8], nrm_nxt[4];
-        auto read_frags = [&](int slot_idx, bool first_of_tile) {
+        auto read_frags = [&](int slot_idx, bool first_of_tile) __attribute__((always_inline)) {
             const unsigned char* sl = ring_ptr + slot_idx * SLOT_BYTES;
             const unsigned char* arow = sl + r31 * 256;
 #pragma unroll
@@ -760,7 +918,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 // the first MFMAs, one of the DMA instructions that refill this unit's slot behind every
                 // few MFMAs after that.  The body is specialised on (refill?, read ahead?) so the block is
                 // free of branches; the measurement-only ablations (debug 1 / 2) are not available here.
-                auto unit = [&](auto iss_c, auto rd_c, const int kc) {
+                auto unit = [&](auto iss_c, auto rd_c, const int kc) __attribute__((always_inline)) {
                     constexpr bool ISS = decltype(iss_c)::value, RD = decltype(rd_c)::value;
 #pragma unroll
                     for (int g = 0; g < 8; ++g) av_cur[g] = av_nxt[g];

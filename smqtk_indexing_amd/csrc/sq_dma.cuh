@@ -6,6 +6,13 @@
 
 namespace sq {
 
+// (readfirstlane: a no-op where hipcc has the wave-uniform value in scalar registers anyway; where it has moved a
+// uniform computation to the vector unit, the "s" constraint alone would be handed a VGPR)
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+    const u64 v = (u64)(uintptr_t)p;
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return (const void*)(uintptr_t)(((u64)hi << 32) | lo);
+}
 // LDS-DMA: 64 lanes x 16 bytes land at lds_dst + lane*16 (wave-uniform base in
 // M0); the global source is a wave-uniform 64-bit base (SGPR pair) plus a
 // per-lane 32-bit byte offset.  Issued from inline asm so that hipcc does not
@@ -20,7 +27,7 @@ __device__ __forceinline__ void glds16(const void* gbase_uniform, u32 voff, u32 
         "global_load_lds_dwordx4 %1, %2\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff), "s"(gbase_uniform), "s"(lds_dst)
+        : "v"(voff), "s"(uniform_ptr(gbase_uniform)), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
         : "memory");
 }
 __device__ __forceinline__ void glds4(const void* gbase_uniform, u32 voff, u32 lds_dst) {
@@ -32,7 +39,7 @@ __device__ __forceinline__ void glds4(const void* gbase_uniform, u32 voff, u32 l
         "global_load_lds_dword %1, %2\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff), "s"(gbase_uniform), "s"(lds_dst)
+        : "v"(voff), "s"(uniform_ptr(gbase_uniform)), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
         : "memory");
 }
 
@@ -41,17 +48,17 @@ __device__ __forceinline__ void glds4(const void* gbase_uniform, u32 voff, u32 l
 // offset.  Used where one wave per SIMD makes scalar issue slots count (five scalar instructions per piece in the
 // self-contained form above).  Nothing else in those kernels touches M0 (gfx9 LDS instructions do not need it).
 __device__ __forceinline__ void glds_set_m0(u32 lds_dst) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void glds16_m0(const void* gbase_uniform, u32 voff) {
     static_assert(OFF >= -4096 && OFF <= 4095, "13-bit signed instruction offset");
-    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(gbase_uniform), "n"(OFF) : "memory");
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(uniform_ptr(gbase_uniform)), "n"(OFF) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void glds4_m0(const void* gbase_uniform, u32 voff) {
     static_assert(OFF >= -4096 && OFF <= 4095, "13-bit signed instruction offset");
-    asm volatile("global_load_lds_dword %0, %1 offset:%2" ::"v"(voff), "s"(gbase_uniform), "n"(OFF) : "memory");
+    asm volatile("global_load_lds_dword %0, %1 offset:%2" ::"v"(voff), "s"(uniform_ptr(gbase_uniform)), "n"(OFF) : "memory");
 }
 // call f(integral_constant<int, j>) for the one j in [0, N) that equals the (compile-time foldable) argument
 template <int N, int J = 0, class F>
