@@ -350,7 +350,10 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         if (stride < 1) stride = 1;
         while (stride > 1 && (n_tiles / stride) * 2 < 8ll * kk) stride >>= 1;
         const long long ns_tiles = (n_tiles + stride - 1) / stride;
-        const long long ns = ns_tiles * 2;  // one sample (a 16-row group minimum) per lane half per tile
+        // one sample (a 16-row group minimum) per lane half per tile; the four-tile sample pass writes runs of four
+        // tiles ([query][half][tiles rounded up to 4], +inf in the padding: dense_scan_kernel CHUNK)
+        const bool sample_runs = qt == 4 && qp == 1 && d_pad == KT;
+        const long long ns = (sample_runs ? (ns_tiles + 3) / 4 * 4 : ns_tiles) * 2;
         SQ_TRY(s.sample.reserve((size_t)nq_pad * ns * 4));
         SQ_TRY(s.keys.reserve((size_t)nq * key_stride * key_bytes));
         const int cus = cu_count(h->device);
@@ -396,7 +399,10 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         a.tile_step = stride;
         a.n_sel = ns_tiles;
         a.nrb = nrb;
-        if (ns_tiles < (long long)nrb * wv) a.nrb = (int)(((ns_tiles + wv - 1) / wv + 7) / 8 * 8);
+        {
+            const long long work = sample_runs ? (ns_tiles + 3) / 4 : ns_tiles;  // runs / tiles a wave takes at a time
+            if (work < (long long)nrb * wv) a.nrb = (int)(((work + wv - 1) / wv + 7) / 8 * 8);
+        }
         SQ_TRY(scan_launch<true>(a, d_pad, qt, qp, st));
         hipLaunchKernelGGL((kth_threshold_f32_kernel<DenseThrPost>), dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr,
                            DenseThrPost{qn2, cosine ? 1 : 0, filter_bound(cosine ? 1 : 0, eps_a, eps_b, h->xn2_max)});

@@ -460,8 +460,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     // Tiles are dealt round-robin over all waves of the launch: at any moment the
     // grid reads one compact window of the matrix.
     const long long gw = (long long)rb * WAVES + wave;
+    // CHUNK (the four-tile sample pass): a wave takes runs of four consecutive sampled tiles and writes its four minima
+    // per (query, row half) as ONE 16-byte store -- with a tile per store the 64 lanes of a store are 64 separate
+    // 4-byte writes (sample_out is query-major), and at four stores per unit the address unit, not the matrix core,
+    // set the pace (10 M rows, 1024 queries: 0.48 ms against 0.2 ms of arithmetic).  Sample layout there:
+    // [query][row half][n_sel rounded up to 4]; the slots behind n_sel hold +inf.
+    constexpr bool CHUNK = SAMPLE && AB && WAVES == 4 && QT == 4 && QP == 1 && KU == 1;
     const long long nwaves = (long long)a.nrb * WAVES;
-    const long long my_tiles = gw < a.n_sel ? (a.n_sel - gw + nwaves - 1) / nwaves : 0;
+    long long my_tiles = gw < a.n_sel ? (a.n_sel - gw + nwaves - 1) / nwaves : 0;
+    if constexpr (CHUNK) {
+        const long long full = a.n_sel >> 2, rem = a.n_sel & 3;  // whole runs, tiles of the last partial run
+        my_tiles = 4 * (gw < full ? (full - gw + nwaves - 1) / nwaves : 0) + ((rem && full % nwaves == gw) ? rem : 0);
+    }
+    const long long sel0 = CHUNK ? 4 * gw : gw;  // this wave's first tile
+    // the tile after `sel` in this wave's order
+    auto next_sel = [&](const long long sel) __attribute__((always_inline)) -> long long {
+        if constexpr (CHUNK) return (sel & 3) == 3 ? sel + 4 * nwaves - 3 : sel + 1;
+        return sel + nwaves;
+    };
     const long long total_units = my_tiles * KU;
 
     const int r31 = lane & 31, h = lane >> 5;
@@ -527,7 +543,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     const u32 voff_norm = (u32)((lane & 31) * 4);
 
     // issue cursor: unit u of this wave = (tile gw + (u / KU) * nwaves, k-unit u % KU), slot u % NSTAGE
-    long long iss_sel = gw;
+    long long iss_sel = sel0;
     int iss_kc = 0, iss_slot = 0;
     long long issued = 0;
     auto issue_unit = [&]() __attribute__((always_inline)) {
@@ -544,7 +560,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         ++issued;
         if (++iss_kc == KU) {
             iss_kc = 0;
-            iss_sel += nwaves;
+            iss_sel = next_sel(iss_sel);
         }
         if (++iss_slot == NSTAGE) iss_slot = 0;
     };
@@ -563,6 +579,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 ++issued;
         }
     };
+    f32x4 sb[QT];  // CHUNK: this lane's minima of the current run, per query tile
     // ---- tile complete: scores for 32 rows x QT*32 queries (lane = query, register i = row (i&3)+8(i>>2)+4h)
     // finish_q: one query tile of a row tile; PIN: the minimum is computed by instructions pinned in program order
     // the survivors of one query tile (hit: ballot of the lanes whose minimum passes): rare next to the tiles without
@@ -589,9 +606,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     // ---- tile complete: scores for 32 rows x QT*32 queries (lane = query, register i = row (i&3)+8(i>>2)+4h)
     // finish_q: one query tile of a row tile; PIN: the minimum is computed by instructions pinned in program order.
     // EMIT scan: returns the ballot of the lanes with a survivor (emit_q writes them out); SAMPLE: stores the minima.
-    auto finish_q = [&](const long long sel, auto t_c, auto pin_c, const f32x16& sc) __attribute__((always_inline)) -> u64 {
+    auto finish_q = [&](const long long sel, auto t_c, auto pin_c, const f32x16& sc, auto j_c) __attribute__((always_inline)) -> u64 {
         constexpr int t = decltype(t_c)::value;
         constexpr bool PIN = decltype(pin_c)::value;
+        constexpr int J = decltype(j_c)::value;  // CHUNK: place of the tile in its run of four (compile time)
 #if defined(SQ_ABL) && (SQ_ABL & 4)
         return 0;  // measurement build: no epilogue
 #endif
@@ -622,17 +640,26 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
 #pragma unroll
                 for (int i = 0; i < 16; ++i) ml = fminf(ml, sc[i]);
             }
-            a.sample_out[(long long)qglob * a.ns + sel * 2 + h] = ml;
+            if constexpr (CHUNK) {
+                // minima of the run so far in registers; the run's last tile (or the pass's last tile) stores them
+                static_assert(J >= 0 && J < 4, "place in the run");
+                if constexpr (J == 0) sb[t] = f32x4{ml, INFINITY, INFINITY, INFINITY};
+                if constexpr (J > 0) sb[t][J] = ml;
+                if (J == 3 || sel == a.n_sel - 1)
+                    *reinterpret_cast<f32x4*>(a.sample_out + (long long)qglob * a.ns + h * (a.ns >> 1) + (sel & ~3ll)) = sb[t];
+            } else {
+                a.sample_out[(long long)qglob * a.ns + sel * 2 + h] = ml;
+            }
             return 0;
         }
     };
-    auto finish_tile = [&](const long long sel, f32x16 (&acc)[QT]) __attribute__((always_inline)) {
+    auto finish_tile = [&](const long long sel, f32x16 (&acc)[QT], auto j_c) __attribute__((always_inline)) {
         u64 hit[QT];
-        hit[0] = finish_q(sel, std::integral_constant<int, 0>{}, std::false_type{}, acc[0]);
-        if constexpr (QT > 1) hit[1] = finish_q(sel, std::integral_constant<int, 1>{}, std::false_type{}, acc[1]);
+        hit[0] = finish_q(sel, std::integral_constant<int, 0>{}, std::false_type{}, acc[0], j_c);
+        if constexpr (QT > 1) hit[1] = finish_q(sel, std::integral_constant<int, 1>{}, std::false_type{}, acc[1], j_c);
         if constexpr (QT > 2) {
-            hit[2] = finish_q(sel, std::integral_constant<int, 2>{}, std::false_type{}, acc[2]);
-            hit[3] = finish_q(sel, std::integral_constant<int, 3>{}, std::false_type{}, acc[3]);
+            hit[2] = finish_q(sel, std::integral_constant<int, 2>{}, std::false_type{}, acc[2], j_c);
+            hit[3] = finish_q(sel, std::integral_constant<int, 3>{}, std::false_type{}, acc[3], j_c);
         }
         if constexpr (!SAMPLE) {
             emit_q(sel, std::integral_constant<int, 0>{}, acc[0], hit[0]);
@@ -718,7 +745,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         const unsigned char* iss_ptr = reinterpret_cast<const unsigned char*>(a.scan) + iss_sel * a.tile_step * TILE_ROWS * (DPAD * 2);
         const float* iss_nptr = a.norms + iss_sel * a.tile_step * TILE_ROWS * a.norm_step;
         const long long iss_ptr_adv = tile_adv * (DPAD * 2), iss_nptr_adv = tile_adv * a.norm_step;
-        // SKEW (four query tiles, one k-unit): the MFMAs of a unit run as two halves -- tiles 0,1 then tiles 2,3 (the A
+        // CHUNK: one tile on inside a run, (4 nwaves - 3) tiles on from a run's last tile
+        const long long step1_rows = a.tile_step * TILE_ROWS;
+        const long long run_ptr_adv = step1_rows * (DPAD * 2), run_nptr_adv = step1_rows * a.norm_step;
+        const long long jump_ptr_adv = (4 * nwaves - 3) * run_ptr_adv, jump_nptr_adv = (4 * nwaves - 3) * run_nptr_adv;
+        // SKEW (four query tiles, one k-unit, the emitting pass): the MFMAs of a unit run as two halves -- tiles 0,1 then tiles 2,3 (the A
         // fragments stay in registers for the whole unit, so the order is free) -- and the epilogue of a half sits
         // between the MFMAs of the next one (tiles 0,1 of this unit under its tiles 2,3; tiles 2,3 under tiles 0,1 of
         // the following unit): with one wave per SIMD nothing else would keep the matrix pipe busy during the ~50-100
@@ -727,7 +758,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
 #ifdef SQ_NO_SKEW
         constexpr bool SKEW = false;  // measurement build
 #else
-        constexpr bool SKEW = QT == 4 && QP == 1 && KU == 1;
+        constexpr bool SKEW = QT == 4 && QP == 1 && KU == 1 && !SAMPLE;
 #endif
         long long prev_sel = 0;
         bool prev_valid = false;
@@ -784,16 +815,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 if constexpr (SKEW) {
                     // minima + ballots in the shadow of the MFMAs; the (rare) survivors are written out where the
                     // MFMA stream has a seam anyway: before the half that overwrites their accumulators
-                    if (slot == 3 && prev_valid) hit2 = finish_q(prev_sel, std::integral_constant<int, 2>{}, std::true_type{}, acc[2]);
-                    if (slot == 9 && prev_valid) hit3 = finish_q(prev_sel, std::integral_constant<int, 3>{}, std::true_type{}, acc[3]);
+                    if (slot == 3 && prev_valid) hit2 = finish_q(prev_sel, std::integral_constant<int, 2>{}, std::true_type{}, acc[2], std::integral_constant<int, (SL + 3) % 4>{});
+                    if (slot == 9 && prev_valid) hit3 = finish_q(prev_sel, std::integral_constant<int, 3>{}, std::true_type{}, acc[3], std::integral_constant<int, (SL + 3) % 4>{});
                     if (slot == 15 && prev_valid) {
                         if constexpr (!SAMPLE) {
                             emit_q(prev_sel, std::integral_constant<int, 2>{}, acc[2], hit2);
                             emit_q(prev_sel, std::integral_constant<int, 3>{}, acc[3], hit3);
                         }
                     }
-                    if (slot == 19) hit0 = finish_q(cur_sel, std::integral_constant<int, 0>{}, std::true_type{}, acc[0]);
-                    if (slot == 25) hit1 = finish_q(cur_sel, std::integral_constant<int, 1>{}, std::true_type{}, acc[1]);
+                    if (slot == 19) hit0 = finish_q(cur_sel, std::integral_constant<int, 0>{}, std::true_type{}, acc[0], std::integral_constant<int, SL % 4>{});
+                    if (slot == 25) hit1 = finish_q(cur_sel, std::integral_constant<int, 1>{}, std::true_type{}, acc[1], std::integral_constant<int, SL % 4>{});
                     if (slot == 31) {
                         if constexpr (!SAMPLE) {
                             emit_q(cur_sel, std::integral_constant<int, 0>{}, acc[0], hit0);
@@ -821,8 +852,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 ++issued;
                 if (++iss_kc == KU) {
                     iss_kc = 0;
-                    iss_ptr += iss_ptr_adv;
-                    iss_nptr += iss_nptr_adv;
+                    if constexpr (CHUNK) {  // the unit just issued has this unit's place in its run (NSTAGE == 4 == run)
+                        iss_ptr += (SL == 3) ? jump_ptr_adv : run_ptr_adv;
+                        iss_nptr += (SL == 3) ? jump_nptr_adv : run_nptr_adv;
+                    } else {
+                        iss_ptr += iss_ptr_adv;
+                        iss_nptr += iss_nptr_adv;
+                    }
                 }
             }
             if constexpr (!SKEW) mfma_fence_out<QT>(acc);
@@ -831,7 +867,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         // (straight-line code: a three-way branch per unit makes hipcc merge the accumulators of its arms with
         // register copies); otherwise each unit picks its variant and the group ends at a tile boundary once the
         // tiles are done.
-        long long sel = gw;
+        long long sel = sel0;
         f32x16 acc[QT];
         auto group = [&](auto&& self, auto u_c, auto steady_c) __attribute__((always_inline)) -> void {
             constexpr int U = decltype(u_c)::value;
@@ -857,10 +893,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 if constexpr (SKEW) {
                     prev_sel = sel;
                     prev_valid = true;
-                    sel += nwaves;
+                    sel = next_sel(sel);
                 } else if constexpr (KC == KU - 1) {
-                    finish_tile(sel, acc);
-                    sel += nwaves;
+                    finish_tile(sel, acc, std::integral_constant<int, U % 4>{});  // (U % 4: CHUNK's place in the run)
+                    sel = next_sel(sel);
                 }
                 self(self, std::integral_constant<int, U + 1>{}, steady_c);
             }
@@ -873,8 +909,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         if constexpr (SKEW) {
             if (prev_valid) {  // the last unit's tiles 2,3
                 mfma_fence_out<QT>(acc);
-                const u64 h2 = finish_q(prev_sel, std::integral_constant<int, 2>{}, std::false_type{}, acc[2]);
-                const u64 h3 = finish_q(prev_sel, std::integral_constant<int, 3>{}, std::false_type{}, acc[3]);
+                u64 h2 = 0, h3 = 0;
+                auto last = [&](auto j_c) __attribute__((always_inline)) {
+                    h2 = finish_q(prev_sel, std::integral_constant<int, 2>{}, std::false_type{}, acc[2], j_c);
+                    h3 = finish_q(prev_sel, std::integral_constant<int, 3>{}, std::false_type{}, acc[3], j_c);
+                };
+                if constexpr (CHUNK) {
+                    static_for_one<4>((int)(prev_sel & 3), last);
+                } else {
+                    last(std::integral_constant<int, 0>{});
+                }
                 if constexpr (!SAMPLE) {
                     emit_q(prev_sel, std::integral_constant<int, 2>{}, acc[2], h2);
                     emit_q(prev_sel, std::integral_constant<int, 3>{}, acc[3], h3);
@@ -1046,7 +1090,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                     }
                 }
             }
-            if (do_math) finish_tile(sel, acc);
+            if (do_math) finish_tile(sel, acc, std::integral_constant<int, 0>{});
         }
     }
     if constexpr (!SAMPLE) {
