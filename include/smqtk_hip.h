@@ -252,7 +252,8 @@ int sq_rows_rerank(sq_handle_t h, const void* queries, int nq, int metric,
  * stable sort, first n (lsh.py:505-519).  Nothing but the queries goes up and the winners come down; between the
  * stages only two integers (candidates in total, longest list) visit the host.
  *   sq_rows_set_buckets: the store as a CSR map over the row matrix: csr_off[n_codes + 1] (code id -> first entry),
- *       csr_rows[n] (row numbers, bucket by bucket, row order inside a bucket); code id = row id of `hamming`
+ *       csr_rows[csr_off[n_codes]] (row numbers, bucket by bucket, row order inside a bucket; every row at most once --
+ *       rows no bucket lists, e.g. descriptors removed from the store, are never candidates); code id = row id of `hamming`
  *       (rank of the code in the sorted unique codes).  Host arrays are copied, device arrays borrowed.
  *   sq_lsh_query: queries [nq][d] in the rows' dtype; `itq` a resident model (sq_itq_model_create) whose codes have
  *       the width of `hamming`'s; n_codes_wanted = the n of HashIndex.nn; k_out = results per query.

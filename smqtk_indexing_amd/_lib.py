@@ -538,8 +538,8 @@ class RowMatrix:
             return
         off = _host(np.asarray(csr_off), np.int64).reshape(-1)
         rows = _host(np.asarray(csr_rows), np.int64).reshape(-1)
-        if rows.shape[0] != self.n:
-            raise ValueError("csr_rows must list every row once")
+        if rows.shape[0] > self.n or off.shape[0] < 2 or int(off[-1]) != rows.shape[0]:
+            raise ValueError("csr_rows must list rows of the matrix at most once each, csr_off[-1] of them")
         _check(load().sq_rows_set_buckets(self._h, _ptr(off), int(off.shape[0] - 1), _ptr(rows), SQ_MEM_HOST),
                "sq_rows_set_buckets")
 

@@ -370,12 +370,14 @@ extern "C" int sq_rows_set_buckets(sq_handle_t hid, const int64_t* csr_off, int6
         h->csr_off = reinterpret_cast<const long long*>(csr_off);
         h->csr_rows = reinterpret_cast<const long long*>(csr_rows);
     } else {
-        if (csr_off[0] != 0 || csr_off[n_codes] != h->n)
-            return fail(SQ_ERR_INVALID, "sq_rows_set_buckets: offsets must start at 0 and end at the row count");
+        // the buckets may leave rows out (descriptors removed from the store keep their slot in the matrix)
+        const long long listed = csr_off[n_codes];
+        if (csr_off[0] != 0 || listed <= 0 || listed > h->n)
+            return fail(SQ_ERR_INVALID, "sq_rows_set_buckets: offsets must start at 0 and end at the number of listed rows (<= the row count)");
         SQ_TRY(h->csr_off_owned.reserve((size_t)(n_codes + 1) * 8));
-        SQ_TRY(h->csr_rows_owned.reserve((size_t)h->n * 8));
+        SQ_TRY(h->csr_rows_owned.reserve((size_t)listed * 8));
         SQ_HIP(hipMemcpy(h->csr_off_owned.p, csr_off, (size_t)(n_codes + 1) * 8, hipMemcpyHostToDevice));
-        SQ_HIP(hipMemcpy(h->csr_rows_owned.p, csr_rows, (size_t)h->n * 8, hipMemcpyHostToDevice));
+        SQ_HIP(hipMemcpy(h->csr_rows_owned.p, csr_rows, (size_t)listed * 8, hipMemcpyHostToDevice));
         h->csr_off = h->csr_off_owned.as<long long>();
         h->csr_rows = h->csr_rows_owned.as<long long>();
     }

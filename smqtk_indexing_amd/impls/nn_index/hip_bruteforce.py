@@ -53,6 +53,10 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
         self._blocks: List[np.ndarray] = []
         self._all_f32 = True     # every indexed vector is float32: the float32 search distances are final
         self._dev: Optional[_lib.DenseIndex] = None
+        # rows removed while a device index is resident stay in it as tombstones (their `_elements` entry is None):
+        # a search asks for k + len(_dead) rows and drops them; the index is rebuilt from the live rows once they pass
+        # a quarter of it (what distributed.MutableShardedIndex does per shard)
+        self._dead: set = set()
 
     def get_config(self) -> Dict[str, Any]:
         return {"distance_method": self.distance_method, "read_only": self.read_only}
@@ -71,6 +75,7 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
 
     def _set(self, elements: List[DescriptorElement], matrix: np.ndarray) -> None:
         self._elements = elements
+        self._dead = set()
         self._row_of = {e.uuid(): i for i, e in enumerate(elements)}
         self._blocks = [matrix] if matrix.shape[0] else []
         self._all_f32 = all(np.asarray(e.vector()).dtype == np.float32 for e in elements)
@@ -99,7 +104,7 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
     # -------------------------------------------------------------- interface
     def count(self) -> int:
         with self._lock:
-            return len(self._elements)
+            return len(self._elements) - len(self._dead)
 
     def _build_index(self, descriptors: Iterable[DescriptorElement]) -> None:
         with self._lock:
@@ -129,7 +134,7 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
                 self._blocks.append(add_m)
                 self._all_f32 = self._all_f32 and all(np.asarray(e.vector()).dtype == np.float32 for e in add)
                 return
-            kept = [e for e in self._elements if e.uuid() not in new]
+            kept = [e for e in self._elements if e is not None and e.uuid() not in new]
             keep_rows = [self._row_of[e.uuid()] for e in kept]
             if kept:
                 matrix = np.vstack([self._matrix[keep_rows], add_m])
@@ -145,7 +150,14 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
                 if u not in self._row_of:
                     raise KeyError(u)          # nothing modified yet
             drop = set(uids)
-            kept = [e for e in self._elements if e.uuid() not in drop]
+            if self._dev is not None and 4 * (len(self._dead) + len(drop)) <= len(self._elements):
+                # tombstones: the resident matrix is neither re-uploaded nor re-indexed
+                for u in drop:
+                    r = self._row_of.pop(u)
+                    self._elements[r] = None       # type: ignore[call-overload]
+                    self._dead.add(r)
+                return
+            kept = [e for e in self._elements if e is not None and e.uuid() not in drop]
             rows = [self._row_of[e.uuid()] for e in kept]
             self._set(kept, np.ascontiguousarray(self._matrix[rows], dtype=np.float32))
 
@@ -155,8 +167,16 @@ class HipBruteForceNearestNeighborsIndex(NearestNeighborsIndex):
             if not self.count():
                 raise ValueError("No index currently set to query from!")
             k = min(int(n), self.count())
-            dist, idx = self._device().search(np.asarray(vectors, dtype=np.float32), k)
-            return idx, dist
+            q = np.asarray(vectors, dtype=np.float32)
+            if not self._dead:
+                dist, idx = self._device().search(q, k)
+                return idx, dist
+            # tombstoned rows: ask for as many more, drop them (the (distance, row) order of the rest is unchanged)
+            dist, idx = self._device().search(q, min(k + len(self._dead), len(self._elements)))
+            dead = np.fromiter(self._dead, dtype=np.int64, count=len(self._dead))
+            live = ~np.isin(idx, dead)
+            pos = np.argsort(~live, axis=1, kind="stable")[:, :k]      # live entries first, in their order
+            return np.take_along_axis(idx, pos, axis=1), np.take_along_axis(dist, pos, axis=1)
 
     def elements_of(self, rows: Sequence[int]) -> Tuple[DescriptorElement, ...]:
         with self._lock:

@@ -59,15 +59,18 @@ class _DeviceMirror:
         self.dtype = matrix.dtype
         self.rows = _lib.RowMatrix(matrix)
         self.packed = np.ascontiguousarray(packed)               # [N, W] code of every row
+        self.dead = np.zeros(len(uuids), dtype=bool)             # rows removed in place (tombstones: `remove`)
+        self._row_of: Optional[Dict[Hashable, int]] = None       # uuid -> row, built at the first removal
         self._index_codes()
 
     def _index_codes(self) -> None:
-        """Unique ascending codes and the CSR map code id -> rows, from the per-row codes."""
-        codes, inverse = np.unique(self.packed, axis=0, return_inverse=True)
+        """Unique ascending codes and the CSR map code id -> rows, from the per-row codes of the live rows."""
+        live_rows = np.flatnonzero(~self.dead)
+        codes, inverse = np.unique(self.packed[live_rows], axis=0, return_inverse=True)
         inverse = np.asarray(inverse).reshape(-1)
         self.codes = np.ascontiguousarray(codes)                 # [C, W] ascending (= HipLinearHashIndex order)
         order = np.argsort(inverse, kind="stable")               # rows grouped by code id, row order inside a bucket
-        self.csr_rows = order.astype(np.int64)
+        self.csr_rows = live_rows[order].astype(np.int64)
         self.csr_off = np.searchsorted(inverse[order], np.arange(codes.shape[0] + 1)).astype(np.int64)
         self.rows.set_buckets(self.csr_off, self.csr_rows)       # the bucket map next to the rows (sq_lsh_query)
         self.own_index: Optional[HipLinearHashIndex] = None      # for hash_index=None
@@ -78,9 +81,30 @@ class _DeviceMirror:
         """New descriptors behind the resident ones: only they are uploaded (sq_rows_append); the code list
         and the CSR map are rebuilt on the host (code ids shift when a new code lands between old ones)."""
         self.rows.append(np.ascontiguousarray(matrix, dtype=self.dtype))
+        if self._row_of is not None:
+            self._row_of.update({u: len(self.uuids) + i for i, u in enumerate(uuids)})
         self.uuids.extend(uuids)
         self.packed = np.vstack([self.packed, np.ascontiguousarray(packed)])
+        self.dead = np.concatenate([self.dead, np.zeros(len(uuids), dtype=bool)])
         self._index_codes()
+
+    def remove(self, uuids: List[Hashable]) -> bool:
+        """Descriptors leave the mirror in place: their rows stay in the resident matrix as tombstones that no bucket
+        refers to any more (the bucket map is re-derived from the live rows' codes and re-uploaded; the descriptors
+        are not).  False = too many tombstones (over a quarter) or an unknown uuid: the caller drops the mirror."""
+        if self._row_of is None:
+            self._row_of = {u: i for i, u in enumerate(self.uuids) if u is not None}
+        rows = [self._row_of.get(u) for u in uuids]
+        if any(r is None for r in rows) or 4 * (int(self.dead.sum()) + len(rows)) > len(self.uuids):
+            return False
+        for u, r in zip(uuids, rows):
+            del self._row_of[u]
+            self.uuids[r] = None                                  # type: ignore[call-overload]
+        self.dead[np.asarray(rows, dtype=np.int64)] = True
+        if not (~self.dead).any():
+            return False
+        self._index_codes()
+        return True
 
     def expand(self, code_ids: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """code ids ``[nq, m]`` (-1 = none) -> (candidate rows concatenated, offsets ``[nq+1]``),
@@ -427,7 +451,11 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
             if self.hash_index and gone:
                 self.hash_index.remove_from_index(gone)
             self.descriptor_set.remove_many_descriptors(uids)
-            self._drop_mirror()
+            m = self._mirror
+            if m is not None and m.remove(uids):
+                self._mirror_key = self._state_key()   # the resident descriptors stay; only the bucket map moved
+            else:
+                self._drop_mirror()
 
     def _nn(self, d: DescriptorElement, n: int = 1
             ) -> Tuple[Tuple[DescriptorElement, ...], Tuple[float, ...]]:

@@ -249,6 +249,47 @@ def test_bruteforce_matches_reference_golden(golden):
         assert r[0].uuid() == int(g[f"nrm128_{metric}_idx"][0][1])
 
 
+def test_bruteforce_removal_keeps_the_resident_index():
+    """remove_from_index with a resident device index: tombstones (no re-upload, no re-index), searches answer like
+    an index built from the live rows -- ids, float32 distances and tie order -- until a quarter of it is dead."""
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((4000, 48)).astype(np.float32)
+    x[1500] = x[20]                                             # a duplicate pair: tie order = row order
+    for metric in ("euclidean", "cosine"):
+        index = HipBruteForceNearestNeighborsIndex(metric)
+        index.build_index(_elems(x))
+        q = DescriptorMemoryElement("q").set_vector(x[20])
+        index.nn(q, 3)
+        dev = index._dev
+        gone = sorted(rng.choice(4000, 300, replace=False).tolist() + [20])
+        gone = sorted(set(gone) - {1500})
+        index.remove_from_index(gone)
+        assert index._dev is dev and len(index._dead) == len(gone) and index.count() == 4000 - len(gone)
+        live = np.setdiff1d(np.arange(4000), gone)
+        for qv in (x[20], x[7], rng.standard_normal(48).astype(np.float32)):
+            r, dists = index.nn(DescriptorMemoryElement("q").set_vector(qv), 40)
+            rd, ri = O.dense_topk(x[live], qv, 40, metric)
+            assert [e.uuid() for e in r] == live[ri].tolist()
+            if metric == "euclidean":
+                np.testing.assert_array_equal(np.float32(dists), rd)
+            else:
+                np.testing.assert_allclose(dists, rd, rtol=1e-12, atol=1e-15)
+        with pytest.raises(KeyError):
+            index.remove_from_index([gone[0]])                  # already gone
+        # everything that is left, in one query (k + tombstones = the whole resident matrix)
+        r, _ = index.nn(q, index.count())
+        assert sorted(e.uuid() for e in r) == live.tolist()
+        # new rows behind the tombstones, then removals past a quarter: rebuilt from the live rows
+        index.update_index(_elems(x[:10] + 1.0, base=9000))
+        assert index._dev is dev and index.count() == 4010 - len(gone)
+        index.remove_from_index(live[:900].tolist())
+        assert not index._dead and index.count() == 4010 - len(gone) - 900
+        r, _ = index.nn(q, 5)
+        keep = np.concatenate([live[900:], 9000 + np.arange(10)])
+        allx = np.vstack([x, np.zeros((5000, 48), np.float32), x[:10] + 1.0])
+        assert [e.uuid() for e in r] == keep[O.dense_topk(allx[keep], x[20], 5, metric)[1]].tolist()
+
+
 # ------------------------------------------------ HipLSHNearestNeighborIndex
 def _lsh(bits, metric, hash_index=True, x=None, seed=0, iters=50):
     f = HipItqFunctor(bit_length=bits, random_seed=seed, itq_iterations=iters)
@@ -392,13 +433,29 @@ def test_lsh_device_rerank_equals_host_path(metric, dt, hash_index):
         for q, b in zip(qs, batch):
             same(dev.nn(q, n), host.nn(q, n))
             same(b, host.nn(q, n))
+    mirror = dev._mirror
     for idx in (dev, host):
         idx.update_index(_elems(x[2500:], base=2500))
         idx.remove_from_index(list(range(0, 300)))
-    assert dev._mirror is None
+    # a tenth of the rows removed: the resident descriptors stay (tombstones), only the bucket map is re-derived
+    assert dev._mirror is mirror and int(mirror.dead.sum()) == 300 and mirror.rows.n == 3000
     for q in qs:
         same(dev.nn(q, 25), host.nn(q, 25))
-    assert dev._mirror is not None and len(dev._mirror.uuids) == 2700
+        assert all(e.uuid() >= 300 for e in dev.nn(q, 25)[0])
+    for b, q in zip(dev.nn_many(qs, 25), qs):
+        same(b, host.nn(q, 25))
+    extra = rng.standard_normal((50, 64)).astype(dt)
+    for idx in (dev, host):                       # an append behind tombstones, then removals past a quarter
+        idx.update_index(_elems(extra, base=5000))
+    assert dev._mirror is mirror and mirror.rows.n == 3050
+    for q in qs:
+        same(dev.nn(q, 25), host.nn(q, 25))
+    for idx in (dev, host):
+        idx.remove_from_index(list(range(300, 1000)))
+    assert dev._mirror is None                     # too many tombstones: rebuilt from the descriptor set
+    for q in qs:
+        same(dev.nn(q, 25), host.nn(q, 25))
+    assert dev._mirror is not None and len(dev._mirror.uuids) == 2050 and not dev._mirror.dead.any()
 
 
 def test_lsh_config_roundtrip_on_gpu():
