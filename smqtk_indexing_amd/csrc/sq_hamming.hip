@@ -424,29 +424,37 @@ __global__ void hamming_thr_kernel(const u32* __restrict__ hist, int nq, int bit
     thr[q] = t;
 }
 
-// sorted keys -> (distance, global id); status bit0 = candidate overflow.
-__global__ void hamming_finalize_kernel(const u64* __restrict__ sorted, const u32* __restrict__ cnt, u32 cap,
-                                        int nq, int k, long long id_base, int* __restrict__ out_dist,
-                                        long long* __restrict__ out_idx, u32* __restrict__ status, int kk,
-                                        u32* __restrict__ host_words, int host_nq, int q0) {
-    const int q = blockIdx.x;
-    for (int j = threadIdx.x; j < k; j += blockDim.x) {
-        u64 key = sorted[(long long)q * k + j];
-        bool pad = key == ~0ull;
-        out_dist[(long long)q * k + j] = pad ? 0x7fffffff : (int)(key >> 32);
-        out_idx[(long long)q * k + j] = pad ? -1ll : id_base + (long long)(key & 0xffffffffull);
-    }
-    if (threadIdx.x == 0) {
-        u32 c = cnt[q];
-        const u32 stw = (c > cap ? 1u : 0u) | (c < (u32)kk ? 4u : 0u);
-        status[q] = stw;
-        // pinned host copy [status (nq) | counts (nq)]: the host only synchronises the stream (no copy launches)
-        if (host_words) {
-            host_words[q0 + q] = stw;
-            host_words[host_nq + q0 + q] = c;
+// sorted keys -> (distance, global id); status bit0 = candidate overflow, bit2 = fewer candidates than k.
+// Runs as the post-operation of the select (sq_select.cuh: `post(q, sorted keys of query q, k)` runs in the
+// selecting workgroup once its k keys are written): one launch less per search.
+struct HammingFinalize {
+    const u32* cnt;
+    u32 cap;
+    int kk;
+    long long id_base;
+    int* out_dist;
+    long long* out_idx;
+    u32* status;
+    u32* host_words;  // pinned [status (host_nq) | counts (host_nq)] or nullptr
+    int host_nq;
+    __device__ __forceinline__ void operator()(int q, const u64* sorted, int k) const {
+        for (int j = threadIdx.x; j < k; j += blockDim.x) {
+            const u64 key = sorted[j];
+            const bool pad = key == ~0ull;
+            out_dist[(long long)q * k + j] = pad ? 0x7fffffff : (int)(key >> 32);
+            out_idx[(long long)q * k + j] = pad ? -1ll : id_base + (long long)(key & 0xffffffffull);
+        }
+        if (threadIdx.x == 0) {
+            const u32 c = cnt[q];
+            const u32 stw = (c > cap ? 1u : 0u) | (c < (u32)kk ? 4u : 0u);
+            status[q] = stw;
+            if (host_words) {
+                host_words[q] = stw;
+                host_words[host_nq + q] = c;
+            }
         }
     }
-}
+};
 
 // ------------------------------------------------------------- host driver
 template <int W, int C>
@@ -504,19 +512,20 @@ static void hist_dispatch(const HammingHandle* h, const u64* qs, int nq, int bit
 
 static constexpr int kSelectLdsKeys64 = 16384;  // 128 KiB of LDS for the candidate keys
 
+template <class Post>
 static int select_launch(const u64* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, u64* out,
-                         hipStream_t st, DevBuf& sort_scratch) {
+                         hipStream_t st, DevBuf& sort_scratch, Post post) {
     static bool attr_set = false;
     if (k > kSelectLdsKeys64)  // linear.py:235-238 has no limit on n: the any-k sorted select (sq_select.cuh)
-        return sort_select_large<u64, SelectNoPost>(keys, cnt, cap, stride, k, nq, out, sort_scratch, SelectNoPost(), st);
+        return sort_select_large<u64, Post>(keys, cnt, cap, stride, k, nq, out, sort_scratch, post, st);
     const size_t lds = (size_t)(kSelectLdsKeys64 + SELECT_SORT_MAX) * sizeof(u64);
     if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<u64>),
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<u64, Post>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((select_topk_kernel<u64>), dim3(nq), dim3(1024), lds, st, keys, cnt, cap, stride, k,
-                       kSelectLdsKeys64, out);
+    hipLaunchKernelGGL((select_topk_kernel<u64, Post>), dim3(nq), dim3(1024), lds, st, keys, cnt, cap, stride, k,
+                       kSelectLdsKeys64, out, post);
     return SQ_OK;
 }
 
@@ -562,9 +571,8 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
         h->stats.scan_launches = 1;
         h->stats.bytes_scanned = n * W * 8;
-        SQ_TRY(select_launch(keys, cnt, (u32)n, key_stride, k, nq, okeys, st, h->sort_tmp));
-        hipLaunchKernelGGL(hamming_finalize_kernel, dim3(nq), dim3(256), 0, st, okeys, cnt, (u32)n, nq, k, h->id_base,
-                           out_dist, out_idx, status, kk, hs_dev, nq, 0);
+        SQ_TRY(select_launch(keys, cnt, (u32)n, key_stride, k, nq, okeys, st, h->sort_tmp,
+                             HammingFinalize{cnt, (u32)n, kk, h->id_base, out_dist, out_idx, status, hs_dev, nq}));
     } else {
         int step = g_opt.sample_stride > 0 ? g_opt.sample_stride : 64;
         // keep the sample comfortably larger than k
@@ -624,9 +632,8 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
         h->stats.scan_launches = 1;
         h->stats.bytes_scanned = n * W * 8;
-        SQ_TRY(select_launch(keys, cnt, cap, key_stride, k, nq, okeys, st, h->sort_tmp));
-        hipLaunchKernelGGL(hamming_finalize_kernel, dim3(nq), dim3(256), 0, st, okeys, cnt, cap, nq, k, h->id_base,
-                           out_dist, out_idx, status, kk, hs_dev, nq, 0);
+        SQ_TRY(select_launch(keys, cnt, cap, key_stride, k, nq, okeys, st, h->sort_tmp,
+                             HammingFinalize{cnt, cap, kk, h->id_base, out_dist, out_idx, status, hs_dev, nq}));
     }
     if (prof) SQ_HIP(hipEventRecord(h->ev[3], st));
     // status words and candidate counts are in pinned host memory once the stream drains (written by the
@@ -649,10 +656,9 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
             u64* bk = h->big_keys.as<u64>();
             hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, cnt + q, 1ll, (u32)(n > 0xffffffffll ? 0xffffffffu : n));
             scan_dispatch(h, qs + (long long)q * W, 1, thr, bk, cnt + q, (u32)n, n, /*mode*/ 1, st);
-            SQ_TRY(select_launch(bk, cnt + q, (u32)n, n, k, 1, okeys + (long long)q * k, st, h->sort_tmp));
-            hipLaunchKernelGGL(hamming_finalize_kernel, dim3(1), dim3(256), 0, st, okeys + (long long)q * k, cnt + q,
-                               (u32)n, 1, k, h->id_base, out_dist + (long long)q * k, out_idx + (long long)q * k,
-                               status + q, kk, nullptr, 0, 0);
+            SQ_TRY(select_launch(bk, cnt + q, (u32)n, n, k, 1, okeys + (long long)q * k, st, h->sort_tmp,
+                                 HammingFinalize{cnt + q, (u32)n, kk, h->id_base, out_dist + (long long)q * k,
+                                                 out_idx + (long long)q * k, status + q, nullptr, 0}));
             h->stats.scan_launches++;
         }
     }
