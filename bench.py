@@ -62,6 +62,13 @@ def parse_args():
     ap.add_argument("--metric", choices=["l2", "cosine"], default="l2")
     ap.add_argument("--sync-search", action="store_true", help="one blocking search call per step (no pipelining)")
     ap.add_argument("--async-streams", type=int, default=0, help="option dense_async_streams (0 = library default)")
+    ap.add_argument("--async-depth", type=int, default=0,
+                    help="asynchronous searches in flight (option dense_async_depth); 0 = 2 on one GPU, 3 with shards "
+                         "(smaller shards: the short kernels of a call weigh more, DESIGN.md section 5)")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="several GPUs: steps per all-gather (PipelinedShardedSearch gather_every); 0 = 4: a collective "
+                         "with its pinned copy and merge hand-off costs about as much host time as a 1.25 M-row shard "
+                         "needs for a step, so four steps share one (all merges still inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--no-other-paths", action="store_true",
@@ -142,6 +149,10 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=metric, device_ptr=True, id_base=r0, keepalive=db)
     stream = torch.cuda.current_stream().cuda_stream
     use_async = not args.sync_search
+    depth = args.async_depth if args.async_depth > 0 else (3 if use_dist else 2)
+    depth = min(max(depth, 2), 4)
+    if use_async:
+        _lib.set_option("dense_async_depth", depth)
 
     scan_ms, cands, fallbacks = [], [], []
 
@@ -162,17 +173,18 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 from smqtk_indexing_amd.distributed import PipelinedShardedSearch
                 # the all-gather of a finished batch (asynchronous, RCCL's stream), its copy to pinned memory and the
                 # host merge (rank 0, a worker thread) run under the searches of the following batches
-                self.pipe = PipelinedShardedSearch(index, nq_, k, ddt, merge_on=0, device=dev, use_async=use_async)
+                self.pipe = PipelinedShardedSearch(index, nq_, k, ddt, merge_on=0, device=dev, use_async=use_async, depth=depth,
+                                                   gather_every=args.gather_every if args.gather_every > 0 else 4)
             else:
-                self.od = [torch.empty((nq_, k), dtype=ddt, device=dev) for _ in range(2)]
-                self.oi = [torch.empty((nq_, k), dtype=torch.int64, device=dev) for _ in range(2)]
+                self.od = [torch.empty((nq_, k), dtype=ddt, device=dev) for _ in range(depth)]   # one per call in flight
+                self.oi = [torch.empty((nq_, k), dtype=torch.int64, device=dev) for _ in range(depth)]
                 self.i = 0
 
         def step(self):
             if self.pipe is not None:
                 res = self.pipe.submit(self.q)
             else:
-                j = self.i & 1
+                j = self.i % depth
                 self.i += 1
                 fn = index.search_device_async if use_async else index.search_device
                 fn(self.q.data_ptr(), self.nq, k, self.od[j].data_ptr(), self.oi[j].data_ptr(), stream)
@@ -189,7 +201,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
             if use_async:
                 index.sync()
                 note_stats()
-            j = (self.i - 1) & 1
+            j = (self.i - 1) % depth
             return self.od[j], self.oi[j]
 
         def close(self):
@@ -391,9 +403,10 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 "db_rows_total": n_total, "db_rows_per_gpu": n_local, "dim": d, "k": k,
                 "queries_per_step": nq,
                 "scaling_definition": "strong: fixed rows in total (row-sharded over the ranks) and the same queries per step at every N, N = 1 included",
-                "search_calls": "pipelined (SQ_MEM_DEVICE_ASYNC): status of step i read after step i+1 is enqueued" if use_async else "one blocking call per step",
+                "search_calls": f"pipelined (SQ_MEM_DEVICE_ASYNC, {depth} calls in flight): the status of a step is read {depth - 1} step(s) later" if use_async else "one blocking call per step",
                 "sharding": "rows" if world > 1 else "none",
-                "collective": "all_gather(top-k dist,idx) + host merge, both under the following batches' searches" if use_dist else "none",
+                "collective": (f"one all_gather(top-k dist,idx) per {args.gather_every if args.gather_every > 0 else 4} steps + host merge, "
+                               "both under the following steps' searches; every merge inside the timed region") if use_dist else "none",
                 "mean_candidates_per_query": head_cands,
                 "fallback_queries": head_fb,
                 "steps_with_stats": n_stats,

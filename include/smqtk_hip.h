@@ -202,7 +202,11 @@ int sq_dense_search(sq_handle_t h, const float* queries, int nq, int k,
  * stay valid and untouched (so consecutive asynchronous calls alternate between two output buffers).  The device
  * never idles between calls, and with option "dense_async_streams" = 2 (default) consecutive calls run on two
  * internal streams so that the short kernels ending call i overlap those starting call i + 1.  sq_get_stats
- * reports the last FINISHED call.  sq_dense_sync finishes every call in flight. */
+ * reports the last FINISHED call.  sq_dense_sync finishes every call in flight.
+ * Option "dense_async_depth" (2 by default, up to 4) keeps that many calls in flight: call i is then final when
+ * call i + depth - 1 returns (callers rotate `depth` output buffers); small matrices -- the shards of a multi-GPU
+ * index -- gain from 3, where the short kernels of a call weigh as much as its scan.  A change of the option takes
+ * effect at the next asynchronous call, which first finishes the calls in flight. */
 int sq_dense_sync(sq_handle_t h);
 int sq_dense_destroy(sq_handle_t h);
 

@@ -62,6 +62,7 @@ struct Options {
     int merge_threads = 0;       // host threads of the shard merge (0 = by size)
     int spin_wait_us = 2000;     // searches poll the stream this long before blocking (0 = block at once)
     int dense_async_streams = 2; // asynchronous dense searches: 2 = the two call slots run on streams of their own (tail of call i overlaps the head of call i + 1), 1 = everything on the caller's stream
+    int dense_async_depth = 2;   // asynchronous dense searches in flight (2..4): the results of a call are final when the (depth - 1)-th call after it returns
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
 };
 extern Options g_opt;

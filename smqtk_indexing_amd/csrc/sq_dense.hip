@@ -79,8 +79,10 @@ struct DenseHandle : HandleBase {
     double xn2_max = 0.0;       // max squared row norm (error bound of the L2 filter)
     DevBuf norms1;  // L2: |x|^2 (1 - alpha) for one query plane (`norms`: two planes)
     DevBuf zeros;   // cosine: the 32 zero "norms" every tile of an AGPR-configuration scan starts from (norm_step 0)
-    DenseSlot slot[2];
-    unsigned long long async_calls = 0;  // asynchronous calls so far (slot = parity)
+    static constexpr int kMaxDepth = 4;
+    DenseSlot slot[kMaxDepth];
+    int depth = 2;                       // asynchronous calls in flight (option dense_async_depth, fixed while any is)
+    unsigned long long async_calls = 0;  // asynchronous calls so far (slot = calls % depth)
     // workspace shared by all calls: host-memory staging, the exact path (runs synchronously), index build
     DevBuf q_dev, out_dist_dev, out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch, fb_cnt;
     PinnedStage stage;
@@ -88,8 +90,7 @@ struct DenseHandle : HandleBase {
         for (DevBuf* b : {&owned, &scan, &norms, &norms1, &zeros, &center, &cos_nx, &q_dev, &out_dist_dev, &out_idx_dev, &big_keys,
                           &fb_sample, &fb_keys, &fb_out, &scratch, &fb_cnt})
             b->release();
-        slot[0].release();
-        slot[1].release();
+        for (auto& sl : slot) sl.release();
         stage.release();
     }
 };
@@ -620,9 +621,8 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
 
 // Finish every asynchronous call still in flight, oldest first.
 static int dense_sync_all(DenseHandle* h) {
-    const int newest = (int)((h->async_calls + 1) & 1);  // slot of the most recent asynchronous call
-    SQ_TRY(dense_resolve(h, h->slot[newest ^ 1]));
-    SQ_TRY(dense_resolve(h, h->slot[newest]));
+    for (int j = 0; j < h->depth; ++j)  // slot of call (async_calls - depth + j): oldest first
+        SQ_TRY(dense_resolve(h, h->slot[(h->async_calls + (unsigned)j) % (unsigned)h->depth]));
     return SQ_OK;
 }
 
@@ -867,8 +867,17 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
         // could not certify) one call later.  With "dense_async_streams" = 2 the two slots run on streams of
         // their own, ordered behind the caller's stream by an event, so the small kernels at the end of call
         // i - 1 (re-rank, select) and at the start of call i (query prep, sample pass, threshold) overlap.
-        DenseSlot& s = h->slot[h->async_calls & 1];
-        SQ_TRY(dense_resolve(h, s));  // (the call two back; normally resolved during the previous call)
+        {
+            int want = g_opt.dense_async_depth;
+            want = want < 2 ? 2 : want > DenseHandle::kMaxDepth ? DenseHandle::kMaxDepth : want;
+            if (want != h->depth) {  // a new depth starts from an empty pipeline
+                SQ_TRY(dense_sync_all(h));
+                h->depth = want;
+                h->async_calls = 0;
+            }
+        }
+        DenseSlot& s = h->slot[h->async_calls % (unsigned)h->depth];
+        SQ_TRY(dense_resolve(h, s));  // (the call `depth` back; normally resolved during an earlier call)
         hipStream_t run = st;
         if (g_opt.dense_async_streams == 2) {
             // One query tile per wave (HBM bound): the two slots alternate between two streams, so neighbouring
@@ -884,7 +893,8 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
         }
         SQ_TRY(dense_enqueue(h, s, queries, nq, k, out_dist, reinterpret_cast<long long*>(out_idx), run, true));
         h->async_calls++;
-        return dense_resolve(h, h->slot[h->async_calls & 1]);  // the previous call: its results are final on return
+        // the oldest call still in flight (depth - 1 calls back): its results are final on return
+        return dense_resolve(h, h->slot[h->async_calls % (unsigned)h->depth]);
     }
     SQ_TRY(dense_sync_all(h));
     if (mem != SQ_MEM_HOST)

@@ -357,12 +357,18 @@ class HipSearcher:
 
     ``search_into(q, k, out_d, out_i)`` writes the shard's top-k for the query batch into the two device tensors.
     ``lag`` says when that answer is final: 0 -- when ``search_into`` returns (the synchronous C ABI call);
-    1 -- when the NEXT ``search_into`` (or ``finish``) returns: ``sq_dense_search`` with ``SQ_MEM_DEVICE_ASYNC``,
-    which keeps the device busy across calls (include/smqtk_hip.h)."""
+    ``depth - 1`` -- when that many further ``search_into`` calls (or ``finish``) have returned: ``sq_dense_search``
+    with ``SQ_MEM_DEVICE_ASYNC``, which keeps ``depth`` calls on the device (include/smqtk_hip.h; option
+    ``dense_async_depth``, 2 by default -- small shards gain from 3: DESIGN.md section 5)."""
 
-    def __init__(self, index, stream_handle: int = 0, use_async: bool = False):
+    def __init__(self, index, stream_handle: int = 0, use_async: bool = False, depth: int = 2):
         self.index, self.stream = index, int(stream_handle)
-        self.lag = 1 if (use_async and hasattr(index, "search_device_async")) else 0
+        self.lag = 0
+        if use_async and hasattr(index, "search_device_async"):
+            depth = min(max(int(depth), 2), 4)
+            from . import _lib
+            _lib.set_option("dense_async_depth", depth)
+            self.lag = depth - 1
 
     def search_into(self, queries, k: int, out_d, out_i) -> None:
         fn = self.index.search_device_async if self.lag else self.index.search_device
@@ -376,21 +382,27 @@ class HipSearcher:
 class PipelinedShardedSearch:
     """Batches through a sharded index with the collective and the merge off the critical path.
 
-    ``submit(queries)`` runs the local search of batch i (``searcher.search_into``: see :class:`HipSearcher`),
-    then -- for the newest batch b = i - lag whose shard answer is final -- starts the all-gather asynchronously
-    (RCCL's stream / gloo's thread) and, on the merging rank, the copy of the gathered buffer to pinned host memory
-    on torch's current stream; both run under the search of the next batch.  It then hands batch b - 1's host
-    buffer to the merge thread (:class:`PipelinedMerger`) and returns the merged result of batch b - 2 (``None``
-    while the pipeline fills, and on the other ranks).  ``flush()`` finishes the searches and returns the results
-    still in flight, oldest first.  Two send / receive / host buffers alternate; every reuse is ordered behind the
-    previous user.  CPU tensors (gloo) take the same path without streams or pinned copies: the CPU tests drive
-    it with an oracle-backed searcher.
+    ``submit(queries)`` runs the local search of batch i (``searcher.search_into``: see :class:`HipSearcher`).
+    ``gather_every`` (G) consecutive batches share one send buffer -- laid out as the packed block of ONE batch of
+    G * nq queries -- and one all-gather: G = 1 exchanges every batch (lowest latency); a larger G pays the fixed
+    host and launch cost of a collective once per G batches, which is what limits small shards (a 1.25 M-row shard
+    answers 32 queries in ~80 us, a collective with its pinned copy and hand-off costs about as much again).  Once
+    the last batch of a group is final (``lag`` submits later) its all-gather starts asynchronously (RCCL's stream /
+    gloo's thread) and, on the merging rank, the copy of the gathered buffer to pinned host memory on torch's current
+    stream; both run under the following searches.  The group before goes to the merge thread
+    (:class:`PipelinedMerger`) and the merged group whose buffers are taken over comes back.
+    ``submit`` returns ``None`` while nothing left the pipeline (and always on the other ranks), else the merged
+    ``(dist, idx)`` of ONE batch (G = 1) or the list of a group's G results, oldest first (G > 1).  ``flush()``
+    finishes the searches and returns every result still in flight as a flat list, oldest first.
+    At least two send / receive / host buffers rotate (more when ``lag`` exceeds a group); every reuse is ordered
+    behind the previous user.  CPU tensors (gloo) take the same path without streams or pinned copies: the CPU tests
+    drive it with an oracle-backed searcher.
     ``searcher``: an object with ``lag``, ``search_into`` and ``finish`` (or a ``_lib`` index: wrapped in a
-    synchronous :class:`HipSearcher` on a compute stream of the pipeline's own).
+    :class:`HipSearcher` on a compute stream of the pipeline's own; ``depth`` = asynchronous searches in flight).
     """
 
     def __init__(self, searcher, nq: int, k: int, dist_dtype, group=None, merge_on: int = 0, device=None,
-                 use_async: bool = False):
+                 use_async: bool = False, depth: int = 2, gather_every: int = 1):
         import torch
         import torch.distributed as dist
         self.nq, self.k, self.group = int(nq), int(k), group
@@ -402,30 +414,35 @@ class PipelinedShardedSearch:
         if not hasattr(searcher, "search_into"):
             # a _lib index: its searches get a stream of their own; collectives and copies stay on the current stream
             self.compute = torch.cuda.Stream(device=dev)
-            searcher = HipSearcher(searcher, self.compute.cuda_stream, use_async)
+            searcher = HipSearcher(searcher, self.compute.cuda_stream, use_async, depth)
         self.searcher = searcher
         self.lag = int(searcher.lag)
+        self.G = G = max(1, int(gather_every))
+        # a group's buffer is refilled (nb - 1) groups after its last batch; its gather starts `lag` batches after it
+        self.nb = nb = max(2, 2 + (self.lag - 1) // G) if self.lag else 2
+        nqt = self.nq * G
         esz = torch.empty(0, dtype=dist_dtype).element_size()
         self.np_dt = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32}[dist_dtype]
-        per = packed_block_bytes(self.nq, self.k, esz)
-        nk = self.nq * self.k
-        self.send = [torch.zeros(per, dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.out_i = [s[: nk * 8].view(torch.int64).view(self.nq, self.k) for s in self.send]
-        self.out_d = [s[nk * 8: nk * (8 + esz)].view(dist_dtype).view(self.nq, self.k) for s in self.send]
-        self.recv = [torch.empty(self.world * per, dtype=torch.uint8, device=dev) for _ in range(2)]   # 1-D: gloo wants it flat
-        self.work = [None, None]
+        per = packed_block_bytes(nqt, self.k, esz)
+        nk = nqt * self.k
+        self.send = [torch.zeros(per, dtype=torch.uint8, device=dev) for _ in range(nb)]
+        self.out_i = [s[: nk * 8].view(torch.int64).view(nqt, self.k) for s in self.send]
+        self.out_d = [s[nk * 8: nk * (8 + esz)].view(dist_dtype).view(nqt, self.k) for s in self.send]
+        self.recv = [torch.empty(self.world * per, dtype=torch.uint8, device=dev) for _ in range(nb)]   # 1-D: gloo wants it flat
+        self.work = [None] * nb
+        self.valid = [0] * nb      # batches in the group a buffer holds (the last group of a run may be short)
         self.i = 0                 # batches submitted
-        self.gathered = 0          # batches whose all-gather has been started
+        self.gathered = 0          # groups whose all-gather has been started
         self.merging = self.rank == merge_on
         if self.merging:
             if self.cuda:
-                self.host = [torch.empty(self.world * per, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-                self.copied = [torch.cuda.Event(), torch.cuda.Event()]   # host[j] holds the gathered buffer of its batch
+                self.host = [torch.empty(self.world * per, dtype=torch.uint8, pin_memory=True) for _ in range(nb)]
+                self.copied = [torch.cuda.Event() for _ in range(nb)]    # host[j] holds the gathered buffer of its group
             else:
                 self.host = self.recv
             self.host_np = [h.numpy().reshape(-1) for h in self.host]
-            self.copy_pending = [False, False]
-            self.ticket = [None, None]                                # merge reading host[j]
+            self.copy_pending = [False] * nb
+            self.ticket = [None] * nb                                 # merge reading host[j]: (ticket, batches)
             self.merger = PipelinedMerger()
 
     def _wait_work(self, j: int) -> None:
@@ -439,7 +456,7 @@ class PipelinedShardedSearch:
             self.work[j] = None
 
     def _merge_ready(self, j: int) -> None:
-        """Batch in buffer j: its host copy is complete -> to the merge thread."""
+        """Group in buffer j: its host copy is complete -> to the merge thread."""
         if self.copy_pending[j]:
             if self.cuda:
                 ev = self.copied[j]
@@ -448,18 +465,27 @@ class PipelinedShardedSearch:
             else:
                 self._wait_work(j)
             self.copy_pending[j] = False
-            self.ticket[j] = self.merger.submit(self.host_np[j], self.world, self.nq, self.k, self.k, self.np_dt)
+            t = self.merger.submit(self.host_np[j], self.world, self.nq * self.G, self.k, self.k, self.np_dt)
+            self.ticket[j] = (t, self.valid[j])
+
+    def _collect(self, j: int):
+        """The merged batches of the group whose merge reads host[j] (oldest first)."""
+        t, batches = self.ticket[j]
+        self.ticket[j] = None
+        dd, ii = self.merger.result(t)
+        return [(dd[g * self.nq:(g + 1) * self.nq], ii[g * self.nq:(g + 1) * self.nq]) for g in range(batches)]
 
     def _gather_next(self):
-        """Start the all-gather of the oldest batch not yet gathered (its send buffer is final) and move the
-        batches behind it one stage on; returns the merged result that left the pipeline, if any."""
+        """Start the all-gather of the oldest group not yet gathered (its send buffer is final) and move the
+        groups behind it one stage on; returns the merged batches that left the pipeline (a list, maybe empty)."""
         import torch.distributed as dist
-        j = self.gathered & 1
+        j = self.gathered % self.nb
+        first = self.gathered * self.G
+        self.valid[j] = min(self.G, self.i - first)
         self.gathered += 1
-        ready = None
+        ready = []
         if self.merging and self.ticket[j] is not None:
-            ready = self.merger.result(self.ticket[j])     # two batches back: merged under the searches since
-            self.ticket[j] = None
+            ready = self._collect(j)                        # `nb` groups back: merged under the searches since
         self.work[j] = w = dist.all_gather_into_tensor(self.recv[j], self.send[j], group=self.group, async_op=True)
         if self.merging:
             if self.cuda:
@@ -467,36 +493,40 @@ class PipelinedShardedSearch:
                 self.host[j].copy_(self.recv[j], non_blocking=True)
                 self.copied[j].record()
             self.copy_pending[j] = True
-            self._merge_ready(j ^ 1)                       # the batch before: gathered and copied meanwhile
+            self._merge_ready((j - 1) % self.nb)           # the group before: gathered and copied meanwhile
         return ready
 
     def submit(self, queries):
-        j = self.i & 1
+        grp, g = divmod(self.i, self.G)
+        j = grp % self.nb
         self.i += 1
-        self._wait_work(j)       # the all-gather two batches back read send[j] and wrote recv[j]
-        self.searcher.search_into(queries, self.k, self.out_d[j], self.out_i[j])
-        # batches up to i - lag are final in their send buffers now
-        if self.i - self.lag > self.gathered:
-            return self._gather_next()
+        if g == 0:
+            self._wait_work(j)   # the all-gather `nb` groups back read send[j] and wrote recv[j]
+        lo, hi = g * self.nq, (g + 1) * self.nq
+        self.searcher.search_into(queries, self.k, self.out_d[j][lo:hi], self.out_i[j][lo:hi])
+        # groups whose last batch is batch i - lag or older are final in their send buffers now
+        if (self.gathered + 1) * self.G + self.lag <= self.i:
+            ready = self._gather_next()
+            if ready:
+                return ready[0] if self.G == 1 else ready
         return None
 
     def flush(self):
         out = []
         self.searcher.finish()
-        while self.gathered < self.i:
-            r = self._gather_next()
-            if r is not None:
-                out.append(r)
+        while self.gathered * self.G < self.i:
+            out += self._gather_next()
         if self.merging:
-            last = (self.gathered - 1) & 1 if self.gathered else 0
-            for j in (last ^ 1, last):                     # oldest first
+            newest = (self.gathered - 1) % self.nb if self.gathered else 0
+            order = [(newest + 1 + t) % self.nb for t in range(self.nb)]     # oldest first
+            for j in order:
                 self._merge_ready(j)
-            for j in (last ^ 1, last):
+            for j in order:
                 if self.ticket[j] is not None:
-                    out.append(self.merger.result(self.ticket[j]))
-                    self.ticket[j] = None
-        for j in range(2):
+                    out += self._collect(j)
+        for j in range(self.nb):
             self._wait_work(j)
+        self.i = self.gathered * self.G          # (a short last group is closed: the next batch starts a new one)
         return out
 
     def close(self) -> None:

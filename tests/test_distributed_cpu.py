@@ -158,13 +158,14 @@ def test_sharded_search_gloo_world2(tmp_path, kind):
 
 
 class _OracleSearcher:
-    """Shard searcher for PipelinedShardedSearch backed by the oracle.  ``lag`` = 1 imitates
-    sq_dense_search(SQ_MEM_DEVICE_ASYNC): a call's answer only appears in its output tensors when the NEXT call
-    (or finish()) returns -- so the test fails if the pipeline gathers a send buffer too early."""
+    """Shard searcher for PipelinedShardedSearch backed by the oracle.  ``lag`` >= 1 imitates
+    sq_dense_search(SQ_MEM_DEVICE_ASYNC) with ``dense_async_depth`` = lag + 1: a call's answer only appears in its
+    output tensors when ``lag`` further calls (or finish()) have returned -- so the test fails if the pipeline gathers
+    a send buffer too early or reuses one too soon."""
 
     def __init__(self, db, r0, lag):
         self.db, self.r0, self.lag = db, r0, lag
-        self.pending = None
+        self.pending = []                      # calls whose answers are not "final" yet, oldest first
 
     def _run(self, job):
         import torch
@@ -181,19 +182,18 @@ class _OracleSearcher:
         if not self.lag:
             self._run(job)
             return
-        out_d.fill_(-1.0)              # garbage until the call is "finished"
+        out_d.fill_(-1.0)              # garbage until the call is "finished": `lag` calls later
         out_i.fill_(-7)
-        if self.pending is not None:
-            self._run(self.pending)
-        self.pending = job
+        self.pending.append(job)
+        while len(self.pending) > self.lag:
+            self._run(self.pending.pop(0))
 
     def finish(self):
-        if self.pending is not None:
-            self._run(self.pending)
-            self.pending = None
+        while self.pending:
+            self._run(self.pending.pop(0))
 
 
-def _pipeline_worker(rank: int, world: int, port: int, lag: int, out_dir: str) -> None:
+def _pipeline_worker(rank: int, world: int, port: int, lag: int, every: int, out_dir: str) -> None:
     import torch
     import torch.distributed as dist
     from smqtk_indexing_amd.distributed import PipelinedShardedSearch, ShardedIndex, shard_range
@@ -205,21 +205,27 @@ def _pipeline_worker(rank: int, world: int, port: int, lag: int, out_dir: str) -
     nq, k, d = 3, 7, 24                                   # nq * k odd: the packed blocks need their 8-byte padding
     db = rng.standard_normal((2001, d)).astype(np.float32)
     db[1500] = db[20]                                      # a tie across the two shards
-    batches = [rng.standard_normal((nq, d)).astype(np.float32) for _ in range(5)]
+    batches = [rng.standard_normal((nq, d)).astype(np.float32) for _ in range(8)]
     batches[1][0] = db[20]
     r0, r1 = shard_range(db.shape[0], world, rank)
-    pipe = PipelinedShardedSearch(_OracleSearcher(db[r0:r1], r0, lag), nq, k, torch.float32, merge_on=0, device="cpu")
+    pipe = PipelinedShardedSearch(_OracleSearcher(db[r0:r1], r0, lag), nq, k, torch.float32, merge_on=0, device="cpu",
+                                  gather_every=every)
     got = []
     for i, q in enumerate(batches):
         r = pipe.submit(torch.from_numpy(q))
-        if rank == 0:
-            assert (r is None) == (i < 2 + lag), (i, lag)
-        else:
+        if rank == 0 and every == 1:
+            assert (r is None) == (i < max(2, lag + 1) + lag), (i, lag)   # buffers in rotation + the lag
+        elif rank != 0:
             assert r is None
         if r is not None:
-            got.append(r)
-    got += pipe.flush()
+            got += r if isinstance(r, list) else [r]       # gather_every > 1: a whole group at a time
+    got += pipe.flush()                                    # (8 batches in groups of 3: the last group is short)
     assert pipe.flush() == []
+    if every > 1:                                          # the pipeline is reusable after a short last group
+        assert pipe.submit(torch.from_numpy(batches[0])) is None
+        again = pipe.flush()
+        if rank == 0:
+            np.testing.assert_array_equal(again[0][1], got[0][1])
     # the packed single-buffer branch of allgather_merge, on CPU tensors
     s = _OracleSearcher(db[r0:r1], r0, 0)
     od, oi = torch.empty((nq, k), dtype=torch.float32), torch.empty((nq, k), dtype=torch.int64)
@@ -245,13 +251,13 @@ def _pipeline_worker(rank: int, world: int, port: int, lag: int, out_dir: str) -
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lag", [0, 1])
-def test_pipelined_sharded_search_and_packed_gather_gloo_world2(tmp_path, lag):
+@pytest.mark.parametrize("lag,every", [(0, 1), (1, 1), (2, 1), (1, 3), (2, 2), (3, 2)])
+def test_pipelined_sharded_search_and_packed_gather_gloo_world2(tmp_path, lag, every):
     """Two ranks through PipelinedShardedSearch (blocking and asynchronous-style searches) and through the packed
     single-buffer branch of allgather_merge, checked against the oracle over the whole database."""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_pipeline_worker, args=(2, port, lag, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_pipeline_worker, args=(2, port, lag, every, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok_pipe").exists()
 
 

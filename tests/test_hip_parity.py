@@ -403,6 +403,48 @@ def test_dense_async_calls_equal_blocking_calls(metric, streams):
     np.testing.assert_array_equal(oi[0].cpu().numpy(), want[0][1])
 
 
+@pytest.mark.parametrize("depth", [3, 4])
+def test_dense_async_depth(depth):
+    """Option dense_async_depth: `depth` asynchronous calls in flight; call i is final when call i + depth - 1 (or
+    sq_dense_sync) returns; changing the depth in mid-stream drains the pipeline first."""
+    import torch
+    rng = np.random.default_rng(43)
+    n, d, k = 200_000, 64, 10
+    dbh = rng.standard_normal((n, d)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    db = torch.from_numpy(dbh).to(dev)
+    idx = _lib.DenseIndex(db.data_ptr(), n=n, d=d, device_ptr=True, keepalive=db)
+    stream = torch.cuda.current_stream().cuda_stream
+    sizes = [8, 40, 8, 1, 8, 8, 33, 8]
+    qs = [rng.standard_normal((b, d)).astype(np.float32) for b in sizes]
+    want = [idx.search(q, k) for q in qs]
+    qd = [torch.from_numpy(q).to(dev) for q in qs]
+    od = [torch.empty((b, k), dtype=torch.float32, device=dev) for b in sizes]
+    oi = [torch.empty((b, k), dtype=torch.int64, device=dev) for b in sizes]
+    try:
+        _lib.set_option("dense_async_depth", depth)
+        for j, q in enumerate(qd):
+            if j == 5:
+                _lib.set_option("force_fallback", 1)     # the calls finished from here on are redone on the exact path
+            idx.search_device_async(q.data_ptr(), sizes[j], k, od[j].data_ptr(), oi[j].data_ptr(), stream)
+            f = j - (depth - 1)
+            if f >= 0:                                   # final now
+                np.testing.assert_array_equal(oi[f].cpu().numpy(), want[f][1])
+                np.testing.assert_array_equal(od[f].cpu().numpy(), want[f][0])
+        _lib.set_option("force_fallback", 0)
+        _lib.set_option("dense_async_depth", 2)          # a new depth: the next call drains the pipeline first
+        idx.search_device_async(qd[0].data_ptr(), sizes[0], k, od[0].data_ptr(), oi[0].data_ptr(), stream)
+        for f in range(1, len(sizes)):
+            np.testing.assert_array_equal(oi[f].cpu().numpy(), want[f][1])
+            np.testing.assert_array_equal(od[f].cpu().numpy(), want[f][0])
+        idx.sync()
+        np.testing.assert_array_equal(oi[0].cpu().numpy(), want[0][1])
+    finally:
+        _lib.set_option("force_fallback", 0)
+        _lib.set_option("dense_async_depth", 2)
+        idx.close()
+
+
 def test_dense_wide_rows_exact_path():
     """d beyond the scan kernel's LDS budget: exact path, numpy pairwise recursion (d > 128)."""
     rng = np.random.default_rng(8)

@@ -16,16 +16,16 @@ for s in range(0, n, 1 << 20):
 q = torch.empty((nq, d), dtype=torch.float32, device=dev).normal_(generator=g)
 idx = _lib.DenseIndex(db.data_ptr(), n=n, d=d, device_ptr=True, keepalive=db)
 st = torch.cuda.current_stream().cuda_stream
-od = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(2)]
-oi = [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(2)]
+od = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(4)]   # (up to dense_async_depth 4 in flight)
+oi = [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(4)]
 
 def run(steps=60):
     for i in range(6):
-        idx.search_device_async(q.data_ptr(), nq, k, od[i & 1].data_ptr(), oi[i & 1].data_ptr(), st)
+        idx.search_device_async(q.data_ptr(), nq, k, od[i & 3].data_ptr(), oi[i & 3].data_ptr(), st)
     idx.sync(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        idx.search_device_async(q.data_ptr(), nq, k, od[i & 1].data_ptr(), oi[i & 1].data_ptr(), st)
+        idx.search_device_async(q.data_ptr(), nq, k, od[i & 3].data_ptr(), oi[i & 3].data_ptr(), st)
     idx.sync(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
@@ -46,4 +46,4 @@ for arg in sys.argv[1:]:
     for v in vals.split(","):
         _lib.set_option(name, int(v))
         print(f"{name}={v}: {run():.4f} ms  cands/q {idx.stats()['candidates'] / nq:.0f} fallbacks {idx.stats()['fallback_queries']}")
-    _lib.set_option(name, 0 if name != "dense_async_streams" else 2)
+    _lib.set_option(name, 2 if name in ("dense_async_streams", "dense_async_depth") else 0)
