@@ -21,7 +21,10 @@ the kernels of step i + 1 are enqueued while step i runs and the status words of
 read one call later, so the device never waits for the host; every step's results are final
 and every merge is collected before the closing fence (`--sync-search`: one blocking call per
 step, the round-1 behaviour).  One process per GPU (torch.distributed / RCCL); rank 0 prints
-ONE JSON line.
+ONE JSON line.  With several ranks three searches are in flight instead of two (`--async-depth`:
+a shard's scan is short, its five small kernels overlap two neighbours) and four steps share
+one all-gather (`--gather-every`: the collective's fixed cost is that of a whole step on a
+1.25 M-row shard); results come back a group at a time, all inside the timed region.
 
 Other workloads (reported with the same contract, not the driver's default):
     --workload lsh_c3        BASELINE config 3: 10M x 128 -> 64-bit ITQ codes -> Hamming top-n
