@@ -68,6 +68,10 @@ def parse_args():
     ap.add_argument("--async-depth", type=int, default=0,
                     help="asynchronous searches in flight (option dense_async_depth); 0 = 2 on one GPU, 3 with shards "
                          "(smaller shards: the short kernels of a call weigh more, DESIGN.md section 5)")
+    ap.add_argument("--async-wait", type=int, default=0,
+                    help="several GPUs: 1 = a search call returns when the oldest call in flight is final, 0 (default) = "
+                         "right after enqueueing (option dense_async_wait): the gather / merge bookkeeping between two "
+                         "calls then overlaps the device")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="several GPUs: steps per all-gather (PipelinedShardedSearch gather_every); 0 = 4: a collective "
                          "with its pinned copy and merge hand-off costs about as much host time as a 1.25 M-row shard "
@@ -177,7 +181,8 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 # the all-gather of a finished batch (asynchronous, RCCL's stream), its copy to pinned memory and the
                 # host merge (rank 0, a worker thread) run under the searches of the following batches
                 self.pipe = PipelinedShardedSearch(index, nq_, k, ddt, merge_on=0, device=dev, use_async=use_async, depth=depth,
-                                                   gather_every=args.gather_every if args.gather_every > 0 else 4)
+                                                   gather_every=args.gather_every if args.gather_every > 0 else 4,
+                                                   wait=bool(args.async_wait))
             else:
                 self.od = [torch.empty((nq_, k), dtype=ddt, device=dev) for _ in range(depth)]   # one per call in flight
                 self.oi = [torch.empty((nq_, k), dtype=torch.int64, device=dev) for _ in range(depth)]

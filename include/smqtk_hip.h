@@ -206,7 +206,10 @@ int sq_dense_search(sq_handle_t h, const float* queries, int nq, int k,
  * Option "dense_async_depth" (2 by default, up to 4) keeps that many calls in flight: call i is then final when
  * call i + depth - 1 returns (callers rotate `depth` output buffers); small matrices -- the shards of a multi-GPU
  * index -- gain from 3, where the short kernels of a call weigh as much as its scan.  A change of the option takes
- * effect at the next asynchronous call, which first finishes the calls in flight. */
+ * effect at the next asynchronous call, which first finishes the calls in flight.  Option "dense_async_wait" = 0
+ * makes the call return right after enqueueing: the wait for the oldest call moves to the start of the next call, so
+ * call i is final when call i + depth returns, and host work between two calls (a collective, a merge hand-off)
+ * no longer delays the next enqueue. */
 int sq_dense_sync(sq_handle_t h);
 int sq_dense_destroy(sq_handle_t h);
 

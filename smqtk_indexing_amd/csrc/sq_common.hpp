@@ -63,6 +63,7 @@ struct Options {
     int spin_wait_us = 2000;     // searches poll the stream this long before blocking (0 = block at once)
     int dense_async_streams = 2; // asynchronous dense searches: 2 = the two call slots run on streams of their own (tail of call i overlaps the head of call i + 1), 1 = everything on the caller's stream
     int dense_async_depth = 2;   // asynchronous dense searches in flight (2..4): the results of a call are final when the (depth - 1)-th call after it returns
+    int dense_async_wait = 1;    // 1: an asynchronous dense search returns once the oldest call in flight is final; 0: it returns right after enqueueing (the wait moves to the start of the next call: one more call of lag, host work between calls overlaps the device)
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
 };
 extern Options g_opt;

@@ -893,7 +893,10 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
         }
         SQ_TRY(dense_enqueue(h, s, queries, nq, k, out_dist, reinterpret_cast<long long*>(out_idx), run, true));
         h->async_calls++;
-        // the oldest call still in flight (depth - 1 calls back): its results are final on return
+        // the oldest call still in flight (depth - 1 calls back): its results are final on return -- unless the caller
+        // asked not to wait here ("dense_async_wait" = 0): that call is then finished at the start of the next call (its
+        // slot is the next one to be reused), and whatever the host does between the two calls overlaps the device
+        if (!g_opt.dense_async_wait) return SQ_OK;
         return dense_resolve(h, h->slot[h->async_calls % (unsigned)h->depth]);
     }
     SQ_TRY(dense_sync_all(h));

@@ -361,22 +361,39 @@ class HipSearcher:
     with ``SQ_MEM_DEVICE_ASYNC``, which keeps ``depth`` calls on the device (include/smqtk_hip.h; option
     ``dense_async_depth``, 2 by default -- small shards gain from 3: DESIGN.md section 5)."""
 
-    def __init__(self, index, stream_handle: int = 0, use_async: bool = False, depth: int = 2):
+    def __init__(self, index, stream_handle: int = 0, use_async: bool = False, depth: int = 2, wait: bool = True):
         self.index, self.stream = index, int(stream_handle)
         self.lag = 0
+        self._opts = None
         if use_async and hasattr(index, "search_device_async"):
             depth = min(max(int(depth), 2), 4)
-            from . import _lib
-            _lib.set_option("dense_async_depth", depth)
-            self.lag = depth - 1
+            # wait=False: a call returns right after enqueueing (option dense_async_wait = 0) and the wait for the oldest
+            # call moves to the start of the next one: one more call of lag, and the host work between two calls (the
+            # pipeline's gather and merge bookkeeping) overlaps the device instead of delaying the next enqueue
+            self._opts = (depth, 1 if wait else 0)
+            self.lag = depth - 1 if wait else depth
+        self._armed = False
+
+    def _arm(self) -> None:
+        """The two options are process-wide: set when a run of searches starts, defaults restored by finish()."""
+        from . import _lib
+        _lib.set_option("dense_async_depth", self._opts[0])
+        _lib.set_option("dense_async_wait", self._opts[1])
+        self._armed = True
 
     def search_into(self, queries, k: int, out_d, out_i) -> None:
+        if self._opts is not None and not self._armed:
+            self._arm()
         fn = self.index.search_device_async if self.lag else self.index.search_device
         fn(queries.data_ptr(), int(queries.shape[0]), int(k), out_d.data_ptr(), out_i.data_ptr(), self.stream)
 
     def finish(self) -> None:
         if self.lag:
             self.index.sync()
+            from . import _lib
+            _lib.set_option("dense_async_depth", 2)
+            _lib.set_option("dense_async_wait", 1)
+            self._armed = False
 
 
 class PipelinedShardedSearch:
@@ -398,11 +415,12 @@ class PipelinedShardedSearch:
     behind the previous user.  CPU tensors (gloo) take the same path without streams or pinned copies: the CPU tests
     drive it with an oracle-backed searcher.
     ``searcher``: an object with ``lag``, ``search_into`` and ``finish`` (or a ``_lib`` index: wrapped in a
-    :class:`HipSearcher` on a compute stream of the pipeline's own; ``depth`` = asynchronous searches in flight).
+    :class:`HipSearcher` on a compute stream of the pipeline's own; ``depth`` = asynchronous searches in flight,
+    ``wait`` = False: searches return right after enqueueing -- see :class:`HipSearcher`).
     """
 
     def __init__(self, searcher, nq: int, k: int, dist_dtype, group=None, merge_on: int = 0, device=None,
-                 use_async: bool = False, depth: int = 2, gather_every: int = 1):
+                 use_async: bool = False, depth: int = 2, gather_every: int = 1, wait: bool = True):
         import torch
         import torch.distributed as dist
         self.nq, self.k, self.group = int(nq), int(k), group
@@ -414,7 +432,7 @@ class PipelinedShardedSearch:
         if not hasattr(searcher, "search_into"):
             # a _lib index: its searches get a stream of their own; collectives and copies stay on the current stream
             self.compute = torch.cuda.Stream(device=dev)
-            searcher = HipSearcher(searcher, self.compute.cuda_stream, use_async, depth)
+            searcher = HipSearcher(searcher, self.compute.cuda_stream, use_async, depth, wait)
         self.searcher = searcher
         self.lag = int(searcher.lag)
         self.G = G = max(1, int(gather_every))

@@ -403,10 +403,11 @@ def test_dense_async_calls_equal_blocking_calls(metric, streams):
     np.testing.assert_array_equal(oi[0].cpu().numpy(), want[0][1])
 
 
-@pytest.mark.parametrize("depth", [3, 4])
-def test_dense_async_depth(depth):
+@pytest.mark.parametrize("depth,wait", [(3, 1), (4, 1), (2, 0), (3, 0)])
+def test_dense_async_depth(depth, wait):
     """Option dense_async_depth: `depth` asynchronous calls in flight; call i is final when call i + depth - 1 (or
-    sq_dense_sync) returns; changing the depth in mid-stream drains the pipeline first."""
+    sq_dense_sync) returns -- one call later with dense_async_wait = 0 (the call returns right after enqueueing);
+    changing the depth in mid-stream drains the pipeline first."""
     import torch
     rng = np.random.default_rng(43)
     n, d, k = 200_000, 64, 10
@@ -423,16 +424,17 @@ def test_dense_async_depth(depth):
     oi = [torch.empty((b, k), dtype=torch.int64, device=dev) for b in sizes]
     try:
         _lib.set_option("dense_async_depth", depth)
+        _lib.set_option("dense_async_wait", wait)
         for j, q in enumerate(qd):
             if j == 5:
                 _lib.set_option("force_fallback", 1)     # the calls finished from here on are redone on the exact path
             idx.search_device_async(q.data_ptr(), sizes[j], k, od[j].data_ptr(), oi[j].data_ptr(), stream)
-            f = j - (depth - 1)
+            f = j - (depth - 1) - (0 if wait else 1)
             if f >= 0:                                   # final now
                 np.testing.assert_array_equal(oi[f].cpu().numpy(), want[f][1])
                 np.testing.assert_array_equal(od[f].cpu().numpy(), want[f][0])
         _lib.set_option("force_fallback", 0)
-        _lib.set_option("dense_async_depth", 2)          # a new depth: the next call drains the pipeline first
+        _lib.set_option("dense_async_depth", 3 if depth == 2 else 2)   # a new depth: the next call drains the pipeline first
         idx.search_device_async(qd[0].data_ptr(), sizes[0], k, od[0].data_ptr(), oi[0].data_ptr(), stream)
         for f in range(1, len(sizes)):
             np.testing.assert_array_equal(oi[f].cpu().numpy(), want[f][1])
@@ -442,6 +444,7 @@ def test_dense_async_depth(depth):
     finally:
         _lib.set_option("force_fallback", 0)
         _lib.set_option("dense_async_depth", 2)
+        _lib.set_option("dense_async_wait", 1)
         idx.close()
 
 
