@@ -52,8 +52,8 @@ MFMA_BF16_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROA
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)   # (short runs weigh the pipeline's fill and drain: with shards the
+    ap.add_argument("--warmup", type=int, default=5)    #  last groups' gathers and merges are inside the timed region)
     ap.add_argument("--rows", type=int, default=10_000_000, help="database rows in total (all shards)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=100)
@@ -150,7 +150,9 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     queries = all_q[:nq].contiguous()
     torch.cuda.synchronize()
 
-    _lib.set_option("profile", 1)
+    # hipEvent timing of the scan inside the library: every search on one GPU; with shards every 4th (four event
+    # records per call cost a 1.25 M-row shard ~30 % of its step)
+    _lib.set_option("profile", 4 if use_dist else 1)
     if args.async_streams:
         _lib.set_option("dense_async_streams", args.async_streams)
     index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=metric, device_ptr=True, id_base=r0, keepalive=db)
@@ -166,7 +168,8 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     def note_stats():
         st = index.stats()
         if st["scan_launches"]:
-            scan_ms.append(st["scan_ms"])
+            if st["scan_ms"] > 0:          # (0: a call that was not timed, see the profile option above)
+                scan_ms.append(st["scan_ms"])
             cands.append(st["candidates"])
             fallbacks.append(st["fallback_queries"])
 
@@ -182,7 +185,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 # host merge (rank 0, a worker thread) run under the searches of the following batches
                 self.pipe = PipelinedShardedSearch(index, nq_, k, ddt, merge_on=0, device=dev, use_async=use_async, depth=depth,
                                                    gather_every=args.gather_every if args.gather_every > 0 else 4,
-                                                   wait=bool(args.async_wait))
+                                                   wait=bool(args.async_wait), queries_ready=True)   # (the queries were generated and synchronised long ago)
             else:
                 self.od = [torch.empty((nq_, k), dtype=ddt, device=dev) for _ in range(depth)]   # one per call in flight
                 self.oi = [torch.empty((nq_, k), dtype=torch.int64, device=dev) for _ in range(depth)]

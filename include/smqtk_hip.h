@@ -209,7 +209,9 @@ int sq_dense_search(sq_handle_t h, const float* queries, int nq, int k,
  * effect at the next asynchronous call, which first finishes the calls in flight.  Option "dense_async_wait" = 0
  * makes the call return right after enqueueing: the wait for the oldest call moves to the start of the next call, so
  * call i is final when call i + depth returns, and host work between two calls (a collective, a merge hand-off)
- * no longer delays the next enqueue. */
+ * no longer delays the next enqueue.  Option "dense_async_order" = 0: the caller guarantees that `queries` are
+ * complete when the call is made (no producer still running on `stream`); the call then skips the event that orders
+ * its internal stream behind `stream` (worth ~10 us of start latency per call on a small matrix). */
 int sq_dense_sync(sq_handle_t h);
 int sq_dense_destroy(sq_handle_t h);
 

@@ -46,7 +46,7 @@ inline int fail(int code, const char* fmt, ...) {
 
 // ----------------------------------------------------------------- options
 struct Options {
-    int profile = 0;
+    int profile = 0;         // 1: hipEvent timing of the search stages into sq_stats_t; N > 1: only every N-th asynchronous dense search is timed (the others report scan_ms = 0)
     int sample_stride = 0;   // 0 = auto
     int candidate_cap = 0;   // 0 = auto
     int force_fallback = 0;
@@ -64,6 +64,7 @@ struct Options {
     int dense_async_streams = 2; // asynchronous dense searches: 2 = the two call slots run on streams of their own (tail of call i overlaps the head of call i + 1), 1 = everything on the caller's stream
     int dense_async_depth = 2;   // asynchronous dense searches in flight (2..4): the results of a call are final when the (depth - 1)-th call after it returns
     int dense_async_wait = 1;    // 1: an asynchronous dense search returns once the oldest call in flight is final; 0: it returns right after enqueueing (the wait moves to the start of the next call: one more call of lag, host work between calls overlaps the device)
+    int dense_async_order = 1;   // 1: an asynchronous dense search on internal streams starts behind the work already on the caller's stream (an event per call); 0: the caller guarantees its queries are complete -- no event, the call starts as soon as the device has room
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
 };
 extern Options g_opt;

@@ -242,7 +242,8 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
     const int d = h->d, d_pad = h->d_pad;
     const int kk = (int)(k < n ? k : n);
     const bool cosine = h->metric == SQ_METRIC_COSINE;
-    const bool prof = g_opt.profile != 0;
+    // (profile = N > 1: every N-th asynchronous call only -- four event records per call weigh on a small shard's step)
+    const bool prof = g_opt.profile == 1 || (g_opt.profile > 1 && (!use_event || h->async_calls % (unsigned)g_opt.profile == 0));
     const size_t key_bytes = cosine ? sizeof(K128) : sizeof(u64);
     u32 cap = g_opt.candidate_cap > 0 ? (u32)g_opt.candidate_cap : 65536u;
     if (cap < (u32)(4 * kk)) cap = (u32)(4 * kk);
@@ -886,9 +887,12 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
             // other's rows from L2 (256 queries: 1.17 -> 1.68 ms per call): they share slot 0's stream.
             DenseSlot& owner = scan_query_tiles(h->d_pad, (nq + TILE_ROWS - 1) / TILE_ROWS) == 1 ? s : h->slot[0];
             if (!owner.own) SQ_HIP(hipStreamCreateWithFlags(&owner.own, hipStreamNonBlocking));
-            if (!s.ev_in) SQ_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
-            SQ_HIP(hipEventRecord(s.ev_in, st));        // the caller's earlier work on `stream` (the queries) comes first
-            SQ_HIP(hipStreamWaitEvent(owner.own, s.ev_in, 0));
+            if (g_opt.dense_async_order) {
+                if (!s.ev_in) SQ_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+                SQ_HIP(hipEventRecord(s.ev_in, st));    // the caller's earlier work on `stream` (the queries) comes first
+                SQ_HIP(hipStreamWaitEvent(owner.own, s.ev_in, 0));
+            }  // else: the caller vouches for its queries ("dense_async_order" = 0: an event on a busy or foreign stream
+               // costs ~10 us of start latency per call, as much as a small shard's whole sample pass)
             run = owner.own;
         }
         SQ_TRY(dense_enqueue(h, s, queries, nq, k, out_dist, reinterpret_cast<long long*>(out_idx), run, true));

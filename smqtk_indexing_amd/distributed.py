@@ -361,7 +361,8 @@ class HipSearcher:
     with ``SQ_MEM_DEVICE_ASYNC``, which keeps ``depth`` calls on the device (include/smqtk_hip.h; option
     ``dense_async_depth``, 2 by default -- small shards gain from 3: DESIGN.md section 5)."""
 
-    def __init__(self, index, stream_handle: int = 0, use_async: bool = False, depth: int = 2, wait: bool = True):
+    def __init__(self, index, stream_handle: int = 0, use_async: bool = False, depth: int = 2, wait: bool = True,
+                 queries_ready: bool = False):
         self.index, self.stream = index, int(stream_handle)
         self.lag = 0
         self._opts = None
@@ -370,7 +371,9 @@ class HipSearcher:
             # wait=False: a call returns right after enqueueing (option dense_async_wait = 0) and the wait for the oldest
             # call moves to the start of the next one: one more call of lag, and the host work between two calls (the
             # pipeline's gather and merge bookkeeping) overlaps the device instead of delaying the next enqueue
-            self._opts = (depth, 1 if wait else 0)
+            # queries_ready=True: every query tensor handed to search_into is complete (nothing still writing it on a
+            # stream): the per-call event that orders the search behind the caller's stream is skipped
+            self._opts = (depth, 1 if wait else 0, 0 if queries_ready else 1)
             self.lag = depth - 1 if wait else depth
         self._armed = False
 
@@ -379,6 +382,7 @@ class HipSearcher:
         from . import _lib
         _lib.set_option("dense_async_depth", self._opts[0])
         _lib.set_option("dense_async_wait", self._opts[1])
+        _lib.set_option("dense_async_order", self._opts[2])
         self._armed = True
 
     def search_into(self, queries, k: int, out_d, out_i) -> None:
@@ -393,6 +397,7 @@ class HipSearcher:
             from . import _lib
             _lib.set_option("dense_async_depth", 2)
             _lib.set_option("dense_async_wait", 1)
+            _lib.set_option("dense_async_order", 1)
             self._armed = False
 
 
@@ -416,11 +421,13 @@ class PipelinedShardedSearch:
     drive it with an oracle-backed searcher.
     ``searcher``: an object with ``lag``, ``search_into`` and ``finish`` (or a ``_lib`` index: wrapped in a
     :class:`HipSearcher` on a compute stream of the pipeline's own; ``depth`` = asynchronous searches in flight,
-    ``wait`` = False: searches return right after enqueueing -- see :class:`HipSearcher`).
+    ``wait`` = False: searches return right after enqueueing; ``queries_ready`` = True: the query tensors handed to
+    ``submit`` are complete, no stream ordering needed -- see :class:`HipSearcher`).
     """
 
     def __init__(self, searcher, nq: int, k: int, dist_dtype, group=None, merge_on: int = 0, device=None,
-                 use_async: bool = False, depth: int = 2, gather_every: int = 1, wait: bool = True):
+                 use_async: bool = False, depth: int = 2, gather_every: int = 1, wait: bool = True,
+                 queries_ready: bool = False):
         import torch
         import torch.distributed as dist
         self.nq, self.k, self.group = int(nq), int(k), group
@@ -430,9 +437,17 @@ class PipelinedShardedSearch:
         dev = torch.device(device)
         self.cuda = dev.type == "cuda"
         if not hasattr(searcher, "search_into"):
-            # a _lib index: its searches get a stream of their own; collectives and copies stay on the current stream
-            self.compute = torch.cuda.Stream(device=dev)
-            searcher = HipSearcher(searcher, self.compute.cuda_stream, use_async, depth, wait)
+            # a _lib index.  Blocking searches get a stream of their own (collectives and copies stay on the current
+            # stream).  Asynchronous searches already run on the library's internal streams and are only ORDERED behind
+            # the stream handed over: no stream is created for them -- the device has few hardware queues (4 by default
+            # on ROCm), and one more active stream made two of the library's streams share a queue: the overlap between
+            # neighbouring searches was lost, 0.075 -> 0.107 ms per step on a 1.25 M-row shard (tools/pipe_ablate.py)
+            if use_async and hasattr(searcher, "search_device_async"):
+                handle = torch.cuda.current_stream(dev).cuda_stream
+            else:
+                self.compute = torch.cuda.Stream(device=dev)
+                handle = self.compute.cuda_stream
+            searcher = HipSearcher(searcher, handle, use_async, depth, wait, queries_ready)
         self.searcher = searcher
         self.lag = int(searcher.lag)
         self.G = G = max(1, int(gather_every))
