@@ -33,6 +33,10 @@ def test_library_answers_without_gpu_calls():
     with pytest.raises(_lib.HipError):
         _lib.set_option("no_such_option", 1)
     assert b"unknown option" in lib.sq_last_error()
+    # the options the pipelined / multi-rank path sets (include/smqtk_hip.h, sq_dense_search): known, and back to defaults
+    for name, default in (("dense_async_streams", 2), ("dense_async_depth", 2), ("dense_async_wait", 1),
+                          ("dense_async_order", 1), ("profile", 0)):
+        _lib.set_option(name, default)
 
 
 def test_host_merge_orders_by_distance_then_id():
