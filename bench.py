@@ -152,9 +152,9 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     queries = all_q[:nq].contiguous()
     torch.cuda.synchronize()
 
-    # hipEvent timing of the scan inside the library: every search on one GPU; with shards every 4th (four event
-    # records per call cost a 1.25 M-row shard ~30 % of its step)
-    _lib.set_option("profile", 4 if use_dist else 1)
+    # hipEvent timing of the scan inside the library (`roofline.kernel_ms`): every 4th search of the timed region --
+    # four event records per call cost ~10 us per step (2 % of a 10 M-row step, a tenth of a 1.25 M-row shard's)
+    _lib.set_option("profile", 4)
     if args.async_streams:
         _lib.set_option("dense_async_streams", args.async_streams)
     index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=metric, device_ptr=True, id_base=r0, keepalive=db)
