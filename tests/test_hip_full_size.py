@@ -95,6 +95,48 @@ def test_dense_l2_10m_x_128_properties():
         h.close()
 
 
+def test_dense_l2_10m_batches_of_every_kernel_agree():
+    """10 M x 128, 1024 queries: the multi-tile scans (4 query tiles per wave for 1024 and 256 queries, 2 for 64) and
+    the one-tile scan (32 queries) are different kernels behind the same exact answer -- ids and float32 distances
+    must agree bit for bit, and no query may need the exact path (also BASELINE config 2's batch, at full rows)."""
+    dev = _dev()
+    n, d, k = 10_000_000, 128, 100
+    g = torch.Generator(device=dev)
+    g.manual_seed(202)
+    db = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for s in range(0, n, 1 << 21):
+        db[s:s + (1 << 21)].normal_(generator=g)
+    q = torch.empty((1024, d), dtype=torch.float32, device=dev).normal_(generator=g)
+    q[5] = db[777_777]
+    index = _lib.DenseIndex(db.data_ptr(), n=n, d=d, device_ptr=True, keepalive=db)
+
+    def run(chunk):
+        od = torch.empty((1024, k), dtype=torch.float32, device=dev)
+        oi = torch.empty((1024, k), dtype=torch.int64, device=dev)
+        fallbacks = 0
+        for s in range(0, 1024, chunk):
+            index.search_device(q[s:s + chunk].data_ptr(), chunk, k, od[s:s + chunk].data_ptr(), oi[s:s + chunk].data_ptr(),
+                                _stream())
+            fallbacks += index.stats()["fallback_queries"]
+        torch.cuda.synchronize()
+        return od.cpu().numpy(), oi.cpu().numpy(), fallbacks
+
+    ref_d, ref_i, ref_fb = run(32)
+    assert ref_fb == 0 and ref_i[5, 0] == 777_777 and ref_d[5, 0] == 0.0
+    assert (np.diff(ref_d, axis=1) >= 0).all()
+    for chunk in (64, 256, 1024):
+        dd, ii, fb = run(chunk)
+        assert fb == 0, chunk
+        np.testing.assert_array_equal(ii, ref_i, err_msg=f"batch {chunk}")
+        np.testing.assert_array_equal(dd.view(np.uint32), ref_d.view(np.uint32), err_msg=f"batch {chunk}")
+    # the returned distances recomputed by the oracle from the returned rows (two queries)
+    for qi in (5, 1000):
+        rows = db[torch.from_numpy(ref_i[qi]).to(dev)].cpu().numpy()
+        want = O.dense_distances(rows, q[qi].cpu().numpy(), "euclidean")
+        np.testing.assert_array_equal(ref_d[qi].view(np.uint32), want.astype(np.float32).view(np.uint32))
+    index.close()
+
+
 def test_dense_cosine_12m_x_512_shard_properties():
     """One shard of BASELINE config 4 (100 M x 512 cosine over 8 GPUs): 12.5 M x 512."""
     dev = _dev()
