@@ -550,13 +550,21 @@ class PipelinedShardedSearch:
         while self.gathered * self.G < self.i:
             out += self._gather_next()
         if self.merging:
+            from . import _lib
             newest = (self.gathered - 1) % self.nb if self.gathered else 0
             order = [(newest + 1 + t) % self.nb for t in range(self.nb)]     # oldest first
             for j in order:
-                self._merge_ready(j)
-            for j in order:
-                if self.ticket[j] is not None:
+                if self.ticket[j] is not None:             # already with the merge thread
                     out += self._collect(j)
+                if self.copy_pending[j]:
+                    # nothing is left to overlap with: merge here instead of paying two thread hand-offs
+                    if self.cuda:
+                        self.copied[j].synchronize()
+                    else:
+                        self._wait_work(j)
+                    self.copy_pending[j] = False
+                    dd, ii = _lib.merge_topk_gathered(self.host_np[j], self.world, self.nq * self.G, self.k, self.k, self.np_dt)
+                    out += [(dd[g * self.nq:(g + 1) * self.nq], ii[g * self.nq:(g + 1) * self.nq]) for g in range(self.valid[j])]
         for j in range(self.nb):
             self._wait_work(j)
         self.i = self.gathered * self.G          # (a short last group is closed: the next batch starts a new one)
