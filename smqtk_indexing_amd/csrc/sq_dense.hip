@@ -365,7 +365,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // the CUs: alone it is as fast (HBM bound: 0.433 ms on 160 workgroups against 0.439 on 256 at 10 M x 128),
         // and the pipelined step drops from 0.50 to 0.46 ms (tools/step_sweep.py dense_blocks=...).
         // (one query tile per wave only: the multi-tile configurations are MFMA bound and want every CU)
-        int nrb = g_opt.dense_blocks > 0 ? g_opt.dense_blocks : (use_event && g_opt.dense_async_streams == 2 && qt == 1 ? cus * 3 / 4 : cus);
+        int nrb = g_opt.dense_blocks > 0 ? g_opt.dense_blocks : (use_event && g_opt.dense_async_streams == 2 && nqt == 1 ? cus * 3 / 4 : cus);
         nrb = (nrb + 7) / 8 * 8;
         const int wv = scan_geometry(d_pad, qt, qp).waves;
         // survivors leave the scan as per-wave segments; the re-rank kernel turns them into per-query key lists
@@ -885,7 +885,11 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
             // calls overlap.  Larger batches (MFMA bound, and kept cheap in HBM traffic by all workgroups of an XCD
             // walking the same rows) must not run two scans at once -- two scans at different rows evict each
             // other's rows from L2 (256 queries: 1.17 -> 1.68 ms per call): they share slot 0's stream.
-            DenseSlot& owner = scan_query_tiles(h->d_pad, (nq + TILE_ROWS - 1) / TILE_ROWS) == 1 ? s : h->slot[0];
+            // (a batch that is ONE group of query tiles -- up to 64 queries at two tiles per wave, 128 at four -- still
+            // reads the matrix once: it overlaps like a one-tile batch)
+            const int tiles = (nq + TILE_ROWS - 1) / TILE_ROWS;
+            const bool one_group = tiles <= scan_query_tiles(h->d_pad, tiles);
+            DenseSlot& owner = one_group ? s : h->slot[0];
             if (!owner.own) SQ_HIP(hipStreamCreateWithFlags(&owner.own, hipStreamNonBlocking));
             if (g_opt.dense_async_order) {
                 if (!s.ev_in) SQ_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
