@@ -102,20 +102,30 @@ static constexpr int kSelectLdsKeys128 = 7168;
 // select + the finalisation post-op (keys -> distances / ids, certification, status) in one launch
 static DevBuf g_dense_sort_scratch[64];  // per device: scratch of the any-k sorted select (rare path; under the handle lock + synchronous use)
 
+// `expect`: candidates per query the caller expects (0 = unknown).  The kernel keeps up to lds_keys keys of a query in
+// LDS and reads longer lists from global memory; sizing the LDS for the expected list instead of the largest possible
+// lets two workgroups share a CU (36-40 registers per thread: LDS is what limits them) -- with one workgroup per query
+// a 1024-query batch is four rounds of workgroups otherwise.
 template <class K, class Post>
 static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out,
-                           const Post& post, hipStream_t st) {
+                           const Post& post, hipStream_t st, long long expect = 0) {
     static bool attr_set = false;
-    const int lds_keys = sizeof(K) == 8 ? kSelectLdsKeys64 : kSelectLdsKeys128;
-    if (k > lds_keys) {  // beyond the one-workgroup select: full sort (sq_select.cuh, "any-k sorted select")
+    const int lds_max = sizeof(K) == 8 ? kSelectLdsKeys64 : kSelectLdsKeys128;
+    if (k > lds_max) {  // beyond the one-workgroup select: full sort (sq_select.cuh, "any-k sorted select")
         int dev = 0;
         SQ_HIP(hipGetDevice(&dev));
         return sort_select_large<K, Post>(keys, cnt, cap, stride, k, nq, out, g_dense_sort_scratch[dev & 63], post, st);
     }
+    int lds_keys = lds_max;
+    if (expect > 0 && nq > 256) {  // (fewer queries than CUs: one round of workgroups either way)
+        const int half = (int)((80 * 1024) / sizeof(K)) - SELECT_SORT_MAX;  // two workgroups in 160 KB
+        if (half >= k && 2 * expect <= half) lds_keys = half;
+    }
+    const size_t lds_full = (size_t)(lds_max + SELECT_SORT_MAX) * sizeof(K);
     const size_t lds = (size_t)(lds_keys + SELECT_SORT_MAX) * sizeof(K);
     if (!attr_set) {
         SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<K, Post>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
         attr_set = true;
     }
     hipLaunchKernelGGL((select_topk_kernel<K, Post>), dim3(nq), dim3(1024), lds, st, keys, cnt, cap, stride, k, lds_keys,
@@ -443,7 +453,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             SQ_TRY(select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(),
                                         DenseFinalizeL2{cnt, cap, kk, h->id_base, thr, qn2, 0.5 * eps_a + eps_b, 1,
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0},
-                                        st));
+                                        st, 4 * stride * kk));   // ~2.7 stride k candidates per query on N(0,1) data
         }
     } else {
         c.all_fallback = true;  // rows wider than the MFMA scan covers: exact path for every query
