@@ -18,17 +18,32 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {
 // per-lane 32-bit byte offset.  Issued from inline asm so that hipcc does not
 // fence every later ds_read with vmcnt(0); completion is tracked by the counted
 // waits below (cdna_hip_programming.md section 5.7).
+// NT: non-temporal cache policy for bytes that are read once (a whole-matrix stream): they do not displace what
+// other kernels keep in L2 / MALL and land sooner (MI355X_MICROARCH.md, "nt-weights").  Never for data that several
+// workgroups re-read from L2.
+template <bool NT = false>
 __device__ __forceinline__ void glds16(const void* gbase_uniform, u32 voff, u32 lds_dst) {
     u32 keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(uniform_ptr(gbase_uniform)), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
-        : "memory");
+    if constexpr (NT)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(uniform_ptr(gbase_uniform)), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+            : "memory");
+    else
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(uniform_ptr(gbase_uniform)), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+            : "memory");
 }
 __device__ __forceinline__ void glds4(const void* gbase_uniform, u32 voff, u32 lds_dst) {
     u32 keep;
@@ -50,10 +65,13 @@ __device__ __forceinline__ void glds4(const void* gbase_uniform, u32 voff, u32 l
 __device__ __forceinline__ void glds_set_m0(u32 lds_dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
-template <int OFF>
+template <int OFF, bool NT = false>
 __device__ __forceinline__ void glds16_m0(const void* gbase_uniform, u32 voff) {
     static_assert(OFF >= -4096 && OFF <= 4095, "13-bit signed instruction offset");
-    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(uniform_ptr(gbase_uniform)), "n"(OFF) : "memory");
+    if constexpr (NT)
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2 nt" ::"v"(voff), "s"(uniform_ptr(gbase_uniform)), "n"(OFF) : "memory");
+    else
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(uniform_ptr(gbase_uniform)), "n"(OFF) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void glds4_m0(const void* gbase_uniform, u32 voff) {

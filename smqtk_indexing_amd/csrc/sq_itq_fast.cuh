@@ -333,7 +333,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
         const u32 dst = ring_base + (u32)iss_slot * ITQF_UNIT_BYTES;
         const unsigned char* base = reinterpret_cast<const unsigned char*>(a.x) + row0 * (D * 4) + iss_kc * 256;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) glds16(base, voff[j], dst + (u32)j * 1024);
+        for (int j = 0; j < 8; ++j) glds16<true>(base, voff[j], dst + (u32)j * 1024);   // non-temporal: the rows are read once
         ++issued;
         if (++iss_kc == KU) {
             iss_kc = 0;
