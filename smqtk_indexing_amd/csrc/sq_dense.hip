@@ -133,15 +133,15 @@ static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long str
     return SQ_OK;
 }
 
-template <int WAVES, int NSTAGE, int KU, int QT, int QP, bool AB, bool SAMPLE>
+template <int WAVES, int NSTAGE, int KU, int QT, int QP, bool AB, bool SAMPLE, bool NT = false>
 static int scan_launch_t(const DenseScanArgs& a, size_t lds, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, AB, SAMPLE>),
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, AB, SAMPLE, NT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, AB, SAMPLE>), dim3((unsigned)(a.nrb * a.nqt)),
+    hipLaunchKernelGGL((dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, AB, SAMPLE, NT>), dim3((unsigned)(a.nrb * a.nqt)),
                        dim3(WAVES * 64), lds, st, a);
     return SQ_OK;
 }
@@ -177,7 +177,12 @@ static ScanGeom scan_geometry(int d_pad, int qt, int qp) {
 template <int KU, bool SAMPLE>
 static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, int qt, int qp, hipStream_t st) {
     if constexpr (KU <= 1) {
+        // one group of query tiles over a copy far beyond the MALL: the non-temporal build of the two kernels that serve
+        // 33 .. 128 queries
+        const bool nt = a.nt && a.nqt == 1;
+        if (qt == 4 && qp == 1 && nt) return scan_launch_t<4, 4, KU, 4, 1, true, SAMPLE, true>(a, g.lds, st);
         if (qt == 4) return qp == 1 ? scan_launch_t<4, 4, KU, 4, 1, true, SAMPLE>(a, g.lds, st) : scan_launch_t<4, 4, KU, 4, 2, true, SAMPLE>(a, g.lds, st);
+        if (qt == 2 && qp == 1 && g.waves == 8 && nt) return scan_launch_t<8, 2, KU, 2, 1, true, SAMPLE, true>(a, g.lds, st);
         if (qt == 2 && qp == 1 && g.waves == 8) return scan_launch_t<8, 2, KU, 2, 1, true, SAMPLE>(a, g.lds, st);
         if (qt == 2) return qp == 1 ? scan_launch_t<4, 4, KU, 2, 1, true, SAMPLE>(a, g.lds, st) : scan_launch_t<4, 4, KU, 2, 2, true, SAMPLE>(a, g.lds, st);
         if (g.waves == 8) return scan_launch_t<8, 2, KU, 1, 2, false, SAMPLE>(a, g.lds, st);

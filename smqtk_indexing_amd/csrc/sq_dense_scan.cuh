@@ -411,7 +411,9 @@ __device__ __forceinline__ void lds_read8_agpr(f32x4 (&dst)[N], int g0, const u3
 // (every multi-tile configuration, and d_pad > 128 with more than one query tile in the batch);
 // otherwise they are compiler-managed VGPRs (KU == 1) or re-read from an LDS copy per MFMA
 // (KU > 1: fine while one tile per wave keeps the kernel HBM bound, LDS bound beyond that).
-template <int WAVES, int NSTAGE, int KU, int QT, int QP, bool AB, bool SAMPLE>
+// NT (the AGPR configurations; compile time because their instruction stream takes no branch): non-temporal row stream
+// for a launch that reads the copy once -- one group of query tiles.
+template <int WAVES, int NSTAGE, int KU, int QT, int QP, bool AB, bool SAMPLE, bool NT = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(DenseScanArgs a) {
     static_assert(AB || (QT == 1 && QP == 2), "several query tiles / one query plane need the AGPR-resident fragments");
     static_assert(!AB || KU * QT * QP * 32 <= 256, "AGPR budget of the query fragments");
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
         // (only the compiler-scheduled one-tile kernel: a branch between the hand-issued MFMAs of the multi-tile
         // kernels upsets hipcc -- see the large-batch notes in DESIGN.md)
         for (int j = 0; j < 8; ++j) {
-            if (!AB && once)
+            if (NT || (!AB && once))
                 glds16<true>(base, voff[j], dst + (u32)j * 1024);
             else
                 glds16<false>(base, voff[j], dst + (u32)j * 1024);
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                 return;  // measurement build: no refill
 #endif
                 if constexpr (J == 0) glds_set_m0(idst + 4096u);
-                if constexpr (J < 8) glds16_m0<J * 1024 - 4096>(ibase, voff_s[J]);
+                if constexpr (J < 8) glds16_m0<J * 1024 - 4096, NT>(ibase, voff_s[J]);
                 if constexpr (J == 8) {
                     if (inorm) {
                         glds_set_m0(idst + UNIT_BYTES);
@@ -1020,14 +1022,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
                                 if constexpr (ISS) {
                                     if (slot >= DMA0 && (slot - DMA0) % DSTEP == 0) {
                                         const int j = (slot - DMA0) / DSTEP;
-                                        if (j < 8) glds16(ibase, voff[j], idst + (u32)j * 1024);
+                                        if (j < 8) glds16<NT>(ibase, voff[j], idst + (u32)j * 1024);
                                         if (j == 8 && inorm) glds4(a.norms + irow0 * a.norm_step, voff_norm, idst + UNIT_BYTES);
                                     }
                                     // fewer slots than DMA pieces (8 MFMAs per unit): the rest goes behind the last MFMA
                                     if (slot == NSLOT - 1) {
 #pragma unroll
                                         for (int j = (NSLOT - 1 - DMA0) / DSTEP + 1; j < 9; ++j) {
-                                            if (j < 8) glds16(ibase, voff[j], idst + (u32)j * 1024);
+                                            if (j < 8) glds16<NT>(ibase, voff[j], idst + (u32)j * 1024);
                                             if (j == 8 && inorm) glds4(a.norms + irow0 * a.norm_step, voff_norm, idst + UNIT_BYTES);
                                         }
                                     }
