@@ -65,7 +65,8 @@ struct Options {
     int dense_async_depth = 2;   // asynchronous dense searches in flight (2..4): the results of a call are final when the (depth - 1)-th call after it returns
     int dense_async_wait = 1;    // 1: an asynchronous dense search returns once the oldest call in flight is final; 0: it returns right after enqueueing (the wait moves to the start of the next call: one more call of lag, host work between calls overlaps the device)
     int dense_async_order = 1;   // 1: an asynchronous dense search on internal streams starts behind the work already on the caller's stream (an event per call); 0: the caller guarantees its queries are complete -- no event, the call starts as soon as the device has room
-    int dense_nt = -1;           // non-temporal LDS-DMA for the one-tile dense scan: -1 = by size (scan copies well beyond the 256 MB MALL), 0 = never, 1 = always
+    int dense_nt = -1;           // non-temporal LDS-DMA of the dense scan's row stream (launches of one query group): -1 = automatic, 0 = never, 1 = every byte
+    int dense_nt_keep_mb = 0;    // one-tile dense scan, automatic mode: MB at the head of the scan copy that keep the default cache policy (0 = 192)
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
 };
 extern Options g_opt;

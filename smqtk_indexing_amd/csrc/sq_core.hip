@@ -94,6 +94,7 @@ extern "C" int sq_set_option(const char* name, int64_t value) {
     else if (n == "dense_async_wait") g_opt.dense_async_wait = (int)value;
     else if (n == "dense_async_order") g_opt.dense_async_order = (int)value;
     else if (n == "dense_nt") g_opt.dense_nt = (int)value;
+    else if (n == "dense_nt_keep_mb") g_opt.dense_nt_keep_mb = (int)value;
     else return fail(SQ_ERR_INVALID, "sq_set_option: unknown option '%s'", name);
     return SQ_OK;
 }

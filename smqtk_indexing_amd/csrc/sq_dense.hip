@@ -398,8 +398,14 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         a.norms = cosine ? nullptr : (qp == 1 ? h->norms1.as<float>() : h->norms.as<float>());  // n' of this plane count
         a.norm_step = 1;
         // non-temporal stream (32 queries, pipelined step): 10 M rows 0.456 -> 0.401 ms, 5 M 0.251 -> 0.227, 2.5 M 0.147 ->
-        // 0.139, 1.25 M unchanged (a copy of a few hundred MB is partly found in the 256 MB MALL by the next call)
-        a.nt = g_opt.dense_nt >= 0 ? g_opt.dense_nt : ((size_t)h->n_pad * d_pad * 2 > ((size_t)512 << 20) ? 1 : 0);
+        // 0.139.  One-tile kernel: everything behind a cacheable head of 192 MB ("dense_nt_keep_mb"); multi-tile kernels
+        // with one query group: their non-temporal build when the copy is far beyond the MALL.
+        {
+            const size_t copy_bytes = (size_t)h->n_pad * d_pad * 2;
+            const long long keep_mb = g_opt.dense_nt_keep_mb > 0 ? g_opt.dense_nt_keep_mb : 192;
+            a.nt = g_opt.dense_nt >= 0 ? g_opt.dense_nt : (copy_bytes > ((size_t)512 << 20) ? 1 : 0);
+            a.nt_from_row = g_opt.dense_nt == 0 ? 0x7fffffffffffffffll : g_opt.dense_nt == 1 ? 0ll : (keep_mb << 20) / ((long long)d_pad * 2);
+        }
         if (cosine && (qt > 1 || qp == 1)) {  // the AGPR configurations always stream a norm piece
             a.norms = h->zeros.as<float>();
             a.norm_step = 0;

@@ -241,7 +241,9 @@ struct DenseScanArgs {
     const uint4* scan;      // scan copy [n_pad][d_pad/8] chunks
     const float* norms;     // |x|^2 per row [n_pad] (L2) or nullptr (cosine; the AGPR configurations get 32 zeros and norm_step 0)
     long long norm_step;    // 1: norms[row]; 0: the same 32 entries for every tile
-    int nt;                 // non-temporal row stream (one-tile kernel, one query group): the copy is far larger than the MALL
+    int nt;                 // the copy is far larger than the MALL: launches of ONE query group take the non-temporal build of the multi-tile kernels
+    long long nt_from_row;  // one-tile kernel, one query group: rows from here on stream non-temporally (LLONG_MAX: none); the head
+                            // of the copy keeps the default policy and is found in the 256 MB MALL again by the next call
     long long n;            // real rows (rows >= n are padding and never emitted)
     long long n_tiles;      // ceil(n / 32)
     const uint4* qs;        // [nqt*32][d_pad/4] prepared queries
@@ -431,7 +433,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     const long long wave_id = (long long)blockIdx.x * WAVES + wave;  // unique per wave of the launch
     uint2* wout = a.wave_out + wave_id * a.wave_cap;
     const bool add_norm = a.norms != nullptr;
-    const bool once = a.nqt <= 1 && a.nt;   // one group of query tiles (every row unit is streamed once by the launch) and a copy too large to be found in the MALL again by the next call
     const bool nine = add_norm && KU == 1;  // DMA instructions per unit: 9 when each unit carries its norms
 
     // block -> (row block, group of QT query tiles); blocks that share an XCD (same id mod 8)
@@ -557,11 +558,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
 #pragma unroll
         // non-temporal while the copy is read ONCE per pass (one group of query tiles): the stream then neither displaces
         // nor waits behind what the neighbouring kernels keep in L2 / MALL -- 10 M x 128, 32 queries: full pass 0.44 ->
-        // 0.39 ms.  Several query groups re-read the rows from L2: default policy there.
+        // 0.39 ms.  The first ~192 MB of the copy keep the default policy: they survive in the MALL from call to call
+        // (a 1.25 M-row shard: 3 % per step).  Several query groups re-read the rows from L2: default policy there.
         // (only the compiler-scheduled one-tile kernel: a branch between the hand-issued MFMAs of the multi-tile
         // kernels upsets hipcc -- see the large-batch notes in DESIGN.md)
         for (int j = 0; j < 8; ++j) {
-            if (NT || (!AB && once))
+            if (NT || (!AB && a.nqt <= 1 && row0 >= a.nt_from_row))
                 glds16<true>(base, voff[j], dst + (u32)j * 1024);
             else
                 glds16<false>(base, voff[j], dst + (u32)j * 1024);
