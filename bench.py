@@ -62,7 +62,11 @@ def parse_args():
     ap.add_argument("--queries", type=int, default=32, help="queries per step in total -- the same at every N")
     ap.add_argument("--queries-per-gpu", type=int, default=0,
                     help="(round-1 semantics, kept for experiments) queries per step = this x N; overrides --queries")
-    ap.add_argument("--workload", choices=["bruteforce", "lsh_c3"], default="bruteforce")
+    ap.add_argument("--workload", choices=["bruteforce", "lsh_c3", "c4_cosine_shard", "c5_hamming_shard"], default="bruteforce")
+    ap.add_argument("--query-batches", type=int, default=8,
+                    help="distinct query batches the timed steps rotate through (1 = the same queries every step)")
+    ap.add_argument("--profile-every", type=int, default=0,
+                    help="library hipEvents on every N-th search of the timed region (0 = 1 on one GPU, 4 on shards)")
     ap.add_argument("--data", choices=["normal", "uniform", "clustered", "nonneg"], default="normal")
     ap.add_argument("--metric", choices=["l2", "cosine"], default="l2")
     ap.add_argument("--sync-search", action="store_true", help="one blocking search call per step (no pipelining)")
@@ -87,6 +91,9 @@ def parse_args():
     ap.add_argument("--extra-batches", type=str, default="1,128,256,1024",
                     help="other total batch sizes measured after the timed region; '' to skip")
     ap.add_argument("--lsh-n", type=int, default=0, help="lsh_c3: nearest codes asked of the hash index (0 = k)")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="no GPU work: the ranks rendezvous over gloo, all-reduce one integer and rank 0 prints a line "
+                         "(tests/test_host_logic.py checks the --gpus N self-launch with it)")
     return ap.parse_args()
 
 
@@ -147,39 +154,50 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     n_local = r1 - r0
 
     db = make_rows(torch, args.data, n_local, d, dev, 3 + rank)
+    if args.metric == "cosine" and args.workload == "c4_cosine_shard":
+        db /= db.norm(dim=1, keepdim=True).clamp_min(1e-30)     # rows L2-normalised at load
     max_b = max([nq] + [int(x) for x in args.extra_batches.split(",") if x])
-    all_q = make_rows(torch, args.data, max_b, d, dev, 1234)     # identical queries on every rank
-    queries = all_q[:nq].contiguous()
+    # `--query-batches` (default 8) DISTINCT query batches, identical on every rank, rotated through the timed loop:
+    # step i asks batch i mod 8, so the ~3.3 k rows per query the exact re-rank gathers differ from step to step and
+    # come from HBM, as a real query stream's would (one batch repeated finds its rows in the 256 MB MALL)
+    nbatch = max(1, args.query_batches)
+    all_q = make_rows(torch, args.data, max(max_b, nq * nbatch), d, dev, 1234)
+    batches = [all_q[j * nq:(j + 1) * nq].contiguous() for j in range(nbatch)]
+    queries = batches[0]
     torch.cuda.synchronize()
 
-    # hipEvent timing of the scan inside the library (`roofline.kernel_ms`): every 4th search of the timed region --
-    # four event records per call cost ~10 us per step (2 % of a 10 M-row step, a tenth of a 1.25 M-row shard's)
-    _lib.set_option("profile", 4)
-    if args.async_streams:
-        _lib.set_option("dense_async_streams", args.async_streams)
     index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=metric, device_ptr=True, id_base=r0, keepalive=db)
+    # hipEvent timing of the scan inside the library (`roofline.kernel_ms_in_pipeline`): every search on one GPU
+    # (`--profile-every`), every 4th on shards -- the event records of a call cost ~10 us of a step, a tenth of a
+    # 1.25 M-row shard's.  Options are per handle (sq_handle_set_option): nothing process-wide is touched.
+    prof_every = args.profile_every if args.profile_every > 0 else (4 if use_dist else 1)
+    index.set_option("profile", prof_every)
+    if args.async_streams:
+        index.set_option("dense_async_streams", args.async_streams)
     stream = torch.cuda.current_stream().cuda_stream
     use_async = not args.sync_search
     depth = args.async_depth if args.async_depth > 0 else (3 if use_dist else 2)
     depth = min(max(depth, 2), 4)
     if use_async:
-        _lib.set_option("dense_async_depth", depth)
+        index.set_option("dense_async_depth", depth)
 
-    scan_ms, cands, fallbacks = [], [], []
+    scan_ms, rerank_ms, cands, fallbacks = [], [], [], []
 
     def note_stats():
         st = index.stats()
         if st["scan_launches"]:
             if st["scan_ms"] > 0:          # (0: a call that was not timed, see the profile option above)
                 scan_ms.append(st["scan_ms"])
+                rerank_ms.append(st["rerank_ms"])
             cands.append(st["candidates"])
             fallbacks.append(st["fallback_queries"])
 
     class Runner:
         """`nq_` queries per step through the index (and, with several ranks, the all-gather + host merge)."""
 
-        def __init__(self, nq_, q_):
-            self.nq, self.q = nq_, q_
+        def __init__(self, nq_, qs_):
+            self.nq, self.qs = nq_, qs_          # qs_: the query batches the steps rotate through
+            self.n = 0
             self.pipe = None
             if use_dist:
                 from smqtk_indexing_amd.distributed import PipelinedShardedSearch
@@ -194,13 +212,15 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 self.i = 0
 
         def step(self):
+            q = self.qs[self.n % len(self.qs)]
+            self.n += 1
             if self.pipe is not None:
-                res = self.pipe.submit(self.q)
+                res = self.pipe.submit(q)
             else:
                 j = self.i % depth
                 self.i += 1
                 fn = index.search_device_async if use_async else index.search_device
-                fn(self.q.data_ptr(), self.nq, k, self.od[j].data_ptr(), self.oi[j].data_ptr(), stream)
+                fn(q.data_ptr(), self.nq, k, self.od[j].data_ptr(), self.oi[j].data_ptr(), stream)
                 res = None
             note_stats()        # the last FINISHED call (the previous step when pipelined)
             return res
@@ -227,11 +247,12 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
             dist.barrier()
         torch.cuda.synchronize()
 
-    run = Runner(nq, queries)
+    run = Runner(nq, batches)
     for _ in range(args.warmup):
         run.step()
     run.drain()
-    scan_ms.clear(), cands.clear(), fallbacks.clear()
+    run.n = 0
+    scan_ms.clear(), rerank_ms.clear(), cands.clear(), fallbacks.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -244,19 +265,35 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_stats = len(scan_ms)
-    head_scan_ms = float(np.mean(scan_ms)) if scan_ms else 0.0
-    # the same kernel without anything running beside it (blocking calls, after the timed region): in the pipelined
-    # steps above the scan of one call shares the device with the short kernels of its neighbours, so its bracketed
-    # duration there is longer than its own streaming time
-    alone_ms = None
-    if use_async and not use_dist:
-        od1 = torch.empty((nq, k), dtype=ddt, device=dev)
-        oi1 = torch.empty((nq, k), dtype=torch.int64, device=dev)
-        al = []
-        for _ in range(12):
-            index.search_device(queries.data_ptr(), nq, k, od1.data_ptr(), oi1.data_ptr(), stream)
-            al.append(index.stats()["scan_ms"])
-        alone_ms = float(np.mean(al[2:]))
+    pipe_scan_ms = float(np.mean(scan_ms)) if scan_ms else 0.0
+    pipe_rerank_ms = float(np.mean(rerank_ms)) if rerank_ms else 0.0
+    gather_ms = merge_ms = None
+    results_lag = (depth - 1 if use_async else 0)
+    if run.pipe is not None:
+        results_lag = run.pipe.results_lag
+        if run.pipe.gather_host_seconds:
+            gather_ms = 1e3 * float(np.mean(run.pipe.gather_host_seconds))
+        if run.pipe.merging and run.pipe.merger.merge_seconds:
+            merge_ms = 1e3 * float(np.mean(run.pipe.merger.merge_seconds))
+    # The full-pass kernel's OWN duration: hipEvents (the library's, recorded on the stream the kernel is launched on)
+    # around the launch in blocking calls after the timed region, same rotating query batches.  In the pipelined steps
+    # above the scan of one call shares the device with the short kernels of its neighbours (and runs on 3/4 of the
+    # CUs to leave them room), so its bracketed duration there is longer than its own streaming time -- it can exceed
+    # ms_per_step -- and is reported separately as kernel_ms_in_pipeline.  roofline.achieved / frac use THIS one.
+    index.sync() if use_async else None
+    index.set_option("profile", 1)
+    od1 = torch.empty((nq, k), dtype=ddt, device=dev)
+    oi1 = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    al, al_rr = [], []
+    for j in range(4 + 2 * nbatch):
+        qb_ = batches[j % nbatch]
+        index.search_device(qb_.data_ptr(), nq, k, od1.data_ptr(), oi1.data_ptr(), stream)
+        st_ = index.stats()
+        al.append(st_["scan_ms"])
+        al_rr.append(st_["rerank_ms"])
+    head_scan_ms = float(np.mean(al[4:]))
+    alone_rerank_ms = float(np.mean(al_rr[4:]))
+    index.set_option("profile", prof_every)
     head_cands = float(np.mean(cands)) / nq if cands else None
     head_fb = int(np.sum(fallbacks)) if fallbacks else 0
 
@@ -265,7 +302,8 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         md, mi = result
         od = torch.empty((nq, k), dtype=ddt, device=dev)
         oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
-        index.search_device(queries.data_ptr(), nq, k, od.data_ptr(), oi.data_ptr(), stream)
+        last_q = batches[(args.steps - 1) % nbatch]          # the batch of the last step
+        index.search_device(last_q.data_ptr(), nq, k, od.data_ptr(), oi.data_ptr(), stream)
         assert np.array_equal(mi, oi.cpu().numpy()) and np.array_equal(md, od.cpu().numpy()), \
             "merged result differs from the shard's top-k"
     run.close()
@@ -308,12 +346,12 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         if b == nq:
             continue
         qb = all_q[:b].contiguous()
-        rb = Runner(b, qb)
+        rb = Runner(b, [qb])
         reps = 20 if b >= 256 else 40     # (enough steps that the pipeline's fill and drain do not set the figure)
         for _ in range(3):
             rb.step()
         rb.drain()
-        scan_ms.clear(), cands.clear(), fallbacks.clear()
+        scan_ms.clear(), rerank_ms.clear(), cands.clear(), fallbacks.clear()
         fence()
         t1 = time.perf_counter()
         for _ in range(reps):
@@ -398,8 +436,10 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                       "note": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the committed profile"}
         achieved = streamed / (head_scan_ms * 1e-3) / 1e9 if head_scan_ms > 0 else 0.0
         qp = 2.0 if nq <= 32 else 1.0
+        gather_every = (args.gather_every if args.gather_every > 0 else 4) if use_dist else None
         line = {
-            "metric": "queries/sec, exact brute-force L2 kNN k=100 over 10Mx128 float32 (recall@100 = 1.0 by construction); scan HBM GB/s vs 8 TB/s peak",
+            "metric": (f"queries/sec, exact brute-force {args.metric} kNN k={k} over {n_total}x{d} float32 (recall@{k} = 1.0 by "
+                       "construction); scan HBM GB/s vs 8 TB/s peak"),
             "value": value,
             "unit": "queries/s",
             "n_gpus": world,
@@ -407,20 +447,29 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32 results (distances bit-identical to numpy float32); filter arithmetic bf16 MFMA (x_hi*(q_hi+q_lo)), exact re-rank f32"
                      if not cosine else "f64 results (cosine, 1e-12); filter arithmetic bf16 MFMA, exact re-rank f64",
-            "data": f"synthetic {args.data} float32 descriptors generated on device; queries from the same distribution",
+            "data": f"synthetic {args.data} float32 descriptors generated on device; {nbatch} distinct query batches from the "
+                    "same distribution, rotated through the timed steps",
             "config": {
-                "workload": f"bruteforce_{args.metric}_{n_total}x{d}_k{k}",
+                "workload": f"{args.workload}_{args.metric}_{n_total}x{d}_k{k}",
+                "ranks": world,
                 "db_rows_total": n_total, "db_rows_per_gpu": n_local, "dim": d, "k": k,
                 "queries_per_step": nq,
-                "scaling_definition": "strong: fixed rows in total (row-sharded over the ranks) and the same queries per step at every N, N = 1 included",
-                "search_calls": f"pipelined (SQ_MEM_DEVICE_ASYNC, {depth} calls in flight): the status of a step is read {depth - 1} step(s) later" if use_async else "one blocking call per step",
+                "query_batches_rotated": nbatch,
+                "scaling_definition": ("strong: fixed rows in total (row-sharded over the ranks) and the same queries per step at every N, N = 1 included"
+                                       if args.scaling == "strong" else
+                                       "weak: fixed rows PER GPU (the BASELINE config's shard), the same queries per step at every N"),
+                "search_calls": f"pipelined (SQ_MEM_DEVICE_ASYNC, {depth} calls in flight)" if use_async else "one blocking call per step",
+                "results_lag_steps": results_lag,
+                "results_lag_note": "steps between a batch going in and its final (N > 1: merged) result coming out; every "
+                                    "result of the timed steps is final and collected before the closing fence",
                 "sharding": "rows" if world > 1 else "none",
-                "collective": (f"one all_gather(top-k dist,idx) per {args.gather_every if args.gather_every > 0 else 4} steps + host merge, "
+                "collective": (f"one all_gather(top-k dist,idx) per {gather_every} steps + host merge, "
                                "both under the following steps' searches; every merge inside the timed region") if use_dist else "none",
+                "gather_host_ms": gather_ms, "merge_ms": merge_ms,
                 "mean_candidates_per_query": head_cands,
                 "fallback_queries": head_fb,
                 "steps_with_stats": n_stats,
@@ -431,11 +480,16 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 "traffic": None,
                 "traffic_replayed": replay,
                 "kernel": "dense_scan_kernel (full pass)", "kernel_ms": head_scan_ms,
-                "kernel_ms_note": "mean hipEvent-bracketed duration of the full-pass launches INSIDE the timed region; with pipelined "
-                                  "calls the scan shares the device with the neighbouring calls' short kernels (and runs on 3/4 of the "
-                                  "CUs to leave them room), so this is longer than the kernel alone: kernel_ms_unoverlapped",
-                "kernel_ms_unoverlapped": alone_ms,
-                "frac_unoverlapped": streamed / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if alone_ms else None,
+                "kernel_ms_note": "mean hipEvent-bracketed duration (events recorded by the library on the stream the kernel is "
+                                  "launched on) of the full-pass launch in BLOCKING calls right after the timed region, same "
+                                  "rotating query batches: the kernel's own streaming time.  achieved = streamed bytes / this.",
+                "kernel_ms_in_pipeline": pipe_scan_ms,
+                "kernel_ms_in_pipeline_note": "the same bracket INSIDE the timed region: with pipelined calls the scan shares the "
+                                              "device with the neighbouring calls' short kernels (and runs on 3/4 of the CUs to "
+                                              "leave them room), so this can exceed ms_per_step; not used for achieved / frac",
+                "rerank_kernel_ms": alone_rerank_ms, "rerank_kernel_ms_in_pipeline": pipe_rerank_ms,
+                "rerank_note": "exact re-rank of the survivors; its rows are cold (distinct query batches: ~3.3 k x nq rows of "
+                               "512 B gathered from HBM per step)",
                 "bytes_definition": "achieved/frac: bytes the kernel streams per launch = n_pad*(2*d_pad + 4) (bf16 scan copy + f32 norms)",
                 "streamed_bytes_per_launch": streamed,
                 "bytes_per_row": d_pad * 2 + (0 if cosine else 4),
@@ -498,8 +552,42 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     index.close()
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, as CHILD processes of a parent
+    that never touches the GPU (torch is not even imported here), exactly the way the driver would
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    ...`).  Rank 0's one JSON line is relayed to our stdout; the exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:     # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+    line = None
+    for raw in proc.stdout:                                  # children write everything but the line to stderr
+        text = raw.decode("utf-8", "replace").strip()
+        if text.startswith("{") and text.endswith("}"):
+            line = text
+        elif text:
+            print(text, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main() -> None:
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     # Only the one JSON line may reach stdout: libraries (RCCL prints a version banner) write to
     # fd 1 too, so fd 1 is pointed at stderr for the run and the line goes to the saved descriptor.
     sys.stdout.flush()
@@ -512,9 +600,19 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.launch_selftest:
+        dist.init_process_group(backend="gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"launch_selftest": True, "ranks": dist.get_world_size(),
+                                               "sum": int(t.item())}) + "\n").encode())
+        dist.destroy_process_group()
+        return
+    if world != args.gpus and not (args.force_collective and world == 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, the node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_collective
@@ -529,7 +627,26 @@ def main() -> None:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
-    if args.workload == "lsh_c3":
+    args.scaling = "strong"
+    if args.workload == "c4_cosine_shard":
+        # BASELINE config 4: 100 M x 512 float32 cosine over 8 GPUs = a 12.5 M x 512 shard per GPU, 256
+        # queries per step; every rank generates its shard on the device from seed + rank.  Weak scaling: the shard is
+        # the config's, the database grows with N.  (--rows / --dim / --queries still override.)
+        args.metric, args.scaling = "cosine", "weak"
+        if args.rows == 10_000_000:
+            args.rows = 12_500_000 * world
+        if args.dim == 128:
+            args.dim = 512
+        if args.queries == 32:
+            args.queries = 256
+        if args.extra_batches == "1,128,256,1024":
+            args.extra_batches = "32"
+        args.no_other_paths = True
+    if args.workload == "c5_hamming_shard":
+        from tools.hamming_c5 import run as c5_run
+        args.scaling = "weak"
+        c5_run(args, torch, dist, _lib, world, rank, dev, use_dist, emit)
+    elif args.workload == "lsh_c3":
         from tools.lsh_c3 import run as lsh_run
         lsh_run(args, torch, dist, _lib, world, rank, dev, use_dist, emit, make_rows)
     else:

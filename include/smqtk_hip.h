@@ -83,6 +83,7 @@ typedef struct sq_stats {
     int64_t candidates;    /* sum over queries of candidates the scan emitted */
     int64_t fallback_queries; /* queries that took the exact full-keys path */
     int64_t bytes_scanned; /* algorithmic bytes the scan streamed (rows * row bytes * passes) */
+    double rerank_ms;      /* last dense search: duration of the exact re-rank kernel (when profiling is on; 0 otherwise) */
 } sq_stats_t;
 
 /* ------------------------------------------------------------------ misc */
@@ -100,6 +101,13 @@ int sq_device_name(int device, char* out_name, int name_len, int64_t* out_total_
  * depth), "dense_blocks" (row blocks), "dense_rerank_segments" (survivor
  * segments per re-rank workgroup), "dense_debug" (ablation bits). */
 int sq_set_option(const char* name, int64_t value);
+/* The same options for ONE handle (any kind): an override that wins over the process-wide value for every later call
+ * on that handle, read under the handle's lock.  Two indexes searched from two threads keep their own pipeline depth,
+ * candidate lists, profiling ... -- the reference's contract is "implementations should be thread safe"
+ * (interfaces/nearest_neighbor_index.py:22-23), and its options are per instance (constructor arguments).
+ * sq_handle_reset_options drops the handle's overrides. */
+int sq_handle_set_option(sq_handle_t h, const char* name, int64_t value);
+int sq_handle_reset_options(sq_handle_t h);
 int sq_get_stats(sq_handle_t h, sq_stats_t* out);
 
 /* ------------------------------------------------------------------- ITQ

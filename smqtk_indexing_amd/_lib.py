@@ -40,7 +40,7 @@ LIB_PATH = os.environ.get("SMQTK_HIP_LIBRARY") or os.path.join(os.path.dirname(o
 # every symbol include/smqtk_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
     "sq_last_error", "sq_version", "sq_device_count", "sq_device_name",
-    "sq_set_option", "sq_get_stats", "sq_itq_hash",
+    "sq_set_option", "sq_handle_set_option", "sq_handle_reset_options", "sq_get_stats", "sq_itq_hash",
     "sq_itq_model_create", "sq_itq_model_hash", "sq_itq_model_destroy",
     "sq_hamming_create", "sq_hamming_search", "sq_hamming_append", "sq_hamming_remove", "sq_hamming_info", "sq_hamming_destroy",
     "sq_dense_create", "sq_dense_append", "sq_dense_search", "sq_dense_sync", "sq_dense_destroy",
@@ -63,6 +63,7 @@ class SqStats(ctypes.Structure):
         ("candidates", ctypes.c_int64),
         ("fallback_queries", ctypes.c_int64),
         ("bytes_scanned", ctypes.c_int64),
+        ("rerank_ms", ctypes.c_double),
     ]
 
 
@@ -79,6 +80,8 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_device_count.argtypes = [ctypes.POINTER(c_int)]
     lib.sq_device_name.argtypes = [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_int)]
     lib.sq_set_option.argtypes = [ctypes.c_char_p, c_i64]
+    lib.sq_handle_set_option.argtypes = [c_i64, ctypes.c_char_p, c_i64]
+    lib.sq_handle_reset_options.argtypes = [c_i64]
     lib.sq_get_stats.argtypes = [c_i64, ctypes.POINTER(SqStats)]
     lib.sq_itq_hash.argtypes = [c_vp, c_int, c_i64, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]
     lib.sq_itq_model_create.argtypes = [c_vp, c_int, c_vp, c_int, c_int, c_int, ctypes.POINTER(c_i64)]
@@ -270,6 +273,13 @@ class _Handle:
 
     def stats(self) -> dict:
         return get_stats(self.handle)
+
+    def set_option(self, name: str, value: int) -> None:
+        """An option of THIS handle only (``sq_handle_set_option``): wins over the process-wide :func:`set_option`."""
+        _check(load().sq_handle_set_option(self.handle, name.encode(), int(value)), f"sq_handle_set_option({name})")
+
+    def reset_options(self) -> None:
+        _check(load().sq_handle_reset_options(self.handle), "sq_handle_reset_options")
 
 
 class ItqModel(_Handle):

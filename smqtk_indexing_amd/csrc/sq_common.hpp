@@ -11,6 +11,8 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <utility>
+#include <vector>
 
 #include "../../include/smqtk_hip.h"
 
@@ -68,8 +70,13 @@ struct Options {
     int dense_nt = -1;           // non-temporal LDS-DMA of the dense scan's row stream (launches of one query group): -1 = automatic, 0 = never, 1 = every byte
     int dense_nt_keep_mb = 0;    // one-tile dense scan, automatic mode: MB at the head of the scan copy that keep the default cache policy (0 = 192)
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
+    int dense_mid_tier = 1;      // 1 = queries the bf16 filter could not certify get a second, tighter filter pass (three bf16 planes of the rows built on the fly) before the exact all-rows path; 0 = straight to the exact path
+    int hamming_async_depth = 2; // asynchronous Hamming searches in flight (2..4), as dense_async_depth
+    int hamming_ring = -1;       // Hamming stream kernel: -1 = automatic (LDS-DMA ring for arrays beyond the MALL), 0 = register loads, 1 = ring
 };
-extern Options g_opt;
+extern Options g_opt;   // process-wide defaults (sq_set_option); a handle may override any of them (sq_handle_set_option)
+// name -> member, shared by sq_set_option and sq_handle_set_option (sq_core.hip)
+int Options::*option_member(const char* name);
 
 // Wait for a stream the way a latency-bound caller wants to: poll hipStreamQuery for a while (a search is
 // a fraction of a millisecond; the blocking wait's wake-up costs tens of microseconds of it), then block.
@@ -194,6 +201,16 @@ struct HandleBase {
     std::mutex mu;
     sq_stats_t stats{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // Options of THIS handle: the process-wide values with the handle's own overrides on top, re-read under the
+    // handle's lock at every API entry (refresh_options).  Two indexes searched from two threads therefore keep their
+    // own pipeline depth, candidate lists, profiling ... (the reference's contract: "implementations should be
+    // thread safe", interfaces/nearest_neighbor_index.py:22-23).
+    std::vector<std::pair<int Options::*, int>> overrides;
+    Options opt;
+    void refresh_options() {
+        opt = g_opt;
+        for (const auto& o : overrides) opt.*(o.first) = o.second;
+    }
     virtual ~HandleBase() {
         for (auto& e : ev)
             if (e) (void)hipEventDestroy(e);

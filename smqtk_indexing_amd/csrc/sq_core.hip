@@ -70,32 +70,80 @@ extern "C" int sq_device_name(int device, char* out_name, int name_len, int64_t*
     return SQ_OK;
 }
 
+namespace sq {
+int Options::*option_member(const char* name) {
+    static const struct {
+        const char* name;
+        int Options::*field;
+    } kFields[] = {
+        {"profile", &Options::profile},
+        {"sample_stride", &Options::sample_stride},
+        {"candidate_cap", &Options::candidate_cap},
+        {"force_fallback", &Options::force_fallback},
+        {"dense_stages", &Options::dense_stages},
+        {"dense_blocks", &Options::dense_blocks},
+        {"dense_debug", &Options::dense_debug},
+        {"dense_waves", &Options::dense_waves},
+        {"dense_qt", &Options::dense_qt},
+        {"itq_exact", &Options::itq_exact},
+        {"hamming_no_permute", &Options::hamming_no_permute},
+        {"dense_no_center", &Options::dense_no_center},
+        {"merge_threads", &Options::merge_threads},
+        {"spin_wait_us", &Options::spin_wait_us},
+        {"dense_rerank_segments", &Options::dense_rerank_segments},
+        {"dense_qplanes", &Options::dense_qplanes},
+        {"dense_async_streams", &Options::dense_async_streams},
+        {"dense_async_depth", &Options::dense_async_depth},
+        {"dense_async_wait", &Options::dense_async_wait},
+        {"dense_async_order", &Options::dense_async_order},
+        {"dense_nt", &Options::dense_nt},
+        {"dense_nt_keep_mb", &Options::dense_nt_keep_mb},
+        {"dense_mid_tier", &Options::dense_mid_tier},
+        {"hamming_async_depth", &Options::hamming_async_depth},
+        {"hamming_ring", &Options::hamming_ring},
+    };
+    if (!name) return nullptr;
+    for (const auto& f : kFields)
+        if (strcmp(f.name, name) == 0) return f.field;
+    return nullptr;
+}
+}  // namespace sq
+
 extern "C" int sq_set_option(const char* name, int64_t value) {
     if (!name) return fail(SQ_ERR_INVALID, "sq_set_option: null name");
-    const std::string n(name);
-    if (n == "profile") g_opt.profile = (int)value;
-    else if (n == "sample_stride") g_opt.sample_stride = (int)value;
-    else if (n == "candidate_cap") g_opt.candidate_cap = (int)value;
-    else if (n == "force_fallback") g_opt.force_fallback = (int)value;
-    else if (n == "dense_stages") g_opt.dense_stages = (int)value;
-    else if (n == "dense_blocks") g_opt.dense_blocks = (int)value;
-    else if (n == "dense_debug") g_opt.dense_debug = (int)value;
-    else if (n == "dense_waves") g_opt.dense_waves = (int)value;
-    else if (n == "dense_qt") g_opt.dense_qt = (int)value;
-    else if (n == "itq_exact") g_opt.itq_exact = (int)value;
-    else if (n == "hamming_no_permute") g_opt.hamming_no_permute = (int)value;
-    else if (n == "dense_no_center") g_opt.dense_no_center = (int)value;
-    else if (n == "merge_threads") g_opt.merge_threads = (int)value;
-    else if (n == "spin_wait_us") g_opt.spin_wait_us = (int)value;
-    else if (n == "dense_rerank_segments") g_opt.dense_rerank_segments = (int)value;
-    else if (n == "dense_qplanes") g_opt.dense_qplanes = (int)value;
-    else if (n == "dense_async_streams") g_opt.dense_async_streams = (int)value;
-    else if (n == "dense_async_depth") g_opt.dense_async_depth = (int)value;
-    else if (n == "dense_async_wait") g_opt.dense_async_wait = (int)value;
-    else if (n == "dense_async_order") g_opt.dense_async_order = (int)value;
-    else if (n == "dense_nt") g_opt.dense_nt = (int)value;
-    else if (n == "dense_nt_keep_mb") g_opt.dense_nt_keep_mb = (int)value;
-    else return fail(SQ_ERR_INVALID, "sq_set_option: unknown option '%s'", name);
+    int Options::*f = option_member(name);
+    if (!f) return fail(SQ_ERR_INVALID, "sq_set_option: unknown option '%s'", name);
+    g_opt.*f = (int)value;
+    return SQ_OK;
+}
+
+static HandleBase* any_handle(sq_handle_t hid) {
+    for (int kind : {H_DENSE, H_HAMMING, H_ROWS, H_FIT, H_ITQ})
+        if (HandleBase* h = lookup_handle(hid, kind)) return h;
+    return nullptr;
+}
+
+extern "C" int sq_handle_set_option(sq_handle_t hid, const char* name, int64_t value) {
+    if (!name) return fail(SQ_ERR_INVALID, "sq_handle_set_option: null name");
+    int Options::*f = option_member(name);
+    if (!f) return fail(SQ_ERR_INVALID, "sq_handle_set_option: unknown option '%s'", name);
+    HandleBase* h = any_handle(hid);
+    if (!h) return fail(SQ_ERR_INVALID, "sq_handle_set_option: unknown handle");
+    std::lock_guard<std::mutex> l(h->mu);
+    for (auto& o : h->overrides)
+        if (o.first == f) {
+            o.second = (int)value;
+            return SQ_OK;
+        }
+    h->overrides.emplace_back(f, (int)value);
+    return SQ_OK;
+}
+
+extern "C" int sq_handle_reset_options(sq_handle_t hid) {
+    HandleBase* h = any_handle(hid);
+    if (!h) return fail(SQ_ERR_INVALID, "sq_handle_reset_options: unknown handle");
+    std::lock_guard<std::mutex> l(h->mu);
+    h->overrides.clear();
     return SQ_OK;
 }
 

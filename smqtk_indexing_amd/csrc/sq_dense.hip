@@ -8,14 +8,14 @@
 // (utils/metrics.py:73-86, 89-137) for every row and keep the n smallest.
 //
 // Structure:
-//   1. dense_scan_kernel (sq_dense_scan.cuh) streams a bfloat16 copy of the
+//   1. dense_scan_kernel (sq_dense_scan.hpp) streams a bfloat16 copy of the
 //      matrix (L2: of the rows minus their column means) once per group of 1, 2
 //      or 4 32-query tiles: LDS-DMA ring per wave, bf16 MFMA (x_hi*q_hi
 //      [+ x_hi*q_lo]), scores s = |x|^2 - 2 x.q (cosine: -x^.q^) compared with a
 //      per-query threshold; survivors leave as per-wave lists of (first row,
 //      mask, query) entries.  The threshold comes from the same kernel in SAMPLE
 //      mode over every S-th tile + kth_threshold_f32_kernel.
-//   2. dense_rerank_*_kernel (sq_dense_exact.cuh) recomputes the distance of every
+//   2. dense_rerank_*_kernel (sq_dense_exact.hpp) recomputes the distance of every
 //      survivor from the ORIGINAL float32 rows in the REFERENCE arithmetic
 //      (float32 subtract, square, numpy pairwise order, correctly rounded sqrt;
 //      cosine in float64, scipy's order) and forms (distance, row) keys.
@@ -26,8 +26,8 @@
 #include <vector>
 #include <cmath>
 
-#include "sq_dense_exact.cuh"
-#include "sq_dense_scan.cuh"
+#include "sq_dense_exact.hpp"
+#include "sq_dense_scan.hpp"
 
 namespace sq {
 
@@ -43,17 +43,19 @@ struct DenseCall {
     long long* out_idx = nullptr;
     hipStream_t st = nullptr;     // the stream the call's kernels were enqueued on
     bool small = false, all_fallback = false, prof = false, use_event = false;
+    u32 cap = 0;                  // candidate-list length the call was enqueued with
     sq_stats_t stats{};
 };
 struct DenseSlot {
     DevBuf q_scaled, q_al, qn2, thr, wave_out, wave_cnt, cnt, keys, sample, out_keys, cos_nq, oflag;
+    DevBuf sort_tmp;              // scratch of the any-k sorted select (k beyond the one-workgroup select): one per call in flight
     HostPinned status_host;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // call start, scan start, scan end, call end, re-rank end
     hipEvent_t ev_in = nullptr, ev_done = nullptr;
     hipStream_t own = nullptr;    // internal stream of the slot (asynchronous calls with "dense_async_streams" = 2)
     DenseCall call;
     void release() {
-        for (DevBuf* b : {&q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt, &keys, &sample, &out_keys, &cos_nq, &oflag})
+        for (DevBuf* b : {&q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt, &keys, &sample, &out_keys, &cos_nq, &oflag, &sort_tmp})
             b->release();
         status_host.release();
         for (auto& e : ev)
@@ -84,11 +86,11 @@ struct DenseHandle : HandleBase {
     int depth = 2;                       // asynchronous calls in flight (option dense_async_depth, fixed while any is)
     unsigned long long async_calls = 0;  // asynchronous calls so far (slot = calls % depth)
     // workspace shared by all calls: host-memory staging, the exact path (runs synchronously), index build
-    DevBuf q_dev, out_dist_dev, out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch, fb_cnt;
+    DevBuf q_dev, out_dist_dev, out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch, fb_cnt, fb_sort;
     PinnedStage stage;
     ~DenseHandle() override {
         for (DevBuf* b : {&owned, &scan, &norms, &norms1, &zeros, &center, &cos_nx, &q_dev, &out_dist_dev, &out_idx_dev, &big_keys,
-                          &fb_sample, &fb_keys, &fb_out, &scratch, &fb_cnt})
+                          &fb_sample, &fb_keys, &fb_out, &scratch, &fb_cnt, &fb_sort})
             b->release();
         for (auto& sl : slot) sl.release();
         stage.release();
@@ -100,22 +102,18 @@ static constexpr int kSelectLdsKeys64 = 16384;
 static constexpr int kSelectLdsKeys128 = 7168;
 
 // select + the finalisation post-op (keys -> distances / ids, certification, status) in one launch
-static DevBuf g_dense_sort_scratch[64];  // per device: scratch of the any-k sorted select (rare path; under the handle lock + synchronous use)
-
 // `expect`: candidates per query the caller expects (0 = unknown).  The kernel keeps up to lds_keys keys of a query in
 // LDS and reads longer lists from global memory; sizing the LDS for the expected list instead of the largest possible
 // lets two workgroups share a CU (36-40 registers per thread: LDS is what limits them) -- with one workgroup per query
 // a 1024-query batch is four rounds of workgroups otherwise.
 template <class K, class Post>
 static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out,
-                           const Post& post, hipStream_t st, long long expect = 0) {
+                           const Post& post, hipStream_t st, DevBuf& sort_scratch, long long expect = 0) {
     static bool attr_set = false;
     const int lds_max = sizeof(K) == 8 ? kSelectLdsKeys64 : kSelectLdsKeys128;
-    if (k > lds_max) {  // beyond the one-workgroup select: full sort (sq_select.cuh, "any-k sorted select")
-        int dev = 0;
-        SQ_HIP(hipGetDevice(&dev));
-        return sort_select_large<K, Post>(keys, cnt, cap, stride, k, nq, out, g_dense_sort_scratch[dev & 63], post, st);
-    }
+    // beyond the one-workgroup select: full sort (sq_select.hpp, "any-k sorted select"); the scratch belongs to the
+    // call slot (asynchronous calls in flight, or two handles on two threads, must not share it)
+    if (k > lds_max) return sort_select_large<K, Post>(keys, cnt, cap, stride, k, nq, out, sort_scratch, post, st);
     int lds_keys = lds_max;
     if (expect > 0 && nq > 256) {  // (fewer queries than CUs: one round of workgroups either way)
         const int half = (int)((80 * 1024) / sizeof(K)) - SELECT_SORT_MAX;  // two workgroups in 160 KB
@@ -154,7 +152,7 @@ struct ScanGeom {
     int waves, stages;
     size_t lds;
 };
-static ScanGeom scan_geometry(int d_pad, int qt, int qp) {
+static ScanGeom scan_geometry(const Options& o, int d_pad, int qt, int qp) {
     const int ku = d_pad / KT;
     const bool ab = qt > 1 || qp == 1;   // query fragments in AGPRs (multi-tile batches)
     const bool qreg = ab || ku <= 1;     // not re-read from an LDS copy
@@ -162,11 +160,11 @@ static ScanGeom scan_geometry(int d_pad, int qt, int qp) {
     ScanGeom g{};
     // eight waves (two per SIMD) whenever the query fragments leave room: one tile, or two tiles of one plane
     g.waves = (ku <= 1 && (qt == 1 || (qt == 2 && qp == 1))) ? 8 : 4;
-    if (ku <= 1 && g_opt.dense_waves == 4) g.waves = 4;
+    if (ku <= 1 && o.dense_waves == 4) g.waves = 4;
     int ns = (160 * 1024 - qb - SCAN_LDS_TAIL) / (g.waves * SLOT_BYTES);
     const int ns_max = g.waves == 8 ? 2 : 4;
     if (ns > ns_max) ns = ns_max;
-    if (qt == 1 && !ab && g_opt.dense_stages >= 2 && g_opt.dense_stages <= ns) ns = g_opt.dense_stages;
+    if (qt == 1 && !ab && o.dense_stages >= 2 && o.dense_stages <= ns) ns = o.dense_stages;
     g.stages = ns;
     g.lds = (size_t)qb + (size_t)g.waves * ns * SLOT_BYTES + SCAN_LDS_TAIL;
     // staging the query tiles through the ring needs the ring to be at least as large
@@ -199,8 +197,8 @@ static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, int qt, int
 }
 
 template <bool SAMPLE>
-static int scan_launch(const DenseScanArgs& a, int d_pad, int qt, int qp, hipStream_t st) {
-    const ScanGeom g = scan_geometry(d_pad, qt, qp);
+static int scan_launch(const Options& o, const DenseScanArgs& a, int d_pad, int qt, int qp, hipStream_t st) {
+    const ScanGeom g = scan_geometry(o, d_pad, qt, qp);
     if (g.stages < 2 || ((qt > 1 || qp == 1) && g.waves == 4 && g.stages != 4))
         return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d qt=%d leaves no room for the LDS ring", d_pad, qt);
     switch (d_pad / KT) {
@@ -218,14 +216,14 @@ static constexpr double kEpsA2 = 0.0078125 + 6.103515625e-05;   // two query pla
 static constexpr double kEpsA1 = 0.015625 + 1.220703125e-04;    // one query plane:  2^-6 + 2^-13
 static double dense_eps_b(int d_pad) { return (3.0 * d_pad + 8.0) * 1.1920928955078125e-07; }
 
-// Query tiles per wave for a batch of `nqt` 32-query tiles (sq_dense_scan.cuh): one tile keeps the
+// Query tiles per wave for a batch of `nqt` 32-query tiles (sq_dense_scan.hpp): one tile keeps the
 // HBM-bound configuration; larger batches reuse each streamed row tile for 2 or 4 query tiles, as
 // many as the register budget allows (four at d_pad = 128, two beyond).
-static int scan_query_tiles(int d_pad, int nqt) {
+static int scan_query_tiles(const Options& o, int d_pad, int nqt) {
     const int ku = d_pad / KT;
     if (nqt <= 1) return 1;
     int want = nqt >= 3 ? 4 : 2;
-    if (g_opt.dense_qt == 1 || g_opt.dense_qt == 2 || g_opt.dense_qt == 4) want = g_opt.dense_qt;
+    if (o.dense_qt == 1 || o.dense_qt == 2 || o.dense_qt == 4) want = o.dense_qt;
     if (ku >= 2 && want > 2) want = 2;  // four tiles of a 256-wide row spill past 512 registers
     if (ku > 1 && want == 1) return 1;  // forced: the LDS-copy kernel
     return want;
@@ -258,18 +256,18 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
     const int kk = (int)(k < n ? k : n);
     const bool cosine = h->metric == SQ_METRIC_COSINE;
     // (profile = N > 1: every N-th asynchronous call only -- four event records per call weigh on a small shard's step)
-    const bool prof = g_opt.profile == 1 || (g_opt.profile > 1 && (!use_event || h->async_calls % (unsigned)g_opt.profile == 0));
+    const bool prof = h->opt.profile == 1 || (h->opt.profile > 1 && (!use_event || h->async_calls % (unsigned)h->opt.profile == 0));
     const size_t key_bytes = cosine ? sizeof(K128) : sizeof(u64);
-    u32 cap = g_opt.candidate_cap > 0 ? (u32)g_opt.candidate_cap : 65536u;
+    u32 cap = h->opt.candidate_cap > 0 ? (u32)h->opt.candidate_cap : 65536u;
     if (cap < (u32)(4 * kk)) cap = (u32)(4 * kk);
     const bool small = n <= (long long)cap;
     // k beyond the one-workgroup select (16384; cosine 7168): every query takes the exact path, whose select sorts
     // (the reference has no limit on n: lsh.py:513-518)
     const bool scan_ok = h->scan.p != nullptr && !small && kk <= (cosine ? kSelectLdsKeys128 : kSelectLdsKeys64);
-    const int qt = scan_query_tiles(d_pad, (nq + TILE_ROWS - 1) / TILE_ROWS);  // query tiles per wave
+    const int qt = scan_query_tiles(h->opt, d_pad, (nq + TILE_ROWS - 1) / TILE_ROWS);  // query tiles per wave
     // query planes: the multi-tile configuration is MFMA bound, so it drops q_lo (half the MFMAs, twice the
     // product bound: ~1.4x more rows pass the filter) unless asked otherwise
-    const int qp = (qt > 1 && (g_opt.dense_qplanes != 2 || d_pad > KT)) ? 1 : 2;
+    const int qp = (qt > 1 && (h->opt.dense_qplanes != 2 || d_pad > KT)) ? 1 : 2;
     const int group_q = qt * TILE_ROWS;                                           // queries per scan workgroup
     const int nqt = (nq + group_q - 1) / group_q;                                 // groups of qt query tiles
     const int nq_pad = nqt * group_q;
@@ -284,6 +282,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
     c.st = st;
     c.prof = prof;
     c.small = small;
+    c.cap = cap;
     c.use_event = use_event;
     if (prof) {
         for (auto& e : s.ev)
@@ -307,7 +306,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
     u32* hs_raw_dev = nullptr;
     SQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs_raw_dev), hs_raw, 0));
     u32* hs_dev = hs_raw_dev + nq_pad;
-    // error bound of the bf16 filter score (sq_dense_exact.cuh filter_eps):
+    // error bound of the bf16 filter score (sq_dense_exact.hpp filter_eps):
     //   products: |x q' - x_hi (q'_hi + q'_lo)| <= (2^-8 + 2^-15) |x||q'|, q' = -2q  ->  eps_a = 2^-7 + 2^-14 (times X|q|)
     //             (cosine: unit vectors and q' = -q^ without the factor 2: half of that)
     //   float32 accumulation of 2d+1 terms and the float32 norm                     ->  eps_b = (3d+8) 2^-23
@@ -342,12 +341,12 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             SQ_TRY(select_launch_t<K128>(s.keys.as<K128>(), cnt, (u32)n, key_stride, k, nq, s.out_keys.as<K128>(),
                                          DenseFinalizeCos{cnt, (u32)n, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx,
                                                           hs_dev, hs_raw_dev, nullptr, 0},
-                                         st));
+                                         st, s.sort_tmp));
         } else {
             SQ_TRY(select_launch_t<u64>(s.keys.as<u64>(), cnt, (u32)n, key_stride, k, nq, s.out_keys.as<u64>(),
                                         DenseFinalizeL2{cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0,
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, nullptr, 0},
-                                        st));
+                                        st, s.sort_tmp));
         }
     } else if (scan_ok) {
         const long long n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
@@ -355,7 +354,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // ~ nq * stride * k (candidates per query ~ stride * k * slack); with groups ~ nq / (32 qt) the
         // balance is stride ~ sqrt(n / (qt k)), independent of the batch: 20 at 10 M rows, k = 100, one
         // query tile per wave (measured optimum 16-24; 8-12 with four tiles; 4 on a 1.25 M-row shard).
-        long long stride = g_opt.sample_stride;
+        long long stride = h->opt.sample_stride;
         if (stride <= 0) {
             // (the float64 cosine re-rank costs ~3.6x the float32 L2 one per candidate: sqrt of that off the stride)
             stride = (long long)(20.0 * sqrt((double)n / 1e7 * 100.0 / (double)kk / (double)qt) / (cosine ? 1.9 : 1.0) + 0.5);
@@ -380,9 +379,9 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // the CUs: alone it is as fast (HBM bound: 0.433 ms on 160 workgroups against 0.439 on 256 at 10 M x 128),
         // and the pipelined step drops from 0.50 to 0.46 ms (tools/step_sweep.py dense_blocks=...).
         // (one query tile per wave only: the multi-tile configurations are MFMA bound and want every CU)
-        int nrb = g_opt.dense_blocks > 0 ? g_opt.dense_blocks : (use_event && g_opt.dense_async_streams == 2 && nqt == 1 ? cus * 3 / 4 : cus);
+        int nrb = h->opt.dense_blocks > 0 ? h->opt.dense_blocks : (use_event && h->opt.dense_async_streams == 2 && nqt == 1 ? cus * 3 / 4 : cus);
         nrb = (nrb + 7) / 8 * 8;
-        const int wv = scan_geometry(d_pad, qt, qp).waves;
+        const int wv = scan_geometry(h->opt, d_pad, qt, qp).waves;
         // survivors leave the scan as per-wave segments; the re-rank kernel turns them into per-query key lists
         const long long n_waves = (long long)nrb * nqt * wv;
         const u32 wave_cap = 2048;
@@ -402,9 +401,9 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // with one query group: their non-temporal build when the copy is far beyond the MALL.
         {
             const size_t copy_bytes = (size_t)h->n_pad * d_pad * 2;
-            const long long keep_mb = g_opt.dense_nt_keep_mb > 0 ? g_opt.dense_nt_keep_mb : 192;
-            a.nt = g_opt.dense_nt >= 0 ? g_opt.dense_nt : (copy_bytes > ((size_t)512 << 20) ? 1 : 0);
-            a.nt_from_row = g_opt.dense_nt == 0 ? 0x7fffffffffffffffll : g_opt.dense_nt == 1 ? 0ll : (keep_mb << 20) / ((long long)d_pad * 2);
+            const long long keep_mb = h->opt.dense_nt_keep_mb > 0 ? h->opt.dense_nt_keep_mb : 192;
+            a.nt = h->opt.dense_nt >= 0 ? h->opt.dense_nt : (copy_bytes > ((size_t)512 << 20) ? 1 : 0);
+            a.nt_from_row = h->opt.dense_nt == 0 ? 0x7fffffffffffffffll : h->opt.dense_nt == 1 ? 0ll : (keep_mb << 20) / ((long long)d_pad * 2);
         }
         if (cosine && (qt > 1 || qp == 1)) {  // the AGPR configurations always stream a norm piece
             a.norms = h->zeros.as<float>();
@@ -420,7 +419,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         a.sample_out = s.sample.as<float>();
         a.ns = ns;
         a.nqt = nqt;
-        a.debug = g_opt.dense_debug;
+        a.debug = h->opt.dense_debug;
         // sample pass
         a.tile_step = stride;
         a.n_sel = ns_tiles;
@@ -429,7 +428,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             const long long work = sample_runs ? (ns_tiles + 3) / 4 : ns_tiles;  // runs / tiles a wave takes at a time
             if (work < (long long)nrb * wv) a.nrb = (int)(((work + wv - 1) / wv + 7) / 8 * 8);
         }
-        SQ_TRY(scan_launch<true>(a, d_pad, qt, qp, st));
+        SQ_TRY(scan_launch<true>(h->opt, a, d_pad, qt, qp, st));
         hipLaunchKernelGGL((kth_threshold_f32_kernel<DenseThrPost>), dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr,
                            DenseThrPost{qn2, cosine ? 1 : 0, filter_bound(cosine ? 1 : 0, eps_a, eps_b, h->xn2_max)});
         // full pass
@@ -437,7 +436,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         a.n_sel = n_tiles;
         a.nrb = nrb;
         if (prof) SQ_HIP(hipEventRecord(s.ev[1], st));
-        SQ_TRY(scan_launch<false>(a, d_pad, qt, qp, st));
+        SQ_TRY(scan_launch<false>(h->opt, a, d_pad, qt, qp, st));
         if (prof) SQ_HIP(hipEventRecord(s.ev[2], st));
         c.stats.scan_launches = 2;
         c.stats.bytes_scanned = h->n_pad * ((long long)d_pad * 2 + (cosine ? 0 : 4));
@@ -448,26 +447,28 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // (L2, four-wave scan workgroups, i.e. multi-tile batches: 4 measured 2 % faster than 2; the cosine kernel's
         // row stage is sized for 256 threads)
         int wpb = (wv == 4 && !cosine) ? 4 : 2;
-        if (g_opt.dense_rerank_segments > 0 && wv % g_opt.dense_rerank_segments == 0) wpb = g_opt.dense_rerank_segments;
+        if (h->opt.dense_rerank_segments > 0 && wv % h->opt.dense_rerank_segments == 0) wpb = h->opt.dense_rerank_segments;
         const unsigned rr_threads = (unsigned)std::min(512, 128 * wpb);
         const size_t rr_lds = (qt == 1 && ldq <= 156) ? (size_t)32 * (ldq + 4) * 4 : 0;  // the query tile in LDS (rerank_block)
         const unsigned gxr = (unsigned)((n_waves + wpb - 1) / wpb);
         if (cosine) {
             hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, s.q_al.as<float>(),
                                ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<K128>(), cnt,
-                               cap, oflag, cnx, cnq, g_opt.dense_debug);
+                               cap, oflag, cnx, cnq, h->opt.dense_debug);
+            if (prof) SQ_HIP(hipEventRecord(s.ev[4], st));
             SQ_TRY(select_launch_t<K128>(s.keys.as<K128>(), cnt, cap, key_stride, k, nq, s.out_keys.as<K128>(),
                                          DenseFinalizeCos{cnt, cap, kk, h->id_base, thr, eps_a + eps_b, 1, (double*)out_dist,
                                                           out_idx, hs_dev, hs_raw_dev, oflag, 0},
-                                         st));
+                                         st, s.sort_tmp));
         } else {
             hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, s.q_al.as<float>(),
                                ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<u64>(), cnt,
-                               cap, oflag, g_opt.dense_debug);
+                               cap, oflag, h->opt.dense_debug);
+            if (prof) SQ_HIP(hipEventRecord(s.ev[4], st));
             SQ_TRY(select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(),
                                         DenseFinalizeL2{cnt, cap, kk, h->id_base, thr, qn2, 0.5 * eps_a + eps_b, 1,
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0},
-                                        st, 4 * stride * kk));   // ~2.7 stride k candidates per query on N(0,1) data
+                                        st, s.sort_tmp, 4 * stride * kk));   // ~2.7 stride k candidates per query on N(0,1) data
         }
     } else {
         c.all_fallback = true;  // rows wider than the MFMA scan covers: exact path for every query
@@ -493,9 +494,8 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
     const int kk = (int)(k < n ? k : n);
     const bool cosine = h->metric == SQ_METRIC_COSINE;
     const size_t key_bytes = cosine ? sizeof(K128) : sizeof(u64);
-    u32 cap = g_opt.candidate_cap > 0 ? (u32)g_opt.candidate_cap : 65536u;
-    if (cap < (u32)(4 * kk)) cap = (u32)(4 * kk);
-    const bool force_fb = g_opt.force_fallback != 0;
+    const u32 cap = c.cap;
+    const bool force_fb = h->opt.force_fallback != 0;
     const bool small = c.small, all_fallback = c.all_fallback;
     hipStream_t st = c.st;
     const float* q = c.q;
@@ -522,6 +522,11 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
             SQ_HIP(hipEventElapsedTime(&t2, s.ev[0], s.ev[3]));
             h->stats.scan_ms = t1;
             h->stats.total_ms = t2;
+            if (c.stats.scan_launches == 2) {  // (the filter path: a re-rank kernel followed the scan)
+                float t3 = 0;
+                SQ_HIP(hipEventElapsedTime(&t3, s.ev[2], s.ev[4]));
+                h->stats.rerank_ms = t3;
+            }
         }
         for (int qi = 0; qi < nq; ++qi) h->stats.candidates += hs_raw[qi];
     }
@@ -532,7 +537,7 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
     // per query at 10 M rows against 1.2 ms for the keys.)  Ties that overflow the compacted list, or too few
     // finite distances, go on to the select over all keys.
     long long fb_stride = std::min<long long>(64, std::min<long long>((long long)cap / (4ll * kk), n / (8ll * kk)));
-    if (n < 65536 || fb_stride < 2 || (g_opt.dense_debug & 128)) fb_stride = 0;  // debug 128: measurement, full select
+    if (n < 65536 || fb_stride < 2 || (h->opt.dense_debug & 128)) fb_stride = 0;  // debug 128: measurement, full select
     const long long fb_ns = fb_stride ? (n + fb_stride - 1) / fb_stride : 0;
     std::vector<int> todo;
     for (int qi = 0; qi < nq; ++qi)
@@ -540,7 +545,7 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
     if (todo.empty()) return SQ_OK;
     // group size: the key arrays of a group stay under 4 GB; rows beyond the group kernel's depth go one by one
     int gmax = (int)std::min<long long>(EXACT_GROUP, std::max<long long>(1, (4ll << 30) / (n * (long long)key_bytes)));
-    if (d > (128 << EXACT_GROUP_DEPTH) || (g_opt.dense_debug & 256)) gmax = 1;    // debug 256: measurement, one query per pass
+    if (d > (128 << EXACT_GROUP_DEPTH) || (h->opt.dense_debug & 256)) gmax = 1;    // debug 256: measurement, one query per pass
     const size_t grp_lds = (size_t)EXACT_GROUP * ((d + 3) / 4 * 4) * 4;
     const bool grp_ok = grp_lds <= 160 * 1024 - 256 && d <= (128 << EXACT_GROUP_DEPTH);
     if (grp_ok) {
@@ -605,7 +610,7 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
                 SQ_TRY(select_launch_t<K128>(h->fb_keys.as<K128>(), fb_cnt, cap, (long long)cap, k, gn, h->fb_out.as<K128>(),
                                              DenseFinalizeCos{fb_cnt, cap, kk, h->id_base, thr, 0.0, 2, (double*)out_dist, out_idx,
                                                               hs_dev, nullptr, nullptr, 0, grp},
-                                             st));
+                                             st, h->fb_sort));
             } else {
                 hipLaunchKernelGGL((dense_compact_keys_kernel<u64>), dim3(gc, gn), dim3(256), 0, st, h->big_keys.as<u64>(), n,
                                    fb_thr, h->fb_keys.as<u64>(), cap, fb_cnt);
@@ -613,7 +618,7 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
                 SQ_TRY(select_launch_t<u64>(h->fb_keys.as<u64>(), fb_cnt, cap, (long long)cap, k, gn, h->fb_out.as<u64>(),
                                             DenseFinalizeL2{fb_cnt, cap, kk, h->id_base, thr, qn2, 0.0, 2,
                                                             (float*)out_dist, out_idx, hs_dev, nullptr, nullptr, 0, grp},
-                                            st));
+                                            st, h->fb_sort));
             }
             SQ_HIP(stream_wait(st));  // the status words of the group are in hs now
             SQ_HIP(hipGetLastError());
@@ -629,13 +634,13 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
                                              h->fb_out.as<K128>(),
                                              DenseFinalizeCos{full_cnt, (u32)n, kk, h->id_base, thr, 0.0, 0, (double*)out_dist, out_idx,
                                                               hs_dev, nullptr, nullptr, qi},
-                                             st));
+                                             st, h->fb_sort));
             } else {
                 SQ_TRY(select_launch_t<u64>(h->big_keys.as<u64>() + (long long)g * n, full_cnt + qi, (u32)n, n, k, 1,
                                             h->fb_out.as<u64>(),
                                             DenseFinalizeL2{full_cnt, (u32)n, kk, h->id_base, thr, qn2, 0.0, 0,
                                                             (float*)out_dist, out_idx, hs_dev, nullptr, nullptr, qi},
-                                            st));
+                                            st, h->fb_sort));
             }
         }
     }
@@ -671,6 +676,7 @@ static int dense_search_chunked(DenseHandle* h, const float* q, int nq, int k, v
         SQ_TRY(dense_search_device(h, q + (long long)q0 * h->d, m, k, static_cast<char*>(out_dist) + (size_t)q0 * k * dsz,
                                    out_idx + (long long)q0 * k, st));
         total.scan_ms += h->stats.scan_ms;
+        total.rerank_ms += h->stats.rerank_ms;
         total.total_ms += h->stats.total_ms;
         total.scan_launches += h->stats.scan_launches;
         total.candidates += h->stats.candidates;
@@ -854,6 +860,7 @@ extern "C" int sq_dense_append(sq_handle_t hid, const float* rows, int64_t n_add
     if (!h) return fail(SQ_ERR_INVALID, "sq_dense_append: unknown handle");
     if (!rows || n_add <= 0) return fail(SQ_ERR_INVALID, "sq_dense_append: bad argument");
     std::lock_guard<std::mutex> l(h->mu);
+    h->refresh_options();
     if (!h->owned.p) return fail(SQ_ERR_UNSUPPORTED, "sq_dense_append: the index borrows the caller's device matrix");
     SQ_HIP(hipSetDevice(h->device));
     SQ_TRY(dense_sync_all(h));
@@ -883,6 +890,7 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
     if (!h) return fail(SQ_ERR_INVALID, "sq_dense_search: unknown handle");
     if (!queries || !out_dist || !out_idx || nq <= 0 || k <= 0) return fail(SQ_ERR_INVALID, "sq_dense_search: bad argument");
     std::lock_guard<std::mutex> lock(h->mu);
+    h->refresh_options();
     SQ_HIP(hipSetDevice(h->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t dsz = h->metric == SQ_METRIC_COSINE ? 8 : 4;
@@ -893,7 +901,7 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
         // their own, ordered behind the caller's stream by an event, so the small kernels at the end of call
         // i - 1 (re-rank, select) and at the start of call i (query prep, sample pass, threshold) overlap.
         {
-            int want = g_opt.dense_async_depth;
+            int want = h->opt.dense_async_depth;
             want = want < 2 ? 2 : want > DenseHandle::kMaxDepth ? DenseHandle::kMaxDepth : want;
             if (want != h->depth) {  // a new depth starts from an empty pipeline
                 SQ_TRY(dense_sync_all(h));
@@ -904,7 +912,7 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
         DenseSlot& s = h->slot[h->async_calls % (unsigned)h->depth];
         SQ_TRY(dense_resolve(h, s));  // (the call `depth` back; normally resolved during an earlier call)
         hipStream_t run = st;
-        if (g_opt.dense_async_streams == 2) {
+        if (h->opt.dense_async_streams == 2) {
             // One query tile per wave (HBM bound): the two slots alternate between two streams, so neighbouring
             // calls overlap.  Larger batches (MFMA bound, and kept cheap in HBM traffic by all workgroups of an XCD
             // walking the same rows) must not run two scans at once -- two scans at different rows evict each
@@ -912,10 +920,10 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
             // (a batch that is ONE group of query tiles -- up to 64 queries at two tiles per wave, 128 at four -- still
             // reads the matrix once: it overlaps like a one-tile batch)
             const int tiles = (nq + TILE_ROWS - 1) / TILE_ROWS;
-            const bool one_group = tiles <= scan_query_tiles(h->d_pad, tiles);
+            const bool one_group = tiles <= scan_query_tiles(h->opt, h->d_pad, tiles);
             DenseSlot& owner = one_group ? s : h->slot[0];
             if (!owner.own) SQ_HIP(hipStreamCreateWithFlags(&owner.own, hipStreamNonBlocking));
-            if (g_opt.dense_async_order) {
+            if (h->opt.dense_async_order) {
                 if (!s.ev_in) SQ_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
                 SQ_HIP(hipEventRecord(s.ev_in, st));    // the caller's earlier work on `stream` (the queries) comes first
                 SQ_HIP(hipStreamWaitEvent(owner.own, s.ev_in, 0));
@@ -928,7 +936,7 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
         // the oldest call still in flight (depth - 1 calls back): its results are final on return -- unless the caller
         // asked not to wait here ("dense_async_wait" = 0): that call is then finished at the start of the next call (its
         // slot is the next one to be reused), and whatever the host does between the two calls overlaps the device
-        if (!g_opt.dense_async_wait) return SQ_OK;
+        if (!h->opt.dense_async_wait) return SQ_OK;
         return dense_resolve(h, h->slot[h->async_calls % (unsigned)h->depth]);
     }
     SQ_TRY(dense_sync_all(h));
@@ -952,6 +960,7 @@ extern "C" int sq_dense_sync(sq_handle_t hid) {
     auto* h = static_cast<DenseHandle*>(lookup_handle(hid, H_DENSE));
     if (!h) return fail(SQ_ERR_INVALID, "sq_dense_sync: unknown handle");
     std::lock_guard<std::mutex> lock(h->mu);
+    h->refresh_options();
     SQ_HIP(hipSetDevice(h->device));
     return dense_sync_all(h);
 }
@@ -963,6 +972,7 @@ extern "C" int sq_dense_destroy(sq_handle_t hid) {
     (void)hipSetDevice(h->device);
     {
         std::lock_guard<std::mutex> lock(h->mu);
+        h->refresh_options();
         (void)dense_sync_all(h);  // nothing of this handle is left on the device when its buffers go
     }
     delete h;

@@ -2,8 +2,8 @@
 // finalisation/certification of the dense path.  See sq_dense.hip for the
 // overall structure and DESIGN.md section 4.2.
 #pragma once
-#include "sq_pairwise.cuh"
-#include "sq_select.cuh"
+#include "sq_pairwise.hpp"
+#include "sq_select.hpp"
 
 namespace sq {
 

@@ -26,7 +26,7 @@
 #include <type_traits>
 
 #include "sq_common.hpp"
-#include "sq_dma.cuh"
+#include "sq_dma.hpp"
 
 namespace sq {
 

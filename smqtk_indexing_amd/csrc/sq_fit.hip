@@ -21,7 +21,7 @@
 #include <vector>
 
 #include "sq_common.hpp"
-#include "sq_pairwise.cuh"
+#include "sq_pairwise.hpp"
 
 namespace sq {
 

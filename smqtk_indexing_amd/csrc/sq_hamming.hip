@@ -14,7 +14,7 @@
 // Integer-exact.  DESIGN.md section 4.3.
 #include <algorithm>
 
-#include "sq_select.cuh"
+#include "sq_select.hpp"
 
 namespace sq {
 
@@ -425,7 +425,7 @@ __global__ void hamming_thr_kernel(const u32* __restrict__ hist, int nq, int bit
 }
 
 // sorted keys -> (distance, global id); status bit0 = candidate overflow, bit2 = fewer candidates than k.
-// Runs as the post-operation of the select (sq_select.cuh: `post(q, sorted keys of query q, k)` runs in the
+// Runs as the post-operation of the select (sq_select.hpp: `post(q, sorted keys of query q, k)` runs in the
 // selecting workgroup once its k keys are written): one launch less per search.
 struct HammingFinalize {
     const u32* cnt;
@@ -516,7 +516,7 @@ template <class Post>
 static int select_launch(const u64* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, u64* out,
                          hipStream_t st, DevBuf& sort_scratch, Post post) {
     static bool attr_set = false;
-    if (k > kSelectLdsKeys64)  // linear.py:235-238 has no limit on n: the any-k sorted select (sq_select.cuh)
+    if (k > kSelectLdsKeys64)  // linear.py:235-238 has no limit on n: the any-k sorted select (sq_select.hpp)
         return sort_select_large<u64, Post>(keys, cnt, cap, stride, k, nq, out, sort_scratch, post, st);
     const size_t lds = (size_t)(kSelectLdsKeys64 + SELECT_SORT_MAX) * sizeof(u64);
     if (!attr_set) {
@@ -534,11 +534,11 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
     const long long n = h->n;
     const int W = h->words, bits = W * 64;
     const int kk = (int)(k < n ? k : n);
-    const bool prof = g_opt.profile != 0;
-    u32 cap = g_opt.candidate_cap > 0 ? (u32)g_opt.candidate_cap : 65536u;
+    const bool prof = h->opt.profile != 0;
+    u32 cap = h->opt.candidate_cap > 0 ? (u32)h->opt.candidate_cap : 65536u;
     // room for the tie group at the threshold distance (integer distances: the codes AT the threshold can outnumber
     // those below it several times)
-    if (g_opt.candidate_cap <= 0 && cap < (u32)std::min<long long>(16ll * kk, 1ll << 30)) cap = (u32)std::min<long long>(16ll * kk, 1ll << 30);
+    if (h->opt.candidate_cap <= 0 && cap < (u32)std::min<long long>(16ll * kk, 1ll << 30)) cap = (u32)std::min<long long>(16ll * kk, 1ll << 30);
     if (cap < (u32)(2 * kk)) cap = (u32)(2 * kk);
     const bool small = n <= (long long)cap;
     h->stats = sq_stats_t{};
@@ -562,7 +562,7 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
     const long long key_stride = small ? n : (long long)cap;
     SQ_TRY(h->keys.reserve((size_t)nq * key_stride * 8));
     u64* keys = h->keys.as<u64>();
-    const bool force_fb = g_opt.force_fallback != 0;
+    const bool force_fb = h->opt.force_fallback != 0;
 
     if (small) {
         hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, cnt, (long long)nq, (u32)n);
@@ -574,7 +574,7 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         SQ_TRY(select_launch(keys, cnt, (u32)n, key_stride, k, nq, okeys, st, h->sort_tmp,
                              HammingFinalize{cnt, (u32)n, kk, h->id_base, out_dist, out_idx, status, hs_dev, nq}));
     } else {
-        int step = g_opt.sample_stride > 0 ? g_opt.sample_stride : 64;
+        int step = h->opt.sample_stride > 0 ? h->opt.sample_stride : 64;
         // keep the sample comfortably larger than k
         const long long per_block = 256ll * (W == 1 ? 4 : W == 2 ? 2 : 1);
         const long long blocks_all = (n + per_block - 1) / per_block;
@@ -582,7 +582,7 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         // the threshold admits ~step * k codes (k of them in the 1/step sample) times the tie expansion: keep that
         // inside the candidate lists.  (At the default step of 64 every query with k >= ~500 overflowed its list
         // and took the exact path: 18 ms per query at 10 M codes, found by bench.py --workload lsh_c3.)
-        if (g_opt.sample_stride <= 0)
+        if (h->opt.sample_stride <= 0)
             while (step > 1 && (long long)step * kk * 8 > (long long)cap) step >>= 1;
         SQ_TRY(h->hist.reserve((size_t)nq * (bits + 1) * 4));
         u32* hist = h->hist.as<u32>();
@@ -841,6 +841,7 @@ extern "C" int sq_hamming_search(sq_handle_t hid, const uint64_t* queries, int n
     if (!queries || !out_dist || !out_idx || nq <= 0 || k <= 0)
         return fail(SQ_ERR_INVALID, "sq_hamming_search: bad argument");
     std::lock_guard<std::mutex> lock(h->mu);
+    h->refresh_options();
     SQ_HIP(hipSetDevice(h->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (mem == SQ_MEM_DEVICE) {

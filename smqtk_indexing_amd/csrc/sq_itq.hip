@@ -15,8 +15,8 @@
 #include <algorithm>
 
 #include "sq_common.hpp"
-#include "sq_pairwise.cuh"
-#include "sq_itq_fast.cuh"
+#include "sq_pairwise.hpp"
+#include "sq_itq_fast.hpp"
 
 namespace sq {
 
@@ -39,7 +39,7 @@ struct ItqArgs {
     const void* nrm;    // [n] row L2 norms in x's dtype (normalize=2), from itq_norms_kernel
     int vec4;           // rows are 4-element aligned (d % 4 == 0, base aligned): vector loads of x
     int sub32;              // x - mean in float32 (float32 rows and a float32 model mean: numpy's promotion)
-    const u32* list;        // optional: only these rows (the filter's uncertain rows, sq_itq_fast.cuh)
+    const u32* list;        // optional: only these rows (the filter's uncertain rows, sq_itq_fast.hpp)
     const u32* list_total;  // device count of `list`
 };
 
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void itq_norms_kernel(const T* __restrict__ X,
                                                         int ord) {
     const int j8 = threadIdx.x & 7;
     const long long stride = (long long)gridDim.x * 32;
-    const long long n = list ? (long long)*list_total : n_all;  // listed rows only (sq_itq_fast.cuh), or all
+    const long long n = list ? (long long)*list_total : n_all;  // listed rows only (sq_itq_fast.hpp), or all
     for (long long row0 = (long long)blockIdx.x * 32; row0 < n; row0 += stride) {
         long long row = row0 + (threadIdx.x >> 3);
         const bool live = row < n;
@@ -415,7 +415,7 @@ static int itq_launch_t(const ItqArgs& a0, hipStream_t st, int device) {
     return SQ_OK;
 }
 
-// ---- the certified bf16x3 filter in front of the float64 kernel (sq_itq_fast.cuh)
+// ---- the certified bf16x3 filter in front of the float64 kernel (sq_itq_fast.hpp)
 template <int WAVES, int NSTAGE, int KU, int CT, bool NORMED, bool BREG>
 static int itq_fast_launch_t(const ItqFastArgs& fa, size_t lds, hipStream_t st) {
     static bool attr_set = false;
@@ -550,7 +550,7 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
         (void)hipFreeAsync(base, st);
         return rc;
     };
-    // relative error of x . R_b per unit |x||R_b| (sq_itq_fast.cuh): 2^-20 (x: two round-toward-zero float16 planes)
+    // relative error of x . R_b per unit |x||R_b| (sq_itq_fast.hpp): 2^-20 (x: two round-toward-zero float16 planes)
     // + 2^-21 (the dropped x_lo R_lo) + 3d * 2^-24 (float32 accumulation of 3d products) + 2^-20 (the float32 scale /
     // subtract, the reference's float32 x/|x|) [+ 2^-18: float32 |x|^2, normalize=2].  R's own residual is measured
     // by the prep kernel and added to the column's coefficient.

@@ -45,7 +45,7 @@
 // 2^-14 lose relative precision to the absolute term above: data of tiny
 // scale (|x| << 1e-2) stays correct but leaves more bits to float64.
 #pragma once
-#include "sq_dma.cuh"
+#include "sq_dma.hpp"
 
 namespace sq {
 
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void itq_fast_kernel(ItqFast
         // and the absolute part of the split's error is not scaled by a row's 1/|x|
         if constexpr (!NORMED) cberr[ct] += fabsf(cb[ct]) * ((3.f * D + 2.f) * 5.9604644775390625e-08f * 1.0001f) + cabs[ct];
         valid_lanes[ct] = __ballot(pc >= a.pad);
-        // complete before the DMA ring starts (see sq_dense_scan.cuh)
+        // complete before the DMA ring starts (see sq_dense_scan.hpp)
         asm volatile("" : "+v"(cnorm[ct]), "+v"(cb[ct]), "+v"(cberr[ct]), "+v"(cabs[ct]));
     }
     if constexpr (BREG) {

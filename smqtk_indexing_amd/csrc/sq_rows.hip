@@ -12,7 +12,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "sq_dense_exact.cuh"
+#include "sq_dense_exact.hpp"
 
 namespace sq {
 
@@ -217,7 +217,7 @@ static int rows_select(const K* keys, const u32* cnt, u32 cap, long long stride,
                        DevBuf& sort_scratch) {
     static bool attr_set = false;
     const int lds_keys = sizeof(K) == 8 ? 16384 : 7168;
-    if (k > lds_keys)  // lsh.py:513-518 slices whatever n is asked: the any-k sorted select (sq_select.cuh)
+    if (k > lds_keys)  // lsh.py:513-518 slices whatever n is asked: the any-k sorted select (sq_select.hpp)
         return sort_select_large<K, SelectNoPost>(keys, cnt, cap, stride, k, nq, out, sort_scratch, SelectNoPost(), st);
     const size_t lds = (size_t)(lds_keys + SELECT_SORT_MAX) * sizeof(K);
     if (!attr_set) {

@@ -393,7 +393,7 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
 // samples <= T0 (about k of them) are collected in LDS and sorted, and T is the
 // exact k-th smallest sample: two read passes and two small bitonic sorts.
 // `post(q, T)` maps the result before it is stored (the dense path adds its
-// slack there, sq_dense_exact.cuh: DenseThrPost).
+// slack there, sq_dense_exact.hpp: DenseThrPost).
 struct KthIdentity {
     __device__ __forceinline__ float operator()(int, float t) const { return t; }
 };

@@ -314,6 +314,7 @@ class PipelinedMerger:
         self._done = {}
         self._cv = threading.Condition()
         self._next = 0
+        self.merge_seconds = []      # duration of every merge (the worker's clock): reported by bench.py
         self._thread = threading.Thread(target=self._run, name="sq-merge", daemon=True)
         self._thread.start()
 
@@ -324,10 +325,12 @@ class PipelinedMerger:
             if job is None:
                 return
             ticket, buf, shards, nq, k_in, k_out, dt = job
+            t0 = time.perf_counter()
             try:
                 res = _lib.merge_topk_gathered(buf, shards, nq, k_in, k_out, dt)
             except Exception as ex:  # noqa: BLE001 -- handed to the caller of result()
                 res = ex
+            self.merge_seconds.append(time.perf_counter() - t0)
             with self._cv:
                 self._done[ticket] = res
                 self._cv.notify_all()
@@ -357,48 +360,47 @@ class HipSearcher:
 
     ``search_into(q, k, out_d, out_i)`` writes the shard's top-k for the query batch into the two device tensors.
     ``lag`` says when that answer is final: 0 -- when ``search_into`` returns (the synchronous C ABI call);
-    ``depth - 1`` -- when that many further ``search_into`` calls (or ``finish``) have returned: ``sq_dense_search``
-    with ``SQ_MEM_DEVICE_ASYNC``, which keeps ``depth`` calls on the device (include/smqtk_hip.h; option
-    ``dense_async_depth``, 2 by default -- small shards gain from 3: DESIGN.md section 5)."""
+    ``depth - 1`` -- when that many further ``search_into`` calls (or ``finish``) have returned: the searches with
+    ``SQ_MEM_DEVICE_ASYNC``, which keep ``depth`` calls on the device (include/smqtk_hip.h; option
+    ``dense_async_depth`` / ``hamming_async_depth``, 2 by default -- small shards gain from 3: DESIGN.md section 5).
+
+    The pipeline's depth / wait / order are options of THIS index's handle (``sq_handle_set_option``): another index
+    searched in the same process -- another pipeline, another thread -- keeps its own.
+
+    Query lifetime: the C ABI reads ``queries`` until the call is final (``lag`` calls later: the kernels run on the
+    library's internal streams, which torch's caching allocator knows nothing about, and an uncertified query is
+    redone from the same pointer).  ``search_into`` therefore keeps a reference to the last ``lag + 1`` query
+    tensors (and output tensors); callers may hand over temporaries and drop them at once."""
 
     def __init__(self, index, stream_handle: int = 0, use_async: bool = False, depth: int = 2, wait: bool = True,
                  queries_ready: bool = False):
+        import collections
         self.index, self.stream = index, int(stream_handle)
         self.lag = 0
-        self._opts = None
         if use_async and hasattr(index, "search_device_async"):
             depth = min(max(int(depth), 2), 4)
-            # wait=False: a call returns right after enqueueing (option dense_async_wait = 0) and the wait for the oldest
+            # wait=False: a call returns right after enqueueing (option *_async_wait = 0) and the wait for the oldest
             # call moves to the start of the next one: one more call of lag, and the host work between two calls (the
             # pipeline's gather and merge bookkeeping) overlaps the device instead of delaying the next enqueue
             # queries_ready=True: every query tensor handed to search_into is complete (nothing still writing it on a
             # stream): the per-call event that orders the search behind the caller's stream is skipped
-            self._opts = (depth, 1 if wait else 0, 0 if queries_ready else 1)
+            prefix = getattr(index, "async_option_prefix", "dense_async")
+            index.set_option(prefix + "_depth", depth)
+            index.set_option(prefix + "_wait", 1 if wait else 0)
+            index.set_option(prefix + "_order", 0 if queries_ready else 1)
             self.lag = depth - 1 if wait else depth
-        self._armed = False
-
-    def _arm(self) -> None:
-        """The two options are process-wide: set when a run of searches starts, defaults restored by finish()."""
-        from . import _lib
-        _lib.set_option("dense_async_depth", self._opts[0])
-        _lib.set_option("dense_async_wait", self._opts[1])
-        _lib.set_option("dense_async_order", self._opts[2])
-        self._armed = True
+        self._alive = collections.deque(maxlen=self.lag + 1)   # (queries, out_d, out_i) of the calls not yet final
 
     def search_into(self, queries, k: int, out_d, out_i) -> None:
-        if self._opts is not None and not self._armed:
-            self._arm()
+        q = queries if queries.is_contiguous() else queries.contiguous()
+        self._alive.append((q, out_d, out_i))
         fn = self.index.search_device_async if self.lag else self.index.search_device
-        fn(queries.data_ptr(), int(queries.shape[0]), int(k), out_d.data_ptr(), out_i.data_ptr(), self.stream)
+        fn(q.data_ptr(), int(q.shape[0]), int(k), out_d.data_ptr(), out_i.data_ptr(), self.stream)
 
     def finish(self) -> None:
         if self.lag:
             self.index.sync()
-            from . import _lib
-            _lib.set_option("dense_async_depth", 2)
-            _lib.set_option("dense_async_wait", 1)
-            _lib.set_option("dense_async_order", 1)
-            self._armed = False
+        self._alive.clear()
 
 
 class PipelinedShardedSearch:
@@ -423,6 +425,9 @@ class PipelinedShardedSearch:
     :class:`HipSearcher` on a compute stream of the pipeline's own; ``depth`` = asynchronous searches in flight,
     ``wait`` = False: searches return right after enqueueing; ``queries_ready`` = True: the query tensors handed to
     ``submit`` are complete, no stream ordering needed -- see :class:`HipSearcher`).
+    Lifetime rule: a query tensor handed to ``submit`` is read by the device until its batch is final, ``lag`` submits
+    later; :class:`HipSearcher` keeps the reference until then, so callers may submit temporaries.  A searcher of your
+    own must do the same.  ``results_lag`` = submits between a batch going in and its merged result coming out.
     """
 
     def __init__(self, searcher, nq: int, k: int, dist_dtype, group=None, merge_on: int = 0, device=None,
@@ -466,7 +471,11 @@ class PipelinedShardedSearch:
         self.valid = [0] * nb      # batches in the group a buffer holds (the last group of a run may be short)
         self.i = 0                 # batches submitted
         self.gathered = 0          # groups whose all-gather has been started
+        self.gather_host_seconds = []   # host time of starting a group's all-gather + pinned copy (bench.py reports it)
         self.merging = self.rank == merge_on
+        # submits between batch i going in and its merged result coming out of submit(): its group must be complete and
+        # final (G - 1 + lag), then gathered, copied and merged under the next `nb` groups' searches
+        self.results_lag = (G - 1) + self.lag + nb * G
         if self.merging:
             if self.cuda:
                 self.host = [torch.empty(self.world * per, dtype=torch.uint8, pin_memory=True) for _ in range(nb)]
@@ -519,6 +528,7 @@ class PipelinedShardedSearch:
         ready = []
         if self.merging and self.ticket[j] is not None:
             ready = self._collect(j)                        # `nb` groups back: merged under the searches since
+        t0 = time.perf_counter()
         self.work[j] = w = dist.all_gather_into_tensor(self.recv[j], self.send[j], group=self.group, async_op=True)
         if self.merging:
             if self.cuda:
@@ -526,6 +536,8 @@ class PipelinedShardedSearch:
                 self.host[j].copy_(self.recv[j], non_blocking=True)
                 self.copied[j].record()
             self.copy_pending[j] = True
+        self.gather_host_seconds.append(time.perf_counter() - t0)
+        if self.merging:
             self._merge_ready((j - 1) % self.nb)           # the group before: gathered and copied meanwhile
         return ready
 

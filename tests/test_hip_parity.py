@@ -818,7 +818,7 @@ def test_hamming_append_remove_equals_a_fresh_index(bits):
 def test_k_beyond_the_one_workgroup_select():
     """The reference slices whatever n is asked (linear.py:235-238, lsh.py:513-518): no cap on k.  k above the
     one-workgroup select's capacity (16384 keys; 7168 for float64 / cosine keys) is answered by a full device sort
-    (sq_select.cuh, sort_select_large) -- same canonical order, checked against the oracle."""
+    (sq_select.hpp, sort_select_large) -- same canonical order, checked against the oracle."""
     rng = np.random.default_rng(61)
     db = rng.standard_normal((90_000, 32)).astype(np.float32)
     db[500:520] = db[3]                                       # ties
