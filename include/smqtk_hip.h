@@ -21,8 +21,8 @@
  *     answer is certified on the device and the host reads the status words
  *     (an uncertified query is redone on the exact path), so the call waits
  *     for its own kernels.  sq_itq_hash / sq_dense_distances with device
- *     buffers only enqueue.  SQ_MEM_DEVICE_ASYNC (sq_dense_search only) is
- *     the pipelined form: see sq_dense_search.
+ *     buffers only enqueue.  SQ_MEM_DEVICE_ASYNC (sq_dense_search,
+ *     sq_hamming_search) is the pipelined form: see sq_dense_search.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *   - all matrices are C-contiguous, row-major.
  *   - hash codes are uint64[n][words], word 0 most significant, bit 0 of the
@@ -52,7 +52,7 @@ extern "C" {
 
 #define SQ_MEM_HOST 0
 #define SQ_MEM_DEVICE 1
-#define SQ_MEM_DEVICE_ASYNC 2 /* sq_dense_search: enqueue and return, results final one call later */
+#define SQ_MEM_DEVICE_ASYNC 2 /* sq_dense_search / sq_hamming_search: enqueue and return, results final one call later */
 
 #define SQ_METRIC_L2 0     /* utils/metrics.py:73-86 euclidean_distance */
 #define SQ_METRIC_COSINE 1 /* utils/metrics.py:89-137 cosine_distance (pos_vectors=True) */
@@ -162,6 +162,13 @@ int sq_hamming_create(const uint64_t* codes, int64_t n, int words, int mem,
  * out_idx int64 [nq][k]. */
 int sq_hamming_search(sq_handle_t h, const uint64_t* queries, int nq, int k,
                       int32_t* out_dist, int64_t* out_idx, int mem, void* stream);
+/* mem = SQ_MEM_DEVICE_ASYNC: the pipelined form, with the contract of sq_dense_search's (below): the call enqueues
+ * on an internal stream of its slot and returns; its results are final when the (depth - 1)-th later call on the
+ * handle -- or sq_hamming_sync, a mutation, the destroy -- returns; until then `queries`, `out_dist` and `out_idx`
+ * stay valid and untouched.  Options "hamming_async_depth" (2 .. 4), "hamming_async_wait", "hamming_async_order" as
+ * their dense_* counterparts.  The shards of BASELINE config 5 (125 M x 256-bit codes per GPU) pipeline their
+ * histogram / threshold / compaction / select kernels under the neighbouring calls' scans this way. */
+int sq_hamming_sync(sq_handle_t h);
 /* Incremental mutation of an index that owns its device copy (created from host memory, or from a device array of
  * at least 4096 codes, which is copied): what LinearHashIndex._update_index / _remove_from_index do with a set
  * union / difference (impls/hash_index/linear.py:167-204), without re-uploading the whole code array.  Row ids are

@@ -42,7 +42,7 @@ EXPORTS = (
     "sq_last_error", "sq_version", "sq_device_count", "sq_device_name",
     "sq_set_option", "sq_handle_set_option", "sq_handle_reset_options", "sq_get_stats", "sq_itq_hash",
     "sq_itq_model_create", "sq_itq_model_hash", "sq_itq_model_destroy",
-    "sq_hamming_create", "sq_hamming_search", "sq_hamming_append", "sq_hamming_remove", "sq_hamming_info", "sq_hamming_destroy",
+    "sq_hamming_create", "sq_hamming_search", "sq_hamming_sync", "sq_hamming_append", "sq_hamming_remove", "sq_hamming_info", "sq_hamming_destroy",
     "sq_dense_create", "sq_dense_append", "sq_dense_search", "sq_dense_sync", "sq_dense_destroy",
     "sq_dense_distances", "sq_merge_topk", "sq_merge_topk_strided",
     "sq_rows_create", "sq_rows_append", "sq_rows_rerank", "sq_rows_set_buckets", "sq_lsh_query", "sq_rows_destroy",
@@ -89,6 +89,7 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_itq_model_destroy.argtypes = [c_i64]
     lib.sq_hamming_create.argtypes = [c_vp, c_i64, c_int, c_int, c_i64, ctypes.POINTER(c_i64)]
     lib.sq_hamming_search.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]
+    lib.sq_hamming_sync.argtypes = [c_i64]
     lib.sq_hamming_append.argtypes = [c_i64, c_vp, c_i64, c_vp]
     lib.sq_hamming_remove.argtypes = [c_i64, c_vp, c_i64]
     lib.sq_hamming_destroy.argtypes = [c_i64]
@@ -380,6 +381,18 @@ class HammingIndex(_Handle):
                                         _ptr(out_idx_ptr), SQ_MEM_DEVICE, ctypes.c_void_p(stream or None)),
                "sq_hamming_search")
 
+    async_option_prefix = "hamming_async"      # (HipSearcher: the names of this index's pipeline options)
+
+    def search_device_async(self, q_ptr: int, nq: int, k: int, out_dist_ptr: int, out_idx_ptr: int, stream: int = 0) -> None:
+        """``SQ_MEM_DEVICE_ASYNC``: enqueue and return; final ``depth - 1`` calls later (or after :meth:`sync`)."""
+        _check(load().sq_hamming_search(self.handle, _ptr(q_ptr), int(nq), int(k), _ptr(out_dist_ptr),
+                                        _ptr(out_idx_ptr), SQ_MEM_DEVICE_ASYNC, ctypes.c_void_p(stream or None)),
+               "sq_hamming_search")
+
+    def sync(self) -> None:
+        """Finish every asynchronous search in flight (``sq_hamming_sync``)."""
+        _check(load().sq_hamming_sync(self.handle), "sq_hamming_sync")
+
 
 class DenseIndex(_Handle):
     """Device-resident float32 matrix + exact L2 / cosine top-k search."""
@@ -442,6 +455,8 @@ class DenseIndex(_Handle):
                                       _ptr(out_idx_ptr), SQ_MEM_DEVICE, ctypes.c_void_p(stream or None)),
                "sq_dense_search")
 
+
+    async_option_prefix = "dense_async"
 
     def search_device_async(self, q_ptr: int, nq: int, k: int, out_dist_ptr: int, out_idx_ptr: int, stream: int = 0) -> None:
         """``SQ_MEM_DEVICE_ASYNC``: enqueue and return.  The results are final when the next call on this index

@@ -72,6 +72,8 @@ struct Options {
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
     int dense_mid_tier = 1;      // 1 = queries the bf16 filter could not certify get a second, tighter filter pass (three bf16 planes of the rows built on the fly) before the exact all-rows path; 0 = straight to the exact path
     int hamming_async_depth = 2; // asynchronous Hamming searches in flight (2..4), as dense_async_depth
+    int hamming_async_wait = 1;  // as dense_async_wait
+    int hamming_async_order = 1; // as dense_async_order
     int hamming_ring = -1;       // Hamming stream kernel: -1 = automatic (LDS-DMA ring for arrays beyond the MALL), 0 = register loads, 1 = ring
 };
 extern Options g_opt;   // process-wide defaults (sq_set_option); a handle may override any of them (sq_handle_set_option)

@@ -100,6 +100,8 @@ int Options::*option_member(const char* name) {
         {"dense_nt_keep_mb", &Options::dense_nt_keep_mb},
         {"dense_mid_tier", &Options::dense_mid_tier},
         {"hamming_async_depth", &Options::hamming_async_depth},
+        {"hamming_async_wait", &Options::hamming_async_wait},
+        {"hamming_async_order", &Options::hamming_async_order},
         {"hamming_ring", &Options::hamming_ring},
     };
     if (!name) return nullptr;

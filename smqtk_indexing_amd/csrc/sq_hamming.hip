@@ -14,6 +14,7 @@
 // Integer-exact.  DESIGN.md section 4.3.
 #include <algorithm>
 
+#include "sq_dma.hpp"
 #include "sq_select.hpp"
 
 namespace sq {
@@ -22,6 +23,39 @@ namespace sq {
 struct RowPerm {
     u64 mul, inv;
     const u32* rank;  // non-null: physical row p holds the code of sorted rank rank[p]
+};
+
+// Per-call workspace.  A synchronous search uses slot 0; asynchronous searches (SQ_MEM_DEVICE_ASYNC) rotate through
+// `depth` slots, each with a stream of its own, so that the short kernels around the scan (histogram, threshold,
+// compaction, select) of neighbouring calls overlap the scans and the host reads a call's status words one call later
+// -- the scheme of the dense search (sq_dense.hip).
+struct HammingCall {
+    bool pending = false;
+    const u64* qs = nullptr;
+    int nq = 0, k = 0;
+    int* out_dist = nullptr;
+    long long* out_idx = nullptr;
+    hipStream_t st = nullptr;
+    bool small = false, prof = false, use_event = false, force_fb = false;
+    u32 cap = 0;
+    sq_stats_t stats{};
+};
+struct HammingSlot {
+    DevBuf keys, cnt, hist, thr, out_keys, status, seg, bcnt, sort_tmp;
+    HostPinned status_host;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_in = nullptr, ev_done = nullptr;
+    hipStream_t own = nullptr;
+    HammingCall call;
+    void release() {
+        for (DevBuf* b : {&keys, &cnt, &hist, &thr, &out_keys, &status, &seg, &bcnt, &sort_tmp}) b->release();
+        status_host.release();
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e), e = nullptr;
+        if (ev_in) (void)hipEventDestroy(ev_in), ev_in = nullptr;
+        if (ev_done) (void)hipEventDestroy(ev_done), ev_done = nullptr;
+        if (own) (void)hipStreamDestroy(own), own = nullptr;
+    }
 };
 
 struct HammingHandle : HandleBase {
@@ -33,29 +67,16 @@ struct HammingHandle : HandleBase {
     RowPerm pmul{1, 0, nullptr};  // physical row p holds caller row (p * pmul.mul) mod n (or pmul.rank[p])
     DevBuf rank;                  // u32[n] explicit ranks, after the first append / remove
     DevBuf mut_tmp;               // scratch of the mutation kernels
-    DevBuf sort_tmp;              // scratch of the any-k sorted select (k > 16384)
-    // workspace
-    DevBuf q_dev, keys, cnt, hist, thr, out_keys, status, out_dist_dev, out_idx_dev, big_keys, seg, bcnt;
-    HostPinned status_host;
+    static constexpr int kMaxDepth = 4;
+    HammingSlot slot[kMaxDepth];
+    int depth = 2;                       // asynchronous calls in flight (option hamming_async_depth, fixed while any is)
+    unsigned long long async_calls = 0;  // asynchronous calls so far (slot = calls % depth)
+    // shared by all calls: host-memory staging and the exact path (both synchronous)
+    DevBuf q_dev, out_dist_dev, out_idx_dev, big_keys, fb_sort;
     PinnedStage stage;
     ~HammingHandle() override {
-        owned.release();
-        rank.release();
-        mut_tmp.release();
-        sort_tmp.release();
-        q_dev.release();
-        keys.release();
-        cnt.release();
-        hist.release();
-        thr.release();
-        out_keys.release();
-        status.release();
-        out_dist_dev.release();
-        out_idx_dev.release();
-        big_keys.release();
-        seg.release();
-        bcnt.release();
-        status_host.release();
+        for (DevBuf* b : {&owned, &rank, &mut_tmp, &q_dev, &out_dist_dev, &out_idx_dev, &big_keys, &fb_sort}) b->release();
+        for (auto& sl : slot) sl.release();
         stage.release();
     }
 };
@@ -270,16 +291,179 @@ __global__ __launch_bounds__(256) void hamming_stream_kernel(const u64* __restri
     for (int i = tid; i < nq; i += 256) bcnt[(long long)blockIdx.x * nq + i] = lcnt[i];
 }
 
+// ---- the same stream through an LDS-DMA ring (arrays far beyond the MALL, few queries: HBM bound) -------------
+// The register-load stream above keeps one chunk per thread in flight (its prefetch) and reaches 5.0 TB/s on the
+// 4 GB shard of BASELINE config 5; the dense scan's ring of `global_load_lds_dwordx4` pieces reaches 6.5-6.8 TB/s on
+// the same HBM (MI355X_MICROARCH.md, "ldsdma-fill").  Here: one 512-thread workgroup per CU; every wave owns a ring
+// of NSTAGE units of 8 KiB in LDS (8 x 1 KiB DMA pieces, lane-linear: the LDS image of a unit is its global image),
+// units dealt round-robin over all waves of the launch, no workgroup barrier in the loop -- a wave consumes only what
+// it loaded, ordered by counted `s_waitcnt vmcnt`.  A lane reads WHOLE codes out of the image (`CPL` consecutive
+// 16-byte chunks at lane stride 16 CPL bytes: 2-way bank conflicts at 256 bits, once per unit, not per query), so
+// the inner loop is xor + v_bcnt per 32 bits + one min per code with the query words and thresholds in scalar
+// registers.  Survivors leave exactly as in the register kernel: LDS counter per query, per-(workgroup, query)
+// mini-lists, hamming_compact_kernel afterwards.  The survivor stores are younger VMEM operations in the same
+// in-order queue as the DMA pieces: a counted wait then waits for a little more than it must (never for less).
+// Code widths 64 .. 1024 bits in powers of two; the array must be 16-byte aligned.  The last partial unit is read by
+// one wave with guarded register loads after its ring has drained.
+template <int W>
+struct RingShape {
+    static constexpr int CPL = W >= 2 ? W / 2 : 1;   // 16-byte chunks a lane reads in a row (one code; W = 1: two codes)
+    static constexpr int NG = 8 / CPL;               // such groups per 8 KiB unit and lane
+    static constexpr int CODES = W == 1 ? 16 : NG;   // codes per lane and unit
+    static constexpr int UNIT_CODES = 1024 / W;      // codes per unit
+    static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16, "ring kernel: 64 .. 1024-bit codes, powers of two");
+};
+static constexpr int HR_WAVES = 8, HR_NSTAGE = 2, HR_UNIT = 8192;
+
+// row of code slot i of lane `lane` in the unit that starts at code `code0`
+template <int W>
+__device__ __forceinline__ long long ring_row(long long code0, int lane, int i) {
+    if constexpr (W == 1)
+        return code0 + ((long long)(i >> 1) * 64 + lane) * 2 + (i & 1);
+    else
+        return code0 + (long long)i * 64 + lane;
+}
+
+// popcount(x) + acc as two v_bcnt_u32_b32 with their accumulate operand: one serial chain per code.  (Left to hipcc the
+// 2 W popcounts of a code become W pairs plus an adder tree: 75 instead of 67 vector instructions per query and four
+// 256-bit codes, in a loop that is VALU bound from ~8 queries per pass on.)
+__device__ __forceinline__ u32 popc64_acc(u64 x, u32 acc) {
+    u32 r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"((u32)x), "v"(acc));
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(acc) : "v"((u32)(x >> 32)), "v"(r));
+    return acc;
+}
+
+template <int W, bool NT>
+__global__ __launch_bounds__(HR_WAVES * 64, 1) void hamming_ring_kernel(const u64* __restrict__ codes, long long n, RowPerm pmul,
+                                                                         const u64* __restrict__ qs, int nq,
+                                                                         const int* __restrict__ thr, u64* __restrict__ seg,
+                                                                         u32* __restrict__ bcnt, u32 S) {
+    using R = RingShape<W>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32* lcnt = reinterpret_cast<u32*>(hsm + (size_t)HR_WAVES * HR_NSTAGE * HR_UNIT);   // [nq]
+    for (int i = threadIdx.x; i < nq; i += HR_WAVES * 64) lcnt[i] = 0u;
+    __syncthreads();
+    const u32 lds_base = (u32)(uintptr_t)hsm;  // low 32 bits of a flat LDS address = LDS offset
+    const u32 ring_base = lds_base + (u32)wave * (HR_NSTAGE * HR_UNIT);
+    const unsigned char* ring_ptr = hsm + (size_t)wave * (HR_NSTAGE * HR_UNIT);
+    u64* myseg = seg + (long long)blockIdx.x * nq * S;
+
+    const long long units = (n * (long long)W * 8) / HR_UNIT;            // whole units; the rest: tail below
+    const long long nwaves = (long long)gridDim.x * HR_WAVES;
+    const long long gw = (long long)blockIdx.x * HR_WAVES + wave;
+    const long long mine = units > gw ? (units - gw + nwaves - 1) / nwaves : 0;   // units of this wave
+    const unsigned char* gbase = reinterpret_cast<const unsigned char*>(codes);
+    const u32 voff = (u32)lane * 16u;
+
+    // compare the codes a lane holds with every query of the batch.  Query words and threshold of query q + 1 are
+    // requested (scalar loads) before query q is compared, so their latency sits under ~70 vector instructions.
+    // Keys carry the PHYSICAL row: the compaction maps it to the caller's row (orig_row) -- a rank-table load here
+    // would be a compiler-visible VMEM load, and hipcc waits for those with vmcnt(0), which drains the ring.
+    auto compare = [&](const u64 (&c)[R::CODES][W], const long long code0) __attribute__((always_inline)) {
+        u64 qn[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) qn[w] = qs[w];
+        int tn = thr[0];
+        for (int q = 0; q < nq; ++q) {
+            u64 qw[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) qw[w] = qn[w];
+            const int t = tn;
+            {
+                const int q1 = q + 1 < nq ? q + 1 : q;   // wave-uniform: scalar loads
+                const u64* qp = qs + (long long)q1 * W;
+#pragma unroll
+                for (int w = 0; w < W; ++w) qn[w] = qp[w];
+                tn = thr[q1];
+            }
+            int dist[R::CODES];
+            int m = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < R::CODES; ++i) {
+                u32 dsum = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) dsum = popc64_acc(c[i][w] ^ qw[w], dsum);
+                dist[i] = (int)dsum;
+                m = (int)dsum < m ? (int)dsum : m;
+            }
+            if (m <= t) {  // rare: one branch per (query, codes of a lane)
+#pragma unroll
+                for (int i = 0; i < R::CODES; ++i) {
+                    const long long row = ring_row<W>(code0, lane, i);
+                    if (dist[i] <= t && row < n) {
+                        const u32 pos = atomicAdd(&lcnt[q], 1u);
+                        if (pos < S) myseg[(long long)q * S + pos] = ((u64)(u32)dist[i] << 32) | (u64)(u32)row;
+                    }
+                }
+            }
+        }
+    };
+
+    long long issued = 0;
+    auto issue_unit = [&]() __attribute__((always_inline)) {
+        const long long u = gw + issued * nwaves;
+        const unsigned char* src = gbase + u * HR_UNIT;
+        const u32 dst = ring_base + (u32)(issued % HR_NSTAGE) * HR_UNIT;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) glds16<NT>(src + j * 1024, voff, dst + (u32)j * 1024);
+        ++issued;
+    };
+    for (int p = 0; p < HR_NSTAGE; ++p)
+        if (issued < mine) issue_unit();
+    for (long long it = 0; it < mine; ++it) {
+        wait_units_in_flight<HR_NSTAGE, 8>((int)(issued - it - 1));   // younger units may stay in flight
+        const unsigned char* sl = ring_ptr + (it % HR_NSTAGE) * HR_UNIT;
+        u64 c[R::CODES][W];
+#pragma unroll
+        for (int g = 0; g < R::NG; ++g) {
+#pragma unroll
+            for (int cc = 0; cc < R::CPL; ++cc) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sl + ((g * 64 + lane) * R::CPL + cc) * 16);
+                if constexpr (W == 1) {
+                    c[2 * g][0] = v.x;
+                    c[2 * g + 1][0] = v.y;
+                } else {
+                    c[g][2 * cc] = v.x;
+                    c[g][2 * cc + 1] = v.y;
+                }
+            }
+        }
+        // the codes are in registers (lgkmcnt(0)): the slot is free for the unit NSTAGE further on
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (issued < mine) issue_unit();
+        compare(c, (gw + it * nwaves) * R::UNIT_CODES);
+    }
+    // the last, partial unit: the wave after the one that took the last whole unit, with guarded register loads
+    const long long tail0 = units * R::UNIT_CODES;
+    if (tail0 < n && gw == units % nwaves) {
+        wait_vmcnt<0>();
+        u64 c[R::CODES][W];
+#pragma unroll
+        for (int i = 0; i < R::CODES; ++i) {
+            const long long row = ring_row<W>(tail0, lane, i);
+#pragma unroll
+            for (int w = 0; w < W; ++w) c[i][w] = row < n ? codes[row * W + w] : 0ull;
+        }
+        compare(c, tail0);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nq; i += HR_WAVES * 64) bcnt[(long long)blockIdx.x * nq + i] = lcnt[i];
+}
+
 // Concatenate the G blocks' mini-lists of a query into keys[q][..] (prefix sum over the fills, no
 // atomics) and publish the total in cnt[q]; a mini-list that overflowed its S slots marks the query
 // (cnt = cap + 1) so that it is recomputed on the exact path.  Grid (nq, COMPACT_SLICES): every
 // workgroup scans all G fills (G <= 2048: eight per thread, wave scan) and copies the lists of its
 // slice -- one workgroup per query with a one-thread prefix loop took 55 us for 32 queries.
 static constexpr int COMPACT_SLICES = 8;
+// map_rows: the mini-lists hold PHYSICAL rows (hamming_ring_kernel); the copy turns them into caller rows.
 __global__ __launch_bounds__(256) void hamming_compact_kernel(const u64* __restrict__ seg,
                                                                const u32* __restrict__ bcnt, int G, int nq, u32 S,
                                                                u64* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
-                                                               long long key_stride) {
+                                                               long long key_stride, int map_rows, RowPerm pm, long long n) {
     __shared__ u32 s_off[2049];
     __shared__ u32 s_wave[4];
     __shared__ u32 s_over;
@@ -326,7 +510,11 @@ __global__ __launch_bounds__(256) void hamming_compact_kernel(const u64* __restr
         const u32 b0 = s_off[g], n_e = s_off[g + 1] - b0;
         const u64* src = seg + ((long long)g * nq + q) * S;
         for (u32 e = threadIdx.x & 7; e < n_e; e += 8)
-            if (b0 + e < cap) keys[(long long)q * key_stride + b0 + e] = src[e];
+            if (b0 + e < cap) {
+                u64 key = src[e];
+                if (map_rows) key = (key & 0xffffffff00000000ull) | (u64)orig_row((long long)(key & 0xffffffffull), pm, n);
+                keys[(long long)q * key_stride + b0 + e] = key;
+            }
     }
     if (threadIdx.x == 0 && blockIdx.y == 0) cnt[q] = s_over ? cap + 1u : total;
 }
@@ -529,49 +717,101 @@ static int select_launch(const u64* keys, const u32* cnt, u32 cap, long long str
     return SQ_OK;
 }
 
-static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k, int* out_dist, long long* out_idx,
-                                 hipStream_t st) {
+// Wait for an event the way stream_wait waits for a stream (poll, then block).
+static hipError_t hamming_event_wait(hipEvent_t ev) {
+    const long long budget_us = g_opt.spin_wait_us;
+    if (budget_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int i = 0; i < 64; ++i) {
+                const hipError_t e = hipEventQuery(ev);
+                if (e != hipErrorNotReady) return e;
+            }
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > budget_us)
+                break;
+        }
+    }
+    return hipEventSynchronize(ev);
+}
+
+template <int W>
+static int ring_launch(const HammingHandle* h, bool nt, int G, const u64* qc, int nqc, const int* thr, u64* seg, u32* bcnt, u32 S,
+                       hipStream_t st) {
+    static bool attr_set[2] = {false, false};
+    const size_t lds = (size_t)HR_WAVES * HR_NSTAGE * HR_UNIT + (size_t)nqc * 4;
+    if (!attr_set[nt ? 1 : 0]) {
+        if (nt)
+            SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hamming_ring_kernel<W, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        else
+            SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hamming_ring_kernel<W, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[nt ? 1 : 0] = true;
+    }
+    if (nt)
+        hipLaunchKernelGGL((hamming_ring_kernel<W, true>), dim3(G), dim3(HR_WAVES * 64), lds, st, h->codes, h->n, h->pmul, qc, nqc, thr,
+                           seg, bcnt, S);
+    else
+        hipLaunchKernelGGL((hamming_ring_kernel<W, false>), dim3(G), dim3(HR_WAVES * 64), lds, st, h->codes, h->n, h->pmul, qc, nqc, thr,
+                           seg, bcnt, S);
+    return SQ_OK;
+}
+
+// Enqueue one search on `st` with the workspace of slot `s`; nothing is waited for.  hamming_resolve() finishes
+// the call: it waits for the kernels, reads the status words and sends overflowing queries down the exact path.
+static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int nq, int k, int* out_dist, long long* out_idx,
+                           hipStream_t st, bool use_event) {
     const long long n = h->n;
     const int W = h->words, bits = W * 64;
     const int kk = (int)(k < n ? k : n);
-    const bool prof = h->opt.profile != 0;
+    const bool prof = h->opt.profile == 1 || (h->opt.profile > 1 && (!use_event || h->async_calls % (unsigned)h->opt.profile == 0));
     u32 cap = h->opt.candidate_cap > 0 ? (u32)h->opt.candidate_cap : 65536u;
     // room for the tie group at the threshold distance (integer distances: the codes AT the threshold can outnumber
     // those below it several times)
     if (h->opt.candidate_cap <= 0 && cap < (u32)std::min<long long>(16ll * kk, 1ll << 30)) cap = (u32)std::min<long long>(16ll * kk, 1ll << 30);
     if (cap < (u32)(2 * kk)) cap = (u32)(2 * kk);
     const bool small = n <= (long long)cap;
-    h->stats = sq_stats_t{};
+    HammingCall& c = s.call;
+    c = HammingCall{};
+    c.qs = qs;
+    c.nq = nq;
+    c.k = k;
+    c.out_dist = out_dist;
+    c.out_idx = out_idx;
+    c.st = st;
+    c.small = small;
+    c.prof = prof;
+    c.use_event = use_event;
+    c.cap = cap;
     if (prof) {
-        for (auto& e : h->ev)
+        for (auto& e : s.ev)
             if (!e) SQ_HIP(hipEventCreate(&e));
-        SQ_HIP(hipEventRecord(h->ev[0], st));
+        SQ_HIP(hipEventRecord(s.ev[0], st));
     }
-    SQ_TRY(h->cnt.reserve((size_t)nq * 4));
-    SQ_TRY(h->thr.reserve((size_t)nq * 4));
-    SQ_TRY(h->out_keys.reserve((size_t)nq * k * 8));
-    SQ_TRY(h->status.reserve((size_t)nq * 4));
-    SQ_TRY(h->status_host.reserve((size_t)nq * 8));
-    u32* hs = reinterpret_cast<u32*>(h->status_host.p);  // [status (nq) | counts (nq)]
+    SQ_TRY(s.cnt.reserve((size_t)nq * 4));
+    SQ_TRY(s.thr.reserve((size_t)nq * 4));
+    SQ_TRY(s.out_keys.reserve((size_t)nq * k * 8));
+    SQ_TRY(s.status.reserve((size_t)nq * 4));
+    SQ_TRY(s.status_host.reserve((size_t)nq * 8));
+    u32* hs = reinterpret_cast<u32*>(s.status_host.p);  // [status (nq) | counts (nq)]
     u32* hs_dev = nullptr;
     SQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs_dev), hs, 0));
-    u32* cnt = h->cnt.as<u32>();
-    int* thr = h->thr.as<int>();
-    u64* okeys = h->out_keys.as<u64>();
-    u32* status = h->status.as<u32>();
+    u32* cnt = s.cnt.as<u32>();
+    int* thr = s.thr.as<int>();
+    u64* okeys = s.out_keys.as<u64>();
+    u32* status = s.status.as<u32>();
     const long long key_stride = small ? n : (long long)cap;
-    SQ_TRY(h->keys.reserve((size_t)nq * key_stride * 8));
-    u64* keys = h->keys.as<u64>();
-    const bool force_fb = h->opt.force_fallback != 0;
+    SQ_TRY(s.keys.reserve((size_t)nq * key_stride * 8));
+    u64* keys = s.keys.as<u64>();
 
     if (small) {
         hipLaunchKernelGGL(fill_u32_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, cnt, (long long)nq, (u32)n);
-        if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
+        if (prof) SQ_HIP(hipEventRecord(s.ev[1], st));
         scan_dispatch(h, qs, nq, thr, keys, cnt, (u32)n, key_stride, /*mode*/ 1, st);
-        if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
-        h->stats.scan_launches = 1;
-        h->stats.bytes_scanned = n * W * 8;
-        SQ_TRY(select_launch(keys, cnt, (u32)n, key_stride, k, nq, okeys, st, h->sort_tmp,
+        if (prof) SQ_HIP(hipEventRecord(s.ev[2], st));
+        c.stats.scan_launches = 1;
+        c.stats.bytes_scanned = n * W * 8;
+        SQ_TRY(select_launch(keys, cnt, (u32)n, key_stride, k, nq, okeys, st, s.sort_tmp,
                              HammingFinalize{cnt, (u32)n, kk, h->id_base, out_dist, out_idx, status, hs_dev, nq}));
     } else {
         int step = h->opt.sample_stride > 0 ? h->opt.sample_stride : 64;
@@ -584,21 +824,39 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
         // and took the exact path: 18 ms per query at 10 M codes, found by bench.py --workload lsh_c3.)
         if (h->opt.sample_stride <= 0)
             while (step > 1 && (long long)step * kk * 8 > (long long)cap) step >>= 1;
-        SQ_TRY(h->hist.reserve((size_t)nq * (bits + 1) * 4));
-        u32* hist = h->hist.as<u32>();
+        SQ_TRY(s.hist.reserve((size_t)nq * (bits + 1) * 4));
+        u32* hist = s.hist.as<u32>();
         SQ_HIP(hipMemsetAsync(hist, 0, (size_t)nq * (bits + 1) * 4, st));
-        if (!(W == 1 || W == 2 || W == 4)) SQ_HIP(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));  // the compaction writes cnt itself
+        const bool stream_ok = W == 1 || W == 2 || W == 4;
+        // LDS-DMA ring (hamming_ring_kernel): HBM bound batches over arrays the MALL cannot hold.  Beyond ~24 queries
+        // the inner loop is VALU bound and the register kernel's 32 waves per CU win.
+        const size_t code_bytes = (size_t)n * W * 8;
+        const bool ring_shape = (W == 1 || W == 2 || W == 4 || W == 8 || W == 16) && (reinterpret_cast<uintptr_t>(h->codes) & 15u) == 0 &&
+                                n * (long long)W * 8 >= 2ll * HR_UNIT * HR_WAVES;
+        const bool ring = ring_shape && (h->opt.hamming_ring == 1 ||
+                                         (h->opt.hamming_ring < 0 && nq <= 24 && code_bytes >= ((size_t)256 << 20)) ||
+                                         (h->opt.hamming_ring < 0 && !stream_ok && nq <= 64));
+        if (!stream_ok && !ring) SQ_HIP(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));  // the compaction writes cnt itself
         hist_dispatch(h, qs, nq, bits, hist, step, st);
         hipLaunchKernelGGL(hamming_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, hist, nq, bits, kk, thr);
-        if (prof) SQ_HIP(hipEventRecord(h->ev[1], st));
-        if (W == 1 || W == 2 || W == 4) {
+        if (prof) SQ_HIP(hipEventRecord(s.ev[1], st));
+        if (stream_ok || ring) {
             // streaming scan into per-(block, query) mini-lists, then a prefix-sum compaction: no global atomics
-            // 8 workgroups per CU (32 waves: the VALU-bound inner loop wants full occupancy); the LDS copy of
-            // the queries (nq * (8W+8) bytes) must fit 8 times, so wide codes take the queries in smaller batches
-            const int qbatch = W == 4 ? 384 : 1024;
-            int G = 8 * cu_count(h->device);
+            // register kernel: 8 workgroups per CU (32 waves: the VALU-bound inner loop wants full occupancy); the LDS copy
+            // of the queries (nq * (8W+8) bytes) must fit 8 times, so wide codes take the queries in smaller batches.
+            // ring kernel: one 512-thread workgroup per CU -- on three quarters of the CUs when calls are pipelined and the
+            // pass is HBM bound: the neighbouring calls' select needs most of a CU's LDS, and such a stream loses
+            // nothing on 192 CUs
+            const int qbatch = ring ? 64 : (W == 4 ? 384 : 1024);
+            const int cus = cu_count(h->device);
+            // (from ~8 queries per pass the ring kernel is VALU bound and wants every CU; the neighbours' short kernels
+            // then simply queue behind it)
+            int G = ring ? (use_event && nq <= 4 ? cus * 3 / 4 : cus) : 8 * cus;
             if (G > 2048) G = 2048;
-            {
+            if (ring) {
+                const long long units = (n * (long long)W * 8) / HR_UNIT;
+                if ((long long)G * HR_WAVES > units) G = (int)std::max<long long>(1, units / HR_WAVES);
+            } else {
                 const long long per_chunk = 256ll * (W == 1 ? 8 : W == 2 ? 4 : 2);
                 const long long nchunks = (n + per_chunk - 1) / per_chunk;
                 if ((long long)G > nchunks) G = (int)nchunks;  // short arrays: fewer, fuller mini-lists
@@ -606,15 +864,25 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
             long long want = 8ll * 128ll * kk / G;  // ~8x the expected fill of a mini-list
             u32 S = 32;
             while ((long long)S < want && S < 4096u) S <<= 1;
-            SQ_TRY(h->bcnt.reserve((size_t)G * nq * 4));
-            u32* bcnt = h->bcnt.as<u32>();
+            SQ_TRY(s.bcnt.reserve((size_t)G * nq * 4));
+            u32* bcnt = s.bcnt.as<u32>();
+            // non-temporal stream for arrays far beyond the MALL (read once per call)
+            const bool nt = code_bytes >= ((size_t)512 << 20);
             for (int q0 = 0; q0 < nq; q0 += qbatch) {
                 const int nqc = nq - q0 < qbatch ? nq - q0 : qbatch;
-                SQ_TRY(h->seg.reserve((size_t)G * nqc * S * 8));
-                u64* seg = h->seg.as<u64>();
+                SQ_TRY(s.seg.reserve((size_t)G * nqc * S * 8));
+                u64* seg = s.seg.as<u64>();
                 const size_t lds = (size_t)nqc * (W * 8 + 8);
                 const u64* qc = qs + (long long)q0 * W;
-                if (W == 1)
+                if (ring) {
+                    switch (W) {
+                        case 1: SQ_TRY(ring_launch<1>(h, nt, G, qc, nqc, thr + q0, seg, bcnt, S, st)); break;
+                        case 2: SQ_TRY(ring_launch<2>(h, nt, G, qc, nqc, thr + q0, seg, bcnt, S, st)); break;
+                        case 4: SQ_TRY(ring_launch<4>(h, nt, G, qc, nqc, thr + q0, seg, bcnt, S, st)); break;
+                        case 8: SQ_TRY(ring_launch<8>(h, nt, G, qc, nqc, thr + q0, seg, bcnt, S, st)); break;
+                        default: SQ_TRY(ring_launch<16>(h, nt, G, qc, nqc, thr + q0, seg, bcnt, S, st)); break;
+                    }
+                } else if (W == 1)
                     hipLaunchKernelGGL((hamming_stream_kernel<1, 8>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
                                        thr + q0, seg, bcnt, S);
                 else if (W == 2)
@@ -624,49 +892,88 @@ static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k,
                     hipLaunchKernelGGL((hamming_stream_kernel<4, 2>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
                                        thr + q0, seg, bcnt, S);
                 hipLaunchKernelGGL(hamming_compact_kernel, dim3(nqc, COMPACT_SLICES), dim3(256), 0, st, seg, bcnt, G, nqc, S,
-                                   keys + (long long)q0 * key_stride, cnt + q0, cap, key_stride);
+                                   keys + (long long)q0 * key_stride, cnt + q0, cap, key_stride, ring ? 1 : 0, h->pmul, n);
             }
         } else {
             scan_dispatch(h, qs, nq, thr, keys, cnt, cap, key_stride, /*mode*/ 0, st);
         }
-        if (prof) SQ_HIP(hipEventRecord(h->ev[2], st));
-        h->stats.scan_launches = 1;
-        h->stats.bytes_scanned = n * W * 8;
-        SQ_TRY(select_launch(keys, cnt, cap, key_stride, k, nq, okeys, st, h->sort_tmp,
+        if (prof) SQ_HIP(hipEventRecord(s.ev[2], st));
+        c.stats.scan_launches = 1;
+        c.stats.bytes_scanned = n * W * 8;
+        SQ_TRY(select_launch(keys, cnt, cap, key_stride, k, nq, okeys, st, s.sort_tmp,
                              HammingFinalize{cnt, cap, kk, h->id_base, out_dist, out_idx, status, hs_dev, nq}));
     }
-    if (prof) SQ_HIP(hipEventRecord(h->ev[3], st));
-    // status words and candidate counts are in pinned host memory once the stream drains (written by the
+    if (prof) SQ_HIP(hipEventRecord(s.ev[3], st));
+    if (use_event) {
+        if (!s.ev_done) SQ_HIP(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+        SQ_HIP(hipEventRecord(s.ev_done, st));
+    }
+    c.force_fb = h->opt.force_fallback != 0;
+    c.pending = true;
+    return SQ_OK;
+}
+
+// Finish the call enqueued on slot `s`: wait for its kernels, collect the statistics and redo every query whose
+// candidate list overflowed on the exact path (synchronously, on the call's stream).  h->stats = this call's.
+static int hamming_resolve(HammingHandle* h, HammingSlot& s) {
+    HammingCall& c = s.call;
+    if (!c.pending) return SQ_OK;
+    c.pending = false;
+    const long long n = h->n;
+    const int W = h->words;
+    const int nq = c.nq, k = c.k;
+    const int kk = (int)(k < n ? k : n);
+    hipStream_t st = c.st;
+    // status words and candidate counts are in pinned host memory once the call has drained (written by the
     // finalisation): the host decides whether any query needs the exact path
-    SQ_HIP(stream_wait(st));
+    SQ_HIP(c.use_event ? hamming_event_wait(s.ev_done) : stream_wait(st));
     SQ_HIP(hipGetLastError());
-    if (prof) {
+    h->stats = c.stats;
+    if (c.prof) {
         float a = 0, b = 0;
-        SQ_HIP(hipEventElapsedTime(&a, h->ev[1], h->ev[2]));
-        SQ_HIP(hipEventElapsedTime(&b, h->ev[0], h->ev[3]));
+        SQ_HIP(hipEventElapsedTime(&a, s.ev[1], s.ev[2]));
+        SQ_HIP(hipEventElapsedTime(&b, s.ev[0], s.ev[3]));
         h->stats.scan_ms = a;
         h->stats.total_ms = b;
     }
+    const u32* hs = reinterpret_cast<const u32*>(s.status_host.p);
+    u32* cnt = s.cnt.as<u32>();
+    int* thr = s.thr.as<int>();
+    u64* okeys = s.out_keys.as<u64>();
+    u32* status = s.status.as<u32>();
     for (int q = 0; q < nq; ++q) h->stats.candidates += hs[nq + q];
     // exact path (candidate overflow): every key of the query, radix-selected from global memory
+    const bool force_fb = c.force_fb || h->opt.force_fallback != 0;
     for (int q = 0; q < nq; ++q) {
-        if (!small && (hs[q] != 0 || force_fb)) {
+        if (!c.small && (hs[q] != 0 || force_fb)) {
             h->stats.fallback_queries++;
             SQ_TRY(h->big_keys.reserve((size_t)n * 8));
             u64* bk = h->big_keys.as<u64>();
             hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, cnt + q, 1ll, (u32)(n > 0xffffffffll ? 0xffffffffu : n));
-            scan_dispatch(h, qs + (long long)q * W, 1, thr, bk, cnt + q, (u32)n, n, /*mode*/ 1, st);
-            SQ_TRY(select_launch(bk, cnt + q, (u32)n, n, k, 1, okeys + (long long)q * k, st, h->sort_tmp,
-                                 HammingFinalize{cnt + q, (u32)n, kk, h->id_base, out_dist + (long long)q * k,
-                                                 out_idx + (long long)q * k, status + q, nullptr, 0}));
+            scan_dispatch(h, c.qs + (long long)q * W, 1, thr, bk, cnt + q, (u32)n, n, /*mode*/ 1, st);
+            SQ_TRY(select_launch(bk, cnt + q, (u32)n, n, k, 1, okeys + (long long)q * k, st, h->fb_sort,
+                                 HammingFinalize{cnt + q, (u32)n, kk, h->id_base, c.out_dist + (long long)q * k,
+                                                 c.out_idx + (long long)q * k, status + q, nullptr, 0}));
             h->stats.scan_launches++;
+            // (one query at a time: big_keys is shared)
+            SQ_HIP(hipStreamSynchronize(st));
+            SQ_HIP(hipGetLastError());
         }
     }
-    if (h->stats.fallback_queries) {
-        SQ_HIP(hipStreamSynchronize(st));
-        SQ_HIP(hipGetLastError());
-    }
     return SQ_OK;
+}
+
+// Finish every asynchronous call still in flight, oldest first.
+static int hamming_sync_all(HammingHandle* h) {
+    for (int j = 0; j < h->depth; ++j)
+        SQ_TRY(hamming_resolve(h, h->slot[(h->async_calls + (unsigned)j) % (unsigned)h->depth]));
+    return SQ_OK;
+}
+
+static int hamming_search_device(HammingHandle* h, const u64* qs, int nq, int k, int* out_dist, long long* out_idx,
+                                 hipStream_t st) {
+    SQ_TRY(hamming_enqueue(h, h->slot[0], qs, nq, k, out_dist, out_idx, st, false));
+    return hamming_resolve(h, h->slot[0]);
 }
 
 // ------------------------------------------------------------------ mutations
@@ -844,6 +1151,31 @@ extern "C" int sq_hamming_search(sq_handle_t hid, const uint64_t* queries, int n
     h->refresh_options();
     SQ_HIP(hipSetDevice(h->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (mem == SQ_MEM_DEVICE_ASYNC) {
+        // The pipelined form (see sq_dense_search): call i is enqueued on its slot's own stream before call i - 1 is
+        // waited for; a call's status words are read -- and its overflowing queries redone -- `depth - 1` calls later.
+        int want = h->opt.hamming_async_depth;
+        want = want < 2 ? 2 : want > HammingHandle::kMaxDepth ? HammingHandle::kMaxDepth : want;
+        if (want != h->depth) {  // a new depth starts from an empty pipeline
+            SQ_TRY(hamming_sync_all(h));
+            h->depth = want;
+            h->async_calls = 0;
+        }
+        HammingSlot& s = h->slot[h->async_calls % (unsigned)h->depth];
+        SQ_TRY(hamming_resolve(h, s));  // (the call `depth` back; normally resolved during an earlier call)
+        if (!s.own) SQ_HIP(hipStreamCreateWithFlags(&s.own, hipStreamNonBlocking));
+        if (h->opt.hamming_async_order) {
+            if (!s.ev_in) SQ_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+            SQ_HIP(hipEventRecord(s.ev_in, st));  // the caller's earlier work on `stream` (the queries) comes first
+            SQ_HIP(hipStreamWaitEvent(s.own, s.ev_in, 0));
+        }
+        SQ_TRY(hamming_enqueue(h, s, reinterpret_cast<const u64*>(queries), nq, k, out_dist, reinterpret_cast<long long*>(out_idx),
+                               s.own, true));
+        h->async_calls++;
+        if (!h->opt.hamming_async_wait) return SQ_OK;
+        return hamming_resolve(h, h->slot[h->async_calls % (unsigned)h->depth]);
+    }
+    SQ_TRY(hamming_sync_all(h));
     if (mem == SQ_MEM_DEVICE) {
         return hamming_search_device(h, reinterpret_cast<const u64*>(queries), nq, k, out_dist,
                                      reinterpret_cast<long long*>(out_idx), st);
@@ -863,11 +1195,22 @@ extern "C" int sq_hamming_search(sq_handle_t hid, const uint64_t* queries, int n
     return SQ_OK;
 }
 
+extern "C" int sq_hamming_sync(sq_handle_t hid) {
+    auto* h = static_cast<HammingHandle*>(lookup_handle(hid, H_HAMMING));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_hamming_sync: unknown handle");
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->refresh_options();
+    SQ_HIP(hipSetDevice(h->device));
+    return hamming_sync_all(h);
+}
+
 extern "C" int sq_hamming_append(sq_handle_t hid, const uint64_t* new_codes, int64_t m, const int64_t* insert_pos) {
     auto* h = static_cast<HammingHandle*>(lookup_handle(hid, H_HAMMING));
     if (!h) return fail(SQ_ERR_INVALID, "sq_hamming_append: unknown handle");
     if (!new_codes || !insert_pos || m <= 0) return fail(SQ_ERR_INVALID, "sq_hamming_append: bad argument");
     std::lock_guard<std::mutex> lock(h->mu);
+    h->refresh_options();
+    SQ_TRY(hamming_sync_all(h));
     if (!h->owned.p) return fail(SQ_ERR_UNSUPPORTED, "sq_hamming_append: the index borrows the caller's device array");
     const long long n_old = h->n, n_new = n_old + m;
     if (n_new >= (1ll << 32)) return fail(SQ_ERR_UNSUPPORTED, "sq_hamming_append: more than 2^32-1 codes per shard");
@@ -894,6 +1237,8 @@ extern "C" int sq_hamming_remove(sq_handle_t hid, const int64_t* ranks, int64_t 
     if (!h) return fail(SQ_ERR_INVALID, "sq_hamming_remove: unknown handle");
     if (!ranks || m <= 0) return fail(SQ_ERR_INVALID, "sq_hamming_remove: bad argument");
     std::lock_guard<std::mutex> lock(h->mu);
+    h->refresh_options();
+    SQ_TRY(hamming_sync_all(h));
     if (!h->owned.p) return fail(SQ_ERR_UNSUPPORTED, "sq_hamming_remove: the index borrows the caller's device array");
     const long long n = h->n;
     if (m >= n) return fail(SQ_ERR_INVALID, "sq_hamming_remove: cannot remove every code (destroy the index instead)");
@@ -931,9 +1276,15 @@ extern "C" int sq_hamming_info(sq_handle_t hid, int64_t* out_n, int* out_words) 
 }
 
 extern "C" int sq_hamming_destroy(sq_handle_t hid) {
-    auto* h = remove_handle(hid, H_HAMMING);
-    if (!h) return fail(SQ_ERR_INVALID, "sq_hamming_destroy: unknown handle");
+    auto* hb = remove_handle(hid, H_HAMMING);
+    if (!hb) return fail(SQ_ERR_INVALID, "sq_hamming_destroy: unknown handle");
+    auto* h = static_cast<HammingHandle*>(hb);
     (void)hipSetDevice(h->device);
+    {
+        std::lock_guard<std::mutex> lock(h->mu);
+        h->refresh_options();
+        (void)hamming_sync_all(h);  // nothing of this handle is left on the device when its buffers go
+    }
     delete h;
     return SQ_OK;
 }

@@ -94,6 +94,7 @@ class _DeviceMirror:
         are not).  False = too many tombstones (over a quarter) or an unknown uuid: the caller drops the mirror."""
         if self._row_of is None:
             self._row_of = {u: i for i, u in enumerate(self.uuids) if u is not None}
+        uuids = list(dict.fromkeys(uuids))       # a uid listed twice leaves once (everything below mutates per entry)
         rows = [self._row_of.get(u) for u in uuids]
         if any(r is None for r in rows) or 4 * (int(self.dead.sum()) + len(rows)) > len(self.uuids):
             return False
@@ -422,7 +423,7 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
                         m.append(uids, mat, pack_bits_msb(np.asarray(hv).astype(bool)))
                         self._mirror_key = self._state_key()
                         appended = True
-                except ValueError:
+                except Exception:      # whatever went wrong half-way: the mirror is rebuilt from the stores, never kept stale
                     appended = False
             if not appended:
                 self._drop_mirror()  # rebuilt from the descriptor set at the next query
@@ -452,7 +453,12 @@ class HipLSHNearestNeighborIndex(NearestNeighborsIndex):
                 self.hash_index.remove_from_index(gone)
             self.descriptor_set.remove_many_descriptors(uids)
             m = self._mirror
-            if m is not None and m.remove(uids):
+            kept = False
+            try:
+                kept = m is not None and m.remove(uids)
+            except Exception:          # the stores have changed already: a half-updated mirror must not answer queries
+                kept = False
+            if kept:
                 self._mirror_key = self._state_key()   # the resident descriptors stay; only the bucket map moved
             else:
                 self._drop_mirror()

@@ -252,3 +252,104 @@ def test_itq_10m_x_128_codes_equal_float64_torch(normalize):
             assert bool((zz.abs().min(dim=1).values <= (1e-6 if normalize else 1e-9) * scale).all())
             bad += int(differ.sum())
     assert bad <= (3000 if normalize else 4)
+    if normalize:
+        # the 3000 above is torch's float32 norm, not the kernel: against numpy's own norm (pairwise float32 sum,
+        # itq.py:185 -- the order itq_norms_kernel claims) on a 1 M-row slice the codes agree as in the other case
+        m = 1 << 20
+        xs = x[:m].cpu().numpy()
+        nrm = np.linalg.norm(xs, ord=2, axis=1, keepdims=True)
+        nrm[nrm == 0] = 1.0
+        v = torch.from_numpy(xs / nrm).to(dev).double() - mean          # float32 division, float64 subtraction (itq.py:404)
+        z = v @ rot
+        code = ((z >= 0).to(torch.int64) << shifts).sum(dim=1)
+        differ = code != out[:m, 0]
+        if bool(differ.any()):
+            zz = z[differ]
+            scale = zz.abs().max(dim=1).values.clamp_min(1e-30)
+            assert bool((zz.abs().min(dim=1).values <= 1e-9 * scale).all())
+        assert int(differ.sum()) <= 4
+
+
+def test_c2_literal_1m_x_128_1024_queries():
+    """BASELINE config 2 at its literal shape: 1 M x 128 float32 N(0,1), 1024 queries, k = 100 -- the
+    sample stride and the select sizing are functions of n, so the 10 M-row tests do not cover it.  32 of the
+    queries against the oracle over the whole matrix (ids and float32 distances bit for bit), no query on the exact
+    path, and the 32-query kernel agreeing with the 1024-query kernel on all of them."""
+    dev = _dev()
+    n, d, k, nq = 1_000_000, 128, 100, 1024
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    db = torch.empty((n, d), dtype=torch.float32, device=dev).normal_(generator=g)
+    q = torch.empty((nq, d), dtype=torch.float32, device=dev).normal_(generator=g)
+    q[7] = db[123_456]
+    index = _lib.DenseIndex(db.data_ptr(), n=n, d=d, device_ptr=True, keepalive=db)
+    dist, ids = _search_dense(index, q, k)
+    assert index.stats()["fallback_queries"] == 0
+    assert ids[7, 0] == 123_456 and dist[7, 0] == 0.0
+    dbh, qh = db.cpu().numpy(), q.cpu().numpy()
+    for j in list(range(0, 1024, 64)) + list(range(5, 21)):
+        rd, ri = O.dense_topk(dbh, qh[j], k)
+        np.testing.assert_array_equal(ids[j], ri, err_msg=f"query {j}")
+        np.testing.assert_array_equal(dist[j].view(np.uint32), rd.view(np.uint32), err_msg=f"query {j}")
+    fb = 0
+    for s in range(0, nq, 32):
+        d32, i32 = _search_dense(index, q[s:s + 32].contiguous(), k)
+        fb += index.stats()["fallback_queries"]
+        np.testing.assert_array_equal(i32, ids[s:s + 32])
+        np.testing.assert_array_equal(d32.view(np.uint32), dist[s:s + 32].view(np.uint32))
+    assert fb == 0
+    index.close()
+
+
+def test_c3_hamming_topk_on_10m_real_itq_codes():
+    """BASELINE config 3's Hamming stage on REAL codes: hash 10 M x 128 descriptors to 64 bits, index the unique codes
+    (row id = rank in unsigned order), top-100 for 32 and for 1024 query codes; integer exact against torch's top-k of
+    (distance, row) keys, no query on the exact path.  (ITQ codes of Gaussian rows are not uniform bit strings: the
+    tie groups and the sampled thresholds differ from the random codes of the other tests.)"""
+    dev = _dev()
+    n, d, bits, k = 10_000_000, 128, 64, 100
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    x = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for s in range(0, n, 1 << 21):
+        x[s:s + (1 << 21)].normal_(generator=g)
+    rot_np, _ = np.linalg.qr(np.random.default_rng(5).standard_normal((d, d)))
+    rot = torch.from_numpy(np.ascontiguousarray(rot_np[:, :bits])).to(dev)
+    mean = x[:100_000].double().mean(dim=0).contiguous()
+    codes = torch.empty((n, 1), dtype=torch.int64, device=dev)
+    _lib.itq_hash_device(x.data_ptr(), 0, n, d, mean.data_ptr(), rot.data_ptr(), bits, _lib.SQ_NORM_NONE, codes.data_ptr(),
+                         _stream())
+    torch.cuda.synchronize()
+    top = torch.tensor(-0x8000000000000000, dtype=torch.int64, device=dev)
+    ucodes = (torch.unique(codes.view(-1) ^ top, sorted=True) ^ top).contiguous()     # ascending as UNSIGNED integers
+    del x, codes
+    m = int(ucodes.numel())
+    assert m > 9_000_000
+    hidx = _lib.HammingIndex(ucodes.data_ptr(), n=m, words=1, device_ptr=True, keepalive=ucodes)
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(77)
+    qc = ucodes[torch.randint(0, m, (1024,), device=dev, generator=gq)].contiguous()
+    qc[1] ^= 5                                         # two bits away from an indexed code
+    rows = torch.arange(m, dtype=torch.int64, device=dev)
+
+    def check(sel, od, oi):
+        for j in sel:
+            key = (_popcount64(ucodes ^ qc[j]) << 32) | rows
+            want = torch.topk(key, k, largest=False, sorted=True).values
+            assert torch.equal(od[j].to(torch.int64), want >> 32), j
+            assert torch.equal(oi[j], want & 0xFFFFFFFF), j
+
+    od32 = torch.empty((32, k), dtype=torch.int32, device=dev)
+    oi32 = torch.empty((32, k), dtype=torch.int64, device=dev)
+    hidx.search_device(qc.data_ptr(), 32, k, od32.data_ptr(), oi32.data_ptr(), _stream())
+    torch.cuda.synchronize()
+    assert hidx.stats()["fallback_queries"] == 0
+    check(range(32), od32, oi32)
+    od = torch.empty((1024, k), dtype=torch.int32, device=dev)
+    oi = torch.empty((1024, k), dtype=torch.int64, device=dev)
+    hidx.search_device(qc.data_ptr(), 1024, k, od.data_ptr(), oi.data_ptr(), _stream())
+    torch.cuda.synchronize()
+    assert hidx.stats()["fallback_queries"] == 0
+    assert torch.equal(od[:32], od32) and torch.equal(oi[:32], oi32)
+    check(range(32, 1024, 16), od, oi)
+    hidx.close()

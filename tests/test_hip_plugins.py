@@ -230,6 +230,25 @@ def test_bruteforce_float64_descriptors_get_original_dtype_distances():
     assert np.asarray(dists).dtype == np.float64 and all(b >= a for a, b in zip(dists, dists[1:]))
 
 
+def test_bruteforce_float64_descriptors_cosine():
+    """The same recompute for the cosine metric: float64 descriptors (SMQTK's default dtype), float32 search, the
+    distances of the n results from the ORIGINAL float64 vectors against the float32 query (faiss.py:776, 818-824
+    with metrics.cosine_distance, utils/metrics.py:89-137), results ordered by them."""
+    rng = np.random.default_rng(32)
+    x = rng.standard_normal((6000, 40)) + 0.3
+    index = HipBruteForceNearestNeighborsIndex(distance_method="cosine")
+    index.build_index(_elems(x))
+    q = rng.standard_normal(40) + 0.3
+    r, dists = index.nn(DescriptorMemoryElement("q").set_vector(q), 30)
+    q32 = q.astype(np.float32)
+    ref_f32 = O.dense_topk(x.astype(np.float32), q32, 30, "cosine")[1]              # the float32 search's choice
+    exact = O.dense_distances(x[ref_f32], q32, "cosine")                            # float64 rows, float32 query
+    order = np.argsort(exact, kind="stable")
+    assert [e.uuid() for e in r] == [int(ref_f32[i]) for i in order]
+    np.testing.assert_allclose(np.asarray(dists), exact[order], rtol=1e-12, atol=1e-15)
+    assert np.asarray(dists).dtype == np.float64 and all(b >= a for a, b in zip(dists, dists[1:]))
+
+
 def test_bruteforce_matches_reference_golden(golden):
     g = golden("g5_dense_nn.npz")
     n, d, nq, seed, dist, dt = GI.DENSE_CASES["nrm128"]

@@ -15,12 +15,23 @@ P1=$(pick SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
 P2=$(pick SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS)
 P3=$(pick SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT)
 i=0
-# optional cache-side passes: PMC_EXTRA="TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY;TCC_HIT TCC_MISS" (passes separated by ';')
-IFS=';' read -r -a EXTRA <<< "${PMC_EXTRA:-}"
+# optional cache-side passes: PMC_EXTRA="TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY;TCC_HIT TCC_MISS" (passes separated by ';').
+# Every extra pass goes through pick() like P1-P3: a counter gfx950 does not have (TA_BUSY ...) is dropped with a
+# message -- handed to `rocprofv3 --pmc` it aborts the profiler (signal 6) before the program starts.
+IFS=';' read -r -a EXTRA_RAW <<< "${PMC_EXTRA:-}"
+EXTRA=()
+for E in "${EXTRA_RAW[@]}"; do
+  [ -z "$E" ] && continue
+  # shellcheck disable=SC2086
+  F=$(pick $E)
+  for c in $E; do have $c || echo "PMC_EXTRA: counter $c is not known to rocprofv3 -L on this device: dropped"; done
+  if [ -z "$F" ]; then echo "PMC_EXTRA pass '$E': nothing left, skipped"; else EXTRA+=("$F"); fi
+done
 for P in "$P1" "$P2" "$P3" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "${EXTRA[@]}"; do
   i=$((i+1))
   [ -z "$P" ] && continue
   echo "pass $i: $P"
+  # shellcheck disable=SC2086
   rocprofv3 --pmc $P --kernel-trace -d $OUT/pmc$i -o pmc --output-format csv -- "$@" > $OUT/pmc$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pmc$i.log; }
 done
 python3 - "$OUT" "$KSUB" <<'PY'
