@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--workload", choices=["bruteforce", "lsh_c3", "c4_cosine_shard", "c5_hamming_shard"], default="bruteforce")
     ap.add_argument("--query-batches", type=int, default=8,
                     help="distinct query batches the timed steps rotate through (1 = the same queries every step)")
+    ap.add_argument("--preroll-ms", type=float, default=30.0,
+                    help="untimed pipelined steps for this long before the warm-up steps (start-up transient of the device; 0 = none)")
     ap.add_argument("--profile-every", type=int, default=0,
                     help="library hipEvents on every N-th search of the timed region (0 = 1 on one GPU, 4 on shards)")
     ap.add_argument("--data", choices=["normal", "uniform", "clustered", "nonneg"], default="normal")
@@ -248,6 +250,15 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         torch.cuda.synchronize()
 
     run = Runner(nq, batches)
+    # Pre-roll (untimed, disclosed in config.preroll_ms): ~30 ms of the same pipelined steps before the W warm-up steps.
+    # After the index build and the host-side setup the first ~10 ms of back-to-back searches run measurably slower
+    # (a 20-step run read 0.44 ms per step where the same process reads 0.41 on its second 20 steps,
+    # tools/step_sweep.py REPS=...): with a 9 ms timed region that start-up transient would be most of the figure.
+    t_pre = time.perf_counter()
+    while args.preroll_ms > 0 and (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
+        for _ in range(8):
+            run.step()
+    run.drain()
     for _ in range(args.warmup):
         run.step()
     run.drain()
@@ -463,6 +474,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                                        if args.scaling == "strong" else
                                        "weak: fixed rows PER GPU (the BASELINE config's shard), the same queries per step at every N"),
                 "search_calls": f"pipelined (SQ_MEM_DEVICE_ASYNC, {depth} calls in flight)" if use_async else "one blocking call per step",
+                "preroll_ms": args.preroll_ms,
                 "results_lag_steps": results_lag,
                 "results_lag_note": "steps between a batch going in and its final (N > 1: merged) result coming out; every "
                                     "result of the timed steps is final and collected before the closing fence",

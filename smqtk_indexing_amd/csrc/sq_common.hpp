@@ -54,6 +54,7 @@ struct Options {
     int force_fallback = 0;
     int dense_stages = 0;    // 0 = auto (LDS ring depth of the dense scan)
     int dense_blocks = 0;    // 0 = auto (row blocks of the dense scan grid)
+    int dense_sample_blocks = 0;  // pipelined one-group searches: workgroups of the SAMPLE pass; 0 = auto (the CUs the full pass leaves free), -1 = as many as the full pass, N = N
     int dense_debug = 0;     // measurement only (see DenseScanArgs::debug)
     int dense_waves = 0;     // 0 = auto, 4 or 8 waves per scan workgroup
     int dense_qt = 0;        // 0 = auto, 1 / 2 / 4 query tiles per scan wave
@@ -70,6 +71,7 @@ struct Options {
     int dense_nt = -1;           // non-temporal LDS-DMA of the dense scan's row stream (launches of one query group): -1 = automatic, 0 = never, 1 = every byte
     int dense_nt_keep_mb = 0;    // one-tile dense scan, automatic mode: MB at the head of the scan copy that keep the default cache policy (0 = 192)
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
+    int dense_fused_prep = 1;    // 1 = L2 searches of one query tile build the query planes inside the scan kernels (no prep launch); 0 = dense_prep_queries_kernel
     int dense_mid_tier = 1;      // 1 = queries the bf16 filter could not certify get a second, tighter filter pass (three bf16 planes of the rows built on the fly) before the exact all-rows path; 0 = straight to the exact path
     int hamming_async_depth = 2; // asynchronous Hamming searches in flight (2..4), as dense_async_depth
     int hamming_async_wait = 1;  // as dense_async_wait
@@ -131,10 +133,12 @@ struct DevBuf {
 struct HostPinned {
     void* p = nullptr;
     size_t cap = 0;
+    void* dev = nullptr;   // the block's device address (looked up once per allocation: device_ptr)
     int reserve(size_t bytes) {
         if (bytes <= cap) return SQ_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr;
+        dev = nullptr;
         cap = 0;
         hipError_t e = hipHostMalloc(&p, bytes + 256, hipHostMallocDefault);
         if (e != hipSuccess) {
@@ -144,9 +148,22 @@ struct HostPinned {
         cap = bytes + 256;
         return SQ_OK;
     }
+    // device address of the block (a runtime call of a few microseconds: cached per allocation)
+    int device_ptr(void** out) {
+        if (!dev) {
+            hipError_t e = hipHostGetDevicePointer(&dev, p, 0);
+            if (e != hipSuccess) {
+                dev = nullptr;
+                return fail(SQ_ERR_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
+            }
+        }
+        *out = dev;
+        return SQ_OK;
+    }
     void release() {
         if (p) (void)hipHostFree(p);
         p = nullptr;
+        dev = nullptr;
         cap = 0;
     }
 };

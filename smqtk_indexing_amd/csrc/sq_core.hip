@@ -82,6 +82,7 @@ int Options::*option_member(const char* name) {
         {"force_fallback", &Options::force_fallback},
         {"dense_stages", &Options::dense_stages},
         {"dense_blocks", &Options::dense_blocks},
+        {"dense_sample_blocks", &Options::dense_sample_blocks},
         {"dense_debug", &Options::dense_debug},
         {"dense_waves", &Options::dense_waves},
         {"dense_qt", &Options::dense_qt},
@@ -99,6 +100,7 @@ int Options::*option_member(const char* name) {
         {"dense_nt", &Options::dense_nt},
         {"dense_nt_keep_mb", &Options::dense_nt_keep_mb},
         {"dense_mid_tier", &Options::dense_mid_tier},
+        {"dense_fused_prep", &Options::dense_fused_prep},
         {"hamming_async_depth", &Options::hamming_async_depth},
         {"hamming_async_wait", &Options::hamming_async_wait},
         {"hamming_async_order", &Options::hamming_async_order},

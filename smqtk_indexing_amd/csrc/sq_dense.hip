@@ -81,7 +81,7 @@ struct DenseHandle : HandleBase {
     double xn2_max = 0.0;       // max squared row norm (error bound of the L2 filter)
     DevBuf norms1;  // L2: |x|^2 (1 - alpha) for one query plane (`norms`: two planes)
     DevBuf zeros;   // cosine: the 32 zero "norms" every tile of an AGPR-configuration scan starts from (norm_step 0)
-    static constexpr int kMaxDepth = 4;
+    static constexpr int kMaxDepth = 6;
     DenseSlot slot[kMaxDepth];
     int depth = 2;                       // asynchronous calls in flight (option dense_async_depth, fixed while any is)
     unsigned long long async_calls = 0;  // asynchronous calls so far (slot = calls % depth)
@@ -304,7 +304,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
     // finalisation (no copy launch): [cnt (nq_pad) | status (nq)]
     u32* hs_raw = reinterpret_cast<u32*>(s.status_host.p);
     u32* hs_raw_dev = nullptr;
-    SQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs_raw_dev), hs_raw, 0));
+    SQ_TRY(s.status_host.device_ptr(reinterpret_cast<void**>(&hs_raw_dev)));
     u32* hs_dev = hs_raw_dev + nq_pad;
     // error bound of the bf16 filter score (sq_dense_exact.hpp filter_eps):
     //   products: |x q' - x_hi (q'_hi + q'_lo)| <= (2^-8 + 2^-15) |x||q'|, q' = -2q  ->  eps_a = 2^-7 + 2^-14 (times X|q|)
@@ -390,9 +390,23 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         SQ_TRY(s.wave_cnt.reserve((size_t)n_waves * 8));
         SQ_TRY(s.q_al.reserve((size_t)nq * ldq * 4));
         u32* oflag = s.oflag.as<u32>();
-        hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, q, nq, d, d_pad, h->metric, qs,
-                           qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq, h->center.p ? h->center.as<float>() : nullptr);
+        // L2, one query tile per wave (the HBM-bound configuration a pipelined step runs): no prep launch -- the scan
+        // kernels build the planes of their query tile themselves and the threshold kernel's prologue does the rest
+        // (DenseScanArgs::raw_q, DenseThrPost).  The head of a call is then sample pass -> threshold: on a 1.25 M-row
+        // shard the three-launch head (prep 6-27 us beside the neighbours' kernels, sample, threshold) no longer
+        // fitted under the previous call's 59 us scan, and the scans did not run back to back.
+        const bool fused_prep = !cosine && qt == 1 && qp == 2 && h->opt.dense_fused_prep != 0;
+        const float* centerp = h->center.p ? h->center.as<float>() : nullptr;
+        if (!fused_prep)
+            hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, q, nq, d, d_pad, h->metric, qs,
+                               qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq, centerp);
         DenseScanArgs a{};
+        if (fused_prep) {
+            a.raw_q = q;
+            a.raw_nq = nq;
+            a.raw_d = d;
+            a.center = centerp;
+        }
         a.scan = h->scan.as<uint4>();
         a.norms = cosine ? nullptr : (qp == 1 ? h->norms1.as<float>() : h->norms.as<float>());  // n' of this plane count
         a.norm_step = 1;
@@ -424,13 +438,37 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         a.tile_step = stride;
         a.n_sel = ns_tiles;
         a.nrb = nrb;
+        // Pipelined one-group calls: the sample pass is a scan kernel too (one workgroup wants most of a CU's LDS), so on
+        // as many workgroups as the full pass it cannot run BESIDE the neighbouring call's full pass (192 of the 256
+        // CUs) -- its tail queues behind that pass and the two scans of a step serialise (a 1.25 M-row shard: 16 + 63 us
+        // of an 83 us step).  On the spare quarter of the CUs it runs wholly under the neighbour's full pass.
+        if (use_event && h->opt.dense_async_streams == 2 && nqt == 1 && h->opt.dense_blocks <= 0) {
+            int sb = h->opt.dense_sample_blocks > 0 ? h->opt.dense_sample_blocks : (h->opt.dense_sample_blocks < 0 ? nrb : cus - nrb);
+            sb = (sb + 7) / 8 * 8;
+            if (sb >= 8 && sb < a.nrb) a.nrb = sb;
+        }
         {
             const long long work = sample_runs ? (ns_tiles + 3) / 4 : ns_tiles;  // runs / tiles a wave takes at a time
             if (work < (long long)nrb * wv) a.nrb = (int)(((work + wv - 1) / wv + 7) / 8 * 8);
         }
         SQ_TRY(scan_launch<true>(h->opt, a, d_pad, qt, qp, st));
-        hipLaunchKernelGGL((kth_threshold_f32_kernel<DenseThrPost>), dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr,
-                           DenseThrPost{qn2, cosine ? 1 : 0, filter_bound(cosine ? 1 : 0, eps_a, eps_b, h->xn2_max)});
+        {
+            DenseThrPost tp{qn2, cosine ? 1 : 0, filter_bound(cosine ? 1 : 0, eps_a, eps_b, h->xn2_max)};
+            if (fused_prep) {
+                tp.raw_q = q;
+                tp.nq = nq;
+                tp.nq_pad = nq_pad;
+                tp.d = d;
+                tp.ldq = ldq;
+                tp.center = centerp;
+                tp.qn2_out = qn2;
+                tp.thr_out = thr;
+                tp.cnt = cnt;
+                tp.oflag = oflag;
+                tp.q_al = s.q_al.as<float>();
+            }
+            hipLaunchKernelGGL((kth_threshold_f32_kernel<DenseThrPost>), dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr, tp);
+        }
         // full pass
         a.tile_step = 1;
         a.n_sel = n_tiles;
@@ -509,7 +547,7 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
     u32* hs_raw = reinterpret_cast<u32*>(s.status_host.p);
     u32* hs = hs_raw + c.nq_pad;
     u32* hs_raw_dev = nullptr;
-    SQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs_raw_dev), hs_raw, 0));
+    SQ_TRY(s.status_host.device_ptr(reinterpret_cast<void**>(&hs_raw_dev)));
     u32* hs_dev = hs_raw_dev + c.nq_pad;
     const size_t l2_lds = (size_t)((d + 3) / 4 * 4) * 4;
     h->stats = c.stats;

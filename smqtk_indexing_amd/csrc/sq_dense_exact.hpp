@@ -786,10 +786,49 @@ __device__ __host__ __forceinline__ FilterBound filter_bound(int cosine, double 
 //       <= U = T + (2alpha + eps_b) min(rho^2, X^2) + beta|q|^2, and a row with s <= U has s~' <= U + beta|q|^2.
 //       (+ 4e-6 |T + |q|^2|: rounding of the float32 numpy-order distance the certification compares with.)
 //   cosine: T' = T + 2 eps.
+// With `raw_q` set the threshold kernel's prologue does what is left of dense_prep_queries_kernel for query q (the bf16
+// planes are built by the scan kernel itself, DenseScanArgs::raw_q): |q - c|^2 in float64, the candidate counter, the
+// overflow flag, the aligned float32 copy the re-rank reads, and the state of the padding queries of the last tile.
 struct DenseThrPost {
     const double* qn2;
     int cosine;
     FilterBound fb;
+    // fused prep (L2 only; nullptr: dense_prep_queries_kernel ran before the sample pass)
+    const float* raw_q = nullptr;
+    int nq = 0, nq_pad = 0, d = 0, ldq = 0;
+    const float* center = nullptr;
+    double* qn2_out = nullptr;
+    float* thr_out = nullptr;
+    u32* cnt = nullptr;
+    u32* oflag = nullptr;
+    float* q_al = nullptr;
+    __device__ __forceinline__ void prologue(int q, double* red) const {
+        if (!raw_q) return;
+        const int T = blockDim.x;
+        for (int i = threadIdx.x; i < ldq; i += T) q_al[(long long)q * ldq + i] = i < d ? raw_q[(long long)q * d + i] : 0.f;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < d; i += T) {
+            const float v = raw_q[(long long)q * d + i];
+            const float c = center ? __fsub_rn(v, center[i]) : v;
+            acc += (double)c * (double)c;
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < (T >> 6); ++w) tot += red[w];
+            qn2_out[q] = tot;
+            cnt[q] = 0u;
+            if (q == 0) *oflag = 0u;
+            for (int p = nq + q; p < nq_pad; p += gridDim.x) {  // padding queries of the last tile: nothing passes
+                qn2_out[p] = 0.0;
+                thr_out[p] = -__builtin_inff();
+                cnt[p] = 0u;
+            }
+        }
+        __syncthreads();  // qn2[q] is read by the thread that publishes the threshold
+    }
     __device__ __forceinline__ float operator()(int q, float t) const {
         if (!(t < __builtin_inff())) return t;
         double slack;

@@ -258,6 +258,13 @@ struct DenseScanArgs {
     int nqt;                // groups of QT query tiles (QT = template parameter of the launch)
     int nrb;                // row blocks (multiple of 8 when nqt > 1)
     int debug;              // measurement only: 1 = skip LDS reads + MFMA, 2 = stop the DMA after the first ring fill
+    // Fused query prep (L2, one query tile per wave): the kernel builds the bf16 planes of its query tile itself from
+    // the caller's float32 queries -- (q - c) * -2, split exactly as dense_prep_queries_kernel splits it -- instead of
+    // reading a prepared copy: one launch less at the head of a call (what remains of the prep -- |q - c|^2, counters,
+    // the aligned copy for the re-rank -- is the prologue of the threshold kernel, DenseThrPost).  nullptr: `qs`.
+    const float* raw_q;     // [raw_nq][raw_d] float32
+    int raw_nq, raw_d;
+    const float* center;    // [d_pad] or nullptr
 };
 
 typedef __attribute__((address_space(3))) u32 lds_u32;
@@ -453,9 +460,39 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_scan_kernel(Dense
     {
         const uint4* qsrc = a.qs + (long long)qt * TILE_ROWS * (DPAD / 4);
         constexpr int cpr = DPAD / 4;
+        bool fused = false;
+        if constexpr (!AB) fused = a.raw_q != nullptr;
         for (int c = threadIdx.x; c < QT * TILE_ROWS * cpr; c += WAVES * 64) {
             const int r = c / cpr, ch = c - r * cpr;
-            const uint4 v = qsrc[c];
+            uint4 v;
+            if (fused) {
+                // chunk ch of query row r: k-unit ch >> 5, plane (ch >> 4) & 1, 8 elements from 16 s + 8 h
+                // (the layout and the arithmetic of dense_prep_queries_kernel, scale -2)
+                const int qi = qt * TILE_ROWS + r;
+                const int unit = ch >> 5, pl = (ch >> 4) & 1, cc = ch & 15;
+                const int k0 = unit * KT + 16 * (cc >> 1) + 8 * (cc & 1);
+                u32 w[4];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    u32 half[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int k = k0 + j + e;
+                        float x = 0.f;
+                        if (qi < a.raw_nq && k < a.raw_d) {
+                            const float qv = a.raw_q[(long long)qi * a.raw_d + k];
+                            x = -2.0f * (a.center ? __fsub_rn(qv, a.center[k]) : qv);
+                        }
+                        u32 hi, lo;
+                        bf16_split(x, hi, lo);
+                        half[e] = pl ? lo : hi;
+                    }
+                    w[j >> 1] = half[0] | (half[1] << 16);
+                }
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+                v = qsrc[c];
+            }
             const int sw = (ch & ~15) | ((ch & 15) ^ (r & 15));
             *reinterpret_cast<uint4*>(smem + (u32)r * DPAD * 4 + sw * 16) = v;
         }

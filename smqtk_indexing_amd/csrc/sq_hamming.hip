@@ -795,7 +795,7 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
     SQ_TRY(s.status_host.reserve((size_t)nq * 8));
     u32* hs = reinterpret_cast<u32*>(s.status_host.p);  // [status (nq) | counts (nq)]
     u32* hs_dev = nullptr;
-    SQ_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hs_dev), hs, 0));
+    SQ_TRY(s.status_host.device_ptr(reinterpret_cast<void**>(&hs_dev)));
     u32* cnt = s.cnt.as<u32>();
     int* thr = s.thr.as<int>();
     u64* okeys = s.out_keys.as<u64>();

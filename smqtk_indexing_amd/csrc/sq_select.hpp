@@ -396,6 +396,7 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
 // slack there, sq_dense_exact.hpp: DenseThrPost).
 struct KthIdentity {
     __device__ __forceinline__ float operator()(int, float t) const { return t; }
+    __device__ __forceinline__ void prologue(int, double*) const {}
 };
 
 __device__ __forceinline__ void bitonic_sort_f32_lds(float* sk, int P) {
@@ -430,11 +431,13 @@ static __global__ __launch_bounds__(1024) void kth_threshold_f32_kernel(const fl
     __shared__ u32 red_c[16];
     __shared__ u32 sh_b, sh_below, sh_cin, sh_cnt;
     __shared__ float sh_t0;
+    __shared__ double pre_red[16];
     const int q = blockIdx.x;
     const int T = blockDim.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = T >> 6;
     const float* s = scores + (long long)q * ns;
     const float INF = __builtin_inff();
+    post.prologue(q, pre_red);  // (what a caller needs done once per query before the threshold is used: see DenseThrPost)
 
     if (k <= T && T <= LCAP) {
         constexpr int U = 8;      // loads in flight per thread when streaming

@@ -19,7 +19,13 @@ st = torch.cuda.current_stream().cuda_stream
 od = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(4)]   # (up to dense_async_depth 4 in flight)
 oi = [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(4)]
 
-def run(steps=60):
+STEPS = int(os.environ.get("STEPS", 60))
+DEPTH = int(os.environ.get("DEPTH", 0))
+if DEPTH:
+    _lib.set_option("dense_async_depth", DEPTH)
+
+
+def run(steps=STEPS):
     for i in range(6):
         idx.search_device_async(q.data_ptr(), nq, k, od[i & 3].data_ptr(), oi[i & 3].data_ptr(), st)
     idx.sync(); torch.cuda.synchronize()
@@ -41,6 +47,8 @@ def run_sync(steps=30):
 
 print(f"blocking calls: {run_sync():.4f} ms")
 print(f"default: {run():.4f} ms  cands/q {idx.stats()['candidates'] / nq:.0f}")
+if os.environ.get("REPS"):
+    print("repeated:", " ".join(f"{run():.4f}" for _ in range(int(os.environ["REPS"]))))
 for arg in sys.argv[1:]:
     name, vals = arg.split("=")
     for v in vals.split(","):
