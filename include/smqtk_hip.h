@@ -84,6 +84,8 @@ typedef struct sq_stats {
     int64_t fallback_queries; /* queries that took the exact full-keys path */
     int64_t bytes_scanned; /* algorithmic bytes the scan streamed (rows * row bytes * passes) */
     double rerank_ms;      /* last dense search: duration of the exact re-rank kernel (when profiling is on; 0 otherwise) */
+    int64_t mid_tier_queries; /* last dense search: queries the first filter could not certify that took the second,
+                               * tighter filter pass; those it could not certify either are in fallback_queries */
 } sq_stats_t;
 
 /* ------------------------------------------------------------------ misc */

@@ -64,6 +64,7 @@ class SqStats(ctypes.Structure):
         ("fallback_queries", ctypes.c_int64),
         ("bytes_scanned", ctypes.c_int64),
         ("rerank_ms", ctypes.c_double),
+        ("mid_tier_queries", ctypes.c_int64),
     ]
 
 

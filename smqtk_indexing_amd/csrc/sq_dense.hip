@@ -28,6 +28,7 @@
 
 #include "sq_dense_exact.hpp"
 #include "sq_dense_scan.hpp"
+#include "sq_dense_mid.hpp"
 
 namespace sq {
 
@@ -87,10 +88,12 @@ struct DenseHandle : HandleBase {
     unsigned long long async_calls = 0;  // asynchronous calls so far (slot = calls % depth)
     // workspace shared by all calls: host-memory staging, the exact path (runs synchronously), index build
     DevBuf q_dev, out_dist_dev, out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch, fb_cnt, fb_sort;
+    DevBuf mid_q, mid_planes, mid_small, mid_qal, mid_wave_out, mid_wave_cnt, mid_keys, mid_out, mid_sample;  // the middle tier (synchronous)
     PinnedStage stage;
     ~DenseHandle() override {
         for (DevBuf* b : {&owned, &scan, &norms, &norms1, &zeros, &center, &cos_nx, &q_dev, &out_dist_dev, &out_idx_dev, &big_keys,
-                          &fb_sample, &fb_keys, &fb_out, &scratch, &fb_cnt, &fb_sort})
+                          &fb_sample, &fb_keys, &fb_out, &scratch, &fb_cnt, &fb_sort, &mid_q, &mid_planes, &mid_small, &mid_qal,
+                          &mid_wave_out, &mid_wave_cnt, &mid_keys, &mid_out, &mid_sample})
             b->release();
         for (auto& sl : slot) sl.release();
         stage.release();
@@ -581,6 +584,115 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
     for (int qi = 0; qi < nq; ++qi)
         if (all_fallback || (!small && (hs[qi] != 0 || force_fb))) todo.push_back(qi);
     if (todo.empty()) return SQ_OK;
+    // ---- middle tier (sq_dense_mid.hpp): the uncertified queries of a filtered L2 call, 32 per pass over the float32
+    // rows, scored with 64 times less slack; whatever it certifies is final, the rest goes on to the exact path
+    if (!all_fallback && !small && !force_fb && !cosine && h->opt.dense_mid_tier != 0 && d % 64 == 0 && d <= 512 &&
+        (reinterpret_cast<uintptr_t>(h->db) & 15u) == 0 && (h->ld & 3) == 0 && h->norms.p != nullptr) {
+        const int d_pad = h->d_pad;
+        const int ldq = (d + 3) / 4 * 4;
+        const double eps_b_mid = (4.0 * d_pad + 8.0) * 1.1920928955078125e-07;
+        const FilterBound fb_mid = filter_bound(0, kEpsAMid, eps_b_mid, h->xn2_max);
+        const double alpha1 = filter_bound(0, kEpsA2, dense_eps_b(d_pad), 0.0).alpha;
+        float c1 = (float)((1.0 - fb_mid.alpha) / (1.0 - alpha1) * (1.0 - 4.8e-7));
+        const int waves = (size_t)TILE_ROWS * d_pad * 4 + (size_t)d_pad * 4 + (size_t)8 * MID_NSTAGE * MID_SLOT_BYTES <= 160 * 1024 - 64 ? 8 : 4;
+        const size_t mid_lds = (size_t)TILE_ROWS * d_pad * 4 + (size_t)d_pad * 4 + (size_t)waves * MID_NSTAGE * MID_SLOT_BYTES;
+        const int cus = cu_count(h->device);
+        const long long n_tiles = (n + 31) / 32;
+        int nrb = cus;
+        if ((long long)nrb * waves > n_tiles) nrb = (int)((n_tiles + waves - 1) / waves);
+        const long long n_waves = (long long)nrb * waves;
+        const u32 wave_cap = 2048;
+        SQ_TRY(h->mid_q.reserve((size_t)MID_MAX_Q * d * 4));
+        SQ_TRY(h->mid_planes.reserve((size_t)MID_MAX_Q * d_pad * 4));
+        // [qn2 f64 x32][thr f32 x32][cnt u32 x32][oflag u32 x16][qmap i32 x32]
+        SQ_TRY(h->mid_small.reserve(32 * 8 + 32 * 4 + 32 * 4 + 64 + 32 * 4));
+        SQ_TRY(h->mid_qal.reserve((size_t)MID_MAX_Q * ldq * 4));
+        SQ_TRY(h->mid_wave_out.reserve((size_t)n_waves * wave_cap * 8));
+        SQ_TRY(h->mid_wave_cnt.reserve((size_t)n_waves * 8));
+        SQ_TRY(h->mid_keys.reserve((size_t)MID_MAX_Q * cap * 8));
+        SQ_TRY(h->mid_out.reserve((size_t)MID_MAX_Q * k * 8));
+        double* m_qn2 = h->mid_small.as<double>();
+        float* m_thr = reinterpret_cast<float*>(m_qn2 + 32);
+        u32* m_cnt = reinterpret_cast<u32*>(m_thr + 32);
+        u32* m_oflag = m_cnt + 32;
+        int* m_map = reinterpret_cast<int*>(m_oflag + 16);
+        static bool attr8 = false, attr4 = false;
+        if (waves == 8 && !attr8) {
+            SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_mid_scan_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr8 = true;
+        }
+        if (waves == 4 && !attr4) {
+            SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_mid_scan_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr4 = true;
+        }
+        // sample of true scores: every mid_stride-th row (about 64 k candidates per query pass the bound it gives)
+        long long mid_stride = std::min<long long>(64, std::min<long long>((long long)cap / (8ll * kk), n / (8ll * kk)));
+        if (mid_stride < 1) mid_stride = 1;
+        const long long mid_ns = (n + mid_stride - 1) / mid_stride;
+        const size_t mid_sample_lds = (size_t)d * 33 * 4;
+        SQ_TRY(h->mid_sample.reserve((size_t)MID_MAX_Q * mid_ns * 4));
+        {
+            static bool attr_s = false;
+            if (!attr_s) {
+                SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_mid_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           512 * 33 * 4));
+                attr_s = true;
+            }
+        }
+        std::vector<int> left;
+        for (size_t t0 = 0; t0 < todo.size(); t0 += MID_MAX_Q) {
+            MidSelection sel{};
+            sel.count = (int)std::min<size_t>(MID_MAX_Q, todo.size() - t0);
+            for (int j = 0; j < MID_MAX_Q; ++j) sel.idx[j] = todo[t0 + (size_t)(j < sel.count ? j : 0)];
+            hipLaunchKernelGGL(dense_mid_gather_kernel, dim3(MID_MAX_Q), dim3(128), 0, st, q, d, sel, h->mid_q.as<float>(), m_map);
+            hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(MID_MAX_Q), dim3(256), 0, st, h->mid_q.as<float>(), sel.count, d, d_pad,
+                               h->metric, h->mid_planes.as<uint4>(), m_qn2, m_thr, m_cnt, m_oflag, h->mid_qal.as<float>(), ldq,
+                               h->center.p ? h->center.as<float>() : nullptr);
+            hipLaunchKernelGGL(dense_mid_sample_kernel, dim3((unsigned)((mid_ns + 7) / 8)), dim3(256), mid_sample_lds, st, h->db, h->ld, d, n,
+                               mid_stride, mid_ns, (const float*)h->mid_q.as<float>(), (const double*)m_qn2, h->mid_sample.as<float>());
+            hipLaunchKernelGGL((kth_threshold_f32_kernel<DenseMidThrPost>), dim3(sel.count), dim3(1024), 0, st, h->mid_sample.as<float>(),
+                               mid_ns, kk, m_thr,
+                               DenseMidThrPost{m_map, (const float*)out_dist, (const u32*)hs_dev, k, kk, m_qn2, fb_mid.beta});
+            DenseMidArgs a{};
+            a.x = h->db;
+            a.n = n;
+            a.ld = h->ld;
+            a.d = d;
+            a.center = h->center.p ? h->center.as<float>() : nullptr;
+            a.norms = h->norms.as<float>();
+            a.norm_scale = c1;
+            a.qs = h->mid_planes.as<uint4>();
+            a.d_pad = d_pad;
+            a.thr = m_thr;
+            a.wave_out = h->mid_wave_out.as<uint2>();
+            a.wave_cnt = h->mid_wave_cnt.as<u32>();
+            a.wave_cap = wave_cap;
+            a.n_tiles = n_tiles;
+            a.nrb = nrb;
+            if (waves == 8)
+                hipLaunchKernelGGL((dense_mid_scan_kernel<8>), dim3(nrb), dim3(512), mid_lds, st, a);
+            else
+                hipLaunchKernelGGL((dense_mid_scan_kernel<4>), dim3(nrb), dim3(256), mid_lds, st, a);
+            const int wpb = 2;
+            const size_t rr_lds = ldq <= 156 ? (size_t)32 * (ldq + 4) * 4 : 0;
+            hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, st, h->db, h->ld, d,
+                               h->mid_qal.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, sel.count, TILE_ROWS,
+                               h->mid_keys.as<u64>(), m_cnt, cap, m_oflag, 0);
+            DenseFinalizeL2 fin{m_cnt, cap, kk, h->id_base, m_thr, m_qn2, fb_mid.beta, 1, (float*)out_dist, out_idx, hs_dev, nullptr, m_oflag, 0};
+            fin.qmap = m_map;
+            SQ_TRY(select_launch_t<u64>(h->mid_keys.as<u64>(), m_cnt, cap, (long long)cap, k, sel.count, h->mid_out.as<u64>(), fin, st,
+                                        h->fb_sort));
+            h->stats.scan_launches++;
+            h->stats.bytes_scanned += n * (long long)d * 4;
+            h->stats.mid_tier_queries += sel.count;
+            SQ_HIP(stream_wait(st));  // the status words of these queries are in hs now
+            SQ_HIP(hipGetLastError());
+            for (int j = 0; j < sel.count; ++j)
+                if (hs[sel.idx[j]] != 0) left.push_back(sel.idx[j]);
+        }
+        todo.swap(left);
+        if (todo.empty()) return SQ_OK;
+    }
     // group size: the key arrays of a group stay under 4 GB; rows beyond the group kernel's depth go one by one
     int gmax = (int)std::min<long long>(EXACT_GROUP, std::max<long long>(1, (4ll << 30) / (n * (long long)key_bytes)));
     if (d > (128 << EXACT_GROUP_DEPTH) || (h->opt.dense_debug & 256)) gmax = 1;    // debug 256: measurement, one query per pass

@@ -875,8 +875,10 @@ struct DenseFinalizeL2 {
     const u32* overflow;
     int q0;
     ExactGroup sel = ExactGroup{{0, 0, 0, 0, 0, 0, 0, 0}, 0};  // count > 0: query ql of the launch is sel.idx[ql], its count cnt[ql]
+    const int* qmap = nullptr;  // the middle tier: query ql of the launch is qmap[ql]; cnt, thr and qn2 are the launch's own arrays
     __device__ __forceinline__ void operator()(int ql, const u64* sorted, int k) const {
-        const int q = sel.count ? sel.idx[ql] : q0 + ql;
+        const int q = qmap ? qmap[ql] : (sel.count ? sel.idx[ql] : q0 + ql);
+        const int qa = qmap ? ql : q;  // index into thr / qn2
         for (int j = threadIdx.x; j < k; j += blockDim.x) {
             const u64 key = sorted[j];
             const bool pad = key == ~0ull;
@@ -885,14 +887,14 @@ struct DenseFinalizeL2 {
         }
         if (threadIdx.x == 0) {
             u32 st = 0;
-            const u32 c = cnt[sel.count ? ql : q];
+            const u32 c = cnt[(sel.count || qmap) ? ql : q];
             if (certify) {
                 if (c > cap || (overflow && *overflow)) st |= 1u;
                 if (c < (u32)kk) st |= 4u;
                 if (st == 0 && certify == 1) {
                     const double dk = (double)unordered_f32((u32)(sorted[kk - 1] >> 32));
-                    const double t = (double)thr[q];
-                    const double lo2 = t + qn2[q] * (1.0 - beta);  // smallest squared distance a non-candidate can have
+                    const double t = (double)thr[qa];
+                    const double lo2 = t + qn2[qa] * (1.0 - beta);  // smallest squared distance a non-candidate can have
                     const double bound = lo2 > 0.0 ? sqrt(lo2) * (1.0 - 1e-6) : 0.0;
                     if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
                 }

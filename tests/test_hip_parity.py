@@ -22,6 +22,8 @@ def _reset_options():
                  "itq_exact", "hamming_no_permute", "dense_no_center", "dense_qplanes"):
         _lib.set_option(name, 0)
     _lib.set_option("dense_async_streams", 2)
+    _lib.set_option("dense_mid_tier", 1)
+    _lib.set_option("dense_fused_prep", 1)
 
 
 # ------------------------------------------------------------------- Hamming
@@ -133,6 +135,39 @@ def _dense_check(db, qs, k, metric="euclidean", exact_dist=True):
             if mism.any():
                 assert np.abs(full[i[qi, :kk][mism]] - full[ri[mism]]).max() < 1e-14
     return idx
+
+
+@pytest.mark.parametrize("d,family", [(128, "long_query"), (64, "two_clusters"), (256, "long_query"), (512, "mixed"), (128, "mixed")])
+def test_dense_middle_tier_certifies_what_the_bf16_filter_cannot(d, family):
+    """Queries the bfloat16 filter cannot certify -- a query hundreds of times longer than the rows, two tight clusters
+    far from their common centre (every row of the query's cluster is inside the bf16 slack) -- take the middle tier
+    (sq_dense_mid.hpp: float32 rows split into two bf16 planes on the fly, 64x less slack) instead of the exact
+    all-rows path; answers stay bit-identical to the oracle either way, and without the tier the same queries fall
+    through to the exact path."""
+    rng = np.random.default_rng(500 + d)
+    n, k = 200_000, 25
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    qs = rng.standard_normal((12, d)).astype(np.float32)
+    if family in ("long_query", "mixed"):
+        qs[:6] *= np.float32(300.0)                       # |q| >> |x|: beta |q|^2 swamps the spread of the scores
+    if family in ("two_clusters", "mixed"):
+        off = np.zeros(d, dtype=np.float32)
+        off[0] = 100.0                                     # clusters at +-100 e_0, spread 0.5: |x - c| = 100 for every row
+        db = (0.5 * db + np.where(np.arange(n)[:, None] % 2 == 0, off, -off)).astype(np.float32)
+        qs[6:] = (0.5 * qs[6:] + off).astype(np.float32)
+    idx = _dense_check(db, qs, k)
+    st = idx.stats()
+    assert st["mid_tier_queries"] > 0, st
+    assert st["fallback_queries"] <= st["mid_tier_queries"] // 4, st           # the tier certifies (almost) all it takes
+    mid = st["mid_tier_queries"]
+    idx.set_option("dense_mid_tier", 0)
+    d0, i0 = idx.search(qs, k)
+    assert idx.stats()["fallback_queries"] >= mid and idx.stats()["mid_tier_queries"] == 0
+    idx.set_option("dense_mid_tier", 1)
+    d1, i1 = idx.search(qs, k)
+    np.testing.assert_array_equal(i0, i1)
+    np.testing.assert_array_equal(d0.view(np.uint32), d1.view(np.uint32))
+    idx.close()
 
 
 @pytest.mark.parametrize("metric", ["euclidean", "cosine"])
@@ -299,8 +334,8 @@ def test_dense_offset_data_is_filtered_around_its_mean():
     assert st["candidates"] < 5 * 20_000, st
     _lib.set_option("dense_no_center", 1)
     try:
-        idx2 = _dense_check(db, qs, 50, "euclidean")            # still exact, through the fallback
-        assert idx2.stats()["fallback_queries"] == 5
+        idx2 = _dense_check(db, qs, 50, "euclidean")            # still exact: the bf16 filter certifies none of them
+        assert idx2.stats()["mid_tier_queries"] == 5            # (the middle tier or, behind it, the exact path answers)
     finally:
         _lib.set_option("dense_no_center", 0)
 
