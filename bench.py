@@ -65,11 +65,15 @@ def parse_args():
     ap.add_argument("--workload", choices=["bruteforce", "lsh_c3", "c4_cosine_shard", "c5_hamming_shard"], default="bruteforce")
     ap.add_argument("--query-batches", type=int, default=8,
                     help="distinct query batches the timed steps rotate through (1 = the same queries every step)")
+    ap.add_argument("--no-mid-tier", action="store_true", help="uncertified queries go straight to the exact path (measurement)")
     ap.add_argument("--preroll-ms", type=float, default=30.0,
                     help="untimed pipelined steps for this long before the warm-up steps (start-up transient of the device; 0 = none)")
     ap.add_argument("--profile-every", type=int, default=0,
                     help="library hipEvents on every N-th search of the timed region (0 = 1 on one GPU, 4 on shards)")
-    ap.add_argument("--data", choices=["normal", "uniform", "clustered", "nonneg"], default="normal")
+    ap.add_argument("--data", choices=["normal", "uniform", "clustered", "nonneg", "far_clusters"], default="normal")
+    ap.add_argument("--query-scale", type=float, default=1.0,
+                    help="multiply the queries by this (300: queries far longer than the rows -- with --data far_clusters the "
+                         "two families the bf16 filter cannot certify; they take the middle tier, sq_dense_mid.hpp)")
     ap.add_argument("--metric", choices=["l2", "cosine"], default="l2")
     ap.add_argument("--sync-search", action="store_true", help="one blocking search call per step (no pipelining)")
     ap.add_argument("--async-streams", type=int, default=0, help="option dense_async_streams (0 = library default)")
@@ -93,6 +97,9 @@ def parse_args():
     ap.add_argument("--extra-batches", type=str, default="1,128,256,1024",
                     help="other total batch sizes measured after the timed region; '' to skip")
     ap.add_argument("--lsh-n", type=int, default=0, help="lsh_c3: nearest codes asked of the hash index (0 = k)")
+    ap.add_argument("--fit", action="store_true",
+                    help="lsh_c3: hash with a model TRAINED on the data (HipItqFunctor.fit on the device) instead of the fixed "
+                         "random rotation of SURVEY 8d; with --data clustered the recall then says something about the method")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="no GPU work: the ranks rendezvous over gloo, all-reduce one integer and rank 0 prints a line "
                          "(tests/test_host_logic.py checks the --gpus N self-launch with it)")
@@ -141,6 +148,12 @@ def make_rows(torch, kind: str, n: int, d: int, dev, seed: int, chunk: int = 1 <
             elif kind == "clustered":
                 which = torch.randint(0, 1024, (e - s,), device=dev, generator=gen)
                 blk.mul_(0.25).add_(centres[which])
+            elif kind == "far_clusters":
+                # two tight clusters at +-100 e_0 (spread 0.5): every row is 100 away from the common centre, so a whole
+                # cluster sits inside the bf16 filter's slack
+                blk.mul_(0.5)
+                sign = (torch.randint(0, 2, (e - s,), device=dev, generator=gen).to(torch.float32) * 2.0 - 1.0) * 100.0
+                blk[:, 0].add_(sign)
     return out
 
 
@@ -164,6 +177,8 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     # come from HBM, as a real query stream's would (one batch repeated finds its rows in the 256 MB MALL)
     nbatch = max(1, args.query_batches)
     all_q = make_rows(torch, args.data, max(max_b, nq * nbatch), d, dev, 1234)
+    if args.query_scale != 1.0:
+        all_q.mul_(args.query_scale)
     batches = [all_q[j * nq:(j + 1) * nq].contiguous() for j in range(nbatch)]
     queries = batches[0]
     torch.cuda.synchronize()
@@ -176,6 +191,8 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     index.set_option("profile", prof_every)
     if args.async_streams:
         index.set_option("dense_async_streams", args.async_streams)
+    if args.no_mid_tier:
+        index.set_option("dense_mid_tier", 0)
     stream = torch.cuda.current_stream().cuda_stream
     use_async = not args.sync_search
     depth = args.async_depth if args.async_depth > 0 else (3 if use_dist else 2)
@@ -183,7 +200,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     if use_async:
         index.set_option("dense_async_depth", depth)
 
-    scan_ms, rerank_ms, cands, fallbacks = [], [], [], []
+    scan_ms, rerank_ms, cands, fallbacks, mids = [], [], [], [], []
 
     def note_stats():
         st = index.stats()
@@ -193,6 +210,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 rerank_ms.append(st["rerank_ms"])
             cands.append(st["candidates"])
             fallbacks.append(st["fallback_queries"])
+            mids.append(st["mid_tier_queries"])
 
     class Runner:
         """`nq_` queries per step through the index (and, with several ranks, the all-gather + host merge)."""
@@ -263,7 +281,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         run.step()
     run.drain()
     run.n = 0
-    scan_ms.clear(), rerank_ms.clear(), cands.clear(), fallbacks.clear()
+    scan_ms.clear(), rerank_ms.clear(), cands.clear(), fallbacks.clear(), mids.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -307,6 +325,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     index.set_option("profile", prof_every)
     head_cands = float(np.mean(cands)) / nq if cands else None
     head_fb = int(np.sum(fallbacks)) if fallbacks else 0
+    head_mid = int(np.sum(mids)) if mids else 0
 
     # ---- one rank through the collective path: the merged answer must be the shard's own answer
     if use_dist and world == 1 and result is not None:
@@ -484,6 +503,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 "gather_host_ms": gather_ms, "merge_ms": merge_ms,
                 "mean_candidates_per_query": head_cands,
                 "fallback_queries": head_fb,
+                "mid_tier_queries": head_mid,
                 "steps_with_stats": n_stats,
             },
             "roofline": {

@@ -588,6 +588,95 @@ static int itq_fast_path(const ItqArgs& a, const ItqFastGeom& g, hipStream_t st,
     return done(rc);
 }
 
+}  // namespace sq
+#include "sq_itq_wide.hpp"   // (needs ItqArgs and the numpy-order helpers above)
+namespace sq {
+
+// The wide filter (sq_itq_wide.hpp): float32 rows beyond the narrow kernel's shapes, float64 rows of every shape it takes.
+template <class T>
+static bool itq_wide_applies(const ItqArgs& a) {
+    return a.d % 64 == 0 && a.d <= 512 && a.words <= 4 && a.n >= 32 && a.n < (1ll << 29) &&
+           (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 && !g_opt.itq_exact && (a.norm == SQ_NORM_NONE || a.norm == SQ_NORM_L2);
+}
+
+template <class T>
+static int itq_wide_path(const ItqArgs& a, hipStream_t st, int device) {
+    const int pc = a.words * 64, ct = a.words * 2;
+    const bool l2 = a.norm == SQ_NORM_L2;
+    const long long n_tiles = (a.n + 31) / 32;
+    int nrb = cu_count(device);
+    if ((long long)nrb * ITQW_WAVES > n_tiles) nrb = (int)((n_tiles + ITQW_WAVES - 1) / ITQW_WAVES);
+    const long long nwaves = (long long)nrb * ITQW_WAVES;
+    const long long rounds = (n_tiles + nwaves - 1) / nwaves;
+    const long long seg_cap = rounds * 32 * ct;   // every (row, column tile) of a wave's tiles
+    const int dp = (a.d + 127) / 128 * 128;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += align256(bytes);
+        return at;
+    };
+    const size_t o_cn = take((size_t)pc * 4), o_cb = take((size_t)pc * 4), o_cbe = take((size_t)pc * 4);
+    const size_t o_cabs = take((size_t)pc * 4);
+    const size_t o_img = take((size_t)pc * dp * 4 + 1024);   // (+ slack: the last k-block of a 384-wide plane is DMA'd whole)
+    const size_t o_seg = take((size_t)nwaves * seg_cap * 8), o_cnt = take((size_t)nwaves * 4);
+    const size_t o_rt = take((size_t)pc * a.d * 8);
+    unsigned char* base = nullptr;
+    SQ_HIP(scratch_alloc(reinterpret_cast<void**>(&base), off, st, device));
+    auto done = [&](int rc) {
+        (void)hipFreeAsync(base, st);
+        return rc;
+    };
+    // relative error of x . R_b per unit |x||R_b|: 2^-20 (x: two truncated float16 planes) + 2^-21 (the dropped
+    // x_lo R_lo) + the float32 accumulation: x_hi R_hi is summed per 256-k block (m = min(d, 256) products each, the
+    // blocks' bounds add up under Cauchy-Schwarz), the 2 d correction products are 2^-10 of that, three final
+    // additions; + 2^-20 (the float32 scale / subtract, the reference's x/|x| rounding) [+ 2^-18: float32 |x|^2].
+    // (k beyond d inside a 256-k block runs with zero row fragments: the image must hold finite numbers there)
+    SQ_HIP(hipMemsetAsync(base + o_img, 0, (size_t)pc * dp * 4 + 1024, st));
+    const int m = a.d < 256 ? a.d : 256;
+    const double eps_rel = ((9.5367431640625e-07 + 4.76837158203125e-07) * 1.001 + 1.5 * (m + 8.0) * 5.9604644775390625e-08 +
+                            2.0 * a.d * 5.9604644775390625e-08 * 9.765625e-04 + 9.5367431640625e-07 + (l2 ? 3.814697265625e-06 : 0.0)) * 1.001;
+    hipLaunchKernelGGL(itq_fast_prep_kernel, dim3((unsigned)pc), dim3(256), 0, st, a.mean, a.rot, a.d, a.bits, a.pad,
+                       reinterpret_cast<unsigned short*>(base + o_img), reinterpret_cast<float*>(base + o_cn),
+                       reinterpret_cast<float*>(base + o_cb), reinterpret_cast<float*>(base + o_cbe),
+                       reinterpret_cast<double*>(base + o_rt), eps_rel, reinterpret_cast<float*>(base + o_cabs));
+    ItqWideArgs wa{};
+    wa.x = a.x;
+    wa.n = a.n;
+    wa.d = a.d;
+    wa.rimage = reinterpret_cast<const uint4*>(base + o_img);
+    wa.colnorm = reinterpret_cast<const float*>(base + o_cn);
+    wa.cb32 = reinterpret_cast<const float*>(base + o_cb);
+    wa.cberr = reinterpret_cast<const float*>(base + o_cbe);
+    wa.cabs = reinterpret_cast<const float*>(base + o_cabs);
+    wa.out = a.out;
+    wa.words = a.words;
+    wa.pad = a.pad;
+    wa.bits = a.bits;
+    wa.ct = ct;
+    wa.seg = reinterpret_cast<u64*>(base + o_seg);
+    wa.seg_cnt = reinterpret_cast<u32*>(base + o_cnt);
+    wa.seg_cap = seg_cap;
+    wa.n_tiles = n_tiles;
+    wa.nrb = nrb;
+    const size_t lds = 2 * (size_t)ITQW_CHUNK_BYTES + 4 * 256 * 4 + (size_t)ITQW_WAVES * ITQW_NSTAGE * ITQF_UNIT_BYTES + ITQW_WAVES * 2048;
+    auto launch = [&](auto kern) -> int {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nrb), dim3(ITQW_WAVES * 64), lds, st, wa);
+        return SQ_OK;
+    };
+    int rc;
+    if (a.d <= 256)
+        rc = l2 ? launch(&itq_wide_kernel<T, true, 1>) : launch(&itq_wide_kernel<T, false, 1>);
+    else
+        rc = l2 ? launch(&itq_wide_kernel<T, true, 2>) : launch(&itq_wide_kernel<T, false, 2>);
+    if (rc != SQ_OK) return done(rc);
+    SQ_HIP(hipGetLastError());
+    hipLaunchKernelGGL((itq_fix_bits_wide_kernel<T>), dim3((unsigned)nwaves, ITQ_FIX_PARTS), dim3(256), 0, st, a, wa.seg, wa.seg_cnt, seg_cap,
+                       reinterpret_cast<const double*>(base + o_rt));
+    return done(SQ_OK);
+}
+
 template <class T>
 static int itq_launch(const ItqArgs& a0, hipStream_t st, int device) {
     ItqArgs a = a0;
@@ -597,6 +686,7 @@ static int itq_launch(const ItqArgs& a0, hipStream_t st, int device) {
             !g_opt.itq_exact && (a.norm == SQ_NORM_NONE || a.norm == SQ_NORM_L2))  // (the other orders: float64 kernel)
             return itq_fast_path(a, g, st, device);
     }
+    if (itq_wide_applies<T>(a)) return itq_wide_path<T>(a, st, device);
     void* nrm = nullptr;
     if (a.norm != SQ_NORM_NONE) {  // stream-ordered scratch: [n] norms in x's dtype
         SQ_HIP(scratch_alloc(&nrm, (size_t)a.n * sizeof(T), st, device));

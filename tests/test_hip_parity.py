@@ -605,6 +605,42 @@ def test_itq_filter_matches_float64_kernel(n, d, bits):
             assert bad.mean() < 1e-2
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("n,d,bits", [(60_001, 512, 256), (50_000, 512, 64), (40_003, 384, 200), (70_000, 128, 256),
+                                      (30_000, 320, 130), (90_001, 128, 64), (25_000, 64, 33), (33, 256, 128)])
+def test_itq_wide_filter_matches_float64_kernel(n, d, bits, dt):
+    """The wide filter (sq_itq_wide.hpp: rows resident as float16 fragments, R streamed through LDS; d <= 512, <= 256
+    bits, float32 AND float64 rows) returns exactly the codes of the all-float64 kernel, and both agree with the oracle:
+    BASELINE config 4's 512-d descriptors, SMQTK's default float64 descriptors, k-blocks that end inside a 256-k block,
+    an all-undecided row, a zero row, a degenerate hash bit, both normalisations, both model dtypes."""
+    if dt == np.float32 and d <= 256 and bits <= 128:
+        pytest.skip("the narrow filter's shape (test_itq_filter_matches_float64_kernel)")
+    rng = np.random.default_rng(n + d + bits)
+    x = (rng.standard_normal((n, d)) * rng.uniform(0.1, 30.0, (n, 1))).astype(dt)
+    mean = x[:2000].mean(axis=0).astype(np.float64)
+    x[5] = mean.astype(dt)                  # z ~ 0 in every bit: the whole row is undecided
+    x[7] = 0.0                              # zero row (norm 0 -> 1 with normalize=2)
+    x[n - 1] = x[0]
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    rot = np.ascontiguousarray(q[:, :bits])
+    rot[:, 3] = 0.0                         # a degenerate hash bit: z == -mean.R == 0 -> True everywhere
+    for mean_m in (mean, mean.astype(np.float32)):
+        for norm, ordv in ((None, _lib.SQ_NORM_NONE), (2, _lib.SQ_NORM_L2)):
+            got = _lib.itq_hash(x, mean_m, rot, ordv)
+            _lib.set_option("itq_exact", 1)
+            try:
+                exact = _lib.itq_hash(x, mean_m, rot, ordv)
+            finally:
+                _lib.set_option("itq_exact", 0)
+            np.testing.assert_array_equal(got, exact)
+            z = O.itq_z(x, mean_m, rot, norm)
+            ref = O.pack_bits_msb(z >= 0)
+            bad = (got != ref).any(axis=1)
+            if bad.any():
+                assert np.abs(z[bad]).min(axis=1).max() < 1e-9
+            assert bad.mean() < 1e-2
+
+
 @pytest.mark.parametrize("d", [2, 64])
 def test_itq_mean_dtype_follows_numpy_promotion(d):
     """`x - mean` is float32 arithmetic when both are float32 (a model fitted on float32

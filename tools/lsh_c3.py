@@ -32,6 +32,20 @@ def run(args, torch, dist, _lib, world, rank, dev, use_dist, emit, make_rows):
     rot_np, _ = np.linalg.qr(np.random.default_rng(5).standard_normal((d, d)))
     rot_np = np.ascontiguousarray(rot_np[:, :bits])
     mean_t = db[:100_000].to(torch.float64).mean(dim=0).contiguous()
+    model_note = "fixed: orthonormal R (QR of a seeded Gaussian, first 64 columns), mean of a 100 k sample (SURVEY 8d, C3)"
+    if getattr(args, "fit", False):
+        # a TRAINED model: ItqFunctor.fit (impls/lsh_functor/itq.py:291-387) on a 1 M-row sample, its O(n) products on the
+        # device (HipItqFunctor._fit_device: mean, covariance, PCA projection, 50 ITQ iterations), outside the timed region
+        from smqtk_indexing_amd.impls.lsh_functor.hip_itq import HipItqFunctor
+        t_fit = time.perf_counter()
+        sample = db[:: max(1, n // 1_000_000)][:1_000_000].cpu().numpy()
+        f = HipItqFunctor(bit_length=bits, itq_iterations=50, random_seed=0)
+        mean_h, rot_h = f._fit_device(sample)
+        rot_np = np.ascontiguousarray(np.real(rot_h)).astype(np.float64)
+        mean_t = torch.from_numpy(np.asarray(mean_h, dtype=np.float64)).to(dev).contiguous()
+        model_note = (f"fitted: HipItqFunctor.fit products on the device over a {sample.shape[0]}-row sample, 50 ITQ iterations, "
+                      f"{time.perf_counter() - t_fit:.2f} s")
+        del sample
     rot_t = torch.from_numpy(rot_np).to(dev)
     codes = torch.empty((n, 1), dtype=torch.int64, device=dev)
     _lib.itq_hash_device(db.data_ptr(), 0, n, d, mean_t.data_ptr(), rot_t.data_ptr(), bits, _lib.SQ_NORM_NONE,
@@ -103,7 +117,7 @@ def run(args, torch, dist, _lib, world, rank, dev, use_dist, emit, make_rows):
         "dtype": "u64 codes (xor + popcount) for the scan; f32 exact re-rank (bit-identical to numpy); ITQ sign bits = float64 evaluation",
         "data": f"synthetic {args.data} float32 descriptors generated on device; queries from the same distribution",
         "config": {"workload": f"lsh_c3_{n}x{d}_bits{bits}_k{k}", "db_rows_total": n, "dim": d, "bits": bits, "k": k,
-                   "unique_codes": n_codes, "queries_per_step": nq, "nearest_codes_per_query": args.lsh_n or k,
+                   "unique_codes": n_codes, "itq_model": model_note, "queries_per_step": nq, "nearest_codes_per_query": args.lsh_n or k,
                    "index_build_s_on_device": build_s,
                    "recall_at_k_vs_exact_L2": head["recall_at_k"], "results_per_query": head["results_per_query"],
                    "recall_note": "the reference's algorithm expands the n nearest CODES (lsh.py:480-501); with 64-bit codes over "
