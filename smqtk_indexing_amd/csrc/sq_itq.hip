@@ -659,6 +659,14 @@ static int itq_wide_path(const ItqArgs& a, hipStream_t st, int device) {
     wa.seg_cap = seg_cap;
     wa.n_tiles = n_tiles;
     wa.nrb = nrb;
+    wa.debug = g_opt.dense_debug & 15;
+    static DevBuf stamp_buf;   // (measurement: option dense_debug bit 16 -> phase stamps of every workgroup, printed by the host)
+    wa.stamps = nullptr;
+    if (g_opt.dense_debug & 16) {
+        SQ_TRY(stamp_buf.reserve((size_t)nrb * 64 * 8));
+        SQ_HIP(hipMemsetAsync(stamp_buf.p, 0, (size_t)nrb * 64 * 8, st));
+        wa.stamps = stamp_buf.as<u64>();
+    }   // (measurement: the ablation bits of sq_itq_wide.hpp ride on option dense_debug)
     const size_t lds = 2 * (size_t)ITQW_CHUNK_BYTES + 4 * 256 * 4 + (size_t)ITQW_WAVES * ITQW_NSTAGE * ITQF_UNIT_BYTES + ITQW_WAVES * 2048;
     auto launch = [&](auto kern) -> int {
         SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -672,6 +680,20 @@ static int itq_wide_path(const ItqArgs& a, hipStream_t st, int device) {
         rc = l2 ? launch(&itq_wide_kernel<T, true, 2>) : launch(&itq_wide_kernel<T, false, 2>);
     if (rc != SQ_OK) return done(rc);
     SQ_HIP(hipGetLastError());
+    if (wa.stamps) {
+        std::vector<unsigned long long> hst((size_t)nrb * 64);
+        SQ_HIP(hipMemcpy(hst.data(), wa.stamps, hst.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < nrb; ++b) if (hst[(size_t)b * 64] && hst[(size_t)b * 64] < t0) t0 = hst[(size_t)b * 64];
+        for (int b : {0, 1, 7, 100, 255}) {
+            if (b >= nrb) continue;
+            fprintf(stderr, "wg %3d:", b);
+            for (int r = 0; r < 8; ++r)
+                fprintf(stderr, " [r%d x %.1f mfma %.1f | start %.1f]", r, (hst[(size_t)b * 64 + 3 * r + 1] - hst[(size_t)b * 64 + 3 * r]) / 100.0,
+                        (hst[(size_t)b * 64 + 3 * r + 2] - hst[(size_t)b * 64 + 3 * r + 1]) / 100.0, (hst[(size_t)b * 64 + 3 * r] - t0) / 100.0);
+            fprintf(stderr, "\n");
+        }
+    }
     hipLaunchKernelGGL((itq_fix_bits_wide_kernel<T>), dim3((unsigned)nwaves, ITQ_FIX_PARTS), dim3(256), 0, st, a, wa.seg, wa.seg_cnt, seg_cap,
                        reinterpret_cast<const double*>(base + o_rt));
     return done(SQ_OK);

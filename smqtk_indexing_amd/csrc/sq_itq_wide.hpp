@@ -49,6 +49,8 @@ struct ItqWideArgs {
     long long seg_cap;
     long long n_tiles;
     int nrb;
+    u64* stamps;           // measurement only: [workgroups][64] wall-clock stamps (100 MHz) of wave 0's phases, or nullptr
+    int debug;             // measurement only (wrong codes): 1 = no R stream (no chunk DMA, no barriers), 2 = rows loaded for the first round only, 4 = no epilogue
 };
 
 // D = A B + D with A in VGPRs and B in AGPRs (the matrix core reads either file; hipcc's builtin would copy B back)
@@ -73,6 +75,46 @@ __device__ __forceinline__ void frag_pair_to_agpr(unsigned char* scr, int lane, 
         : "=a"(xh), "=a"(xl)
         : "v"(addr)
         : "memory");
+}
+
+// ... a whole row unit at a time: the unit's own ring slot (8 KiB, its raw rows are in registers by then) takes the
+// converted fragments, one asm block reads them back into AGPRs and waits ONCE (a bounce per k-step exposed the LDS
+// round trip 32 times per tile: ~4 us of a 14 us row phase).
+template <int KSU>
+__device__ __forceinline__ void unit_frags_to_agpr(unsigned char* slot, int lane, const itq_u32x4 (&hw)[KSU], const itq_u32x4 (&lw)[KSU],
+                                                   itq_f16x8* xh, itq_f16x8* xl) {
+#pragma unroll
+    for (int s = 0; s < KSU; ++s) {
+        *reinterpret_cast<itq_u32x4*>(slot + (2 * s) * 1024 + lane * 16) = hw[s];
+        *reinterpret_cast<itq_u32x4*>(slot + (2 * s + 1) * 1024 + lane * 16) = lw[s];
+    }
+    const u32 addr = (u32)(uintptr_t)slot + (u32)lane * 16u;
+    if constexpr (KSU == 4) {
+        asm volatile(
+            "ds_read_b128 %0, %8\n\t"
+            "ds_read_b128 %1, %8 offset:1024\n\t"
+            "ds_read_b128 %2, %8 offset:2048\n\t"
+            "ds_read_b128 %3, %8 offset:3072\n\t"
+            "ds_read_b128 %4, %8 offset:4096\n\t"
+            "ds_read_b128 %5, %8 offset:5120\n\t"
+            "ds_read_b128 %6, %8 offset:6144\n\t"
+            "ds_read_b128 %7, %8 offset:7168\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=a"(xh[0]), "=a"(xl[0]), "=a"(xh[1]), "=a"(xl[1]), "=a"(xh[2]), "=a"(xl[2]), "=a"(xh[3]), "=a"(xl[3])
+            : "v"(addr)
+            : "memory");
+    } else {
+        static_assert(KSU == 2, "k-steps per row unit");
+        asm volatile(
+            "ds_read_b128 %0, %4\n\t"
+            "ds_read_b128 %1, %4 offset:1024\n\t"
+            "ds_read_b128 %2, %4 offset:2048\n\t"
+            "ds_read_b128 %3, %4 offset:3072\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=a"(xh[0]), "=a"(xl[0]), "=a"(xh[1]), "=a"(xl[1])
+            : "v"(addr)
+            : "memory");
+    }
 }
 
 // NKB: 256-k blocks of a row (1: d <= 256, 2: d <= 512).  A block always runs its 16 k-steps: fragments beyond d are
@@ -139,6 +181,7 @@ __global__ __launch_bounds__(ITQW_WAVES * 64, 1) void itq_wide_kernel(ItqWideArg
         }
     };
 
+    long long x_issued = 0, x_consumed = 0;   // row units DMA'd / taken into registers by this wave, all rounds
     for (long long round = 0; round < rounds; ++round) {
         long long tile = wave_id + round * nwaves;
         const bool active = tile < a.n_tiles;
@@ -146,20 +189,42 @@ __global__ __launch_bounds__(ITQW_WAVES * 64, 1) void itq_wide_kernel(ItqWideArg
         long long row0 = tile * 32;
         const long long shift = row0 + 32 > a.n ? row0 + 32 - a.n : 0;   // the last tile: the window moves back
         row0 -= shift;
-        // ---- the tile's rows: DMA ring -> registers, split into float16 planes (A fragments of every k-step)
+        if (a.stamps && wave == 0 && lane == 0 && round < 20) a.stamps[(size_t)blockIdx.x * 64 + 3 * round] = wall_clock64();
+        // ---- the tile's rows: DMA ring -> registers, split into float16 planes (A fragments of every k-step).
+        // Four slots of 8 KiB per wave: the wave's own two, and -- the R buffers are idle while the rows load -- a 16 KiB
+        // quarter of the R area (between the barrier that ends a round's MFMA phase and the one before chunk 0).  Units
+        // 0 and 1 of the NEXT round's tile go into the own slots as soon as this tile's last units have left them: they
+        // land under the MFMA phase.  (Two slots and no prefetch: the row phase ran at 64 KiB in flight per CU, 0.85 ms
+        // of a 2.1 ms kernel during which the matrix cores idle.)
         itq_f16x8 xh[KS], xl[KS];
         float sumsq = 0.f;
-        {
+        if (!(a.debug & 2) || round == 0) {
             const unsigned char* xbase = reinterpret_cast<const unsigned char*>(a.x) + row0 * (long long)D * (long long)sizeof(T);
-            int issued = 0;
-            auto issue_unit = [&]() __attribute__((always_inline)) {
-                const u32 dst = ring_base + (u32)(issued % ITQW_NSTAGE) * ITQF_UNIT_BYTES;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) glds16<true>(xbase + issued * 256, voff[j], dst + (u32)j * 1024);
-                ++issued;
+            // the next round's window (same clamping as above)
+            long long ntile = wave_id + (round + 1) * nwaves;
+            if (ntile >= a.n_tiles) ntile = a.n_tiles - 1;
+            long long nrow0 = ntile * 32;
+            if (nrow0 + 32 > a.n) nrow0 = a.n - 32;
+            const unsigned char* nbase = reinterpret_cast<const unsigned char*>(a.x) + nrow0 * (long long)D * (long long)sizeof(T);
+            const bool has_next = round + 1 < rounds;
+            auto slot_lds = [&](int sl4) __attribute__((always_inline)) -> u32 {
+                return sl4 < 2 ? ring_base + (u32)sl4 * ITQF_UNIT_BYTES : lds_base + (u32)wave * 16384u + (u32)(sl4 - 2) * ITQF_UNIT_BYTES;
             };
-            for (int p = 0; p < ITQW_NSTAGE; ++p)
-                if (issued < NU) issue_unit();
+            auto slot_ptr = [&](int sl4) __attribute__((always_inline)) -> const unsigned char* {
+                return sl4 < 2 ? ring_ptr + sl4 * ITQF_UNIT_BYTES : smem + wave * 16384 + (sl4 - 2) * ITQF_UNIT_BYTES;
+            };
+            auto issue_unit = [&](const unsigned char* base, int unit, int sl4) __attribute__((always_inline)) {
+                const u32 dst = slot_lds(sl4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) glds16<true>(base + unit * 256, voff[j], dst + (u32)j * 1024);
+                ++x_issued;
+            };
+            if (round == 0) {   // (later rounds: units 0 and 1 were prefetched by the round before)
+                issue_unit(xbase, 0, 0);
+                if (NU > 1) issue_unit(xbase, 1, 1);
+            }
+            if (NU > 2) issue_unit(xbase, 2, 2);
+            if (NU > 3) issue_unit(xbase, 3, 3);
 #pragma unroll
             for (int u = 0; u < KS / KSU; ++u) {
                 if (u >= NU) {   // beyond d: zero fragments (wave-uniform)
@@ -167,8 +232,17 @@ __global__ __launch_bounds__(ITQW_WAVES * 64, 1) void itq_wide_kernel(ItqWideArg
 #pragma unroll
                     for (int s2 = 0; s2 < KSU; ++s2) frag_pair_to_agpr(scr, lane, zero, zero, xh[u * KSU + s2], xl[u * KSU + s2]);
                 } else {
-                    wait_units_in_flight<ITQW_NSTAGE, 8>(issued - u - 1);
-                    const unsigned char* sl = ring_ptr + (u % ITQW_NSTAGE) * ITQF_UNIT_BYTES + r31 * 256;
+                    wait_units_in_flight<4, 8>((int)(x_issued - x_consumed - 1));
+                    ++x_consumed;
+                    const unsigned char* sl = slot_ptr(u & 3) + r31 * 256;
+                    // the slot is free once the unit is in registers: this tile's unit u + 4, or -- own slots only -- the
+                    // next tile's unit u & 3
+                    auto refill = [&]() __attribute__((always_inline)) {
+                        if (u + 4 < NU)
+                            issue_unit(xbase, u + 4, u & 3);
+                        else if ((u & 3) < 2 && has_next && (u & 3) < NU)
+                            issue_unit(nbase, u & 3, u & 3);
+                    };
                     if constexpr (sizeof(T) == 4) {
                         itq_f32x4 xa[KSU][2];
 #pragma unroll
@@ -177,10 +251,9 @@ __global__ __launch_bounds__(ITQW_WAVES * 64, 1) void itq_wide_kernel(ItqWideArg
                             for (int e = 0; e < 2; ++e)
                                 xa[s][e] = *reinterpret_cast<const itq_f32x4*>(sl + (((4 * s + 2 * h + e) ^ (r31 & 15)) * 16));
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (issued < NU) issue_unit();
+                        itq_u32x4 hwv[KSU], lwv[KSU];
 #pragma unroll
                         for (int s = 0; s < KSU; ++s) {
-                            itq_u32x4 hw, lw;
 #pragma unroll
                             for (int j = 0; j < 8; j += 2) {
                                 const float u0 = j < 4 ? xa[s][0][j] : xa[s][1][j - 4];
@@ -189,11 +262,12 @@ __global__ __launch_bounds__(ITQW_WAVES * 64, 1) void itq_wide_kernel(ItqWideArg
                                 sumsq = __fmaf_rn(u1, u1, sumsq);
                                 u32 hh, ll;
                                 split_f16_pair(u0, u1, hh, ll);
-                                hw[j >> 1] = hh;
-                                lw[j >> 1] = ll;
+                                hwv[s][j >> 1] = hh;
+                                lwv[s][j >> 1] = ll;
                             }
-                            frag_pair_to_agpr(scr, lane, hw, lw, xh[u * KSU + s], xl[u * KSU + s]);
                         }
+                        unit_frags_to_agpr<KSU>(const_cast<unsigned char*>(slot_ptr(u & 3)), lane, hwv, lwv, &xh[u * KSU], &xl[u * KSU]);
+                        refill();   // (the slot served as the bounce buffer: free only now)
                     } else {
                         typedef double f64x2 __attribute__((ext_vector_type(2)));
                         f64x2 xa[KSU][4];
@@ -203,10 +277,9 @@ __global__ __launch_bounds__(ITQW_WAVES * 64, 1) void itq_wide_kernel(ItqWideArg
                             for (int e = 0; e < 4; ++e)
                                 xa[s][e] = *reinterpret_cast<const f64x2*>(sl + (((8 * s + 4 * h + e) ^ (r31 & 15)) * 16));
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (issued < NU) issue_unit();
+                        itq_u32x4 hwv[KSU], lwv[KSU];
 #pragma unroll
                         for (int s = 0; s < KSU; ++s) {
-                            itq_u32x4 hw, lw;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const double d0 = xa[s][e][0], d1 = xa[s][e][1];
@@ -216,11 +289,12 @@ __global__ __launch_bounds__(ITQW_WAVES * 64, 1) void itq_wide_kernel(ItqWideArg
                                 const auto hv = __builtin_amdgcn_cvt_pkrtz(f0, f1);   // two float16, round toward zero
                                 // the residual is formed in float64 (x - hi is exact there), rounded to float32, truncated to float16
                                 const float l0 = (float)(d0 - (double)(float)hv[0]), l1 = (float)(d1 - (double)(float)hv[1]);
-                                hw[e] = __builtin_bit_cast(u32, hv);
-                                lw[e] = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+                                hwv[s][e] = __builtin_bit_cast(u32, hv);
+                                lwv[s][e] = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(l0, l1));
                             }
-                            frag_pair_to_agpr(scr, lane, hw, lw, xh[u * KSU + s], xl[u * KSU + s]);
                         }
+                        unit_frags_to_agpr<KSU>(const_cast<unsigned char*>(slot_ptr(u & 3)), lane, hwv, lwv, &xh[u * KSU], &xl[u * KSU]);
+                        refill();
                     }
                 }
             }
@@ -245,12 +319,15 @@ __global__ __launch_bounds__(ITQW_WAVES * 64, 1) void itq_wide_kernel(ItqWideArg
         }
         const bool bad_rows = __ballot(!(big < 1e9f)) != 0ull;   // a float16 plane saturates from |x_k| = 65504 on
 
-        // ---- R streams past the resident tile
-        wait_vmcnt<0>();
+        if (a.stamps && wave == 0 && lane == 0 && round < 20) a.stamps[(size_t)blockIdx.x * 64 + 3 * round + 1] = wall_clock64();
+        // ---- R streams past the resident tile (every wave has taken its rows out of the R area: barrier)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         issue_chunk(0, 0);
         u32 word_hi = 0;   // sign bits of the even column tile of the current output word (this lane's row)
         for (int ct = 0; ct < a.ct; ++ct) {
-            itq_f32x16 accM0, accM1, accC;
+            itq_f32x16 accM0, accM1, accC, accD;   // accC: x_lo R_hi (and -c_b), accD: x_hi R_lo: no two MFMAs in a row share an accumulator
             {
                 // -c_b of this lane's 16 columns: register i <-> column (i & 3) + 8 (i >> 2) + 4 h
                 itq_f32x4 cbv[4];
@@ -260,43 +337,54 @@ __global__ __launch_bounds__(ITQW_WAVES * 64, 1) void itq_wide_kernel(ItqWideArg
                 for (int i = 0; i < 16; ++i) {
                     accM0[i] = 0.f;
                     accM1[i] = 0.f;
+                    accD[i] = 0.f;
                     accC[i] = NORMED ? 0.f : -cbv[i >> 2][i & 3];   // without normalisation the sum ends as z~ = x . R_b - c_b
                 }
             }
-            asm volatile("s_nop 1" : "+v"(accM0), "+v"(accM1), "+v"(accC));   // VALU write of C -> MFMA read
+            asm volatile("s_nop 1" : "+v"(accM0), "+v"(accM1), "+v"(accC), "+v"(accD));   // VALU write of C -> MFMA read
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 {
                     const int c = ct * NKB + kb;
                     // chunk c: every wave's pieces have landed (own pieces: vmcnt; the others': the barrier), and every wave
                     // has finished reading the buffer chunk c + 1 is about to overwrite
-                    wait_vmcnt<0>();
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if (c + 1 < n_chunks) issue_chunk(c + 1, (c + 1) & 1);
+                    if (!(a.debug & 1)) {   // (measurement: the R stream and its barriers left out)
+                        wait_vmcnt<0>();
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        if (c + 1 < n_chunks) issue_chunk(c + 1, (c + 1) & 1);
+                    }
                     const unsigned char* cb_ptr = smem + (size_t)(c & 1) * ITQW_CHUNK_BYTES + r31 * 1024;
+                    // R's fragments of k-step s + 1 are requested before the MFMAs of k-step s are issued: read after
+                    // them, their ~130-cycle LDS latency followed every 96 cycles of matrix work and the pipe sat idle
+                    // half the time (PMC: 31 % busy; the same loop without this: 43 % of the MFMA rate)
+                    auto frag_ptr = [&](int s2) __attribute__((always_inline)) {
+                        return cb_ptr + (s2 >> 3) * 256 + (((2 * (s2 & 7) + h) ^ (r31 & 15)) * 16);
+                    };
+                    itq_f16x8 bh_n = *reinterpret_cast<const itq_f16x8*>(frag_ptr(0));
+                    itq_f16x8 bl_n = *reinterpret_cast<const itq_f16x8*>(frag_ptr(0) + 512);
 #pragma unroll
                     for (int s = 0; s < 16; ++s) {
                         const int ks = kb * 16 + s;
-                        {
-                            const unsigned char* fp = cb_ptr + (s >> 3) * 256 + (((2 * (s & 7) + h) ^ (r31 & 15)) * 16);
-                            const itq_f16x8 bh = *reinterpret_cast<const itq_f16x8*>(fp);
-                            const itq_f16x8 bl = *reinterpret_cast<const itq_f16x8*>(fp + 512);
-                            // A = R's fragment (VGPR), B = the resident row fragment (AGPR): D[column][row]
-                            mfma_f16_agpr_b(accC, bh, xl[ks]);
-                            mfma_f16_agpr_b(accC, bl, xh[ks]);
-                            if (kb == 0)
-                                mfma_f16_agpr_b(accM0, bh, xh[ks]);
-                            else
-                                mfma_f16_agpr_b(accM1, bh, xh[ks]);
+                        const itq_f16x8 bh = bh_n, bl = bl_n;
+                        if (s + 1 < 16) {
+                            bh_n = *reinterpret_cast<const itq_f16x8*>(frag_ptr(s + 1));
+                            bl_n = *reinterpret_cast<const itq_f16x8*>(frag_ptr(s + 1) + 512);
                         }
+                        // A = R's fragment (VGPR), B = the resident row fragment (AGPR): D[column][row]
+                        mfma_f16_agpr_b(accC, bh, xl[ks]);
+                        if (kb == 0)
+                            mfma_f16_agpr_b(accM0, bh, xh[ks]);
+                        else
+                            mfma_f16_agpr_b(accM1, bh, xh[ks]);
+                        mfma_f16_agpr_b(accD, bl, xh[ks]);
                     }
                 }
             }
-            asm volatile("s_nop 15" : "+v"(accM0), "+v"(accM1), "+v"(accC));   // MFMA result -> VALU read
+            asm volatile("s_nop 15" : "+v"(accM0), "+v"(accM1), "+v"(accC), "+v"(accD));   // MFMA result -> VALU read
             // ---- column tile complete: lane = row r31, register i = column (i & 3) + 8 (i >> 2) + 4 h of the tile
             u32 bits = 0, unc = 0;
-            {
+            if (!(a.debug & 4)) {
                 itq_f32x4 cbv[4], eav[4], ebv[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -307,7 +395,7 @@ __global__ __launch_bounds__(ITQW_WAVES * 64, 1) void itq_wide_kernel(ItqWideArg
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int col = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    const float raw = (accM0[i] + accM1[i]) + accC[i];
+                    const float raw = (accM0[i] + accM1[i]) + (accC[i] + accD[i]);
                     float z;
                     if constexpr (NORMED)
                         z = __fmaf_rn(raw, rowscale, -cbv[i >> 2][i & 3]);
@@ -342,6 +430,11 @@ __global__ __launch_bounds__(ITQW_WAVES * 64, 1) void itq_wide_kernel(ItqWideArg
                 wcount += (u32)__popcll(nb);
             }
         }
+        if (a.stamps && wave == 0 && lane == 0 && round < 20) a.stamps[(size_t)blockIdx.x * 64 + 3 * round + 2] = wall_clock64();
+        // every wave is done with the R buffers: the next round's rows may land there
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
     if (lane == 0) a.seg_cnt[wave_id] = wcount;
 }

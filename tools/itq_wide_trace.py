@@ -17,6 +17,12 @@ rot = torch.from_numpy(np.ascontiguousarray(rot_np[:, :bits])).to(dev)
 mean = x[:100_000].double().mean(dim=0).contiguous()
 out = torch.empty((n, (bits + 63) // 64), dtype=torch.int64, device=dev)
 code = _lib.SQ_DTYPE_F32 if dt == torch.float32 else _lib.SQ_DTYPE_F64
-for i in range(4):
+import time
+if os.environ.get("DEBUG"):
+    _lib.set_option("dense_debug", int(os.environ["DEBUG"]))
+ts = []
+for i in range(5):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     _lib.itq_hash_device(x.data_ptr(), code, n, d, mean.data_ptr(), rot.data_ptr(), bits, norm, out.data_ptr(), st)
-torch.cuda.synchronize()
+    torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+print(f"DEBUG={os.environ.get('DEBUG', 0)} DT={os.environ.get('DT', 'f32')} NORM={os.environ.get('NORM', 'none')}: call {min(ts[1:]) * 1e3:.3f} ms")
