@@ -35,7 +35,7 @@ for P in "$P1" "$P2" "$P3" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "${EXTRA[
   rocprofv3 --pmc $P --kernel-trace -d $OUT/pmc$i -o pmc --output-format csv -- "$@" > $OUT/pmc$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pmc$i.log; }
 done
 python3 - "$OUT" "$KSUB" <<'PY'
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 out, ksub = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
@@ -45,7 +45,7 @@ for path in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
 # kernel durations of the SAME passes (--kernel-trace rides along: clocks differ between profiled passes, so a
 # counter is only comparable with the duration of its own pass)
 for path in glob.glob(out + "/pmc*/**/*kernel_trace.csv", recursive=True):
-    tag = "duration_ns_pass_" + path.split("/pmc")[1].split("/")[0]
+    tag = "duration_ns_pass_" + os.path.basename(os.path.dirname(path)).replace("pmc", "")
     for r in csv.DictReader(open(path)):
         if ksub in r["Kernel_Name"]:
             acc[r["Kernel_Name"][:100]][tag].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
