@@ -6,6 +6,8 @@ searches are covered by the GPU tests.
 """
 from io import BytesIO
 
+import os
+
 import numpy as np
 import pytest
 
@@ -402,3 +404,34 @@ def test_lsh_bucket_construction_and_refresh():
     assert idx.count() == 4                                     # not visible to the cheap key ...
     idx.refresh()
     assert idx.count() == 5                                     # ... refresh() re-reads the stores
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher starts its N ranks as child processes (torch.distributed.run,
+    127.0.0.1 rendezvous on a free port), relays rank 0's one JSON line to stdout and returns the launcher's exit
+    code.  --launch-selftest does no GPU work (gloo), so the launch itself is covered here; without it the ranks
+    fail on a box without GPUs and the failure must come back as a non-zero exit code with no result line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    got = json.loads(lines[0])
+    assert got == {"launch_selftest": True, "ranks": 2, "sum": 2}
+    try:
+        import torch
+        has_gpu = torch.cuda.device_count() > 0
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root,
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode != 0
+        assert not [ln for ln in p.stdout.decode().splitlines() if ln.strip().startswith("{")]
