@@ -29,6 +29,7 @@
 #include "sq_dense_exact.hpp"
 #include "sq_dense_scan.hpp"
 #include "sq_dense_mid.hpp"
+#include "sq_dense_i8.hpp"
 
 namespace sq {
 
@@ -43,12 +44,13 @@ struct DenseCall {
     void* out_dist = nullptr;
     long long* out_idx = nullptr;
     hipStream_t st = nullptr;     // the stream the call's kernels were enqueued on
-    bool small = false, all_fallback = false, prof = false, use_event = false;
+    bool small = false, all_fallback = false, prof = false, use_event = false, int8 = false;
     u32 cap = 0;                  // candidate-list length the call was enqueued with
     sq_stats_t stats{};
 };
 struct DenseSlot {
     DevBuf q_scaled, q_al, qn2, thr, wave_out, wave_cnt, cnt, keys, sample, out_keys, cos_nq, oflag;
+    DevBuf q8, par8;              // int8 filter: the query tile's plane and {score unit, e_q}
     DevBuf sort_tmp;              // scratch of the any-k sorted select (k beyond the one-workgroup select): one per call in flight
     HostPinned status_host;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // call start, scan start, scan end, call end, re-rank end
@@ -56,7 +58,7 @@ struct DenseSlot {
     hipStream_t own = nullptr;    // internal stream of the slot (asynchronous calls with "dense_async_streams" = 2)
     DenseCall call;
     void release() {
-        for (DevBuf* b : {&q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt, &keys, &sample, &out_keys, &cos_nq, &oflag, &sort_tmp})
+        for (DevBuf* b : {&q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt, &keys, &sample, &out_keys, &cos_nq, &oflag, &sort_tmp, &q8, &par8})
             b->release();
         status_host.release();
         for (auto& e : ev)
@@ -80,6 +82,13 @@ struct DenseHandle : HandleBase {
     int metric = SQ_METRIC_L2;
     long long id_base = 0;
     double xn2_max = 0.0;       // max squared row norm (error bound of the L2 filter)
+    // the int8 first-stage filter (sq_dense_i8.hpp): copy, row terms, and what the build measured
+    DevBuf scan8, nrow8;
+    bool use8 = false;
+    long long n_pad64 = 0;
+    double dx8 = 0.0, rmax8 = 0.0, xmax8 = 0.0;
+    long long flagged8 = 0;
+    int overflow8 = 0;          // calls in a row in which the int8 filter's lists overflowed (data it does not suit): it is dropped
     DevBuf norms1;  // L2: |x|^2 (1 - alpha) for one query plane (`norms`: two planes)
     DevBuf zeros;   // cosine: the 32 zero "norms" every tile of an AGPR-configuration scan starts from (norm_step 0)
     static constexpr int kMaxDepth = 6;
@@ -91,7 +100,7 @@ struct DenseHandle : HandleBase {
     DevBuf mid_q, mid_planes, mid_small, mid_qal, mid_wave_out, mid_wave_cnt, mid_keys, mid_out, mid_sample;  // the middle tier (synchronous)
     PinnedStage stage;
     ~DenseHandle() override {
-        for (DevBuf* b : {&owned, &scan, &norms, &norms1, &zeros, &center, &cos_nx, &q_dev, &out_dist_dev, &out_idx_dev, &big_keys,
+        for (DevBuf* b : {&owned, &scan, &scan8, &nrow8, &norms, &norms1, &zeros, &center, &cos_nx, &q_dev, &out_dist_dev, &out_idx_dev, &big_keys,
                           &fb_sample, &fb_keys, &fb_out, &scratch, &fb_cnt, &fb_sort, &mid_q, &mid_planes, &mid_small, &mid_qal,
                           &mid_wave_out, &mid_wave_cnt, &mid_keys, &mid_out, &mid_sample})
             b->release();
@@ -351,6 +360,97 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, nullptr, 0},
                                         st, s.sort_tmp));
         }
+    } else if (scan_ok && h->use8 && nq <= TILE_ROWS && h->opt.dense_int8 != 0 && kk <= kSelectLdsKeys64) {
+        // ---- the int8 first-stage filter (sq_dense_i8.hpp): half the bytes per row, measured error bound
+        c.int8 = true;
+        const long long n_units = (n + I8_UNIT_ROWS - 1) / I8_UNIT_ROWS;
+        long long stride = h->opt.sample_stride;
+        if (stride <= 0) {
+            // units of 64 rows, four samples per unit: the bf16 path's cost model in units of two tiles
+            stride = (long long)(10.0 * sqrt((double)n / 1e7 * 100.0 / (double)kk) + 0.5);
+            if (stride > 12) stride = 12;
+            if (stride < 1) stride = 1;
+            if (stride > (long long)cap / (16ll * kk)) stride = std::max<long long>(1, (long long)cap / (16ll * kk));
+        }
+        while (stride > 1 && (n_units / stride) * 4 < 8ll * kk) stride >>= 1;
+        const long long ns_units = (n_units + stride - 1) / stride;
+        const long long ns = ns_units * 4;
+        SQ_TRY(s.sample.reserve((size_t)TILE_ROWS * ns * 4));
+        SQ_TRY(s.keys.reserve((size_t)nq * key_stride * key_bytes));
+        SQ_TRY(s.q8.reserve((size_t)TILE_ROWS * I8_ROW_BYTES));
+        SQ_TRY(s.par8.reserve((size_t)TILE_ROWS * 8));
+        const int cus = cu_count(h->device);
+        int nrb = h->opt.dense_blocks > 0 ? h->opt.dense_blocks : (use_event && h->opt.dense_async_streams == 2 ? cus * 3 / 4 : cus);
+        nrb = (nrb + 7) / 8 * 8;
+        const long long n_waves = (long long)nrb * I8_WAVES;
+        const u32 wave_cap = 2048;
+        const int ldq = (d + 3) / 4 * 4;
+        SQ_TRY(s.wave_out.reserve((size_t)n_waves * wave_cap * 8));
+        SQ_TRY(s.wave_cnt.reserve((size_t)n_waves * 8));
+        SQ_TRY(s.q_al.reserve((size_t)nq * ldq * 4));
+        u32* oflag = s.oflag.as<u32>();
+        const float* centerp = h->center.p ? h->center.as<float>() : nullptr;
+        hipLaunchKernelGGL(dense8_prep_queries_kernel, dim3(TILE_ROWS), dim3(128), 0, st, q, nq, d, centerp, h->dx8, h->rmax8, h->xmax8,
+                           s.q8.as<signed char>(), s.par8.as<float2>(), qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq);
+        Dense8ScanArgs a{};
+        a.scan8 = h->scan8.as<signed char>();
+        a.nrow = h->nrow8.as<float>();
+        a.n = n;
+        a.n_units = n_units;
+        a.qs8 = s.q8.as<signed char>();
+        a.par = s.par8.as<float2>();
+        a.thr = thr;
+        a.wave_out = s.wave_out.as<uint2>();
+        a.wave_cnt = s.wave_cnt.as<u32>();
+        a.wave_cap = wave_cap;
+        a.sample_out = s.sample.as<float>();
+        a.ns = ns;
+        {
+            const size_t copy_bytes = (size_t)h->n_pad64 * I8_ROW_BYTES;
+            const long long keep_mb = h->opt.dense_nt_keep_mb > 0 ? h->opt.dense_nt_keep_mb : 192;
+            a.nt = h->opt.dense_nt >= 0 ? h->opt.dense_nt : (copy_bytes > ((size_t)512 << 20) ? 1 : 0);
+            a.nt_from_row = h->opt.dense_nt == 0 ? 0x7fffffffffffffffll : h->opt.dense_nt == 1 ? 0ll : (keep_mb << 20) / I8_ROW_BYTES;
+        }
+        static bool attr8 = false;
+        const size_t lds8 = (size_t)I8_WAVES * I8_NSTAGE * I8_SLOT_BYTES;
+        if (!attr8) {
+            SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr8 = true;
+        }
+        // sample pass (on the CUs the pipelined full pass leaves free)
+        a.unit_step = stride;
+        a.n_sel = ns_units;
+        a.nrb = nrb;
+        if (use_event && h->opt.dense_async_streams == 2 && h->opt.dense_blocks <= 0) {
+            int sb = h->opt.dense_sample_blocks > 0 ? h->opt.dense_sample_blocks : (h->opt.dense_sample_blocks < 0 ? nrb : cus - nrb);
+            sb = (sb + 7) / 8 * 8;
+            if (sb >= 8 && sb < a.nrb) a.nrb = sb;
+        }
+        if (ns_units < (long long)a.nrb * I8_WAVES) a.nrb = (int)(((ns_units + I8_WAVES - 1) / I8_WAVES + 7) / 8 * 8);
+        hipLaunchKernelGGL((dense8_scan_kernel<true>), dim3((unsigned)a.nrb), dim3(I8_WAVES * 64), lds8, st, a);
+        hipLaunchKernelGGL((kth_threshold_f32_kernel<Dense8ThrPost>), dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr,
+                           Dense8ThrPost{s.par8.as<float2>(), qn2});
+        // full pass
+        a.unit_step = 1;
+        a.n_sel = n_units;
+        a.nrb = nrb;
+        if (prof) SQ_HIP(hipEventRecord(s.ev[1], st));
+        hipLaunchKernelGGL((dense8_scan_kernel<false>), dim3((unsigned)a.nrb), dim3(I8_WAVES * 64), lds8, st, a);
+        if (prof) SQ_HIP(hipEventRecord(s.ev[2], st));
+        c.stats.scan_launches = 2;
+        c.stats.bytes_scanned = h->n_pad64 * ((long long)I8_ROW_BYTES + 4);
+        const int wpb = 2;
+        const size_t rr_lds = ldq <= 156 ? (size_t)32 * (ldq + 4) * 4 : 0;
+        hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, st, h->db, h->ld, d,
+                           s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, TILE_ROWS, s.keys.as<u64>(), cnt,
+                           cap, oflag, h->opt.dense_debug);
+        if (prof) SQ_HIP(hipEventRecord(s.ev[4], st));
+        {
+            DenseFinalizeL2 fin{cnt, cap, kk, h->id_base, thr, qn2, 0.0, 1, (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0};
+            fin.lin = s.par8.as<float2>();
+            SQ_TRY(select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(), fin, st, s.sort_tmp, 8 * stride * kk));
+        }
     } else if (scan_ok) {
         const long long n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
         // Sample every stride-th tile.  The sample pass costs ~ n * groups / stride, the re-rank + select
@@ -570,6 +670,14 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
             }
         }
         for (int qi = 0; qi < nq; ++qi) h->stats.candidates += hs_raw[qi];
+        if (c.int8) {
+            // data the measured bound does not suit (every row of a tight cluster inside the slack): the lists overflow call
+            // after call and each query pays a second tier -- after three such calls in a row the handle goes back to bf16
+            int over = 0;
+            for (int qi = 0; qi < nq; ++qi) over += (hs[qi] & 1u) ? 1 : 0;
+            h->overflow8 = 2 * over > nq ? h->overflow8 + 1 : 0;
+            if (h->overflow8 >= 3 && h->opt.dense_int8 < 0) h->use8 = false;
+        }
     }
     // Exact full-keys path, a group of up to 8 queries per pass over the matrix (dense_exact_group_kernel):
     // exact keys for all n rows, then a two-level select -- the k-th smallest of every fb_stride-th exact
@@ -884,6 +992,72 @@ static int dense_build_rows(DenseHandle* h, long long row_base) {
     return SQ_OK;
 }
 
+// The int8 first-stage copy (sq_dense_i8.hpp), built at create for L2 matrices of up to 128 dimensions: the clamp from the
+// element rms (5 rms: one element in two million of a Gaussian is cut), the copy and the measured residuals, then the
+// choice of R: rows whose residual is beyond 1.5 times the typical one become always-candidates; more than 0.2 % of them
+// (heavy tails, a few wild rows aside) and the matrix keeps the bf16 filter alone.  Failure to allocate is not an error.
+static int dense8_build(DenseHandle* h) {
+    h->use8 = false;
+    if (h->metric != SQ_METRIC_L2 || h->d_pad != I8_ROW_BYTES || h->n < 65536 || g_opt.dense_int8 == 0) return SQ_OK;
+    const long long n = h->n;
+    const int d = h->d;
+    const long long n_pad64 = (n + I8_UNIT_ROWS - 1) / I8_UNIT_ROWS * I8_UNIT_ROWS;
+    const float* centerp = h->center.p ? h->center.as<float>() : nullptr;
+    DevBuf tmp;   // [sum f64 x2 | max bits u32 x2 | flagged u32]
+    DevBuf r2row;
+    auto quit = [&](int rc) {
+        tmp.release();
+        r2row.release();
+        if (!h->use8) {
+            h->scan8.release();
+            h->nrow8.release();
+        }
+        return rc;
+    };
+    if (tmp.reserve(64) != SQ_OK || r2row.reserve((size_t)n_pad64 * 4) != SQ_OK || h->scan8.reserve((size_t)n_pad64 * I8_ROW_BYTES) != SQ_OK ||
+        h->nrow8.reserve((size_t)n_pad64 * 4) != SQ_OK) {
+        (void)hipGetLastError();
+        return quit(SQ_OK);
+    }
+    SQ_HIP(hipMemset(tmp.p, 0, 64));
+    hipLaunchKernelGGL(dense8_energy_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, tmp.as<double>());
+    double energy = 0.0;
+    SQ_HIP(hipMemcpy(&energy, tmp.p, 8, hipMemcpyDeviceToHost));
+    const double rms = sqrt(energy / ((double)n * d));
+    if (!(rms > 0.0) || !(rms < 1e30)) return quit(SQ_OK);
+    const double dx = 5.0 * rms / 127.0;
+    hipLaunchKernelGGL(dense8_build_kernel, dim3((unsigned)((n_pad64 + 3) / 4)), dim3(256), 0, 0, h->db, n, h->ld, d, n_pad64, centerp,
+                       (float)(1.0 / dx), (float)dx, h->scan8.as<signed char>(), h->nrow8.as<float>(), r2row.as<float>(), 0ll);
+    double* sum_r2 = tmp.as<double>() + 1;
+    u32* maxb = reinterpret_cast<u32*>(tmp.as<double>() + 2);
+    u32* flagged = maxb + 2;
+    hipLaunchKernelGGL(dense8_resid_stats_kernel, dim3(1024), dim3(256), 0, 0, r2row.as<float>(), h->nrow8.as<float>(), n, sum_r2, maxb);
+    struct {
+        double energy, sum_r2;
+        u32 max_r2, max_n, flagged, pad;
+    } host{};
+    SQ_HIP(hipMemcpy(&host, tmp.p, sizeof(host), hipMemcpyDeviceToHost));
+    float max_r2, max_n;
+    memcpy(&max_r2, &host.max_r2, 4);
+    memcpy(&max_n, &host.max_n, 4);
+    const double mean_r2 = host.sum_r2 / (double)n;
+    double cut = 2.25 * mean_r2;                 // R = 1.5 x the typical residual (uniform quantisation noise spreads by ~8 %)
+    if ((double)max_r2 <= cut) cut = (double)max_r2;   // nothing beyond: R is simply the largest
+    hipLaunchKernelGGL(dense8_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, r2row.as<float>(), h->nrow8.as<float>(), n,
+                       (float)cut, flagged, 0ll);
+    u32 nflag = 0;
+    SQ_HIP(hipMemcpy(&nflag, flagged, 4, hipMemcpyDeviceToHost));
+    SQ_HIP(hipDeviceSynchronize());
+    if ((double)nflag > 0.002 * (double)n) return quit(SQ_OK);   // heavy tails: the bf16 filter's relative bound suits such data better
+    h->dx8 = (double)(float)dx;   // (the kernel multiplies by the float32 value)
+    h->rmax8 = sqrt(cut) * (1.0 + 1e-6);
+    h->xmax8 = sqrt((double)max_n) * (1.0 + 1e-6);
+    h->flagged8 = nflag;
+    h->n_pad64 = n_pad64;
+    h->use8 = true;
+    return quit(SQ_OK);
+}
+
 // Room for `n_new` rows in every per-row buffer, contents kept (grown by half again at least, so a stream of
 // small appends copies the matrix O(log) times).
 static int grow_keep(DevBuf& b, size_t used, size_t need) {
@@ -999,6 +1173,7 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
         }
         if (rc == SQ_OK && d_pad <= MAX_DPAD) rc = h->scan.reserve((size_t)h->n_pad * d_pad * 2);
         if (rc == SQ_OK) rc = dense_build_rows(h, 0);
+        if (rc == SQ_OK) rc = dense8_build(h);
         if (rc != SQ_OK) return bail(rc);
     }
     *out = register_handle(h);
@@ -1030,6 +1205,11 @@ extern "C" int sq_dense_append(sq_handle_t hid, const float* rows, int64_t n_add
     if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_dense_append: copy failed: %s", hipGetErrorString(e));
     h->n = n_new;
     h->n_pad = (n_new + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
+    if (h->use8) {   // (the int8 copy was scaled and sized for the rows of the build: appended-to indexes keep the bf16 filter)
+        h->use8 = false;
+        h->scan8.release();
+        h->nrow8.release();
+    }
     // the tile the old rows ended in is rebuilt together with the new ones (its padding rows become real rows)
     return dense_build_rows(h, n_old / TILE_ROWS * TILE_ROWS);
 }

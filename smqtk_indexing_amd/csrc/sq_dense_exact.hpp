@@ -876,6 +876,7 @@ struct DenseFinalizeL2 {
     int q0;
     ExactGroup sel = ExactGroup{{0, 0, 0, 0, 0, 0, 0, 0}, 0};  // count > 0: query ql of the launch is sel.idx[ql], its count cnt[ql]
     const int* qmap = nullptr;  // the middle tier: query ql of the launch is qmap[ql]; cnt, thr and qn2 are the launch's own arrays
+    const float2* lin = nullptr;  // the int8 filter: a non-candidate (s~ > T') has s > T' - lin[q].y (its slack is linear in |q|, not beta |q|^2)
     __device__ __forceinline__ void operator()(int ql, const u64* sorted, int k) const {
         const int q = qmap ? qmap[ql] : (sel.count ? sel.idx[ql] : q0 + ql);
         const int qa = qmap ? ql : q;  // index into thr / qn2
@@ -894,7 +895,7 @@ struct DenseFinalizeL2 {
                 if (st == 0 && certify == 1) {
                     const double dk = (double)unordered_f32((u32)(sorted[kk - 1] >> 32));
                     const double t = (double)thr[qa];
-                    const double lo2 = t + qn2[qa] * (1.0 - beta);  // smallest squared distance a non-candidate can have
+                    const double lo2 = t + qn2[qa] * (1.0 - beta) - (lin ? (double)lin[qa].y : 0.0);  // smallest squared distance a non-candidate can have
                     const double bound = lo2 > 0.0 ? sqrt(lo2) * (1.0 - 1e-6) : 0.0;
                     if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
                 }

@@ -1,0 +1,384 @@
+// The int8 first-stage filter of the dense L2 search (d <= 128, one query tile per call): half the bytes of the
+// bfloat16 scan copy, exact integer accumulation, and an error bound that is MEASURED per row instead of assumed.
+//
+// The bf16 filter (sq_dense_scan.hpp) streams 2 d_pad + 4 bytes per row and is HBM bound: a pass over 10 M x 128 is 2.6 GB
+// and 0.39 ms at 0.82 of the peak -- the kernel is where the hardware lets it be, so the only way on is fewer bytes.  Here a
+// row is d_pad signed bytes: x' = x - c (the filter's origin, as before) quantised with ONE scale for the whole matrix,
+//     x8_k = clamp(rint(x'_k / Dx), -127, 127),      Dx = 5 rms(x'_k) / 127,
+// and the part a byte cannot hold is not bounded by a worst case but measured at build time, in float64, per row:
+//     r_row = | x' - Dx x8 |_2        (quantisation noise ~ Dx sqrt(d / 12), plus whatever the clamp cut off).
+// With the query scaled per query, Q8_k = rint(-2 q''_k / Dq), q'' = q - c, rq = |-2 q'' - Dq Q8|_2 measured the same
+// way, the kernel's score
+//     s~ = N_row + (Dx Dq) * sum_k x8_k Q8_k             (v_mfma_i32_32x32x32_i8: the sum is an exact integer)
+// differs from the true score s = |x'|^2 - 2 x'.q'' by at most
+//     e(row, q) = 2 r_row |q''| + |Dx x8| rq + rounding <= 2 R |q''| + (X + R) rq + rounding =: e_q
+// (Cauchy-Schwarz on the two measured residuals; R = the largest r_row of the rows that take part, X = the largest
+// |x'|).  Rows whose r_row is far above the rest (an element far beyond the clamp) would widen every query's slack:
+// they get N_row = -inf instead, pass every threshold and are simply re-ranked exactly (a matrix with more than 0.2 %
+// of such rows keeps the bf16 filter).  Everything downstream is the bf16 filter's: the sampled k-th score T_s bounds
+// the true k-th score by T_s + e_q, the threshold is T' = T_s + 2 e_q, survivors leave as (first row, mask, query)
+// entries of per-wave segments, are re-ranked in the reference's float32 arithmetic from the ORIGINAL rows
+// (dense_rerank_l2_kernel), selected, and certified: a non-candidate has s > T' - e_q.  Queries that fail take the
+// middle tier and the exact path as before, so results never depend on the filter.
+//
+// Layout: the copy is plain row-major int8 [n_pad][128]; a ring unit is 64 rows (8 KiB: two 32-row MFMA tiles) DMA'd as
+// 8 pieces of 8 rows, the 16-byte chunks of a row XOR-swizzled by (row >> 1) & 7 on the SOURCE side so that the
+// ds_read_b128 of a fragment (lane = row, 16 consecutive k) is conflict-free.  One 16-byte read feeds one MFMA
+// (K = 32): four reads and four MFMAs per tile, against eight and sixteen in the bf16 kernel.
+#pragma once
+#include "sq_dense_scan.hpp"
+
+namespace sq {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int I8_ROW_BYTES = 128;                  // d_pad = 128
+static constexpr int I8_UNIT_ROWS = 64;
+static constexpr int I8_UNIT_BYTES = I8_UNIT_ROWS * I8_ROW_BYTES;   // 8 KiB
+static constexpr int I8_SLOT_BYTES = I8_UNIT_BYTES + 256;           // + the unit's 64 row terms N_row
+static constexpr int I8_WAVES = 8, I8_NSTAGE = 2;
+
+// ---------------------------------------------------------------- build
+// sum over rows of |x - c|^2 (float64), for the element rms that sets the clamp
+static __global__ __launch_bounds__(256) void dense8_energy_kernel(const float* __restrict__ db, long long n, long long ld, int d,
+                                                                    const float* __restrict__ center, double* __restrict__ sum) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const long long rows_per_block = 64;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    for (long long i = threadIdx.x; i < rows_per_block * d; i += 256) {
+        const long long r = r0 + i / d;
+        const int k = (int)(i % d);
+        if (r < n) {
+            const float v = db[r * ld + k];
+            const float xc = center ? __fsub_rn(v, center[k]) : v;
+            if (xc == xc && fabsf(xc) < 3.0e38f) acc += (double)xc * (double)xc;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+// One wave per row: the int8 row, N_row = RD(|x'|^2) and the measured residual r_row^2 (rounded up) of rows
+// [row_base, n_pad).  Padding rows: zeros and N_row = +inf.  Rows with a non-finite element: N_row = +inf (their true
+// distance is inf / NaN: they rank last, as in the bf16 filter) and no residual.
+static __global__ __launch_bounds__(256) void dense8_build_kernel(const float* __restrict__ db, long long n, long long ld, int d,
+                                                                   long long n_pad, const float* __restrict__ center, float inv_dx,
+                                                                   float dx, signed char* __restrict__ out8, float* __restrict__ nrow,
+                                                                   float* __restrict__ r2row, long long row_base) {
+    const int lane = threadIdx.x & 63;
+    const long long row = row_base + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_pad) return;
+    signed char q[2] = {0, 0};
+    double e2 = 0.0, r2 = 0.0;
+    bool finite = true;
+    if (row < n) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = 2 * lane + j;
+            if (k < d) {
+                const float v = db[row * ld + k];
+                const float xc = center ? __fsub_rn(v, center[k]) : v;
+                if (!(xc == xc) || !(fabsf(xc) < 3.0e38f)) finite = false;
+                float t = rintf(xc * inv_dx);
+                t = fminf(fmaxf(t, -127.f), 127.f);
+                if (!(t == t)) t = 0.f;
+                q[j] = (signed char)(int)t;
+                const double res = (double)xc - (double)t * (double)dx;
+                e2 += (double)xc * (double)xc;
+                r2 += res * res;
+            }
+        }
+    }
+    finite = __ballot(!finite) == 0ull;
+    for (int o = 32; o > 0; o >>= 1) {
+        e2 += __shfl_xor(e2, o);
+        r2 += __shfl_xor(r2, o);
+    }
+    reinterpret_cast<short*>(out8 + row * I8_ROW_BYTES)[lane] = (short)((unsigned char)q[0] | ((unsigned short)(unsigned char)q[1] << 8));
+    if (lane == 0) {
+        float nr = __builtin_inff(), rr = 0.f;
+        if (row < n && finite) {
+            nr = (float)e2;
+            if ((double)nr > e2) nr = __uint_as_float(__float_as_uint(nr) - 1u);   // round down (e2 >= 0)
+            rr = (float)r2;
+            if ((double)rr < r2) rr = __uint_as_float(__float_as_uint(rr) + 1u);   // round up
+        }
+        nrow[row] = nr;
+        r2row[row] = rr;
+    }
+}
+
+// sum and maximum of the measured residuals r_row^2 and the largest N_row (finite rows), for the choice of R
+static __global__ __launch_bounds__(256) void dense8_resid_stats_kernel(const float* __restrict__ r2row, const float* __restrict__ nrow,
+                                                                         long long n, double* __restrict__ sum_r2,
+                                                                         u32* __restrict__ max_bits) {   // [0]: max r2, [1]: max N
+    __shared__ double red[4];
+    __shared__ float rmax[4], nmax[4];
+    double acc = 0.0;
+    float m = 0.f, mn = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float nv = nrow[i];
+        if (nv < __builtin_inff()) {
+            const float v = r2row[i];
+            acc += (double)v;
+            m = fmaxf(m, v);
+            mn = fmaxf(mn, nv);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o);
+        m = fmaxf(m, __shfl_xor(m, o));
+        mn = fmaxf(mn, __shfl_xor(mn, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = acc;
+        rmax[threadIdx.x >> 6] = m;
+        nmax[threadIdx.x >> 6] = mn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sum_r2, red[0] + red[1] + red[2] + red[3]);
+        atomicMax(max_bits, __float_as_uint(fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]))));   // non-negative floats order like their bits
+        atomicMax(max_bits + 1, __float_as_uint(fmaxf(fmaxf(nmax[0], nmax[1]), fmaxf(nmax[2], nmax[3]))));
+    }
+}
+
+// rows whose residual is above the cut take part as "always a candidate": N_row = -inf
+static __global__ __launch_bounds__(256) void dense8_flag_kernel(const float* __restrict__ r2row, float* __restrict__ nrow, long long n,
+                                                                  float r2_cut, u32* __restrict__ flagged, long long row_base) {
+    const long long i = row_base + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (nrow[i] < __builtin_inff() && r2row[i] > r2_cut) {
+        nrow[i] = -__builtin_inff();
+        atomicAdd(flagged, 1u);
+    }
+}
+
+// ---------------------------------------------------------------- per call
+// Query prep of the int8 filter: the int8 plane Q8 = rint(-2 (q - c) / Dq) with the query's own scale, the measured
+// residual rq, |q - c|^2, the score unit Dx Dq and the query's error bound e_q (all float64, rounded up where they
+// widen the bound), plus what dense_prep_queries_kernel does besides (counters, overflow flag, the aligned copy).
+//   per query p < nq_pad:  qs8[p][128] int8, par[p] = {unit (Dx Dq), e_q}
+static __global__ __launch_bounds__(128) void dense8_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
+                                                                          const float* __restrict__ center, double dx, double r_max,
+                                                                          double x_max, signed char* __restrict__ qs8,
+                                                                          float2* __restrict__ par, double* __restrict__ qn2,
+                                                                          float* __restrict__ thr, u32* __restrict__ cnt,
+                                                                          u32* __restrict__ oflag, float* __restrict__ q_al, int ldq) {
+    const int qi = blockIdx.x, t = threadIdx.x;
+    __shared__ double red[2];
+    __shared__ float redm[2];
+    if (t == 0) {
+        // padding queries of the tile: a NaN threshold -- no comparison passes, not even an always-candidate row's -inf
+        thr[qi] = qi < nq ? -__builtin_inff() : __builtin_nanf("");
+        cnt[qi] = 0u;
+        if (qi == 0) *oflag = 0u;
+    }
+    float v = 0.f;
+    if (qi < nq && t < d) {
+        const float raw = q[(long long)qi * d + t];
+        v = center ? __fsub_rn(raw, center[t]) : raw;
+    }
+    if (qi < nq)
+        for (int i = t; i < ldq; i += 128) q_al[(long long)qi * ldq + i] = i < d ? q[(long long)qi * d + i] : 0.f;
+    // |q''|^2 and max |2 q''_k|
+    double a2 = (double)v * (double)v;
+    float m = fabsf(2.f * v);
+    if (!(m == m)) m = __builtin_inff();
+    for (int o = 32; o > 0; o >>= 1) {
+        a2 += __shfl_xor(a2, o);
+        m = fmaxf(m, __shfl_xor(m, o));
+    }
+    if ((t & 63) == 0) {
+        red[t >> 6] = a2;
+        redm[t >> 6] = m;
+    }
+    __syncthreads();
+    const double Q = red[0] + red[1];
+    const float mx = fmaxf(redm[0], redm[1]);
+    __syncthreads();
+    const bool ok = qi < nq && mx < 3.0e38f && mx > 0.f;   // zero / non-finite / padding queries: an all-zero plane, nothing certified by it
+    const double dq = ok ? (double)mx / 127.0 : 1.0;
+    float qt8 = 0.f;
+    if (ok) {
+        qt8 = rintf((float)((double)(-2.f * v) / dq));
+        qt8 = fminf(fmaxf(qt8, -127.f), 127.f);
+    }
+    qs8[(long long)qi * I8_ROW_BYTES + t] = (signed char)(int)qt8;
+    const double res = (double)(-2.f * v) - (double)qt8 * dq;
+    double r2 = res * res;
+    for (int o = 32; o > 0; o >>= 1) r2 += __shfl_xor(r2, o);
+    if ((t & 63) == 0) red[t >> 6] = r2;
+    __syncthreads();
+    if (t == 0) {
+        const double rq = sqrt(red[0] + red[1]) * (1.0 + 1e-9);
+        const double unit = dx * dq;
+        // e_q: 2 R |q''| (the rows' measured residual) + (X + R) rq (the query's) + the float32 evaluation of
+        // N + unit * sum (|sum| unit <= (X + R)(2 |q''| + rq): three roundings) + N's own rounding
+        const double xr = x_max + r_max, qn = sqrt(Q);
+        double e = 2.0 * r_max * qn + xr * rq + 4.0 * 5.9604644775390625e-08 * (xr * (2.0 * qn + rq) + x_max * x_max);
+        e *= 1.0 + 1e-6;
+        float ef = (float)e;
+        if ((double)ef < e) ef = __uint_as_float(__float_as_uint(ef) + 1u);
+        if (!ok && qi < nq) ef = __builtin_inff();   // (a zero or non-finite query: Dense8ThrPost gives it a NaN threshold, it takes the next tier)
+        par[qi] = make_float2((float)unit, qi < nq ? ef : 0.f);
+        qn2[qi] = qi < nq ? Q : 0.0;
+    }
+}
+
+// T_s (the sampled k-th score) -> T' = T_s + 2 e_q: at least k rows have a true score <= T_s + e_q, and a row
+// with a true score <= T_s + e_q has a kernel score <= T_s + 2 e_q.  (+ the rounding of the float32 distance the
+// certification compares with.)
+struct Dense8ThrPost {
+    const float2* par;
+    const double* qn2;
+    __device__ __forceinline__ void prologue(int, double*) const {}
+    __device__ __forceinline__ float operator()(int q, float t) const {
+        if (!(t < __builtin_inff())) return t;
+        if (!(par[q].y < __builtin_inff())) return __builtin_nanf("");   // nothing certifiable: no candidates, the next tier takes it
+        const double tt = (double)t + 2.0 * (double)par[q].y + 4e-6 * fabs((double)t + qn2[q]);
+        float r = (float)tt;
+        if ((double)r < tt) r = __uint_as_float(__float_as_uint(r) + (r >= 0.f ? 1 : -1));
+        return r;
+    }
+};
+
+struct Dense8ScanArgs {
+    const signed char* scan8;   // [n_pad][128]
+    const float* nrow;          // [n_pad64] N_row (+inf padding, -inf always-candidate rows)
+    long long n;
+    long long n_units;          // ceil(n / 64)
+    const signed char* qs8;     // [32][128]
+    const float2* par;          // [32] {unit, e_q}
+    const float* thr;           // [32]
+    uint2* wave_out;
+    u32* wave_cnt;
+    u32 wave_cap;
+    float* sample_out;          // [32][ns]
+    long long ns;
+    long long unit_step;        // SAMPLE: every unit_step-th unit; EMIT: 1
+    long long n_sel;            // units this launch visits
+    int nrb;
+    int nt;                     // non-temporal stream beyond nt_from_row
+    long long nt_from_row;
+};
+
+template <bool SAMPLE>
+__global__ __launch_bounds__(I8_WAVES * 64, 2) void dense8_scan_kernel(Dense8ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r31 = lane & 31, h = lane >> 5;
+    const u32 lds_base = (u32)(uintptr_t)smem;
+    const u32 ring_base = lds_base + (u32)wave * (I8_NSTAGE * I8_SLOT_BYTES);
+    const unsigned char* ring_ptr = smem + wave * (I8_NSTAGE * I8_SLOT_BYTES);
+    const long long wave_id = (long long)blockIdx.x * I8_WAVES + wave;
+    const long long nwaves = (long long)a.nrb * I8_WAVES;
+    uint2* wout = a.wave_out + wave_id * a.wave_cap;
+
+    // this lane's query (column r31 of the tile): its int8 plane as B fragments (k = 32 s + 16 h ..), unit and threshold
+    i32x4 bq[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bq[s] = *reinterpret_cast<const i32x4*>(a.qs8 + r31 * I8_ROW_BYTES + (2 * s + h) * 16);
+    float unit = a.par[r31].x;
+    float thr_l = SAMPLE ? 0.f : a.thr[r31];
+    asm volatile("" : "+v"(unit), "+v"(thr_l), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));   // complete before the ring starts
+
+    const long long my_units = wave_id < a.n_sel ? (a.n_sel - wave_id + nwaves - 1) / nwaves : 0;
+    // DMA piece j: rows 8j .. 8j+7 of the unit; lane -> (row 8j + lane / 8, source chunk (lane % 8) ^ ((row >> 1) & 7))
+    u32 voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 8 * j + (lane >> 3);
+        voff[j] = (u32)(r * I8_ROW_BYTES + (((lane & 7) ^ ((r >> 1) & 7)) * 16));
+    }
+    const u32 voff_n = (u32)lane * 4u;
+    long long issued = 0;
+    auto issue_next = [&]() __attribute__((always_inline)) {
+        if (issued >= my_units) return;
+        const long long unit_idx = (wave_id + issued * nwaves) * a.unit_step;
+        const long long row0 = unit_idx * I8_UNIT_ROWS;
+        const u32 dst = ring_base + (u32)(issued % I8_NSTAGE) * I8_SLOT_BYTES;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan8) + row0 * I8_ROW_BYTES;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (a.nt && row0 >= a.nt_from_row)
+                glds16<true>(base, voff[j], dst + (u32)j * 1024);
+            else
+                glds16<false>(base, voff[j], dst + (u32)j * 1024);
+        }
+        glds4(a.nrow + row0, voff_n, dst + I8_UNIT_BYTES);
+        ++issued;
+    };
+    for (int p = 0; p < I8_NSTAGE; ++p) issue_next();
+
+    u32 wcount = 0;
+    for (long long it = 0; it < my_units; ++it) {
+        const long long unit_idx = (wave_id + it * nwaves) * a.unit_step;
+        const long long row0 = unit_idx * I8_UNIT_ROWS;
+        wait_units_in_flight<I8_NSTAGE, 9>((int)(issued - it - 1));   // every unit is 9 DMA instructions
+        const unsigned char* sl = ring_ptr + (it % I8_NSTAGE) * I8_SLOT_BYTES;
+        i32x4 av[2][4];
+        f32x4 nr[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r = 32 * t + r31;   // this lane's row of the unit (A operand: lane = row)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                av[t][s] = *reinterpret_cast<const i32x4*>(sl + r * I8_ROW_BYTES + (((2 * s + h) ^ ((r >> 1) & 7)) * 16));
+            // N of the 16 rows this lane's accumulator registers hold: rows (i & 3) + 8 (i >> 2) + 4 h of tile t
+#pragma unroll
+            for (int c = 0; c < 4; ++c) nr[t][c] = *reinterpret_cast<const f32x4*>(sl + I8_UNIT_BYTES + (32 * t + 8 * c + 4 * h) * 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the unit is in registers: its slot is free
+        issue_next();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            i32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t][s], bq[s], acc, 0, 0, 0);
+            // scores of 32 rows x 32 queries (lane = query, register i = row (i & 3) + 8 (i >> 2) + 4 h)
+            float sc[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float nv = nr[t][i >> 2][i & 3];
+                if constexpr (SAMPLE) nv = nv == -__builtin_inff() ? __builtin_inff() : nv;   // an always-candidate row is no sample
+                sc[i] = __fmaf_rn((float)acc[i], unit, nv);
+            }
+            float m = sc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) m = fminf(m, sc[i]);
+            if constexpr (SAMPLE) {
+                const long long sel = wave_id + it * nwaves;
+                a.sample_out[(long long)r31 * a.ns + sel * 4 + t * 2 + h] = m;
+            } else {
+                const u64 hit = __ballot(m <= thr_l);
+                if (hit != 0) {
+                    u32 mask = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mask |= (sc[i] <= thr_l ? 1u : 0u) << i;   // (+inf padding rows never pass)
+                    const u64 bal = __ballot(mask != 0);
+                    if (mask) {
+                        const u32 pos = wcount + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                        if (pos < a.wave_cap) wout[pos] = make_uint2((u32)(row0 + 32 * t + 4 * h), (mask << 16) | (u32)r31);
+                    }
+                    wcount += (u32)__popcll(bal);
+                }
+            }
+        }
+    }
+    if constexpr (!SAMPLE) {
+        if (lane == 0) {
+            a.wave_cnt[2 * wave_id] = wcount;
+            a.wave_cnt[2 * wave_id + 1] = 0u;
+        }
+    }
+}
+
+}  // namespace sq
