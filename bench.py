@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--query-batches", type=int, default=8,
                     help="distinct query batches the timed steps rotate through (1 = the same queries every step)")
     ap.add_argument("--no-mid-tier", action="store_true", help="uncertified queries go straight to the exact path (measurement)")
+    ap.add_argument("--no-int8", action="store_true", help="bf16 first-stage filter only: no int8 copy is built (measurement)")
     ap.add_argument("--preroll-ms", type=float, default=30.0,
                     help="untimed pipelined steps for this long before the warm-up steps (start-up transient of the device; 0 = none)")
     ap.add_argument("--profile-every", type=int, default=0,
@@ -185,6 +186,8 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     queries = batches[0]
     torch.cuda.synchronize()
 
+    if args.no_int8:
+        _lib.set_option("dense_int8", 0)   # (read at create: the copy is not built)
     index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=metric, device_ptr=True, id_base=r0, keepalive=db)
     # hipEvent timing of the scan inside the library (`roofline.kernel_ms_in_pipeline`): every search on one GPU
     # (`--profile-every`), every 4th on shards -- the event records of a call cost ~10 us of a step, a tenth of a
@@ -323,6 +326,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         st_ = index.stats()
         al.append(st_["scan_ms"])
         al_rr.append(st_["rerank_ms"])
+        lib_bytes = float(st_["bytes_scanned"])
     head_scan_ms = float(np.mean(al[4:]))
     alone_rerank_ms = float(np.mean(al_rr[4:]))
     index.set_option("profile", prof_every)
@@ -460,12 +464,20 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         d_pad = -(-d // 128) * 128
         n_pad = -(-n_local // 32) * 32
         streamed = float(n_pad) * (d_pad * 2 + (0 if cosine else 4))
+        # the int8 first-stage filter (L2, d <= 128, one query tile: DESIGN.md 4.1b) streams d_pad + 4 bytes per row; the library
+        # reports what its full pass read (sq_stats_t.bytes_scanned) and that is what the roofline prices
+        n_pad64 = -(-n_local // 64) * 64
+        int8_filter = (not cosine) and lib_bytes == float(n_pad64) * (d_pad + 4)
+        if int8_filter:
+            streamed = lib_bytes
+        row_bytes = (d_pad + 4) if int8_filter else d_pad * 2 + (0 if cosine else 4)
         f32_bytes = float(n_local) * d * 4
         replay = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         if os.path.isfile(tpath) and n_local == 10_000_000 and d == 128 and not cosine:
             tj = json.load(open(tpath))
-            replay = {"hbm_bytes_per_launch": tj.get("dense_scan_full_pass_hbm_bytes"), "file": "profiles/latest_traffic.json",
+            replay = {"hbm_bytes_per_launch": tj.get("dense8_scan_full_pass_hbm_bytes" if int8_filter else "dense_scan_full_pass_hbm_bytes"),
+                      "file": "profiles/latest_traffic.json",
                       "note": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the committed profile"}
         achieved = streamed / (head_scan_ms * 1e-3) / 1e9 if head_scan_ms > 0 else 0.0
         qp = 2.0 if nq <= 32 else 1.0
@@ -482,7 +494,9 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32 results (distances bit-identical to numpy float32); filter arithmetic bf16 MFMA (x_hi*(q_hi+q_lo)), exact re-rank f32"
+            "dtype": ("f32 results (distances bit-identical to numpy float32); filter arithmetic int8 MFMA (i32 accumulation, measured "
+                      "per-row error bound), exact re-rank f32" if int8_filter else
+                      "f32 results (distances bit-identical to numpy float32); filter arithmetic bf16 MFMA (x_hi*(q_hi+q_lo)), exact re-rank f32")
                      if not cosine else "f64 results (cosine, 1e-12); filter arithmetic bf16 MFMA, exact re-rank f64",
             "data": f"synthetic {args.data} float32 descriptors generated on device; {nbatch} distinct query batches from the "
                     "same distribution, rotated through the timed steps",
@@ -514,7 +528,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "traffic_replayed": replay,
-                "kernel": "dense_scan_kernel (full pass)", "kernel_ms": head_scan_ms,
+                "kernel": "dense8_scan_kernel<false> (full pass)" if int8_filter else "dense_scan_kernel (full pass)", "kernel_ms": head_scan_ms,
                 "kernel_ms_note": "mean hipEvent-bracketed duration (events recorded by the library on the stream the kernel is "
                                   "launched on) of the full-pass launch in BLOCKING calls right after the timed region, same "
                                   "rotating query batches: the kernel's own streaming time.  achieved = streamed bytes / this.",
@@ -525,9 +539,12 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 "rerank_kernel_ms": alone_rerank_ms, "rerank_kernel_ms_in_pipeline": pipe_rerank_ms,
                 "rerank_note": "exact re-rank of the survivors; its rows are cold (distinct query batches: ~3.3 k x nq rows of "
                                "512 B gathered from HBM per step)",
-                "bytes_definition": "achieved/frac: bytes the kernel streams per launch = n_pad*(2*d_pad + 4) (bf16 scan copy + f32 norms)",
+                "bytes_definition": ("achieved/frac: bytes the kernel streams per launch = n_pad64*(d_pad + 4) (int8 scan copy + f32 row terms)"
+                                     if int8_filter else
+                                     "achieved/frac: bytes the kernel streams per launch = n_pad*(2*d_pad + 4) (bf16 scan copy + f32 norms)"),
                 "streamed_bytes_per_launch": streamed,
-                "bytes_per_row": d_pad * 2 + (0 if cosine else 4),
+                "bytes_per_row": row_bytes,
+                "first_stage_filter": "int8" if int8_filter else "bf16",
                 "algorithmic_bytes_survey_8d": f32_bytes,
                 "achieved_survey_8d": f32_bytes / (head_scan_ms * 1e-3) / 1e9 if head_scan_ms > 0 else None,
                 "frac_survey_8d": f32_bytes / (head_scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if head_scan_ms > 0 else None,
@@ -535,7 +552,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 "frac_step": streamed / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "frac_step_note": "streamed bytes / ms_per_step / peak: the whole search step (sample pass, threshold, re-rank, select, launch gaps) priced as if it were the scan",
                 "mfma_TFLOPs_executed": 2 * qp * n_pad * d_pad * (-(-nq // 32) * 32) / (head_scan_ms * 1e-3) / 1e12 if head_scan_ms > 0 else None,
-                "mfma_peak_TFLOPs": MFMA_BF16_PEAK_TF,
+                "mfma_peak_TFLOPs": 2 * MFMA_BF16_PEAK_TF if int8_filter else MFMA_BF16_PEAK_TF,
             },
         }
         if parity is not None:

@@ -367,8 +367,9 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         long long stride = h->opt.sample_stride;
         if (stride <= 0) {
             // units of 64 rows, four samples per unit: the bf16 path's cost model in units of two tiles
-            stride = (long long)(10.0 * sqrt((double)n / 1e7 * 100.0 / (double)kk) + 0.5);
-            if (stride > 12) stride = 12;
+            // (measured at 10 M x 128, k = 100: 0.293 / 0.269 / 0.262 / 0.258 / 0.257 / 0.257 / 0.263 ms per step at 6 / 8 / 10 / 12 / 16 / 20 / 24)
+            stride = (long long)(14.0 * sqrt((double)n / 1e7 * 100.0 / (double)kk) + 0.5);
+            if (stride > 16) stride = 16;
             if (stride < 1) stride = 1;
             if (stride > (long long)cap / (16ll * kk)) stride = std::max<long long>(1, (long long)cap / (16ll * kk));
         }
@@ -377,7 +378,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         const long long ns = ns_units * 4;
         SQ_TRY(s.sample.reserve((size_t)TILE_ROWS * ns * 4));
         SQ_TRY(s.keys.reserve((size_t)nq * key_stride * key_bytes));
-        SQ_TRY(s.q8.reserve((size_t)TILE_ROWS * I8_ROW_BYTES));
+        SQ_TRY(s.q8.reserve((size_t)2 * TILE_ROWS * I8_ROW_BYTES));
         SQ_TRY(s.par8.reserve((size_t)TILE_ROWS * 8));
         const int cus = cu_count(h->device);
         int nrb = h->opt.dense_blocks > 0 ? h->opt.dense_blocks : (use_event && h->opt.dense_async_streams == 2 ? cus * 3 / 4 : cus);
@@ -675,7 +676,11 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
             // after call and each query pays a second tier -- after three such calls in a row the handle goes back to bf16
             int over = 0;
             for (int qi = 0; qi < nq; ++qi) over += (hs[qi] & 1u) ? 1 : 0;
-            h->overflow8 = 2 * over > nq ? h->overflow8 + 1 : 0;
+            long long cands = 0;
+            for (int qi = 0; qi < nq; ++qi) cands += hs_raw[qi];
+            // (... or pass so many rows that the re-rank outweighs the bytes saved: the bf16 filter passes ~50 k of 10 M)
+            const bool heavy = 2 * over > nq || cands > (long long)nq * std::max<long long>(24ll * 1024, n / 128);
+            h->overflow8 = heavy ? h->overflow8 + 1 : 0;
             if (h->overflow8 >= 3 && h->opt.dense_int8 < 0) h->use8 = false;
         }
     }
@@ -992,10 +997,11 @@ static int dense_build_rows(DenseHandle* h, long long row_base) {
     return SQ_OK;
 }
 
-// The int8 first-stage copy (sq_dense_i8.hpp), built at create for L2 matrices of up to 128 dimensions: the clamp from the
-// element rms (5 rms: one element in two million of a Gaussian is cut), the copy and the measured residuals, then the
-// choice of R: rows whose residual is beyond 1.5 times the typical one become always-candidates; more than 0.2 % of them
-// (heavy tails, a few wild rows aside) and the matrix keeps the bf16 filter alone.  Failure to allocate is not an error.
+// The int8 first-stage copy (sq_dense_i8.hpp), built at create for L2 matrices of up to 128 dimensions: the clamp and the
+// residual bound R chosen from the measured residuals of ten candidate clamps (the pair with the least R that leaves
+// no more than 20 rows per million beyond it: those become always-candidates), the copy, its float64 residuals.  Data
+// whose residual bound is no small fraction of the rows' scale keeps the bf16 filter alone, and so does a failure to
+// allocate: neither is an error.
 static int dense8_build(DenseHandle* h) {
     h->use8 = false;
     if (h->metric != SQ_METRIC_L2 || h->d_pad != I8_ROW_BYTES || h->n < 65536 || g_opt.dense_int8 == 0) return SQ_OK;
@@ -1025,9 +1031,49 @@ static int dense8_build(DenseHandle* h) {
     SQ_HIP(hipMemcpy(&energy, tmp.p, 8, hipMemcpyDeviceToHost));
     const double rms = sqrt(energy / ((double)n * d));
     if (!(rms > 0.0) || !(rms < 1e30)) return quit(SQ_OK);
-    const double dx = 5.0 * rms / 127.0;
+    // the clamp and R from the measured residuals of ten candidate clamps (dense8_clip_stats_kernel)
+    static const double kClip[I8_NCLIP] = {1.75, 2.25, 2.75, 3.25, 3.75, 4.25, 4.75, 5.25, 6.0, 7.0};
+    static const double kCut[I8_NCUT] = {1.10, 1.15, 1.20, 1.30, 1.50, 2.0, 3.0, 6.0};   // R as a multiple of the rms residual
+    Dense8ClipArgs ca{};
+    for (int c = 0; c < I8_NCLIP; ++c) {
+        ca.dx[c] = (float)(kClip[c] * rms / 127.0);
+        ca.inv_dx[c] = 1.0f / ca.dx[c];
+    }
+    DevBuf clipbuf;   // [sum f64 x NCLIP | counts u32 x NCLIP x NCUT]
+    const size_t clip_bytes = I8_NCLIP * 8 + I8_NCLIP * I8_NCUT * 4;
+    if (clipbuf.reserve(clip_bytes) != SQ_OK) return quit(SQ_OK);
+    SQ_HIP(hipMemset(clipbuf.p, 0, clip_bytes));
+    const int stat_blocks = cu_count(h->device) * 8;
+    hipLaunchKernelGGL((dense8_clip_stats_kernel<false>), dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, ca,
+                       clipbuf.as<double>(), (u32*)nullptr);
+    struct {
+        double sum[I8_NCLIP];
+        u32 counts[I8_NCLIP][I8_NCUT];
+    } cs{};
+    SQ_HIP(hipMemcpy(&cs, clipbuf.p, I8_NCLIP * 8, hipMemcpyDeviceToHost));
+    for (int c = 0; c < I8_NCLIP; ++c)
+        for (int m = 0; m < I8_NCUT; ++m) ca.cut[c][m] = (float)(kCut[m] * kCut[m] * cs.sum[c] / (double)n);
+    hipLaunchKernelGGL((dense8_clip_stats_kernel<true>), dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, ca,
+                       (double*)nullptr, reinterpret_cast<u32*>(clipbuf.as<double>() + I8_NCLIP));
+    SQ_HIP(hipMemcpy(&cs, clipbuf.p, clip_bytes, hipMemcpyDeviceToHost));
+    clipbuf.release();
+    // rows beyond R are candidates of every query: a handful per million at most
+    const double budget = std::max(16.0, 2e-5 * (double)n);
+    int best_c = -1, best_m = -1;
+    double best_r = 0.0;
+    for (int c = 0; c < I8_NCLIP; ++c)
+        for (int m = 0; m < I8_NCUT; ++m)
+            if ((double)cs.counts[c][m] <= budget) {
+                const double r = kCut[m] * sqrt(cs.sum[c] / (double)n);
+                if (best_c < 0 || r < best_r) best_c = c, best_m = m, best_r = r;
+                break;
+            }
+    // a residual bound that is no small fraction of the rows' own scale (heavy tails: a few huge elements set the rms and
+    // the bulk of the rows falls into a few steps) would let most rows through: the bf16 filter's relative bound suits such data
+    if (best_c < 0 || !(best_r < 0.05 * rms * sqrt((double)d))) return quit(SQ_OK);
+    const double dx = (double)ca.dx[best_c];
     hipLaunchKernelGGL(dense8_build_kernel, dim3((unsigned)((n_pad64 + 3) / 4)), dim3(256), 0, 0, h->db, n, h->ld, d, n_pad64, centerp,
-                       (float)(1.0 / dx), (float)dx, h->scan8.as<signed char>(), h->nrow8.as<float>(), r2row.as<float>(), 0ll);
+                       ca.inv_dx[best_c], ca.dx[best_c], h->scan8.as<signed char>(), h->nrow8.as<float>(), r2row.as<float>(), 0ll);
     double* sum_r2 = tmp.as<double>() + 1;
     u32* maxb = reinterpret_cast<u32*>(tmp.as<double>() + 2);
     u32* flagged = maxb + 2;
@@ -1040,19 +1086,21 @@ static int dense8_build(DenseHandle* h) {
     float max_r2, max_n;
     memcpy(&max_r2, &host.max_r2, 4);
     memcpy(&max_n, &host.max_n, 4);
-    const double mean_r2 = host.sum_r2 / (double)n;
-    double cut = 2.25 * mean_r2;                 // R = 1.5 x the typical residual (uniform quantisation noise spreads by ~8 %)
+    double cut = best_r * best_r * (1.0 + 1e-4);   // (the choice was made in float32)
     if ((double)max_r2 <= cut) cut = (double)max_r2;   // nothing beyond: R is simply the largest
     hipLaunchKernelGGL(dense8_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, r2row.as<float>(), h->nrow8.as<float>(), n,
                        (float)cut, flagged, 0ll);
     u32 nflag = 0;
     SQ_HIP(hipMemcpy(&nflag, flagged, 4, hipMemcpyDeviceToHost));
     SQ_HIP(hipDeviceSynchronize());
-    if ((double)nflag > 0.002 * (double)n) return quit(SQ_OK);   // heavy tails: the bf16 filter's relative bound suits such data better
-    h->dx8 = (double)(float)dx;   // (the kernel multiplies by the float32 value)
+    if ((double)nflag > 4.0 * budget) return quit(SQ_OK);
+    h->dx8 = dx;
     h->rmax8 = sqrt(cut) * (1.0 + 1e-6);
     h->xmax8 = sqrt((double)max_n) * (1.0 + 1e-6);
     h->flagged8 = nflag;
+    if (getenv("SQ_INT8_REPORT"))   // (measurement aid: what the build chose)
+        fprintf(stderr, "[smqtk_hip] int8 filter: clamp %.2f rms, step %.5g, R %.5g (%.2f x rms residual), X %.5g, %u always-candidate rows of %lld\n",
+                kClip[best_c], dx, h->rmax8, kCut[best_m], h->xmax8, nflag, n);
     h->n_pad64 = n_pad64;
     h->use8 = true;
     return quit(SQ_OK);

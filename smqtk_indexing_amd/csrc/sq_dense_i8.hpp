@@ -9,7 +9,8 @@
 //     r_row = | x' - Dx x8 |_2        (quantisation noise ~ Dx sqrt(d / 12), plus whatever the clamp cut off).
 // With the query scaled per query, Q8_k = rint(-2 q''_k / Dq), q'' = q - c, rq = |-2 q'' - Dq Q8|_2 measured the same
 // way, the kernel's score
-//     s~ = N_row + (Dx Dq) * sum_k x8_k Q8_k             (v_mfma_i32_32x32x32_i8: the sum is an exact integer)
+//     s~ = N_row + (Dx Dq) * sum_k x8_k Q8_k             (v_mfma_i32_32x32x32_i8: the sum is an exact integer;
+//                                                          Q8 is two int8 planes, the second in units of Dq / 254)
 // differs from the true score s = |x'|^2 - 2 x'.q'' by at most
 //     e(row, q) = 2 r_row |q''| + |Dx x8| rq + rounding <= 2 R |q''| + (X + R) rq + rounding =: e_q
 // (Cauchy-Schwarz on the two measured residuals; R = the largest r_row of the rows that take part, X = the largest
@@ -24,7 +25,7 @@
 // Layout: the copy is plain row-major int8 [n_pad][128]; a ring unit is 64 rows (8 KiB: two 32-row MFMA tiles) DMA'd as
 // 8 pieces of 8 rows, the 16-byte chunks of a row XOR-swizzled by (row >> 1) & 7 on the SOURCE side so that the
 // ds_read_b128 of a fragment (lane = row, 16 consecutive k) is conflict-free.  One 16-byte read feeds one MFMA
-// (K = 32): four reads and four MFMAs per tile, against eight and sixteen in the bf16 kernel.
+// (K = 32) per query plane: four reads and eight MFMAs per tile, against eight and sixteen in the bf16 kernel.
 #pragma once
 #include "sq_dense_scan.hpp"
 
@@ -60,6 +61,77 @@ static __global__ __launch_bounds__(256) void dense8_energy_kernel(const float* 
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+// The clamp is CHOSEN from the data: for each of I8_NCLIP candidate clamps (multiples of the element rms) the row
+// residuals r_row^2 = |x' - Dx x8|^2 are evaluated (float32 is enough for a choice; the copy's own residuals are measured
+// in float64 by the build kernel) -- pass 1 their sums, pass 2 how many rows lie beyond each of I8_NCUT multiples of the
+// mean.  A narrow clamp has the finer step but cuts more elements off; the host takes the clamp whose residual bound R
+// (the smallest cut that leaves no more than a handful of rows beyond it) is least.
+static constexpr int I8_NCLIP = 10, I8_NCUT = 8;
+struct Dense8ClipArgs {
+    float inv_dx[I8_NCLIP], dx[I8_NCLIP];
+    float cut[I8_NCLIP][I8_NCUT];   // pass 2: r_row^2 thresholds
+};
+
+template <bool COUNT>
+static __global__ __launch_bounds__(256) void dense8_clip_stats_kernel(const float* __restrict__ db, long long n, long long ld, int d,
+                                                                        const float* __restrict__ center, Dense8ClipArgs ca,
+                                                                        double* __restrict__ sum_r2, u32* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    double acc[I8_NCLIP];
+    u32 cnt[I8_NCLIP][I8_NCUT];
+#pragma unroll
+    for (int c = 0; c < I8_NCLIP; ++c) {
+        acc[c] = 0.0;
+#pragma unroll
+        for (int m = 0; m < I8_NCUT; ++m) cnt[c][m] = 0u;
+    }
+    for (long long row = wave0; row < n; row += nw) {
+        float r2[I8_NCLIP];
+#pragma unroll
+        for (int c = 0; c < I8_NCLIP; ++c) r2[c] = 0.f;
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = 2 * lane + j;
+            if (k < d) {
+                const float v = db[row * ld + k];
+                const float xc = center ? __fsub_rn(v, center[k]) : v;
+                if (!(fabsf(xc) < 3.0e38f)) bad = true;
+#pragma unroll
+                for (int c = 0; c < I8_NCLIP; ++c) {
+                    const float t = fminf(fmaxf(rintf(xc * ca.inv_dx[c]), -127.f), 127.f);
+                    const float res = __fmaf_rn(-t, ca.dx[c], xc);
+                    r2[c] = __fmaf_rn(res, res, r2[c]);
+                }
+            }
+        }
+        if (__ballot(bad) != 0ull) continue;
+#pragma unroll
+        for (int c = 0; c < I8_NCLIP; ++c) {
+            for (int o = 32; o > 0; o >>= 1) r2[c] += __shfl_xor(r2[c], o);
+            if constexpr (COUNT) {
+#pragma unroll
+                for (int m = 0; m < I8_NCUT; ++m) cnt[c][m] += r2[c] > ca.cut[c][m] ? 1u : 0u;
+            } else {
+                acc[c] += (double)r2[c];
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < I8_NCLIP; ++c) {
+            if constexpr (COUNT) {
+#pragma unroll
+                for (int m = 0; m < I8_NCUT; ++m)
+                    if (cnt[c][m]) atomicAdd(&counts[c * I8_NCUT + m], cnt[c][m]);
+            } else {
+                atomicAdd(&sum_r2[c], acc[c]);
+            }
+        }
+    }
 }
 
 // One wave per row: the int8 row, N_row = RD(|x'|^2) and the measured residual r_row^2 (rounded up) of rows
@@ -159,10 +231,12 @@ static __global__ __launch_bounds__(256) void dense8_flag_kernel(const float* __
 }
 
 // ---------------------------------------------------------------- per call
-// Query prep of the int8 filter: the int8 plane Q8 = rint(-2 (q - c) / Dq) with the query's own scale, the measured
+// Query prep of the int8 filter: the int8 planes Q8 = rint(-2 (q - c) / Dq) with the query's own scale and
+// Q8' = rint(254 (-2 (q - c) / Dq - Q8)) (the matrix cores idle under the stream: a second plane is free and takes the
+// query's own quantisation out of the bound: rq shrinks 254-fold), the measured
 // residual rq, |q - c|^2, the score unit Dx Dq and the query's error bound e_q (all float64, rounded up where they
 // widen the bound), plus what dense_prep_queries_kernel does besides (counters, overflow flag, the aligned copy).
-//   per query p < nq_pad:  qs8[p][128] int8, par[p] = {unit (Dx Dq), e_q}
+//   per query p < nq_pad:  qs8[plane][p][128] int8 (plane 1 in units of Dq / 254), par[p] = {unit (Dx Dq), e_q}
 static __global__ __launch_bounds__(128) void dense8_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
                                                                           const float* __restrict__ center, double dx, double r_max,
                                                                           double x_max, signed char* __restrict__ qs8,
@@ -208,8 +282,15 @@ static __global__ __launch_bounds__(128) void dense8_prep_queries_kernel(const f
         qt8 = rintf((float)((double)(-2.f * v) / dq));
         qt8 = fminf(fmaxf(qt8, -127.f), 127.f);
     }
+    // second plane: what the first leaves, in steps of Dq / 254
+    float ql8 = 0.f;
+    if (ok) {
+        ql8 = rintf((float)((((double)(-2.f * v) / dq) - (double)qt8) * 254.0));
+        ql8 = fminf(fmaxf(ql8, -127.f), 127.f);
+    }
     qs8[(long long)qi * I8_ROW_BYTES + t] = (signed char)(int)qt8;
-    const double res = (double)(-2.f * v) - (double)qt8 * dq;
+    qs8[(long long)(TILE_ROWS + qi) * I8_ROW_BYTES + t] = (signed char)(int)ql8;
+    const double res = (double)(-2.f * v) - ((double)qt8 + (double)ql8 / 254.0) * dq;
     double r2 = res * res;
     for (int o = 32; o > 0; o >>= 1) r2 += __shfl_xor(r2, o);
     if ((t & 63) == 0) red[t >> 6] = r2;
@@ -252,7 +333,7 @@ struct Dense8ScanArgs {
     const float* nrow;          // [n_pad64] N_row (+inf padding, -inf always-candidate rows)
     long long n;
     long long n_units;          // ceil(n / 64)
-    const signed char* qs8;     // [32][128]
+    const signed char* qs8;     // [2][32][128]: plane, query
     const float2* par;          // [32] {unit, e_q}
     const float* thr;           // [32]
     uint2* wave_out;
@@ -281,12 +362,17 @@ __global__ __launch_bounds__(I8_WAVES * 64, 2) void dense8_scan_kernel(Dense8Sca
     uint2* wout = a.wave_out + wave_id * a.wave_cap;
 
     // this lane's query (column r31 of the tile): its int8 plane as B fragments (k = 32 s + 16 h ..), unit and threshold
-    i32x4 bq[4];
+    i32x4 bq[4], bl[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bq[s] = *reinterpret_cast<const i32x4*>(a.qs8 + r31 * I8_ROW_BYTES + (2 * s + h) * 16);
+    for (int s = 0; s < 4; ++s) {
+        bq[s] = *reinterpret_cast<const i32x4*>(a.qs8 + r31 * I8_ROW_BYTES + (2 * s + h) * 16);
+        bl[s] = *reinterpret_cast<const i32x4*>(a.qs8 + (TILE_ROWS + r31) * I8_ROW_BYTES + (2 * s + h) * 16);
+    }
     float unit = a.par[r31].x;
+    float unit_lo = __fdiv_rn(unit, 254.f);
     float thr_l = SAMPLE ? 0.f : a.thr[r31];
-    asm volatile("" : "+v"(unit), "+v"(thr_l), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));   // complete before the ring starts
+    asm volatile("" : "+v"(unit), "+v"(unit_lo), "+v"(thr_l), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(bl[0]), "+v"(bl[1]),
+                 "+v"(bl[2]), "+v"(bl[3]));   // complete before the ring starts
 
     const long long my_units = wave_id < a.n_sel ? (a.n_sel - wave_id + nwaves - 1) / nwaves : 0;
     // DMA piece j: rows 8j .. 8j+7 of the unit; lane -> (row 8j + lane / 8, source chunk (lane % 8) ^ ((row >> 1) & 7))
@@ -338,18 +424,21 @@ __global__ __launch_bounds__(I8_WAVES * 64, 2) void dense8_scan_kernel(Dense8Sca
         issue_next();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            i32x16 acc;
+            i32x16 acc, acl;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0;
+            for (int i = 0; i < 16; ++i) acc[i] = acl[i] = 0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t][s], bq[s], acc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t][s], bq[s], acc, 0, 0, 0);
+                acl = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t][s], bl[s], acl, 0, 0, 0);
+            }
             // scores of 32 rows x 32 queries (lane = query, register i = row (i & 3) + 8 (i >> 2) + 4 h)
             float sc[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float nv = nr[t][i >> 2][i & 3];
                 if constexpr (SAMPLE) nv = nv == -__builtin_inff() ? __builtin_inff() : nv;   // an always-candidate row is no sample
-                sc[i] = __fmaf_rn((float)acc[i], unit, nv);
+                sc[i] = __fmaf_rn((float)acl[i], unit_lo, __fmaf_rn((float)acc[i], unit, nv));
             }
             float m = sc[0];
 #pragma unroll

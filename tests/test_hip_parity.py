@@ -24,6 +24,7 @@ def _reset_options():
     _lib.set_option("dense_async_streams", 2)
     _lib.set_option("dense_mid_tier", 1)
     _lib.set_option("dense_fused_prep", 1)
+    _lib.set_option("dense_int8", -1)
 
 
 # ------------------------------------------------------------------- Hamming
@@ -137,6 +138,156 @@ def _dense_check(db, qs, k, metric="euclidean", exact_dist=True):
     return idx
 
 
+def _int8_bytes(n):
+    return (-(-n // 64) * 64) * 132
+
+
+def _bf16_bytes(n, d):
+    return (-(-n // 32) * 32) * (-(-d // 128) * 256 + 4)
+
+
+def _int8_family(rng, family, n, d, nq):
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    if family == "uniform":
+        db = rng.random((n, d), dtype=np.float32)
+        qs = rng.random((nq, d), dtype=np.float32)
+    elif family == "clustered":
+        cent = (4.0 * rng.standard_normal((200, d))).astype(np.float32)
+        db = (db + cent[rng.integers(0, 200, n)]).astype(np.float32)
+        qs = (qs + cent[rng.integers(0, 200, nq)]).astype(np.float32)
+    elif family == "scaled":
+        db = (db * np.float32(37.5) + np.float32(11.0)).astype(np.float32)
+        qs = (qs * np.float32(37.5) + np.float32(11.0)).astype(np.float32)
+    elif family == "near_rows":
+        # queries next to rows of the index (the usual case of a descriptor looked up in its own index), duplicates included
+        qs = (db[rng.integers(0, n, nq)] + np.float32(0.05) * qs).astype(np.float32)
+        qs[0] = db[123]
+        db[4567] = db[123]
+    return db, qs
+
+
+@pytest.mark.parametrize("n,d,nq,k,family", [(200_000, 128, 32, 100, "normal"), (150_001, 100, 7, 10, "uniform"),
+                                              (100_000, 65, 1, 1, "normal"), (180_000, 128, 20, 1000, "clustered"),
+                                              (70_000, 17, 32, 50, "scaled"), (130_000, 128, 31, 100, "near_rows"),
+                                              (66_000, 64, 5, 3, "clustered")])
+def test_dense_int8_filter_equals_bf16_filter_and_oracle(n, d, nq, k, family):
+    """The int8 first-stage filter (sq_dense_i8.hpp: L2, d <= 128, one query tile, n >= 65536) is a filter only: survivors
+    are re-ranked in the reference's float32 arithmetic and every query is certified against the measured error bound, so
+    neighbours and distance bits equal the bf16 filter's and the oracle's -- on benign data without a query leaving the
+    first tier.  sq_stats_t.bytes_scanned tells which copy the full pass streamed."""
+    rng = np.random.default_rng(n + d + k)
+    db, qs = _int8_family(rng, family, n, d, nq)
+    idx = _lib.DenseIndex(db)
+    idx.set_option("dense_int8", 1)
+    d8, i8 = idx.search(qs, k)
+    st = idx.stats()
+    assert st["bytes_scanned"] == _int8_bytes(n), st
+    assert st["fallback_queries"] == 0 and st["mid_tier_queries"] == 0, st
+    idx.set_option("dense_int8", 0)
+    d16, i16 = idx.search(qs, k)
+    assert idx.stats()["bytes_scanned"] == _bf16_bytes(n, d)
+    np.testing.assert_array_equal(i8, i16)
+    np.testing.assert_array_equal(d8.view(np.uint32), d16.view(np.uint32))
+    for qi in range(0, nq, max(1, nq // 6)):
+        rd, ri = O.dense_topk(db, qs[qi], k)
+        np.testing.assert_array_equal(i8[qi], ri)
+        np.testing.assert_array_equal(d8[qi].view(np.uint32), rd.view(np.uint32))
+    idx.close()
+
+
+def test_dense_int8_outlier_rows_and_odd_queries():
+    """Rows far outside the clamp (their residual is beyond R: they carry N_row = -inf and are re-ranked for every query),
+    rows with non-finite elements (N_row = +inf), and queries the filter cannot serve (all zero: no scale; one huge
+    element; a NaN) -- the answers are the oracle's in every case; the odd queries take the later tiers."""
+    rng = np.random.default_rng(2024)
+    n, d, k = 120_000, 128, 20
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    out = rng.choice(n, size=40, replace=False)
+    db[out[:20]] *= np.float32(50.0)                              # whole rows 50x the rest
+    db[out[20:30], 5] = np.float32(400.0)                         # one wild element
+    db[out[30:35], 7] = np.nan
+    db[out[35:], 9] = np.inf
+    qs = rng.standard_normal((12, d)).astype(np.float32)
+    qs[0] = db[out[0]] * np.float32(1.001)                        # nearest neighbour is an outlier row
+    qs[1] = db[out[21]]
+    qs[1, 5] = 399.0
+    qs[2] = 0.0
+    qs[3, 17] = 1.0e6
+    qs[4, 3] = np.nan
+    with np.errstate(invalid="ignore", over="ignore"):
+        idx = _lib.DenseIndex(db)
+        idx.set_option("dense_int8", 1)
+        idx.search(qs[5:], k)
+        st = idx.stats()
+        assert st["bytes_scanned"] == _int8_bytes(n) and st["mid_tier_queries"] + st["fallback_queries"] == 0, st
+        dd, ii = idx.search(qs, k)
+        st = idx.stats()
+        assert 3 <= st["mid_tier_queries"] <= 5 and st["fallback_queries"] <= st["mid_tier_queries"], st
+        for qi in range(len(qs)):
+            if qi == 4:
+                assert not np.isfinite(dd[qi]).any()
+                continue
+            rd, ri = O.dense_topk(db, qs[qi], k)
+            np.testing.assert_array_equal(ii[qi], ri)
+            np.testing.assert_array_equal(dd[qi].view(np.uint32), rd.view(np.uint32))
+        assert ii[0, 0] == out[0] and ii[1, 0] == out[21]
+    idx.close()
+
+
+def test_dense_int8_heavy_tails_and_tight_clusters():
+    """Data the measured bound does not suit.  Heavy tails (Student t, 2 degrees of freedom: a few huge elements set the
+    rms and the bulk of the rows falls into a few int8 steps): the build declines and the matrix keeps the bf16 filter.
+    Two tight clusters (every row of the query's cluster inside the int8 slack): the filter is built, its lists overflow
+    call after call, the queries are served by the later tiers, and after three such calls the handle goes back to the
+    bf16 filter by itself.  Results are the oracle's throughout."""
+    rng = np.random.default_rng(99)
+    n, d, k = 160_000, 128, 10
+    db = rng.standard_t(2.0, size=(n, d)).astype(np.float32)
+    qs = rng.standard_t(2.0, size=(6, d)).astype(np.float32)
+    idx = _dense_check(db, qs, k)
+    assert idx.stats()["bytes_scanned"] == _bf16_bytes(n, d), idx.stats()
+    idx.close()
+    u = rng.standard_normal(d).astype(np.float32)
+    u *= np.float32(10.0) / np.linalg.norm(u)
+    sign = np.where(np.arange(n) % 2 == 0, 1.0, -1.0).astype(np.float32)[:, None]
+    db = (sign * u + np.float32(0.02) * rng.standard_normal((n, d))).astype(np.float32)
+    qs = (u + np.float32(0.02) * rng.standard_normal((8, d))).astype(np.float32)
+    idx = _lib.DenseIndex(db)
+    seen = []
+    for rep in range(5):
+        dd, ii = idx.search(qs, k)
+        seen.append(idx.stats()["bytes_scanned"])
+        for qi in (0, 5):
+            rd, ri = O.dense_topk(db, qs[qi], k)
+            np.testing.assert_array_equal(ii[qi], ri)
+            np.testing.assert_array_equal(dd[qi].view(np.uint32), rd.view(np.uint32))
+    # (the later tiers add the float32 rows they read: the same in every call here)
+    later = seen[0] - _int8_bytes(n)
+    assert later > 0 and later % (n * d * 4) == 0 and seen[-1] == _bf16_bytes(n, d) + later, seen
+    idx.close()
+
+
+def test_dense_int8_copy_is_dropped_by_an_append():
+    """The int8 copy is scaled and sized for the rows of the build: an index that grows keeps the bf16 filter
+    (sq_dense_append rebuilds only that copy's tail)."""
+    rng = np.random.default_rng(5)
+    n, d, k = 100_000, 96, 10
+    db = rng.standard_normal((n + 3000, d)).astype(np.float32)
+    qs = rng.standard_normal((9, d)).astype(np.float32)
+    idx = _lib.DenseIndex(np.ascontiguousarray(db[:n]))
+    idx.search(qs, k)
+    assert idx.stats()["bytes_scanned"] == _int8_bytes(n)
+    idx.append(np.ascontiguousarray(db[n:]))
+    dd, ii = idx.search(qs, k)
+    assert idx.stats()["bytes_scanned"] == _bf16_bytes(n + 3000, d)
+    for qi in range(len(qs)):
+        rd, ri = O.dense_topk(db, qs[qi], k)
+        np.testing.assert_array_equal(ii[qi], ri)
+        np.testing.assert_array_equal(dd[qi].view(np.uint32), rd.view(np.uint32))
+    idx.close()
+
+
 @pytest.mark.parametrize("d,family", [(128, "long_query"), (64, "two_clusters"), (256, "long_query"), (512, "mixed"), (128, "mixed")])
 def test_dense_middle_tier_certifies_what_the_bf16_filter_cannot(d, family):
     """Queries the bfloat16 filter cannot certify -- a query hundreds of times longer than the rows, two tight clusters
@@ -155,6 +306,7 @@ def test_dense_middle_tier_certifies_what_the_bf16_filter_cannot(d, family):
         off[0] = 100.0                                     # clusters at +-100 e_0, spread 0.5: |x - c| = 100 for every row
         db = (0.5 * db + np.where(np.arange(n)[:, None] % 2 == 0, off, -off)).astype(np.float32)
         qs[6:] = (0.5 * qs[6:] + off).astype(np.float32)
+    _lib.set_option("dense_int8", 0)                      # (the tiers behind the bf16 filter are the subject)
     idx = _dense_check(db, qs, k)
     st = idx.stats()
     assert st["mid_tier_queries"] > 0, st
