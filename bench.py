@@ -200,7 +200,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         index.set_option("dense_mid_tier", 0)
     stream = torch.cuda.current_stream().cuda_stream
     use_async = not args.sync_search
-    depth = args.async_depth if args.async_depth > 0 else (3 if use_dist else 2)
+    depth = args.async_depth if args.async_depth > 0 else 3
     depth = min(max(depth, 2), 4)
     if use_async:
         index.set_option("dense_async_depth", depth)

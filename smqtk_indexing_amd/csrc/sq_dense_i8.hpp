@@ -41,53 +41,69 @@ static constexpr int I8_SLOT_BYTES = I8_UNIT_BYTES + 256;           // + the uni
 static constexpr int I8_WAVES = 8, I8_NSTAGE = 2;
 
 // ---------------------------------------------------------------- build
-// sum over rows of |x - c|^2 (float64), for the element rms that sets the clamp
+// sum over rows of |x - c|^2 (float64) and their number, rows with |x - c|^2 > cap left out: the element rms the clamp
+// candidates are multiples of.  The host runs it three times, cap = inf, then 16 x the mean of the pass before: a few
+// rows thousands of times the size of the rest would otherwise own the rms (they end up beyond R either way).
 static __global__ __launch_bounds__(256) void dense8_energy_kernel(const float* __restrict__ db, long long n, long long ld, int d,
-                                                                    const float* __restrict__ center, double* __restrict__ sum) {
-    __shared__ double red[4];
-    double acc = 0.0;
-    const long long rows_per_block = 64;
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
-    for (long long i = threadIdx.x; i < rows_per_block * d; i += 256) {
-        const long long r = r0 + i / d;
-        const int k = (int)(i % d);
-        if (r < n) {
-            const float v = db[r * ld + k];
-            const float xc = center ? __fsub_rn(v, center[k]) : v;
-            if (xc == xc && fabsf(xc) < 3.0e38f) acc += (double)xc * (double)xc;
+                                                                    const float* __restrict__ center, double cap,
+                                                                    double* __restrict__ sum) {   // [0]: energy, [1]: rows
+    __shared__ double red[4][2];
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    double acc = 0.0, rows = 0.0;
+    for (long long row = wave0; row < n; row += nw) {
+        double e = 0.0;
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = 2 * lane + j;
+            if (k < d) {
+                const float v = db[row * ld + k];
+                const float xc = center ? __fsub_rn(v, center[k]) : v;
+                if (!(fabsf(xc) < 3.0e38f)) bad = true;
+                e += (double)xc * (double)xc;
+            }
+        }
+        if (__ballot(bad) != 0ull) continue;
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+        if (e <= cap) {
+            acc += e;
+            rows += 1.0;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    if (lane == 0) {
+        red[threadIdx.x >> 6][0] = acc;
+        red[threadIdx.x >> 6][1] = rows;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(sum, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        atomicAdd(sum, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+        atomicAdd(sum + 1, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+    }
 }
 
 // The clamp is CHOSEN from the data: for each of I8_NCLIP candidate clamps (multiples of the element rms) the row
 // residuals r_row^2 = |x' - Dx x8|^2 are evaluated (float32 is enough for a choice; the copy's own residuals are measured
-// in float64 by the build kernel) -- pass 1 their sums, pass 2 how many rows lie beyond each of I8_NCUT multiples of the
-// mean.  A narrow clamp has the finer step but cuts more elements off; the host takes the clamp whose residual bound R
-// (the smallest cut that leaves no more than a handful of rows beyond it) is least.
-static constexpr int I8_NCLIP = 10, I8_NCUT = 8;
+// in float64 by the build kernel) and the rows beyond each of I8_NCUT candidate bounds counted.  The bounds are multiples
+// of what rounding alone leaves, Dx sqrt(d / 12) -- not of the measured mean, which a few wild rows would own.  A narrow
+// clamp has the finer step but cuts more elements off; the host takes the pair with the least bound R that leaves no
+// more than a few hundred rows beyond it.
+static constexpr int I8_NCLIP = 10, I8_NCUT = 10;
 struct Dense8ClipArgs {
     float inv_dx[I8_NCLIP], dx[I8_NCLIP];
-    float cut[I8_NCLIP][I8_NCUT];   // pass 2: r_row^2 thresholds
+    float cut[I8_NCLIP][I8_NCUT];   // r_row^2 thresholds
 };
 
-template <bool COUNT>
 static __global__ __launch_bounds__(256) void dense8_clip_stats_kernel(const float* __restrict__ db, long long n, long long ld, int d,
                                                                         const float* __restrict__ center, Dense8ClipArgs ca,
-                                                                        double* __restrict__ sum_r2, u32* __restrict__ counts) {
+                                                                        u32* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
-    double acc[I8_NCLIP];
     u32 cnt[I8_NCLIP][I8_NCUT];
 #pragma unroll
-    for (int c = 0; c < I8_NCLIP; ++c) {
-        acc[c] = 0.0;
+    for (int c = 0; c < I8_NCLIP; ++c)
 #pragma unroll
         for (int m = 0; m < I8_NCUT; ++m) cnt[c][m] = 0u;
-    }
     for (long long row = wave0; row < n; row += nw) {
         float r2[I8_NCLIP];
 #pragma unroll
@@ -112,25 +128,16 @@ static __global__ __launch_bounds__(256) void dense8_clip_stats_kernel(const flo
 #pragma unroll
         for (int c = 0; c < I8_NCLIP; ++c) {
             for (int o = 32; o > 0; o >>= 1) r2[c] += __shfl_xor(r2[c], o);
-            if constexpr (COUNT) {
 #pragma unroll
-                for (int m = 0; m < I8_NCUT; ++m) cnt[c][m] += r2[c] > ca.cut[c][m] ? 1u : 0u;
-            } else {
-                acc[c] += (double)r2[c];
-            }
+            for (int m = 0; m < I8_NCUT; ++m) cnt[c][m] += r2[c] > ca.cut[c][m] ? 1u : 0u;
         }
     }
     if (lane == 0) {
 #pragma unroll
-        for (int c = 0; c < I8_NCLIP; ++c) {
-            if constexpr (COUNT) {
+        for (int c = 0; c < I8_NCLIP; ++c)
 #pragma unroll
-                for (int m = 0; m < I8_NCUT; ++m)
-                    if (cnt[c][m]) atomicAdd(&counts[c * I8_NCUT + m], cnt[c][m]);
-            } else {
-                atomicAdd(&sum_r2[c], acc[c]);
-            }
-        }
+            for (int m = 0; m < I8_NCUT; ++m)
+                if (cnt[c][m]) atomicAdd(&counts[c * I8_NCUT + m], cnt[c][m]);
     }
 }
 

@@ -223,7 +223,7 @@ def test_dense_int8_outlier_rows_and_odd_queries():
         assert st["bytes_scanned"] == _int8_bytes(n) and st["mid_tier_queries"] + st["fallback_queries"] == 0, st
         dd, ii = idx.search(qs, k)
         st = idx.stats()
-        assert 3 <= st["mid_tier_queries"] <= 5 and st["fallback_queries"] <= st["mid_tier_queries"], st
+        assert 2 <= st["mid_tier_queries"] + st["fallback_queries"] <= 5, st   # the zero and the NaN query at least
         for qi in range(len(qs)):
             if qi == 4:
                 assert not np.isfinite(dd[qi]).any()
