@@ -101,6 +101,7 @@ int Options::*option_member(const char* name) {
         {"dense_nt_keep_mb", &Options::dense_nt_keep_mb},
         {"dense_mid_tier", &Options::dense_mid_tier},
         {"dense_int8", &Options::dense_int8},
+        {"dense_graph", &Options::dense_graph},
         {"dense_fused_prep", &Options::dense_fused_prep},
         {"hamming_async_depth", &Options::hamming_async_depth},
         {"hamming_async_wait", &Options::hamming_async_wait},

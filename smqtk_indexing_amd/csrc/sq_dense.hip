@@ -53,6 +53,10 @@ struct DenseSlot {
     DevBuf q8, par8;              // int8 filter: the query tile's plane and {score unit, e_q}
     DevBuf sort_tmp;              // scratch of the any-k sorted select (k beyond the one-workgroup select): one per call in flight
     HostPinned status_host;
+    // captured call graph of the int8 path ("dense_graph"): one hipGraphLaunch instead of six kernel launches per call
+    HostPinned call_ptrs;         // DenseCallPtrs of the call in flight
+    hipGraphExec_t gexec = nullptr;
+    u64 gkey = 0, seen_key = 0;   // what gexec was captured for / the key of the slot's last eager call
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // call start, scan start, scan end, call end, re-rank end
     hipEvent_t ev_in = nullptr, ev_done = nullptr;
     hipStream_t own = nullptr;    // internal stream of the slot (asynchronous calls with "dense_async_streams" = 2)
@@ -61,6 +65,9 @@ struct DenseSlot {
         for (DevBuf* b : {&q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt, &keys, &sample, &out_keys, &cos_nq, &oflag, &sort_tmp, &q8, &par8})
             b->release();
         status_host.release();
+        call_ptrs.release();
+        if (gexec) (void)hipGraphExecDestroy(gexec), gexec = nullptr;
+        gkey = seen_key = 0;
         for (auto& e : ev)
             if (e) (void)hipEventDestroy(e), e = nullptr;
         if (ev_in) (void)hipEventDestroy(ev_in), ev_in = nullptr;
@@ -99,7 +106,9 @@ struct DenseHandle : HandleBase {
     DevBuf q_dev, out_dist_dev, out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch, fb_cnt, fb_sort;
     DevBuf mid_q, mid_planes, mid_small, mid_qal, mid_wave_out, mid_wave_cnt, mid_keys, mid_out, mid_sample;  // the middle tier (synchronous)
     PinnedStage stage;
+    hipEvent_t ev_ref = nullptr;   // SQ_TRACE (measurement aid): the origin of the printed call timelines
     ~DenseHandle() override {
+        if (ev_ref) (void)hipEventDestroy(ev_ref);
         for (DevBuf* b : {&owned, &scan, &scan8, &nrow8, &norms, &norms1, &zeros, &center, &cos_nx, &q_dev, &out_dist_dev, &out_idx_dev, &big_keys,
                           &fb_sample, &fb_keys, &fb_out, &scratch, &fb_cnt, &fb_sort, &mid_q, &mid_planes, &mid_small, &mid_qal,
                           &mid_wave_out, &mid_wave_cnt, &mid_keys, &mid_out, &mid_sample})
@@ -299,6 +308,10 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
     if (prof) {
         for (auto& e : s.ev)
             if (!e) SQ_HIP(hipEventCreate(&e));
+        if (!h->ev_ref && getenv("SQ_TRACE")) {
+            SQ_HIP(hipEventCreate(&h->ev_ref));
+            SQ_HIP(hipEventRecord(h->ev_ref, st));
+        }
         SQ_HIP(hipEventRecord(s.ev[0], st));
     }
     SQ_TRY(s.cnt.reserve((size_t)nq_pad * 4));
@@ -391,8 +404,6 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         SQ_TRY(s.q_al.reserve((size_t)nq * ldq * 4));
         u32* oflag = s.oflag.as<u32>();
         const float* centerp = h->center.p ? h->center.as<float>() : nullptr;
-        hipLaunchKernelGGL(dense8_prep_queries_kernel, dim3(TILE_ROWS), dim3(128), 0, st, q, nq, d, centerp, h->dx8, h->rmax8, h->xmax8,
-                           s.q8.as<signed char>(), s.par8.as<float2>(), qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq);
         Dense8ScanArgs a{};
         a.scan8 = h->scan8.as<signed char>();
         a.nrow = h->nrow8.as<float>();
@@ -420,38 +431,98 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr8 = true;
         }
-        // sample pass (on the CUs the pipelined full pass leaves free)
-        a.unit_step = stride;
-        a.n_sel = ns_units;
-        a.nrb = nrb;
+        int nrb_sample = nrb;
         if (use_event && h->opt.dense_async_streams == 2 && h->opt.dense_blocks <= 0) {
             int sb = h->opt.dense_sample_blocks > 0 ? h->opt.dense_sample_blocks : (h->opt.dense_sample_blocks < 0 ? nrb : cus - nrb);
             sb = (sb + 7) / 8 * 8;
-            if (sb >= 8 && sb < a.nrb) a.nrb = sb;
+            if (sb >= 8 && sb < nrb_sample) nrb_sample = sb;
         }
-        if (ns_units < (long long)a.nrb * I8_WAVES) a.nrb = (int)(((ns_units + I8_WAVES - 1) / I8_WAVES + 7) / 8 * 8);
-        hipLaunchKernelGGL((dense8_scan_kernel<true>), dim3((unsigned)a.nrb), dim3(I8_WAVES * 64), lds8, st, a);
-        hipLaunchKernelGGL((kth_threshold_f32_kernel<Dense8ThrPost>), dim3(nq), dim3(1024), 0, st, a.sample_out, ns, kk, thr,
-                           Dense8ThrPost{s.par8.as<float2>(), qn2});
-        // full pass
-        a.unit_step = 1;
-        a.n_sel = n_units;
-        a.nrb = nrb;
-        if (prof) SQ_HIP(hipEventRecord(s.ev[1], st));
-        hipLaunchKernelGGL((dense8_scan_kernel<false>), dim3((unsigned)a.nrb), dim3(I8_WAVES * 64), lds8, st, a);
-        if (prof) SQ_HIP(hipEventRecord(s.ev[2], st));
-        c.stats.scan_launches = 2;
-        c.stats.bytes_scanned = h->n_pad64 * ((long long)I8_ROW_BYTES + 4);
+        if (ns_units < (long long)nrb_sample * I8_WAVES) nrb_sample = (int)(((ns_units + I8_WAVES - 1) / I8_WAVES + 7) / 8 * 8);
         const int wpb = 2;
         const size_t rr_lds = ldq <= 156 ? (size_t)32 * (ldq + 4) * 4 : 0;
-        hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, st, h->db, h->ld, d,
-                           s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, TILE_ROWS, s.keys.as<u64>(), cnt,
-                           cap, oflag, h->opt.dense_debug);
-        if (prof) SQ_HIP(hipEventRecord(s.ev[4], st));
-        {
+        // The chain of six launches, eagerly or as a captured graph.  A pipelined call on a small shard is bound by the
+        // HOST: a launch costs ~2.8 us of host time (tools/micro/launch_cost.hip: 19.3 us for a chain of seven, 5.6-6.3 us
+        // for one hipGraphLaunch of the same chain), and a 1.25 M-row shard's whole step is ~55 us.  The slot's first
+        // call of a shape runs eagerly (it sizes the workspace and sets the kernels' attributes), the second captures,
+        // later ones launch the graph; the caller's pointers travel through a pinned block (DenseCallPtrs).
+        const DenseCallPtrs* ind = nullptr;
+        auto chain = [&](hipStream_t cs) -> int {
+            hipLaunchKernelGGL(dense8_prep_queries_kernel, dim3(TILE_ROWS), dim3(128), 0, cs, q, nq, d, centerp, h->dx8, h->rmax8, h->xmax8,
+                               s.q8.as<signed char>(), s.par8.as<float2>(), qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq, ind);
+            Dense8ScanArgs b = a;
+            b.unit_step = stride;   // sample pass (on the CUs the pipelined full pass leaves free)
+            b.n_sel = ns_units;
+            b.nrb = nrb_sample;
+            hipLaunchKernelGGL((dense8_scan_kernel<true>), dim3((unsigned)b.nrb), dim3(I8_WAVES * 64), lds8, cs, b);
+            hipLaunchKernelGGL((kth_threshold_f32_kernel<Dense8ThrPost>), dim3(nq), dim3(1024), 0, cs, a.sample_out, ns, kk, thr,
+                               Dense8ThrPost{s.par8.as<float2>(), qn2});
+            b.unit_step = 1;        // full pass
+            b.n_sel = n_units;
+            b.nrb = nrb;
+            if (prof) SQ_HIP(hipEventRecord(s.ev[1], cs));
+            hipLaunchKernelGGL((dense8_scan_kernel<false>), dim3((unsigned)b.nrb), dim3(I8_WAVES * 64), lds8, cs, b);
+            if (prof) SQ_HIP(hipEventRecord(s.ev[2], cs));
+            hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, cs, h->db, h->ld, d,
+                               s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, TILE_ROWS, s.keys.as<u64>(), cnt,
+                               cap, oflag, h->opt.dense_debug);
+            if (prof) SQ_HIP(hipEventRecord(s.ev[4], cs));
             DenseFinalizeL2 fin{cnt, cap, kk, h->id_base, thr, qn2, 0.0, 1, (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0};
             fin.lin = s.par8.as<float2>();
-            SQ_TRY(select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(), fin, st, s.sort_tmp, 8 * stride * kk));
+            fin.ind = ind;
+            return select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(), fin, cs, s.sort_tmp, 8 * stride * kk);
+        };
+        c.stats.scan_launches = 2;
+        c.stats.bytes_scanned = h->n_pad64 * ((long long)I8_ROW_BYTES + 4);
+        bool launched = false;
+        if (use_event && !prof && h->opt.dense_graph != 0 && st != nullptr && st == s.own) {   // (never a capture on the caller's stream)
+            // everything the captured launches were given by value: shapes, the slot's and the handle's buffers
+            u64 key = 0xcbf29ce484222325ull;
+            auto mix = [&key](u64 v) { key = (key ^ v) * 0x100000001b3ull; };
+            for (u64 v : {(u64)nq, (u64)k, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
+                          (u64)h->opt.dense_debug, (u64)h->id_base, (u64)(uintptr_t)st, (u64)(uintptr_t)h->db, (u64)(uintptr_t)centerp,
+                          (u64)(uintptr_t)h->scan8.p, (u64)(uintptr_t)h->nrow8.p, (u64)(uintptr_t)s.q8.p, (u64)(uintptr_t)s.par8.p,
+                          (u64)(uintptr_t)s.sample.p, (u64)(uintptr_t)s.keys.p, (u64)(uintptr_t)s.wave_out.p, (u64)(uintptr_t)s.wave_cnt.p,
+                          (u64)(uintptr_t)s.q_al.p, (u64)(uintptr_t)cnt, (u64)(uintptr_t)thr, (u64)(uintptr_t)qn2, (u64)(uintptr_t)oflag,
+                          (u64)(uintptr_t)s.out_keys.p, (u64)(uintptr_t)hs_raw_dev})
+                mix(v);
+            if (key == 0) key = 1;
+            if (s.gexec && s.gkey != key) {
+                (void)hipGraphExecDestroy(s.gexec);
+                s.gexec = nullptr;
+            }
+            if (!s.gexec && s.seen_key == key) {   // second call of this shape on this slot: capture
+                SQ_TRY(s.call_ptrs.reserve(sizeof(DenseCallPtrs)));
+                void* ind_dev = nullptr;
+                SQ_TRY(s.call_ptrs.device_ptr(&ind_dev));
+                ind = static_cast<const DenseCallPtrs*>(ind_dev);
+                hipGraph_t g = nullptr;
+                SQ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                const int rc = chain(st);
+                const hipError_t ec = hipStreamEndCapture(st, &g);
+                if (rc != SQ_OK || ec != hipSuccess || !g) {
+                    if (g) (void)hipGraphDestroy(g);
+                    (void)hipGetLastError();
+                    return fail(SQ_ERR_HIP, "sq_dense_search: capturing the call graph failed");
+                }
+                const hipError_t ei = hipGraphInstantiate(&s.gexec, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (ei != hipSuccess) {
+                    s.gexec = nullptr;
+                    return fail(SQ_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+                }
+                s.gkey = key;
+                if (getenv("SQ_INT8_REPORT")) fprintf(stderr, "[smqtk_hip] call graph captured (%d queries, k = %d)\n", nq, k);
+            }
+            s.seen_key = key;
+            if (s.gexec) {
+                *static_cast<DenseCallPtrs*>(s.call_ptrs.p) = DenseCallPtrs{q, out_dist, out_idx};
+                SQ_HIP(hipGraphLaunch(s.gexec, st));
+                launched = true;
+            }
+        }
+        if (!launched) {
+            ind = nullptr;
+            SQ_TRY(chain(st));
         }
     } else if (scan_ok) {
         const long long n_tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
@@ -665,6 +736,13 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
             SQ_HIP(hipEventElapsedTime(&t2, s.ev[0], s.ev[3]));
             h->stats.scan_ms = t1;
             h->stats.total_ms = t2;
+            if (h->ev_ref) {   // when the call's head / scan / re-rank / select ended, on the clock of the first traced call
+                float e[5] = {0, 0, 0, 0, 0};
+                const int order[5] = {0, 1, 2, 4, 3};
+                for (int j = 0; j < 5; ++j) (void)hipEventElapsedTime(&e[j], h->ev_ref, s.ev[order[j]]);
+                fprintf(stderr, "[smqtk_hip] trace slot %d: start %.1f | head-> %.1f | scan-> %.1f | rerank-> %.1f | select-> %.1f us\n",
+                        (int)(&s - h->slot), e[0] * 1e3f, e[1] * 1e3f, e[2] * 1e3f, e[3] * 1e3f, e[4] * 1e3f);
+            }
             if (c.stats.scan_launches == 2) {  // (the filter path: a re-rank kernel followed the scan)
                 float t3 = 0;
                 SQ_HIP(hipEventElapsedTime(&t3, s.ev[2], s.ev[4]));

@@ -859,6 +859,14 @@ struct DenseThrPost {
 // certification, status word.  `status` and `cnt_out` may be host-mapped memory: the host then only
 // has to synchronise the stream.  q0: index of the launch's first query in the per-query arrays
 // (the exact path runs one query per launch).
+// What changes from call to call in a captured call graph (sq_dense.hip, "dense_graph"): the caller's pointers, read by the
+// first and the last kernel of the chain from a pinned block the host fills before each launch of the graph.
+struct DenseCallPtrs {
+    const float* q;
+    void* out_dist;
+    long long* out_idx;
+};
+
 struct DenseFinalizeL2 {
     const u32* cnt;
     u32 cap;
@@ -877,9 +885,12 @@ struct DenseFinalizeL2 {
     ExactGroup sel = ExactGroup{{0, 0, 0, 0, 0, 0, 0, 0}, 0};  // count > 0: query ql of the launch is sel.idx[ql], its count cnt[ql]
     const int* qmap = nullptr;  // the middle tier: query ql of the launch is qmap[ql]; cnt, thr and qn2 are the launch's own arrays
     const float2* lin = nullptr;  // the int8 filter: a non-candidate (s~ > T') has s > T' - lin[q].y (its slack is linear in |q|, not beta |q|^2)
+    const DenseCallPtrs* ind = nullptr;  // captured call graph: the outputs of THIS launch
     __device__ __forceinline__ void operator()(int ql, const u64* sorted, int k) const {
         const int q = qmap ? qmap[ql] : (sel.count ? sel.idx[ql] : q0 + ql);
         const int qa = qmap ? ql : q;  // index into thr / qn2
+        float* out_dist = ind ? static_cast<float*>(ind->out_dist) : this->out_dist;
+        long long* out_idx = ind ? ind->out_idx : this->out_idx;
         for (int j = threadIdx.x; j < k; j += blockDim.x) {
             const u64 key = sorted[j];
             const bool pad = key == ~0ull;

@@ -10,7 +10,8 @@
 // With the query scaled per query, Q8_k = rint(-2 q''_k / Dq), q'' = q - c, rq = |-2 q'' - Dq Q8|_2 measured the same
 // way, the kernel's score
 //     s~ = N_row + (Dx Dq) * sum_k x8_k Q8_k             (v_mfma_i32_32x32x32_i8: the sum is an exact integer;
-//                                                          Q8 is two int8 planes, the second in units of Dq / 254)
+//                                                          Q8 is two int8 planes, the second in units of Dq / 256:
+//                                                          256 * sum + sum' is one shift-add of the two accumulators)
 // differs from the true score s = |x'|^2 - 2 x'.q'' by at most
 //     e(row, q) = 2 r_row |q''| + |Dx x8| rq + rounding <= 2 R |q''| + (X + R) rq + rounding =: e_q
 // (Cauchy-Schwarz on the two measured residuals; R = the largest r_row of the rows that take part, X = the largest
@@ -239,17 +240,19 @@ static __global__ __launch_bounds__(256) void dense8_flag_kernel(const float* __
 
 // ---------------------------------------------------------------- per call
 // Query prep of the int8 filter: the int8 planes Q8 = rint(-2 (q - c) / Dq) with the query's own scale and
-// Q8' = rint(254 (-2 (q - c) / Dq - Q8)) (the matrix cores idle under the stream: a second plane is free and takes the
-// query's own quantisation out of the bound: rq shrinks 254-fold), the measured
+// Q8' = rint(256 (-2 (q - c) / Dq - Q8)) (the matrix cores idle under the stream: a second plane is free and takes the
+// query's own quantisation out of the bound: rq shrinks ~250-fold), the measured
 // residual rq, |q - c|^2, the score unit Dx Dq and the query's error bound e_q (all float64, rounded up where they
 // widen the bound), plus what dense_prep_queries_kernel does besides (counters, overflow flag, the aligned copy).
-//   per query p < nq_pad:  qs8[plane][p][128] int8 (plane 1 in units of Dq / 254), par[p] = {unit (Dx Dq), e_q}
+//   per query p < nq_pad:  qs8[plane][p][128] int8 (plane 1 in units of Dq / 256), par[p] = {unit (Dx Dq), e_q}
 static __global__ __launch_bounds__(128) void dense8_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
                                                                           const float* __restrict__ center, double dx, double r_max,
                                                                           double x_max, signed char* __restrict__ qs8,
                                                                           float2* __restrict__ par, double* __restrict__ qn2,
                                                                           float* __restrict__ thr, u32* __restrict__ cnt,
-                                                                          u32* __restrict__ oflag, float* __restrict__ q_al, int ldq) {
+                                                                          u32* __restrict__ oflag, float* __restrict__ q_al, int ldq,
+                                                                          const DenseCallPtrs* __restrict__ ind) {
+    if (ind) q = ind->q;   // (captured call graph: this launch's queries)
     const int qi = blockIdx.x, t = threadIdx.x;
     __shared__ double red[2];
     __shared__ float redm[2];
@@ -289,15 +292,15 @@ static __global__ __launch_bounds__(128) void dense8_prep_queries_kernel(const f
         qt8 = rintf((float)((double)(-2.f * v) / dq));
         qt8 = fminf(fmaxf(qt8, -127.f), 127.f);
     }
-    // second plane: what the first leaves, in steps of Dq / 254
+    // second plane: what the first leaves, in steps of Dq / 256 (the kernel joins the two integer sums by a shift)
     float ql8 = 0.f;
     if (ok) {
-        ql8 = rintf((float)((((double)(-2.f * v) / dq) - (double)qt8) * 254.0));
+        ql8 = rintf((float)((((double)(-2.f * v) / dq) - (double)qt8) * 256.0));
         ql8 = fminf(fmaxf(ql8, -127.f), 127.f);
     }
     qs8[(long long)qi * I8_ROW_BYTES + t] = (signed char)(int)qt8;
     qs8[(long long)(TILE_ROWS + qi) * I8_ROW_BYTES + t] = (signed char)(int)ql8;
-    const double res = (double)(-2.f * v) - ((double)qt8 + (double)ql8 / 254.0) * dq;
+    const double res = (double)(-2.f * v) - ((double)qt8 + (double)ql8 / 256.0) * dq;
     double r2 = res * res;
     for (int o = 32; o > 0; o >>= 1) r2 += __shfl_xor(r2, o);
     if ((t & 63) == 0) red[t >> 6] = r2;
@@ -376,9 +379,9 @@ __global__ __launch_bounds__(I8_WAVES * 64, 2) void dense8_scan_kernel(Dense8Sca
         bl[s] = *reinterpret_cast<const i32x4*>(a.qs8 + (TILE_ROWS + r31) * I8_ROW_BYTES + (2 * s + h) * 16);
     }
     float unit = a.par[r31].x;
-    float unit_lo = __fdiv_rn(unit, 254.f);
+    float unit_lo = unit * 0.00390625f;   // Dx Dq / 256, exact
     float thr_l = SAMPLE ? 0.f : a.thr[r31];
-    asm volatile("" : "+v"(unit), "+v"(unit_lo), "+v"(thr_l), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(bl[0]), "+v"(bl[1]),
+    asm volatile("" : "+v"(unit_lo), "+v"(thr_l), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(bl[0]), "+v"(bl[1]),
                  "+v"(bl[2]), "+v"(bl[3]));   // complete before the ring starts
 
     const long long my_units = wave_id < a.n_sel ? (a.n_sel - wave_id + nwaves - 1) / nwaves : 0;
@@ -445,7 +448,9 @@ __global__ __launch_bounds__(I8_WAVES * 64, 2) void dense8_scan_kernel(Dense8Sca
             for (int i = 0; i < 16; ++i) {
                 float nv = nr[t][i >> 2][i & 3];
                 if constexpr (SAMPLE) nv = nv == -__builtin_inff() ? __builtin_inff() : nv;   // an always-candidate row is no sample
-                sc[i] = __fmaf_rn((float)acl[i], unit_lo, __fmaf_rn((float)acc[i], unit, nv));
+                // 256 acc + acl: |acc| <= 128 * 127 * 127, so the sum stays below 2^30; its float32 conversion is one of the
+                // roundings e_q pays for
+                sc[i] = __fmaf_rn((float)((acc[i] << 8) + acl[i]), unit_lo, nv);
             }
             float m = sc[0];
 #pragma unroll
