@@ -1118,7 +1118,8 @@ static int dense8_build(DenseHandle* h) {
     if (!(rms > 0.0) || !(rms < 1e30)) return quit(SQ_OK);
     SQ_HIP(hipMemset(tmp.p, 0, 64));
     // the clamp and R from the measured residuals of ten candidate clamps (dense8_clip_stats_kernel)
-    static const double kClip[I8_NCLIP] = {1.75, 2.25, 2.75, 3.25, 3.75, 4.25, 4.75, 5.25, 6.0, 7.0};
+    // (1.75 rms: where a uniform distribution ends; 9-11 rms: one-sided data -- max(N(0,1), 0) reaches 8.4 rms of its centred self)
+    static const double kClip[I8_NCLIP] = {1.75, 2.5, 3.25, 4.0, 4.75, 5.5, 6.5, 7.5, 9.0, 11.0};
     static const double kCut[I8_NCUT] = {0.6, 0.8, 1.0, 1.10, 1.15, 1.20, 1.30, 1.50, 2.0, 3.0};   // R in units of Dx sqrt(d / 12)
     Dense8ClipArgs ca{};
     const double round_unit = sqrt((double)d / 12.0);
