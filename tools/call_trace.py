@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Measurement helper: when each pipelined search call's head (prep, sample pass, threshold), full pass, re-rank and select
+END, on one clock (SQ_TRACE=1: the library prints hipEvent times of every profiled call relative to the first one).
+usage: SQ_TRACE=1 python3 tools/call_trace.py   (env: N rows, DEPTH calls in flight).  The five event records per call cost
+~10 us of host time: the traced step is slower than the untraced one."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
