@@ -468,10 +468,11 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         # the int8 first-stage filter (L2, d <= 128, one query tile: DESIGN.md 4.1b) streams d_pad + 4 bytes per row; the library
         # reports what its full pass read (sq_stats_t.bytes_scanned) and that is what the roofline prices
         n_pad64 = -(-n_local // 64) * 64
-        int8_filter = (not cosine) and lib_bytes == float(n_pad64) * (d_pad + 4)
+        row8 = 128 if d <= 128 else (256 if d <= 256 else 512)      # the int8 copy's row (sq_dense_i8.hpp i8_row_bytes)
+        int8_filter = (not cosine) and d <= 512 and lib_bytes == float(n_pad64) * (row8 + 4)
         if int8_filter:
             streamed = lib_bytes
-        row_bytes = (d_pad + 4) if int8_filter else d_pad * 2 + (0 if cosine else 4)
+        row_bytes = (row8 + 4) if int8_filter else d_pad * 2 + (0 if cosine else 4)
         f32_bytes = float(n_local) * d * 4
         replay = None
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
@@ -529,7 +530,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "traffic_replayed": replay,
-                "kernel": "dense8_scan_kernel<false> (full pass)" if int8_filter else "dense_scan_kernel (full pass)", "kernel_ms": head_scan_ms,
+                "kernel": f"dense8_scan_kernel<{row8 // 32}, false> (full pass)" if int8_filter else "dense_scan_kernel (full pass)", "kernel_ms": head_scan_ms,
                 "kernel_ms_note": "mean hipEvent-bracketed duration (events recorded by the library on the stream the kernel is "
                                   "launched on) of the full-pass launch in BLOCKING calls right after the timed region, same "
                                   "rotating query batches: the kernel's own streaming time.  achieved = streamed bytes / this.",
@@ -540,7 +541,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 "rerank_kernel_ms": alone_rerank_ms, "rerank_kernel_ms_in_pipeline": pipe_rerank_ms,
                 "rerank_note": "exact re-rank of the survivors; its rows are cold (distinct query batches: ~3.3 k x nq rows of "
                                "512 B gathered from HBM per step)",
-                "bytes_definition": ("achieved/frac: bytes the kernel streams per launch = n_pad64*(d_pad + 4) (int8 scan copy + f32 row terms)"
+                "bytes_definition": ("achieved/frac: bytes the kernel streams per launch = n_pad64*(row bytes + 4) (int8 scan copy: 128 / 256 / 512 bytes per row, + f32 row terms)"
                                      if int8_filter else
                                      "achieved/frac: bytes the kernel streams per launch = n_pad*(2*d_pad + 4) (bf16 scan copy + f32 norms)"),
                 "streamed_bytes_per_launch": streamed,

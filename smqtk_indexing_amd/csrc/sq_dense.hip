@@ -92,6 +92,7 @@ struct DenseHandle : HandleBase {
     // the int8 first-stage filter (sq_dense_i8.hpp): copy, row terms, and what the build measured
     DevBuf scan8, nrow8;
     bool use8 = false;
+    int row8 = 0;               // bytes per row of the copy: 128, 256 or 512
     long long n_pad64 = 0;
     double dx8 = 0.0, rmax8 = 0.0, xmax8 = 0.0;
     long long flagged8 = 0;
@@ -267,6 +268,29 @@ static hipError_t event_wait(hipEvent_t ev) {
     return hipEventSynchronize(ev);
 }
 
+// the int8 scan for a row width (sq_dense_i8.hpp I8Geom): launch, and the attribute every instantiation needs once
+template <int KS, bool SAMPLE>
+static int dense8_scan_launch_t(const Dense8ScanArgs& a, hipStream_t st) {
+    using G = I8Geom<KS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_kernel<KS, SAMPLE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dense8_scan_kernel<KS, SAMPLE>), dim3((unsigned)a.nrb), dim3(G::WAVES * 64), (size_t)G::WAVES * G::NSTAGE * G::SLOT_BYTES, st, a);
+    return SQ_OK;
+}
+template <bool SAMPLE>
+static int dense8_scan_launch(int row_bytes, const Dense8ScanArgs& a, hipStream_t st) {
+    switch (row_bytes) {
+        case 128: return dense8_scan_launch_t<4, SAMPLE>(a, st);
+        case 256: return dense8_scan_launch_t<8, SAMPLE>(a, st);
+        case 512: return dense8_scan_launch_t<16, SAMPLE>(a, st);
+    }
+    return fail(SQ_ERR_INVALID, "int8 scan: unsupported row width %d", row_bytes);
+}
+static int i8_waves(int row_bytes) { return row_bytes == 512 ? I8Geom<16>::WAVES : I8Geom<4>::WAVES; }
+
 // Enqueue one search (nq <= kDenseQueryChunk queries) on `st` with the workspace of slot `s`; nothing is
 // waited for.  dense_resolve() finishes the call: it waits for the kernels, reads the status words and
 // sends uncertified queries down the exact path.
@@ -376,7 +400,8 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
     } else if (scan_ok && h->use8 && nq <= TILE_ROWS && h->opt.dense_int8 != 0 && kk <= kSelectLdsKeys64) {
         // ---- the int8 first-stage filter (sq_dense_i8.hpp): half the bytes per row, measured error bound
         c.int8 = true;
-        const long long n_units = (n + I8_UNIT_ROWS - 1) / I8_UNIT_ROWS;
+        const int row8 = h->row8, unit_rows = i8_unit_rows(row8), spu = 2 * (unit_rows / 32), waves8 = i8_waves(row8);   // samples per unit
+        const long long n_units = (n + unit_rows - 1) / unit_rows;
         long long stride = h->opt.sample_stride;
         if (stride <= 0) {
             // units of 64 rows, four samples per unit: the bf16 path's cost model in units of two tiles
@@ -386,17 +411,17 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             if (stride < 1) stride = 1;
             if (stride > (long long)cap / (16ll * kk)) stride = std::max<long long>(1, (long long)cap / (16ll * kk));
         }
-        while (stride > 1 && (n_units / stride) * 4 < 8ll * kk) stride >>= 1;
+        while (stride > 1 && (n_units / stride) * spu < 8ll * kk) stride >>= 1;
         const long long ns_units = (n_units + stride - 1) / stride;
-        const long long ns = ns_units * 4;
+        const long long ns = ns_units * spu;
         SQ_TRY(s.sample.reserve((size_t)TILE_ROWS * ns * 4));
         SQ_TRY(s.keys.reserve((size_t)nq * key_stride * key_bytes));
-        SQ_TRY(s.q8.reserve((size_t)2 * TILE_ROWS * I8_ROW_BYTES));
+        SQ_TRY(s.q8.reserve((size_t)2 * TILE_ROWS * row8));
         SQ_TRY(s.par8.reserve((size_t)TILE_ROWS * 8));
         const int cus = cu_count(h->device);
         int nrb = h->opt.dense_blocks > 0 ? h->opt.dense_blocks : (use_event && h->opt.dense_async_streams == 2 ? cus * 3 / 4 : cus);
         nrb = (nrb + 7) / 8 * 8;
-        const long long n_waves = (long long)nrb * I8_WAVES;
+        const long long n_waves = (long long)nrb * waves8;
         const u32 wave_cap = 2048;
         const int ldq = (d + 3) / 4 * 4;
         SQ_TRY(s.wave_out.reserve((size_t)n_waves * wave_cap * 8));
@@ -419,17 +444,10 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         a.ns = ns;
         {
             // (cacheable head: 32-64 MB measured best here -- 0.244 ms per step at 10 M rows against 0.250 at the bf16 copy's 192 MB)
-            const size_t copy_bytes = (size_t)h->n_pad64 * I8_ROW_BYTES;
+            const size_t copy_bytes = (size_t)h->n_pad64 * row8;
             const long long keep_mb = h->opt.dense_nt_keep_mb > 0 ? h->opt.dense_nt_keep_mb : 64;
             a.nt = h->opt.dense_nt >= 0 ? h->opt.dense_nt : (copy_bytes > ((size_t)512 << 20) ? 1 : 0);
-            a.nt_from_row = h->opt.dense_nt == 0 ? 0x7fffffffffffffffll : h->opt.dense_nt == 1 ? 0ll : (keep_mb << 20) / I8_ROW_BYTES;
-        }
-        static bool attr8 = false;
-        const size_t lds8 = (size_t)I8_WAVES * I8_NSTAGE * I8_SLOT_BYTES;
-        if (!attr8) {
-            SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr8 = true;
+            a.nt_from_row = h->opt.dense_nt == 0 ? 0x7fffffffffffffffll : h->opt.dense_nt == 1 ? 0ll : (keep_mb << 20) / row8;
         }
         int nrb_sample = nrb;
         if (use_event && h->opt.dense_async_streams == 2 && h->opt.dense_blocks <= 0) {
@@ -437,7 +455,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             sb = (sb + 7) / 8 * 8;
             if (sb >= 8 && sb < nrb_sample) nrb_sample = sb;
         }
-        if (ns_units < (long long)nrb_sample * I8_WAVES) nrb_sample = (int)(((ns_units + I8_WAVES - 1) / I8_WAVES + 7) / 8 * 8);
+        if (ns_units < (long long)nrb_sample * waves8) nrb_sample = (int)(((ns_units + waves8 - 1) / waves8 + 7) / 8 * 8);
         const int wpb = 2;
         const size_t rr_lds = ldq <= 156 ? (size_t)32 * (ldq + 4) * 4 : 0;
         // The chain of six launches, eagerly or as a captured graph.  A pipelined call on a small shard is bound by the
@@ -447,20 +465,20 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // later ones launch the graph; the caller's pointers travel through a pinned block (DenseCallPtrs).
         const DenseCallPtrs* ind = nullptr;
         auto chain = [&](hipStream_t cs) -> int {
-            hipLaunchKernelGGL(dense8_prep_queries_kernel, dim3(TILE_ROWS), dim3(128), 0, cs, q, nq, d, centerp, h->dx8, h->rmax8, h->xmax8,
+            hipLaunchKernelGGL(dense8_prep_queries_kernel, dim3(TILE_ROWS), dim3(row8), 0, cs, q, nq, d, centerp, h->dx8, h->rmax8, h->xmax8,
                                s.q8.as<signed char>(), s.par8.as<float2>(), qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq, ind);
             Dense8ScanArgs b = a;
             b.unit_step = stride;   // sample pass (on the CUs the pipelined full pass leaves free)
             b.n_sel = ns_units;
             b.nrb = nrb_sample;
-            hipLaunchKernelGGL((dense8_scan_kernel<true>), dim3((unsigned)b.nrb), dim3(I8_WAVES * 64), lds8, cs, b);
+            if (const int rc = dense8_scan_launch<true>(row8, b, cs)) return rc;
             hipLaunchKernelGGL((kth_threshold_f32_kernel<Dense8ThrPost>), dim3(nq), dim3(1024), 0, cs, a.sample_out, ns, kk, thr,
                                Dense8ThrPost{s.par8.as<float2>(), qn2});
             b.unit_step = 1;        // full pass
             b.n_sel = n_units;
             b.nrb = nrb;
             if (prof) SQ_HIP(hipEventRecord(s.ev[1], cs));
-            hipLaunchKernelGGL((dense8_scan_kernel<false>), dim3((unsigned)b.nrb), dim3(I8_WAVES * 64), lds8, cs, b);
+            if (const int rc = dense8_scan_launch<false>(row8, b, cs)) return rc;
             if (prof) SQ_HIP(hipEventRecord(s.ev[2], cs));
             hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, cs, h->db, h->ld, d,
                                s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, TILE_ROWS, s.keys.as<u64>(), cnt,
@@ -472,13 +490,13 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             return select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(), fin, cs, s.sort_tmp, 8 * stride * kk);
         };
         c.stats.scan_launches = 2;
-        c.stats.bytes_scanned = h->n_pad64 * ((long long)I8_ROW_BYTES + 4);
+        c.stats.bytes_scanned = h->n_pad64 * ((long long)row8 + 4);
         bool launched = false;
         if (use_event && !prof && h->opt.dense_graph != 0 && st != nullptr && st == s.own) {   // (never a capture on the caller's stream)
             // everything the captured launches were given by value: shapes, the slot's and the handle's buffers
             u64 key = 0xcbf29ce484222325ull;
             auto mix = [&key](u64 v) { key = (key ^ v) * 0x100000001b3ull; };
-            for (u64 v : {(u64)nq, (u64)k, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
+            for (u64 v : {(u64)nq, (u64)k, (u64)row8, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
                           (u64)h->opt.dense_debug, (u64)h->id_base, (u64)(uintptr_t)st, (u64)(uintptr_t)h->db, (u64)(uintptr_t)centerp,
                           (u64)(uintptr_t)h->scan8.p, (u64)(uintptr_t)h->nrow8.p, (u64)(uintptr_t)s.q8.p, (u64)(uintptr_t)s.par8.p,
                           (u64)(uintptr_t)s.sample.p, (u64)(uintptr_t)s.keys.p, (u64)(uintptr_t)s.wave_out.p, (u64)(uintptr_t)s.wave_cnt.p,
@@ -1083,10 +1101,11 @@ static int dense_build_rows(DenseHandle* h, long long row_base) {
 // allocate: neither is an error.
 static int dense8_build(DenseHandle* h) {
     h->use8 = false;
-    if (h->metric != SQ_METRIC_L2 || h->d_pad != I8_ROW_BYTES || h->n < 65536 || g_opt.dense_int8 == 0) return SQ_OK;
+    if (h->metric != SQ_METRIC_L2 || h->d > I8_MAX_ROW_BYTES || h->n < 65536 || g_opt.dense_int8 == 0) return SQ_OK;
     const long long n = h->n;
     const int d = h->d;
-    const long long n_pad64 = (n + I8_UNIT_ROWS - 1) / I8_UNIT_ROWS * I8_UNIT_ROWS;
+    const int row8 = i8_row_bytes(d);
+    const long long n_pad64 = (n + 63) / 64 * 64;
     const float* centerp = h->center.p ? h->center.as<float>() : nullptr;
     DevBuf tmp;   // [sum f64 x2 | max bits u32 x2 | flagged u32]
     DevBuf r2row;
@@ -1099,8 +1118,8 @@ static int dense8_build(DenseHandle* h) {
         }
         return rc;
     };
-    if (tmp.reserve(64) != SQ_OK || r2row.reserve((size_t)n_pad64 * 4) != SQ_OK || h->scan8.reserve((size_t)n_pad64 * I8_ROW_BYTES) != SQ_OK ||
-        h->nrow8.reserve((size_t)n_pad64 * 4) != SQ_OK) {
+    if (tmp.reserve(64) != SQ_OK || r2row.reserve((size_t)n_pad64 * 4) != SQ_OK || h->scan8.reserve((size_t)n_pad64 * row8) != SQ_OK ||
+        h->nrow8.reserve((size_t)(n_pad64 + 64) * 4) != SQ_OK) {   // (+ 64: a 32-row unit's DMA fetches 64 row terms)
         (void)hipGetLastError();
         return quit(SQ_OK);
     }
@@ -1109,7 +1128,11 @@ static int dense8_build(DenseHandle* h) {
     for (int pass = 0; pass < 3; ++pass) {
         double er[2] = {0.0, 0.0};
         SQ_HIP(hipMemset(tmp.p, 0, 64));
-        hipLaunchKernelGGL(dense8_energy_kernel, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, cap_e, tmp.as<double>());
+        switch (row8) {
+            case 128: hipLaunchKernelGGL(dense8_energy_kernel<2>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, cap_e, tmp.as<double>()); break;
+            case 256: hipLaunchKernelGGL(dense8_energy_kernel<4>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, cap_e, tmp.as<double>()); break;
+            default: hipLaunchKernelGGL(dense8_energy_kernel<8>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, cap_e, tmp.as<double>()); break;
+        }
         SQ_HIP(hipMemcpy(er, tmp.p, 16, hipMemcpyDeviceToHost));
         if (!(er[1] >= 0.5 * (double)n)) return quit(SQ_OK);   // (half the rows non-finite or beyond 16 x the mean: not this filter's data)
         rms = sqrt(er[0] / (er[1] * d));
@@ -1135,7 +1158,11 @@ static int dense8_build(DenseHandle* h) {
     const size_t clip_bytes = I8_NCLIP * I8_NCUT * 4;
     if (clipbuf.reserve(clip_bytes) != SQ_OK) return quit(SQ_OK);
     SQ_HIP(hipMemset(clipbuf.p, 0, clip_bytes));
-    hipLaunchKernelGGL(dense8_clip_stats_kernel, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, ca, clipbuf.as<u32>());
+    switch (row8) {
+        case 128: hipLaunchKernelGGL(dense8_clip_stats_kernel<2>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, ca, clipbuf.as<u32>()); break;
+        case 256: hipLaunchKernelGGL(dense8_clip_stats_kernel<4>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, ca, clipbuf.as<u32>()); break;
+        default: hipLaunchKernelGGL(dense8_clip_stats_kernel<8>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, ca, clipbuf.as<u32>()); break;
+    }
     u32 counts[I8_NCLIP][I8_NCUT];
     SQ_HIP(hipMemcpy(counts, clipbuf.p, clip_bytes, hipMemcpyDeviceToHost));
     clipbuf.release();
@@ -1152,8 +1179,18 @@ static int dense8_build(DenseHandle* h) {
             }
     if (best_c < 0) return quit(SQ_OK);   // every clamp leaves too many rows beyond every bound (heavy tails): the bf16 filter's relative bound suits such data
     const double dx = (double)ca.dx[best_c];
-    hipLaunchKernelGGL(dense8_build_kernel, dim3((unsigned)((n_pad64 + 3) / 4)), dim3(256), 0, 0, h->db, n, h->ld, d, n_pad64, centerp,
-                       ca.inv_dx[best_c], ca.dx[best_c], h->scan8.as<signed char>(), h->nrow8.as<float>(), r2row.as<float>(), 0ll);
+    {
+        const dim3 grid((unsigned)((n_pad64 + 3) / 4)), blk(256);
+        signed char* o8 = h->scan8.as<signed char>();
+        float* nr8 = h->nrow8.as<float>();
+        float* r2p = r2row.as<float>();
+        switch (row8) {
+            case 128: hipLaunchKernelGGL(dense8_build_kernel<2>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
+            case 256: hipLaunchKernelGGL(dense8_build_kernel<4>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
+            default: hipLaunchKernelGGL(dense8_build_kernel<8>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
+        }
+        SQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(nr8 + n_pad64), 0x7f800000, 64));   // (+inf behind the last unit)
+    }
     double* sum_r2 = tmp.as<double>() + 1;
     u32* maxb = reinterpret_cast<u32*>(tmp.as<double>() + 2);
     u32* flagged = maxb + 2;
@@ -1182,6 +1219,7 @@ static int dense8_build(DenseHandle* h) {
         fprintf(stderr, "[smqtk_hip] int8 filter: clamp %.2f rms, step %.5g, R %.5g (%.2f x the rounding residual), X %.5g, %u always-candidate rows of %lld\n",
                 kClip[best_c], dx, h->rmax8, kCut[best_m], h->xmax8, nflag, n);
     h->n_pad64 = n_pad64;
+    h->row8 = row8;
     h->use8 = true;
     return quit(SQ_OK);
 }

@@ -35,16 +35,31 @@ namespace sq {
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
-static constexpr int I8_ROW_BYTES = 128;                  // d_pad = 128
-static constexpr int I8_UNIT_ROWS = 64;
-static constexpr int I8_UNIT_BYTES = I8_UNIT_ROWS * I8_ROW_BYTES;   // 8 KiB
-static constexpr int I8_SLOT_BYTES = I8_UNIT_BYTES + 256;           // + the unit's 64 row terms N_row
-static constexpr int I8_WAVES = 8, I8_NSTAGE = 2;
+// Geometry for KS = d_pad8 / 32 k-steps per row (d_pad8 = 128, 256 or 512 bytes per row): a ring unit is 64 rows of 128
+// bytes or 32 rows of 256 / 512 bytes (8, 8, 16 KiB) + 256 B for its row terms; eight waves per workgroup, four for 512-byte rows
+// (two 16.25 KiB slots per wave: 130 KiB of LDS either way, and the 128 query-plane registers of a 512-byte row
+// want a SIMD to themselves).
+template <int KS>
+struct I8Geom {
+    static constexpr int ROW_BYTES = KS * 32;
+    static constexpr int UNIT_ROWS = KS == 4 ? 64 : 32;
+    static constexpr int TILES = UNIT_ROWS / 32;
+    static constexpr int UNIT_BYTES = UNIT_ROWS * ROW_BYTES;
+    static constexpr int SLOT_BYTES = UNIT_BYTES + 256;
+    static constexpr int WAVES = KS <= 8 ? 8 : 4;
+    static constexpr int NSTAGE = 2;
+    static constexpr int PIECES = UNIT_BYTES / 1024;   // DMA instructions per unit (+ 1 for the row terms)
+    static constexpr int SAMPLES_PER_UNIT = 2 * TILES;
+};
+static constexpr int I8_MAX_ROW_BYTES = 512;
+__host__ __device__ constexpr int i8_row_bytes(int d) { return d <= 128 ? 128 : (d <= 256 ? 256 : 512); }
+__host__ __device__ constexpr int i8_unit_rows(int row_bytes) { return row_bytes == 128 ? 64 : 32; }
 
 // ---------------------------------------------------------------- build
 // sum over rows of |x - c|^2 (float64) and their number, rows with |x - c|^2 > cap left out: the element rms the clamp
 // candidates are multiples of.  The host runs it three times, cap = inf, then 16 x the mean of the pass before: a few
 // rows thousands of times the size of the rest would otherwise own the rms (they end up beyond R either way).
+template <int EPL>   // elements per lane: row_bytes / 64
 static __global__ __launch_bounds__(256) void dense8_energy_kernel(const float* __restrict__ db, long long n, long long ld, int d,
                                                                     const float* __restrict__ center, double cap,
                                                                     double* __restrict__ sum) {   // [0]: energy, [1]: rows
@@ -56,8 +71,8 @@ static __global__ __launch_bounds__(256) void dense8_energy_kernel(const float* 
         double e = 0.0;
         bool bad = false;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = 2 * lane + j;
+        for (int j = 0; j < EPL; ++j) {
+            const int k = EPL * lane + j;
             if (k < d) {
                 const float v = db[row * ld + k];
                 const float xc = center ? __fsub_rn(v, center[k]) : v;
@@ -95,6 +110,7 @@ struct Dense8ClipArgs {
     float cut[I8_NCLIP][I8_NCUT];   // r_row^2 thresholds
 };
 
+template <int EPL>
 static __global__ __launch_bounds__(256) void dense8_clip_stats_kernel(const float* __restrict__ db, long long n, long long ld, int d,
                                                                         const float* __restrict__ center, Dense8ClipArgs ca,
                                                                         u32* __restrict__ counts) {
@@ -111,8 +127,8 @@ static __global__ __launch_bounds__(256) void dense8_clip_stats_kernel(const flo
         for (int c = 0; c < I8_NCLIP; ++c) r2[c] = 0.f;
         bool bad = false;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = 2 * lane + j;
+        for (int j = 0; j < EPL; ++j) {
+            const int k = EPL * lane + j;
             if (k < d) {
                 const float v = db[row * ld + k];
                 const float xc = center ? __fsub_rn(v, center[k]) : v;
@@ -145,6 +161,7 @@ static __global__ __launch_bounds__(256) void dense8_clip_stats_kernel(const flo
 // One wave per row: the int8 row, N_row = RD(|x'|^2) and the measured residual r_row^2 (rounded up) of rows
 // [row_base, n_pad).  Padding rows: zeros and N_row = +inf.  Rows with a non-finite element: N_row = +inf (their true
 // distance is inf / NaN: they rank last, as in the bf16 filter) and no residual.
+template <int EPL>
 static __global__ __launch_bounds__(256) void dense8_build_kernel(const float* __restrict__ db, long long n, long long ld, int d,
                                                                    long long n_pad, const float* __restrict__ center, float inv_dx,
                                                                    float dx, signed char* __restrict__ out8, float* __restrict__ nrow,
@@ -152,13 +169,15 @@ static __global__ __launch_bounds__(256) void dense8_build_kernel(const float* _
     const int lane = threadIdx.x & 63;
     const long long row = row_base + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_pad) return;
-    signed char q[2] = {0, 0};
+    unsigned char q[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) q[j] = 0;
     double e2 = 0.0, r2 = 0.0;
     bool finite = true;
     if (row < n) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = 2 * lane + j;
+        for (int j = 0; j < EPL; ++j) {
+            const int k = EPL * lane + j;
             if (k < d) {
                 const float v = db[row * ld + k];
                 const float xc = center ? __fsub_rn(v, center[k]) : v;
@@ -166,7 +185,7 @@ static __global__ __launch_bounds__(256) void dense8_build_kernel(const float* _
                 float t = rintf(xc * inv_dx);
                 t = fminf(fmaxf(t, -127.f), 127.f);
                 if (!(t == t)) t = 0.f;
-                q[j] = (signed char)(int)t;
+                q[j] = (unsigned char)(signed char)(int)t;
                 const double res = (double)xc - (double)t * (double)dx;
                 e2 += (double)xc * (double)xc;
                 r2 += res * res;
@@ -178,7 +197,18 @@ static __global__ __launch_bounds__(256) void dense8_build_kernel(const float* _
         e2 += __shfl_xor(e2, o);
         r2 += __shfl_xor(r2, o);
     }
-    reinterpret_cast<short*>(out8 + row * I8_ROW_BYTES)[lane] = (short)((unsigned char)q[0] | ((unsigned short)(unsigned char)q[1] << 8));
+    // EPL bytes per lane, packed: the row is EPL * 64 bytes
+    unsigned char* dst = reinterpret_cast<unsigned char*>(out8) + row * (EPL * 64) + EPL * lane;
+    if constexpr (EPL == 2) {
+        *reinterpret_cast<unsigned short*>(dst) = (unsigned short)(q[0] | (q[1] << 8));
+    } else if constexpr (EPL == 4) {
+        *reinterpret_cast<u32*>(dst) = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
+    } else {
+        uint2 w;
+        w.x = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
+        w.y = (u32)q[4] | ((u32)q[5] << 8) | ((u32)q[6] << 16) | ((u32)q[7] << 24);
+        *reinterpret_cast<uint2*>(dst) = w;
+    }
     if (lane == 0) {
         float nr = __builtin_inff(), rr = 0.f;
         if (row < n && finite) {
@@ -245,7 +275,8 @@ static __global__ __launch_bounds__(256) void dense8_flag_kernel(const float* __
 // residual rq, |q - c|^2, the score unit Dx Dq and the query's error bound e_q (all float64, rounded up where they
 // widen the bound), plus what dense_prep_queries_kernel does besides (counters, overflow flag, the aligned copy).
 //   per query p < nq_pad:  qs8[plane][p][128] int8 (plane 1 in units of Dq / 256), par[p] = {unit (Dx Dq), e_q}
-static __global__ __launch_bounds__(128) void dense8_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
+// (one workgroup per query of the padded tile, one thread per byte of a plane row: blockDim.x = the copy's row bytes)
+static __global__ __launch_bounds__(512) void dense8_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
                                                                           const float* __restrict__ center, double dx, double r_max,
                                                                           double x_max, signed char* __restrict__ qs8,
                                                                           float2* __restrict__ par, double* __restrict__ qn2,
@@ -254,8 +285,9 @@ static __global__ __launch_bounds__(128) void dense8_prep_queries_kernel(const f
                                                                           const DenseCallPtrs* __restrict__ ind) {
     if (ind) q = ind->q;   // (captured call graph: this launch's queries)
     const int qi = blockIdx.x, t = threadIdx.x;
-    __shared__ double red[2];
-    __shared__ float redm[2];
+    const int row_bytes = blockDim.x, nw = blockDim.x >> 6;
+    __shared__ double red[8];
+    __shared__ float redm[8];
     if (t == 0) {
         // padding queries of the tile: a NaN threshold -- no comparison passes, not even an always-candidate row's -inf
         thr[qi] = qi < nq ? -__builtin_inff() : __builtin_nanf("");
@@ -268,7 +300,7 @@ static __global__ __launch_bounds__(128) void dense8_prep_queries_kernel(const f
         v = center ? __fsub_rn(raw, center[t]) : raw;
     }
     if (qi < nq)
-        for (int i = t; i < ldq; i += 128) q_al[(long long)qi * ldq + i] = i < d ? q[(long long)qi * d + i] : 0.f;
+        for (int i = t; i < ldq; i += row_bytes) q_al[(long long)qi * ldq + i] = i < d ? q[(long long)qi * d + i] : 0.f;
     // |q''|^2 and max |2 q''_k|
     double a2 = (double)v * (double)v;
     float m = fabsf(2.f * v);
@@ -282,8 +314,12 @@ static __global__ __launch_bounds__(128) void dense8_prep_queries_kernel(const f
         redm[t >> 6] = m;
     }
     __syncthreads();
-    const double Q = red[0] + red[1];
-    const float mx = fmaxf(redm[0], redm[1]);
+    double Q = 0.0;
+    float mx = 0.f;
+    for (int w = 0; w < nw; ++w) {
+        Q += red[w];
+        mx = fmaxf(mx, redm[w]);
+    }
     __syncthreads();
     const bool ok = qi < nq && mx < 3.0e38f && mx > 0.f;   // zero / non-finite / padding queries: an all-zero plane, nothing certified by it
     const double dq = ok ? (double)mx / 127.0 : 1.0;
@@ -298,18 +334,20 @@ static __global__ __launch_bounds__(128) void dense8_prep_queries_kernel(const f
         ql8 = rintf((float)((((double)(-2.f * v) / dq) - (double)qt8) * 256.0));
         ql8 = fminf(fmaxf(ql8, -127.f), 127.f);
     }
-    qs8[(long long)qi * I8_ROW_BYTES + t] = (signed char)(int)qt8;
-    qs8[(long long)(TILE_ROWS + qi) * I8_ROW_BYTES + t] = (signed char)(int)ql8;
+    qs8[(long long)qi * row_bytes + t] = (signed char)(int)qt8;
+    qs8[(long long)(TILE_ROWS + qi) * row_bytes + t] = (signed char)(int)ql8;
     const double res = (double)(-2.f * v) - ((double)qt8 + (double)ql8 / 256.0) * dq;
     double r2 = res * res;
     for (int o = 32; o > 0; o >>= 1) r2 += __shfl_xor(r2, o);
     if ((t & 63) == 0) red[t >> 6] = r2;
     __syncthreads();
     if (t == 0) {
-        const double rq = sqrt(red[0] + red[1]) * (1.0 + 1e-9);
+        double r2s = 0.0;
+        for (int w = 0; w < nw; ++w) r2s += red[w];
+        const double rq = sqrt(r2s) * (1.0 + 1e-9);
         const double unit = dx * dq;
         // e_q: 2 R |q''| (the rows' measured residual) + (X + R) rq (the query's) + the float32 evaluation of
-        // N + unit * sum (|sum| unit <= (X + R)(2 |q''| + rq): three roundings) + N's own rounding
+        // N + unit * sum (|sum| unit <= (X + R)(2 |q''| + rq): conversion, unit and fma roundings) + N's own rounding
         const double xr = x_max + r_max, qn = sqrt(Q);
         double e = 2.0 * r_max * qn + xr * rq + 4.0 * 5.9604644775390625e-08 * (xr * (2.0 * qn + rq) + x_max * x_max);
         e *= 1.0 + 1e-6;
@@ -339,11 +377,11 @@ struct Dense8ThrPost {
 };
 
 struct Dense8ScanArgs {
-    const signed char* scan8;   // [n_pad][128]
-    const float* nrow;          // [n_pad64] N_row (+inf padding, -inf always-candidate rows)
+    const signed char* scan8;   // [n_pad][row bytes]
+    const float* nrow;          // [n_pad64 + 64] N_row (+inf padding, -inf always-candidate rows)
     long long n;
-    long long n_units;          // ceil(n / 64)
-    const signed char* qs8;     // [2][32][128]: plane, query
+    long long n_units;          // ceil(n / unit rows)
+    const signed char* qs8;     // [2][32][row bytes]: plane, query
     const float2* par;          // [32] {unit, e_q}
     const float* thr;           // [32]
     uint2* wave_out;
@@ -358,89 +396,116 @@ struct Dense8ScanArgs {
     long long nt_from_row;
 };
 
-template <bool SAMPLE>
-__global__ __launch_bounds__(I8_WAVES * 64, 2) void dense8_scan_kernel(Dense8ScanArgs a) {
+// LDS chunk position (16-byte units inside a row) of source chunk c of row r: the XOR swizzle that makes the fragment reads
+// of 16 consecutive rows hit 16 different bank groups.  128-byte rows: two rows share 256 bytes, (r >> 1) & 7 over the row's
+// eight chunks; wider rows: r & 15 inside each 256-byte plane.  An involution: the DMA applies it to the SOURCE chunk.
+template <int KS>
+__device__ __forceinline__ int i8_swz(int c, int r) {
+    if constexpr (KS == 4) return c ^ ((r >> 1) & 7);
+    return (c & ~15) | ((c & 15) ^ (r & 15));
+}
+
+template <int KS, bool SAMPLE>
+__global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dense8_scan_kernel(Dense8ScanArgs a) {
+    using G = I8Geom<KS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r31 = lane & 31, h = lane >> 5;
     const u32 lds_base = (u32)(uintptr_t)smem;
-    const u32 ring_base = lds_base + (u32)wave * (I8_NSTAGE * I8_SLOT_BYTES);
-    const unsigned char* ring_ptr = smem + wave * (I8_NSTAGE * I8_SLOT_BYTES);
-    const long long wave_id = (long long)blockIdx.x * I8_WAVES + wave;
-    const long long nwaves = (long long)a.nrb * I8_WAVES;
+    const u32 ring_base = lds_base + (u32)wave * (G::NSTAGE * G::SLOT_BYTES);
+    const unsigned char* ring_ptr = smem + wave * (G::NSTAGE * G::SLOT_BYTES);
+    const long long wave_id = (long long)blockIdx.x * G::WAVES + wave;
+    const long long nwaves = (long long)a.nrb * G::WAVES;
     uint2* wout = a.wave_out + wave_id * a.wave_cap;
 
-    // this lane's query (column r31 of the tile): its int8 plane as B fragments (k = 32 s + 16 h ..), unit and threshold
-    i32x4 bq[4], bl[4];
+    // this lane's query (column r31 of the tile): its int8 planes as B fragments (k = 32 s + 16 h ..), unit and threshold
+    i32x4 bq[KS], bl[KS];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        bq[s] = *reinterpret_cast<const i32x4*>(a.qs8 + r31 * I8_ROW_BYTES + (2 * s + h) * 16);
-        bl[s] = *reinterpret_cast<const i32x4*>(a.qs8 + (TILE_ROWS + r31) * I8_ROW_BYTES + (2 * s + h) * 16);
+    for (int s = 0; s < KS; ++s) {
+        bq[s] = *reinterpret_cast<const i32x4*>(a.qs8 + r31 * G::ROW_BYTES + (2 * s + h) * 16);
+        bl[s] = *reinterpret_cast<const i32x4*>(a.qs8 + (TILE_ROWS + r31) * G::ROW_BYTES + (2 * s + h) * 16);
     }
-    float unit = a.par[r31].x;
-    float unit_lo = unit * 0.00390625f;   // Dx Dq / 256, exact
+    float unit_lo = a.par[r31].x * 0.00390625f;   // Dx Dq / 256, exact
     float thr_l = SAMPLE ? 0.f : a.thr[r31];
-    asm volatile("" : "+v"(unit_lo), "+v"(thr_l), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(bl[0]), "+v"(bl[1]),
-                 "+v"(bl[2]), "+v"(bl[3]));   // complete before the ring starts
+    asm volatile("" : "+v"(unit_lo), "+v"(thr_l));
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(bq[s]), "+v"(bl[s]));   // complete before the ring starts
 
     const long long my_units = wave_id < a.n_sel ? (a.n_sel - wave_id + nwaves - 1) / nwaves : 0;
-    // DMA piece j: rows 8j .. 8j+7 of the unit; lane -> (row 8j + lane / 8, source chunk (lane % 8) ^ ((row >> 1) & 7))
-    u32 voff[8];
+    // DMA piece j: bytes 1024 j .. 1024 j + 1023 of the unit's LDS image; lane -> 16 bytes at (row, chunk position), read
+    // from the row's source chunk swz(position)
+    u32 voff[G::PIECES];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = 8 * j + (lane >> 3);
-        voff[j] = (u32)(r * I8_ROW_BYTES + (((lane & 7) ^ ((r >> 1) & 7)) * 16));
+    for (int j = 0; j < G::PIECES; ++j) {
+        const int lin = j * 1024 + lane * 16;
+        const int r = lin / G::ROW_BYTES, cpos = (lin % G::ROW_BYTES) >> 4;
+        voff[j] = (u32)(r * G::ROW_BYTES + i8_swz<KS>(cpos, r) * 16);
     }
     const u32 voff_n = (u32)lane * 4u;
     long long issued = 0;
     auto issue_next = [&]() __attribute__((always_inline)) {
         if (issued >= my_units) return;
         const long long unit_idx = (wave_id + issued * nwaves) * a.unit_step;
-        const long long row0 = unit_idx * I8_UNIT_ROWS;
-        const u32 dst = ring_base + (u32)(issued % I8_NSTAGE) * I8_SLOT_BYTES;
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan8) + row0 * I8_ROW_BYTES;
+        const long long row0 = unit_idx * G::UNIT_ROWS;
+        const u32 dst = ring_base + (u32)(issued % G::NSTAGE) * G::SLOT_BYTES;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan8) + row0 * G::ROW_BYTES;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < G::PIECES; ++j) {
             if (a.nt && row0 >= a.nt_from_row)
                 glds16<true>(base, voff[j], dst + (u32)j * 1024);
             else
                 glds16<false>(base, voff[j], dst + (u32)j * 1024);
         }
-        glds4(a.nrow + row0, voff_n, dst + I8_UNIT_BYTES);
+        glds4(a.nrow + row0, voff_n, dst + G::UNIT_BYTES);   // (64 floats: the unit's, and for 32-row units the next one's as well)
         ++issued;
     };
-    for (int p = 0; p < I8_NSTAGE; ++p) issue_next();
+    for (int p = 0; p < G::NSTAGE; ++p) issue_next();
 
     u32 wcount = 0;
     for (long long it = 0; it < my_units; ++it) {
         const long long unit_idx = (wave_id + it * nwaves) * a.unit_step;
-        const long long row0 = unit_idx * I8_UNIT_ROWS;
-        wait_units_in_flight<I8_NSTAGE, 9>((int)(issued - it - 1));   // every unit is 9 DMA instructions
-        const unsigned char* sl = ring_ptr + (it % I8_NSTAGE) * I8_SLOT_BYTES;
-        i32x4 av[2][4];
-        f32x4 nr[2][4];
+        const long long row0 = unit_idx * G::UNIT_ROWS;
+        wait_units_in_flight<G::NSTAGE, G::PIECES + 1>((int)(issued - it - 1));
+        const unsigned char* sl = ring_ptr + (it % G::NSTAGE) * G::SLOT_BYTES;
+        // A fragments (lane = row): all of the unit's for rows up to 256 bytes; a 512-byte row in two halves of eight
+        // k-steps, the second read while the first half's MFMAs run (its slot is refilled after the second read)
+        constexpr int KH = KS == 16 ? 8 : KS;      // k-steps per fragment batch
+        i32x4 av[G::TILES][KH];
+        f32x4 nr[G::TILES][4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int r = 32 * t + r31;   // this lane's row of the unit (A operand: lane = row)
+        for (int t = 0; t < G::TILES; ++t) {
+            const int r = 32 * t + r31;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                av[t][s] = *reinterpret_cast<const i32x4*>(sl + r * I8_ROW_BYTES + (((2 * s + h) ^ ((r >> 1) & 7)) * 16));
+            for (int s = 0; s < KH; ++s)
+                av[t][s] = *reinterpret_cast<const i32x4*>(sl + r * G::ROW_BYTES + i8_swz<KS>(2 * s + h, r) * 16);
             // N of the 16 rows this lane's accumulator registers hold: rows (i & 3) + 8 (i >> 2) + 4 h of tile t
 #pragma unroll
-            for (int c = 0; c < 4; ++c) nr[t][c] = *reinterpret_cast<const f32x4*>(sl + I8_UNIT_BYTES + (32 * t + 8 * c + 4 * h) * 4);
+            for (int c = 0; c < 4; ++c) nr[t][c] = *reinterpret_cast<const f32x4*>(sl + G::UNIT_BYTES + (32 * t + 8 * c + 4 * h) * 4);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the unit is in registers: its slot is free
-        issue_next();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (KS != 16) issue_next();   // the unit is in registers: its slot is free
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < G::TILES; ++t) {
             i32x16 acc, acl;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = acl[i] = 0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < KH; ++s) {
                 acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t][s], bq[s], acc, 0, 0, 0);
                 acl = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t][s], bl[s], acl, 0, 0, 0);
+            }
+            if constexpr (KS == 16) {
+#pragma unroll
+                for (int s = 0; s < KH; ++s)
+                    av[t][s] = *reinterpret_cast<const i32x4*>(sl + r31 * G::ROW_BYTES + i8_swz<KS>(2 * (KH + s) + h, r31) * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                issue_next();
+#pragma unroll
+                for (int s = 0; s < KH; ++s) {
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t][s], bq[KH + s], acc, 0, 0, 0);
+                    acl = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t][s], bl[KH + s], acl, 0, 0, 0);
+                }
             }
             // scores of 32 rows x 32 queries (lane = query, register i = row (i & 3) + 8 (i >> 2) + 4 h)
             float sc[16];
@@ -448,7 +513,7 @@ __global__ __launch_bounds__(I8_WAVES * 64, 2) void dense8_scan_kernel(Dense8Sca
             for (int i = 0; i < 16; ++i) {
                 float nv = nr[t][i >> 2][i & 3];
                 if constexpr (SAMPLE) nv = nv == -__builtin_inff() ? __builtin_inff() : nv;   // an always-candidate row is no sample
-                // 256 acc + acl: |acc| <= 128 * 127 * 127, so the sum stays below 2^30; its float32 conversion is one of the
+                // 256 acc + acl: |acc| <= 512 * 127 * 127, so the sum stays below 2^31; its float32 conversion is one of the
                 // roundings e_q pays for
                 sc[i] = __fmaf_rn((float)((acc[i] << 8) + acl[i]), unit_lo, nv);
             }
@@ -457,7 +522,7 @@ __global__ __launch_bounds__(I8_WAVES * 64, 2) void dense8_scan_kernel(Dense8Sca
             for (int i = 1; i < 16; ++i) m = fminf(m, sc[i]);
             if constexpr (SAMPLE) {
                 const long long sel = wave_id + it * nwaves;
-                a.sample_out[(long long)r31 * a.ns + sel * 4 + t * 2 + h] = m;
+                a.sample_out[(long long)r31 * a.ns + sel * G::SAMPLES_PER_UNIT + t * 2 + h] = m;
             } else {
                 const u64 hit = __ballot(m <= thr_l);
                 if (hit != 0) {

@@ -139,8 +139,9 @@ def _dense_check(db, qs, k, metric="euclidean", exact_dist=True):
     return idx
 
 
-def _int8_bytes(n):
-    return (-(-n // 64) * 64) * 132
+def _int8_bytes(n, d=128):
+    row = 128 if d <= 128 else (256 if d <= 256 else 512)
+    return (-(-n // 64) * 64) * (row + 4)
 
 
 def _bf16_bytes(n, d):
@@ -171,9 +172,13 @@ def _int8_family(rng, family, n, d, nq):
 @pytest.mark.parametrize("n,d,nq,k,family", [(200_000, 128, 32, 100, "normal"), (150_001, 100, 7, 10, "uniform"),
                                               (100_000, 65, 1, 1, "normal"), (180_000, 128, 20, 1000, "clustered"),
                                               (70_000, 17, 32, 50, "scaled"), (130_000, 128, 31, 100, "near_rows"),
-                                              (66_000, 64, 5, 3, "clustered")])
+                                              (66_000, 64, 5, 3, "clustered"),
+                                              # rows of 256 and 512 bytes (32-row ring units; four waves per workgroup at 512)
+                                              (120_000, 256, 32, 100, "normal"), (90_001, 200, 9, 10, "uniform"),
+                                              (100_000, 512, 32, 100, "normal"), (80_000, 300, 17, 25, "clustered"),
+                                              (70_003, 384, 3, 1, "near_rows"), (66_000, 129, 32, 7, "scaled")])
 def test_dense_int8_filter_equals_bf16_filter_and_oracle(n, d, nq, k, family):
-    """The int8 first-stage filter (sq_dense_i8.hpp: L2, d <= 128, one query tile, n >= 65536) is a filter only: survivors
+    """The int8 first-stage filter (sq_dense_i8.hpp: L2, d <= 512, one query tile, n >= 65536) is a filter only: survivors
     are re-ranked in the reference's float32 arithmetic and every query is certified against the measured error bound, so
     neighbours and distance bits equal the bf16 filter's and the oracle's -- on benign data without a query leaving the
     first tier.  sq_stats_t.bytes_scanned tells which copy the full pass streamed."""
@@ -183,7 +188,7 @@ def test_dense_int8_filter_equals_bf16_filter_and_oracle(n, d, nq, k, family):
     idx.set_option("dense_int8", 1)
     d8, i8 = idx.search(qs, k)
     st = idx.stats()
-    assert st["bytes_scanned"] == _int8_bytes(n), st
+    assert st["bytes_scanned"] == _int8_bytes(n, d), st
     assert st["fallback_queries"] == 0 and st["mid_tier_queries"] == 0, st
     idx.set_option("dense_int8", 0)
     d16, i16 = idx.search(qs, k)
@@ -278,7 +283,7 @@ def test_dense_int8_copy_is_dropped_by_an_append():
     qs = rng.standard_normal((9, d)).astype(np.float32)
     idx = _lib.DenseIndex(np.ascontiguousarray(db[:n]))
     idx.search(qs, k)
-    assert idx.stats()["bytes_scanned"] == _int8_bytes(n)
+    assert idx.stats()["bytes_scanned"] == _int8_bytes(n, d)
     idx.append(np.ascontiguousarray(db[n:]))
     dd, ii = idx.search(qs, k)
     assert idx.stats()["bytes_scanned"] == _bf16_bytes(n + 3000, d)
