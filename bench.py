@@ -60,7 +60,7 @@ def parse_args():
     ap.add_argument("--rows", type=int, default=10_000_000, help="database rows in total (all shards)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--queries", type=int, default=32, help="queries per step in total -- the same at every N")
+    ap.add_argument("--queries", type=int, default=0, help="queries per step in total -- the same at every N (0 = the workload's: 32; c4_cosine_shard 256)")
     ap.add_argument("--queries-per-gpu", type=int, default=0,
                     help="(round-1 semantics, kept for experiments) queries per step = this x N; overrides --queries")
     ap.add_argument("--workload", choices=["bruteforce", "lsh_c3", "c4_cosine_shard", "c5_hamming_shard"], default="bruteforce")
@@ -469,7 +469,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         # reports what its full pass read (sq_stats_t.bytes_scanned) and that is what the roofline prices
         n_pad64 = -(-n_local // 64) * 64
         row8 = 128 if d <= 128 else (256 if d <= 256 else 512)      # the int8 copy's row (sq_dense_i8.hpp i8_row_bytes)
-        int8_filter = (not cosine) and d <= 512 and lib_bytes == float(n_pad64) * (row8 + 4)
+        int8_filter = d <= 512 and lib_bytes == float(n_pad64) * (row8 + 4)
         if int8_filter:
             streamed = lib_bytes
         row_bytes = (row8 + 4) if int8_filter else d_pad * 2 + (0 if cosine else 4)
@@ -691,11 +691,13 @@ def main() -> None:
             args.rows = 12_500_000 * world
         if args.dim == 128:
             args.dim = 512
-        if args.queries == 32:
+        if args.queries == 0:
             args.queries = 256
         if args.extra_batches == "1,128,256,1024":
             args.extra_batches = "32"
         args.no_other_paths = True
+    if args.queries == 0 and args.workload != "c5_hamming_shard":
+        args.queries = 32
     if args.workload == "c5_hamming_shard":
         from tools.hamming_c5 import run as c5_run
         args.scaling = "weak"

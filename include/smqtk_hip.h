@@ -229,8 +229,8 @@ int sq_dense_search(sq_handle_t h, const float* queries, int nq, int k,
  * no longer delays the next enqueue.  Option "dense_async_order" = 0: the caller guarantees that `queries` are
  * complete when the call is made (no producer still running on `stream`); the call then skips the event that orders
  * its internal stream behind `stream` (worth ~10 us of start latency per call on a small matrix).
- * Option "dense_int8" (-1 by default): L2 indexes of up to 128 dimensions and at least 65536 rows also keep an int8 copy
- * of the rows (+ d_pad + 4 bytes per row) and calls of up to 32 queries filter on it -- half the bytes of the bfloat16
+ * Option "dense_int8" (-1 by default): indexes of up to 512 dimensions and at least 65536 rows also keep an int8 copy
+ * of the rows (128 / 256 / 512 + 4 bytes per row) and calls of up to 32 queries filter on it -- half the bytes of the bfloat16
  * pass; the results are the same bits (exact re-rank + certificate, as ever).  0 at create: no copy; 0 on a handle: the
  * copy is not used; 1: used even after its candidate lists overflowed three calls in a row (-1 goes back to bfloat16 then).
  * Option "dense_graph" (1 by default): asynchronous int8 calls of one shape replay a captured graph (one launch per call). */

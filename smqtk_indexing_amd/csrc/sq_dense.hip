@@ -397,7 +397,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, nullptr, 0},
                                         st, s.sort_tmp));
         }
-    } else if (scan_ok && h->use8 && nq <= TILE_ROWS && h->opt.dense_int8 != 0 && kk <= kSelectLdsKeys64) {
+    } else if (scan_ok && h->use8 && nq <= TILE_ROWS && h->opt.dense_int8 != 0 && kk <= (cosine ? kSelectLdsKeys128 : kSelectLdsKeys64)) {
         // ---- the int8 first-stage filter (sq_dense_i8.hpp): half the bytes per row, measured error bound
         c.int8 = true;
         const int row8 = h->row8, unit_rows = i8_unit_rows(row8), spu = 2 * (unit_rows / 32), waves8 = i8_waves(row8);   // samples per unit
@@ -406,7 +406,9 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         if (stride <= 0) {
             // units of 64 rows, four samples per unit: the bf16 path's cost model in units of two tiles
             // (measured at 10 M x 128, k = 100: 0.293 / 0.269 / 0.262 / 0.258 / 0.257 / 0.257 / 0.263 ms per step at 6 / 8 / 10 / 12 / 16 / 20 / 24)
-            stride = (long long)(14.0 * sqrt((double)n / 1e7 * 100.0 / (double)kk) + 0.5);
+            // 256- and 512-byte rows: flat from 8 to 14, best at 10 (0.471 / 0.988 ms per step at 10 M x 256 / 512); the float64 cosine
+            // re-rank costs ~3.6x the float32 one per candidate: sqrt of that off the stride, as in the bf16 path
+            stride = (long long)((row8 == 128 ? 14.0 : 10.0) * sqrt((double)n / 1e7 * 100.0 / (double)kk) / (cosine ? 1.9 : 1.0) + 0.5);
             if (stride > 16) stride = 16;
             if (stride < 1) stride = 1;
             if (stride > (long long)cap / (16ll * kk)) stride = std::max<long long>(1, (long long)cap / (16ll * kk));
@@ -428,7 +430,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         SQ_TRY(s.wave_cnt.reserve((size_t)n_waves * 8));
         SQ_TRY(s.q_al.reserve((size_t)nq * ldq * 4));
         u32* oflag = s.oflag.as<u32>();
-        const float* centerp = h->center.p ? h->center.as<float>() : nullptr;
+        const float* centerp = (!cosine && h->center.p) ? h->center.as<float>() : nullptr;
         Dense8ScanArgs a{};
         a.scan8 = h->scan8.as<signed char>();
         a.nrow = h->nrow8.as<float>();
@@ -466,7 +468,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         const DenseCallPtrs* ind = nullptr;
         auto chain = [&](hipStream_t cs) -> int {
             hipLaunchKernelGGL(dense8_prep_queries_kernel, dim3(TILE_ROWS), dim3(row8), 0, cs, q, nq, d, centerp, h->dx8, h->rmax8, h->xmax8,
-                               s.q8.as<signed char>(), s.par8.as<float2>(), qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq, ind);
+                               s.q8.as<signed char>(), s.par8.as<float2>(), qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq, ind, cosine ? 1 : 0);
             Dense8ScanArgs b = a;
             b.unit_step = stride;   // sample pass (on the CUs the pipelined full pass leaves free)
             b.n_sel = ns_units;
@@ -480,6 +482,16 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             if (prof) SQ_HIP(hipEventRecord(s.ev[1], cs));
             if (const int rc = dense8_scan_launch<false>(row8, b, cs)) return rc;
             if (prof) SQ_HIP(hipEventRecord(s.ev[2], cs));
+            if (cosine) {
+                hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, cs, h->db, h->ld, d,
+                                   s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, TILE_ROWS, s.keys.as<K128>(), cnt,
+                                   cap, oflag, cnx, cnq, h->opt.dense_debug);
+                if (prof) SQ_HIP(hipEventRecord(s.ev[4], cs));
+                DenseFinalizeCos fin{cnt, cap, kk, h->id_base, thr, 0.0, 1, (double*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0};
+                fin.lin = s.par8.as<float2>();
+                fin.ind = ind;
+                return select_launch_t<K128>(s.keys.as<K128>(), cnt, cap, key_stride, k, nq, s.out_keys.as<K128>(), fin, cs, s.sort_tmp, 8 * stride * kk);
+            }
             hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, cs, h->db, h->ld, d,
                                s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, TILE_ROWS, s.keys.as<u64>(), cnt,
                                cap, oflag, h->opt.dense_debug);
@@ -501,7 +513,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                           (u64)(uintptr_t)h->scan8.p, (u64)(uintptr_t)h->nrow8.p, (u64)(uintptr_t)s.q8.p, (u64)(uintptr_t)s.par8.p,
                           (u64)(uintptr_t)s.sample.p, (u64)(uintptr_t)s.keys.p, (u64)(uintptr_t)s.wave_out.p, (u64)(uintptr_t)s.wave_cnt.p,
                           (u64)(uintptr_t)s.q_al.p, (u64)(uintptr_t)cnt, (u64)(uintptr_t)thr, (u64)(uintptr_t)qn2, (u64)(uintptr_t)oflag,
-                          (u64)(uintptr_t)s.out_keys.p, (u64)(uintptr_t)hs_raw_dev})
+                          (u64)(uintptr_t)s.out_keys.p, (u64)(uintptr_t)hs_raw_dev, (u64)(uintptr_t)cnx, (u64)(uintptr_t)cnq, (u64)(cosine ? 1 : 0)})
                 mix(v);
             if (key == 0) key = 1;
             if (s.gexec && s.gkey != key) {
@@ -1101,12 +1113,14 @@ static int dense_build_rows(DenseHandle* h, long long row_base) {
 // allocate: neither is an error.
 static int dense8_build(DenseHandle* h) {
     h->use8 = false;
-    if (h->metric != SQ_METRIC_L2 || h->d > I8_MAX_ROW_BYTES || h->n < 65536 || g_opt.dense_int8 == 0) return SQ_OK;
+    if (h->d > I8_MAX_ROW_BYTES || h->n < 65536 || g_opt.dense_int8 == 0) return SQ_OK;
+    const bool cosine = h->metric == SQ_METRIC_COSINE;
+    const double* nx64 = cosine ? h->cos_nx.as<double>() : nullptr;   // cosine: the copy holds the unit-length rows
     const long long n = h->n;
     const int d = h->d;
     const int row8 = i8_row_bytes(d);
     const long long n_pad64 = (n + 63) / 64 * 64;
-    const float* centerp = h->center.p ? h->center.as<float>() : nullptr;
+    const float* centerp = (!cosine && h->center.p) ? h->center.as<float>() : nullptr;
     DevBuf tmp;   // [sum f64 x2 | max bits u32 x2 | flagged u32]
     DevBuf r2row;
     auto quit = [&](int rc) {
@@ -1129,9 +1143,9 @@ static int dense8_build(DenseHandle* h) {
         double er[2] = {0.0, 0.0};
         SQ_HIP(hipMemset(tmp.p, 0, 64));
         switch (row8) {
-            case 128: hipLaunchKernelGGL(dense8_energy_kernel<2>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, cap_e, tmp.as<double>()); break;
-            case 256: hipLaunchKernelGGL(dense8_energy_kernel<4>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, cap_e, tmp.as<double>()); break;
-            default: hipLaunchKernelGGL(dense8_energy_kernel<8>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, cap_e, tmp.as<double>()); break;
+            case 128: hipLaunchKernelGGL(dense8_energy_kernel<2>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, nx64, cap_e, tmp.as<double>()); break;
+            case 256: hipLaunchKernelGGL(dense8_energy_kernel<4>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, nx64, cap_e, tmp.as<double>()); break;
+            default: hipLaunchKernelGGL(dense8_energy_kernel<8>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, nx64, cap_e, tmp.as<double>()); break;
         }
         SQ_HIP(hipMemcpy(er, tmp.p, 16, hipMemcpyDeviceToHost));
         if (!(er[1] >= 0.5 * (double)n)) return quit(SQ_OK);   // (half the rows non-finite or beyond 16 x the mean: not this filter's data)
@@ -1159,9 +1173,9 @@ static int dense8_build(DenseHandle* h) {
     if (clipbuf.reserve(clip_bytes) != SQ_OK) return quit(SQ_OK);
     SQ_HIP(hipMemset(clipbuf.p, 0, clip_bytes));
     switch (row8) {
-        case 128: hipLaunchKernelGGL(dense8_clip_stats_kernel<2>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, ca, clipbuf.as<u32>()); break;
-        case 256: hipLaunchKernelGGL(dense8_clip_stats_kernel<4>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, ca, clipbuf.as<u32>()); break;
-        default: hipLaunchKernelGGL(dense8_clip_stats_kernel<8>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, ca, clipbuf.as<u32>()); break;
+        case 128: hipLaunchKernelGGL(dense8_clip_stats_kernel<2>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, nx64, ca, clipbuf.as<u32>()); break;
+        case 256: hipLaunchKernelGGL(dense8_clip_stats_kernel<4>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, nx64, ca, clipbuf.as<u32>()); break;
+        default: hipLaunchKernelGGL(dense8_clip_stats_kernel<8>, dim3(stat_blocks), dim3(256), 0, 0, h->db, n, h->ld, d, centerp, nx64, ca, clipbuf.as<u32>()); break;
     }
     u32 counts[I8_NCLIP][I8_NCUT];
     SQ_HIP(hipMemcpy(counts, clipbuf.p, clip_bytes, hipMemcpyDeviceToHost));
@@ -1185,9 +1199,9 @@ static int dense8_build(DenseHandle* h) {
         float* nr8 = h->nrow8.as<float>();
         float* r2p = r2row.as<float>();
         switch (row8) {
-            case 128: hipLaunchKernelGGL(dense8_build_kernel<2>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
-            case 256: hipLaunchKernelGGL(dense8_build_kernel<4>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
-            default: hipLaunchKernelGGL(dense8_build_kernel<8>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
+            case 128: hipLaunchKernelGGL(dense8_build_kernel<2>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
+            case 256: hipLaunchKernelGGL(dense8_build_kernel<4>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
+            default: hipLaunchKernelGGL(dense8_build_kernel<8>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
         }
         SQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(nr8 + n_pad64), 0x7f800000, 64));   // (+inf behind the last unit)
     }
@@ -1213,7 +1227,7 @@ static int dense8_build(DenseHandle* h) {
     if ((double)nflag > 4.0 * budget) return quit(SQ_OK);
     h->dx8 = dx;
     h->rmax8 = sqrt(cut) * (1.0 + 1e-6);
-    h->xmax8 = sqrt((double)max_n) * (1.0 + 1e-6);
+    h->xmax8 = cosine ? 1.0 + 1e-6 : sqrt((double)max_n) * (1.0 + 1e-6);   // (cosine: unit rows; their row term is 0)
     h->flagged8 = nflag;
     if (getenv("SQ_INT8_REPORT"))   // (measurement aid: what the build chose)
         fprintf(stderr, "[smqtk_hip] int8 filter: clamp %.2f rms, step %.5g, R %.5g (%.2f x the rounding residual), X %.5g, %u always-candidate rows of %lld\n",

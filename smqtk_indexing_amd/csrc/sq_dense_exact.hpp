@@ -932,8 +932,12 @@ struct DenseFinalizeCos {
     const u32* overflow;
     int q0;
     ExactGroup sel = ExactGroup{{0, 0, 0, 0, 0, 0, 0, 0}, 0};
+    const float2* lin = nullptr;          // the int8 filter: the query's own slack lin[q].y instead of `eps`
+    const DenseCallPtrs* ind = nullptr;   // captured call graph: the outputs of THIS launch
     __device__ __forceinline__ void operator()(int ql, const K128* sorted, int k) const {
         const int q = sel.count ? sel.idx[ql] : q0 + ql;
+        double* out_dist = ind ? static_cast<double*>(ind->out_dist) : this->out_dist;
+        long long* out_idx = ind ? ind->out_idx : this->out_idx;
         for (int j = threadIdx.x; j < k; j += blockDim.x) {
             const K128 key = sorted[j];
             const bool pad = key.hi == ~0ull && key.lo == ~0ull;
@@ -950,7 +954,7 @@ struct DenseFinalizeCos {
                     const double dk = unordered_f64(sorted[kk - 1].hi);
                     const double t = (double)thr[q];  // threshold on -sim~
                     // non-candidates: -sim~ > t  =>  sim < -t + eps  =>  dist > 2 acos(min(1,-t+eps))/pi
-                    double smax = -t + eps;
+                    double smax = -t + (lin ? (double)lin[q].y : eps);
                     smax = smax > 1.0 ? 1.0 : (smax < -1.0 ? -1.0 : smax);
                     const double bound = 2.0 * acos(smax) / 3.141592653589793 - 1e-9;
                     if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;

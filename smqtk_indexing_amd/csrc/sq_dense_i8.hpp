@@ -56,13 +56,21 @@ __host__ __device__ constexpr int i8_row_bytes(int d) { return d <= 128 ? 128 : 
 __host__ __device__ constexpr int i8_unit_rows(int row_bytes) { return row_bytes == 128 ? 64 : 32; }
 
 // ---------------------------------------------------------------- build
+// The value the copy quantises: L2 the row minus the filter's origin; cosine the row scaled to unit length, rounded to
+// float32 -- the residuals are measured against this very value; what it differs from the exact x / |x| by (2^-24 per
+// element, relative) is part of the rounding term of e_q.
+__device__ __forceinline__ float i8_element(float v, const float* __restrict__ center, int k, bool cosine, double inv_norm) {
+    if (cosine) return (float)((double)v * inv_norm);
+    return center ? __fsub_rn(v, center[k]) : v;
+}
+
 // sum over rows of |x - c|^2 (float64) and their number, rows with |x - c|^2 > cap left out: the element rms the clamp
 // candidates are multiples of.  The host runs it three times, cap = inf, then 16 x the mean of the pass before: a few
 // rows thousands of times the size of the rest would otherwise own the rms (they end up beyond R either way).
 template <int EPL>   // elements per lane: row_bytes / 64
 static __global__ __launch_bounds__(256) void dense8_energy_kernel(const float* __restrict__ db, long long n, long long ld, int d,
-                                                                    const float* __restrict__ center, double cap,
-                                                                    double* __restrict__ sum) {   // [0]: energy, [1]: rows
+                                                                    const float* __restrict__ center, const double* __restrict__ nx64,
+                                                                    double cap, double* __restrict__ sum) {   // [0]: energy, [1]: rows
     __shared__ double red[4][2];
     const int lane = threadIdx.x & 63;
     const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
@@ -70,12 +78,13 @@ static __global__ __launch_bounds__(256) void dense8_energy_kernel(const float* 
     for (long long row = wave0; row < n; row += nw) {
         double e = 0.0;
         bool bad = false;
+        const double inv_norm = nx64 ? 1.0 / sqrt(nx64[row]) : 1.0;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             const int k = EPL * lane + j;
             if (k < d) {
                 const float v = db[row * ld + k];
-                const float xc = center ? __fsub_rn(v, center[k]) : v;
+                const float xc = i8_element(v, center, k, nx64 != nullptr, inv_norm);
                 if (!(fabsf(xc) < 3.0e38f)) bad = true;
                 e += (double)xc * (double)xc;
             }
@@ -112,8 +121,8 @@ struct Dense8ClipArgs {
 
 template <int EPL>
 static __global__ __launch_bounds__(256) void dense8_clip_stats_kernel(const float* __restrict__ db, long long n, long long ld, int d,
-                                                                        const float* __restrict__ center, Dense8ClipArgs ca,
-                                                                        u32* __restrict__ counts) {
+                                                                        const float* __restrict__ center, const double* __restrict__ nx64,
+                                                                        Dense8ClipArgs ca, u32* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
     u32 cnt[I8_NCLIP][I8_NCUT];
@@ -126,12 +135,13 @@ static __global__ __launch_bounds__(256) void dense8_clip_stats_kernel(const flo
 #pragma unroll
         for (int c = 0; c < I8_NCLIP; ++c) r2[c] = 0.f;
         bool bad = false;
+        const double inv_norm = nx64 ? 1.0 / sqrt(nx64[row]) : 1.0;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             const int k = EPL * lane + j;
             if (k < d) {
                 const float v = db[row * ld + k];
-                const float xc = center ? __fsub_rn(v, center[k]) : v;
+                const float xc = i8_element(v, center, k, nx64 != nullptr, inv_norm);
                 if (!(fabsf(xc) < 3.0e38f)) bad = true;
 #pragma unroll
                 for (int c = 0; c < I8_NCLIP; ++c) {
@@ -163,8 +173,9 @@ static __global__ __launch_bounds__(256) void dense8_clip_stats_kernel(const flo
 // distance is inf / NaN: they rank last, as in the bf16 filter) and no residual.
 template <int EPL>
 static __global__ __launch_bounds__(256) void dense8_build_kernel(const float* __restrict__ db, long long n, long long ld, int d,
-                                                                   long long n_pad, const float* __restrict__ center, float inv_dx,
-                                                                   float dx, signed char* __restrict__ out8, float* __restrict__ nrow,
+                                                                   long long n_pad, const float* __restrict__ center,
+                                                                   const double* __restrict__ nx64, float inv_dx, float dx,
+                                                                   signed char* __restrict__ out8, float* __restrict__ nrow,
                                                                    float* __restrict__ r2row, long long row_base) {
     const int lane = threadIdx.x & 63;
     const long long row = row_base + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -175,12 +186,13 @@ static __global__ __launch_bounds__(256) void dense8_build_kernel(const float* _
     double e2 = 0.0, r2 = 0.0;
     bool finite = true;
     if (row < n) {
+        const double inv_norm = nx64 ? 1.0 / sqrt(nx64[row]) : 1.0;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             const int k = EPL * lane + j;
             if (k < d) {
                 const float v = db[row * ld + k];
-                const float xc = center ? __fsub_rn(v, center[k]) : v;
+                const float xc = i8_element(v, center, k, nx64 != nullptr, inv_norm);
                 if (!(xc == xc) || !(fabsf(xc) < 3.0e38f)) finite = false;
                 float t = rintf(xc * inv_dx);
                 t = fminf(fmaxf(t, -127.f), 127.f);
@@ -212,7 +224,7 @@ static __global__ __launch_bounds__(256) void dense8_build_kernel(const float* _
     if (lane == 0) {
         float nr = __builtin_inff(), rr = 0.f;
         if (row < n && finite) {
-            nr = (float)e2;
+            nr = nx64 ? 0.f : (float)e2;   // (cosine: the score is -x^.q^ alone)
             if ((double)nr > e2) nr = __uint_as_float(__float_as_uint(nr) - 1u);   // round down (e2 >= 0)
             rr = (float)r2;
             if ((double)rr < r2) rr = __uint_as_float(__float_as_uint(rr) + 1u);   // round up
@@ -282,7 +294,7 @@ static __global__ __launch_bounds__(512) void dense8_prep_queries_kernel(const f
                                                                           float2* __restrict__ par, double* __restrict__ qn2,
                                                                           float* __restrict__ thr, u32* __restrict__ cnt,
                                                                           u32* __restrict__ oflag, float* __restrict__ q_al, int ldq,
-                                                                          const DenseCallPtrs* __restrict__ ind) {
+                                                                          const DenseCallPtrs* __restrict__ ind, int cosine) {
     if (ind) q = ind->q;   // (captured call graph: this launch's queries)
     const int qi = blockIdx.x, t = threadIdx.x;
     const int row_bytes = blockDim.x, nw = blockDim.x >> 6;
@@ -294,16 +306,28 @@ static __global__ __launch_bounds__(512) void dense8_prep_queries_kernel(const f
         cnt[qi] = 0u;
         if (qi == 0) *oflag = 0u;
     }
+    // L2: q'' = q - c and the planes hold -2 q''; cosine: q'' = q / |q| (float64 norm, rounded to float32) and the planes hold -q''
+    const float sc = cosine ? -1.f : -2.f;
     float v = 0.f;
     if (qi < nq && t < d) {
         const float raw = q[(long long)qi * d + t];
         v = center ? __fsub_rn(raw, center[t]) : raw;
     }
+    if (cosine) {
+        double n2 = (double)v * (double)v;
+        for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);
+        if ((t & 63) == 0) red[t >> 6] = n2;
+        __syncthreads();
+        double nn = 0.0;
+        for (int w = 0; w < nw; ++w) nn += red[w];
+        __syncthreads();
+        v = (float)((double)v / sqrt(nn));   // (a zero query: NaN -- no scale, the exact path answers it as the reference does)
+    }
     if (qi < nq)
         for (int i = t; i < ldq; i += row_bytes) q_al[(long long)qi * ldq + i] = i < d ? q[(long long)qi * d + i] : 0.f;
-    // |q''|^2 and max |2 q''_k|
+    // |q''|^2 and the largest plane element
     double a2 = (double)v * (double)v;
-    float m = fabsf(2.f * v);
+    float m = fabsf(sc * v);
     if (!(m == m)) m = __builtin_inff();
     for (int o = 32; o > 0; o >>= 1) {
         a2 += __shfl_xor(a2, o);
@@ -325,18 +349,18 @@ static __global__ __launch_bounds__(512) void dense8_prep_queries_kernel(const f
     const double dq = ok ? (double)mx / 127.0 : 1.0;
     float qt8 = 0.f;
     if (ok) {
-        qt8 = rintf((float)((double)(-2.f * v) / dq));
+        qt8 = rintf((float)((double)(sc * v) / dq));
         qt8 = fminf(fmaxf(qt8, -127.f), 127.f);
     }
     // second plane: what the first leaves, in steps of Dq / 256 (the kernel joins the two integer sums by a shift)
     float ql8 = 0.f;
     if (ok) {
-        ql8 = rintf((float)((((double)(-2.f * v) / dq) - (double)qt8) * 256.0));
+        ql8 = rintf((float)((((double)(sc * v) / dq) - (double)qt8) * 256.0));
         ql8 = fminf(fmaxf(ql8, -127.f), 127.f);
     }
     qs8[(long long)qi * row_bytes + t] = (signed char)(int)qt8;
     qs8[(long long)(TILE_ROWS + qi) * row_bytes + t] = (signed char)(int)ql8;
-    const double res = (double)(-2.f * v) - ((double)qt8 + (double)ql8 / 256.0) * dq;
+    const double res = (double)(sc * v) - ((double)qt8 + (double)ql8 / 256.0) * dq;
     double r2 = res * res;
     for (int o = 32; o > 0; o >>= 1) r2 += __shfl_xor(r2, o);
     if ((t & 63) == 0) red[t >> 6] = r2;
@@ -346,10 +370,10 @@ static __global__ __launch_bounds__(512) void dense8_prep_queries_kernel(const f
         for (int w = 0; w < nw; ++w) r2s += red[w];
         const double rq = sqrt(r2s) * (1.0 + 1e-9);
         const double unit = dx * dq;
-        // e_q: 2 R |q''| (the rows' measured residual) + (X + R) rq (the query's) + the float32 evaluation of
+        // e_q: R |w| (the rows' measured residual; w = -2 q'' or -q'') + (X + R) rq (the query's) + the float32 evaluation of
         // N + unit * sum (|sum| unit <= (X + R)(2 |q''| + rq): conversion, unit and fma roundings) + N's own rounding
-        const double xr = x_max + r_max, qn = sqrt(Q);
-        double e = 2.0 * r_max * qn + xr * rq + 4.0 * 5.9604644775390625e-08 * (xr * (2.0 * qn + rq) + x_max * x_max);
+        const double xr = x_max + r_max, qn = sqrt(Q), wn = (cosine ? 1.0 : 2.0) * qn;   // wn: the length of what the planes hold
+        double e = r_max * wn + xr * rq + 4.0 * 5.9604644775390625e-08 * (xr * (wn + rq) + x_max * x_max);
         e *= 1.0 + 1e-6;
         float ef = (float)e;
         if ((double)ef < e) ef = __uint_as_float(__float_as_uint(ef) + 1u);

@@ -202,6 +202,39 @@ def test_dense_int8_filter_equals_bf16_filter_and_oracle(n, d, nq, k, family):
     idx.close()
 
 
+@pytest.mark.parametrize("n,d,nq,k,family", [(150_000, 128, 32, 100, "normal"), (100_000, 512, 32, 50, "clustered"),
+                                              (90_001, 100, 7, 10, "uniform"), (80_000, 300, 20, 25, "normal")])
+def test_dense_int8_filter_cosine(n, d, nq, k, family):
+    """Cosine with the int8 first stage: the copy holds the unit-length rows (row term 0), the planes -q / |q|; survivors
+    are re-ranked by the float64 cosine kernel, so the answers are the bf16 filter's bit for bit and the oracle's within
+    its 1e-12.  A zero row and a zero query keep the reference's behaviour (NaN distance, ranked last / all NaN)."""
+    rng = np.random.default_rng(n + d)
+    db, qs = _int8_family(rng, family, n, d, nq)
+    db[777] = 0.0
+    qs[nq - 1] = 0.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        idx = _lib.DenseIndex(db, metric=_lib.SQ_METRIC_COSINE)
+        idx.set_option("dense_int8", 1)
+        d8, i8 = idx.search(qs, k)
+        st = idx.stats()
+        assert st["bytes_scanned"] >= _int8_bytes(n, d) and (st["bytes_scanned"] - _int8_bytes(n, d)) % (n * d * 4) == 0, st
+        assert st["fallback_queries"] <= 1, st                       # the zero query
+        idx.set_option("dense_int8", 0)
+        d16, i16 = idx.search(qs, k)
+        np.testing.assert_array_equal(i8[:-1], i16[:-1])
+        np.testing.assert_array_equal(d8[:-1].view(np.uint64), d16[:-1].view(np.uint64))
+        assert np.isnan(d8[-1]).all()
+        for qi in range(0, nq - 1, max(1, nq // 5)):
+            rd, ri = O.dense_topk(db, qs[qi], k, "cosine")
+            np.testing.assert_allclose(d8[qi], rd, rtol=1e-12, atol=1e-15)
+            mism = i8[qi] != ri
+            if mism.any():
+                full = O.dense_distances(db, qs[qi], "cosine")
+                assert np.abs(full[i8[qi][mism]] - full[ri[mism]]).max() < 1e-14
+            assert 777 not in i8[qi]
+    idx.close()
+
+
 def test_dense_int8_outlier_rows_and_odd_queries():
     """Rows far outside the clamp (their residual is beyond R: they carry N_row = -inf and are re-ranked for every query),
     rows with non-finite elements (N_row = +inf), and queries the filter cannot serve (all zero: no scale; one huge

@@ -23,7 +23,7 @@ HBM_PEAK_GBS = 8000.0
 def run(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     n_local = 125_000_000 if args.rows == 10_000_000 else args.rows // world     # (--rows: codes in total)
     w, k = 4, args.k
-    nq = 256 if args.queries == 32 else args.queries
+    nq = 256 if args.queries == 0 else args.queries
     stream = torch.cuda.current_stream().cuda_stream
     gen = torch.Generator(device=dev)
     gen.manual_seed(5 + rank)

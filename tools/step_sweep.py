@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from smqtk_indexing_amd import _lib
 
-n, d, nq, k = int(os.environ.get("N", 10_000_000)), 128, int(os.environ.get("NQ", 32)), 100
+n, d, nq, k = int(os.environ.get("N", 10_000_000)), int(os.environ.get("D", 128)), int(os.environ.get("NQ", 32)), 100
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(3)
 db = torch.empty((n, d), dtype=torch.float32, device=dev)
