@@ -1107,7 +1107,7 @@ static int dense_build_rows(DenseHandle* h, long long row_base) {
 }
 
 // The int8 first-stage copy (sq_dense_i8.hpp), built at create for L2 matrices of up to 128 dimensions: the clamp and the
-// residual bound R chosen from the measured residuals of ten candidate clamps (the pair with the least R that leaves
+// residual bound R chosen from the measured residuals of twelve candidate clamps (the pair with the least R that leaves
 // no more than 256 rows, or 20 per million, beyond it: those become always-candidates), the copy, its float64 residuals.  Data
 // no clamp suits (heavy tails: too many rows beyond every bound) keeps the bf16 filter alone, and so does a failure to
 // allocate: neither is an error.
@@ -1154,9 +1154,10 @@ static int dense8_build(DenseHandle* h) {
     }
     if (!(rms > 0.0) || !(rms < 1e30)) return quit(SQ_OK);
     SQ_HIP(hipMemset(tmp.p, 0, 64));
-    // the clamp and R from the measured residuals of ten candidate clamps (dense8_clip_stats_kernel)
-    // (1.75 rms: where a uniform distribution ends; 9-11 rms: one-sided data -- max(N(0,1), 0) reaches 8.4 rms of its centred self)
-    static const double kClip[I8_NCLIP] = {1.75, 2.5, 3.25, 4.0, 4.75, 5.5, 6.5, 7.5, 9.0, 11.0};
+    // the clamp and R from the measured residuals of twelve candidate clamps (dense8_clip_stats_kernel)
+    // (1.75 rms: where a uniform distribution ends; 9-11 rms: one-sided data -- max(N(0,1), 0) reaches 8.4 rms of its centred
+    // self; 14-18 rms: sparse rows -- with 10 % of the elements set their rms is a third of an element's own scale)
+    static const double kClip[I8_NCLIP] = {1.75, 2.5, 3.25, 4.0, 4.75, 5.5, 6.5, 7.5, 9.0, 11.0, 14.0, 18.0};
     static const double kCut[I8_NCUT] = {0.6, 0.8, 1.0, 1.10, 1.15, 1.20, 1.30, 1.50, 2.0, 3.0};   // R in units of Dx sqrt(d / 12)
     Dense8ClipArgs ca{};
     const double round_unit = sqrt((double)d / 12.0);

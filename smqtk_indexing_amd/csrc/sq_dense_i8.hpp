@@ -113,7 +113,7 @@ static __global__ __launch_bounds__(256) void dense8_energy_kernel(const float* 
 // of what rounding alone leaves, Dx sqrt(d / 12) -- not of the measured mean, which a few wild rows would own.  A narrow
 // clamp has the finer step but cuts more elements off; the host takes the pair with the least bound R that leaves no
 // more than a few hundred rows beyond it.
-static constexpr int I8_NCLIP = 10, I8_NCUT = 10;
+static constexpr int I8_NCLIP = 12, I8_NCUT = 10;
 struct Dense8ClipArgs {
     float inv_dx[I8_NCLIP], dx[I8_NCLIP];
     float cut[I8_NCLIP][I8_NCUT];   // r_row^2 thresholds

@@ -235,6 +235,15 @@ def test_dense_int8_filter_cosine(n, d, nq, k, family):
     idx.close()
 
 
+@pytest.mark.parametrize("seed", [3, 12, 25, 31, 44, 58, 101, 202])
+def test_dense_int8_random_cases(seed):
+    """tools/int8_fuzz.py: random shape (n, d <= 512, nq <= 32, k), metric and data family (ties, sparse rows, offsets,
+    outliers, tiny / huge scales): the int8 filter's answers are the bf16 filter's bit for bit and the oracle's."""
+    from tools.int8_fuzz import run_case
+    ok, _, desc = run_case(seed)
+    assert ok, desc
+
+
 def test_dense_int8_outlier_rows_and_odd_queries():
     """Rows far outside the clamp (their residual is beyond R: they carry N_row = -inf and are re-ranked for every query),
     rows with non-finite elements (N_row = +inf), and queries the filter cannot serve (all zero: no scale; one huge
