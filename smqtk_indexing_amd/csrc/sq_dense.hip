@@ -15,6 +15,8 @@
 //      per-query threshold; survivors leave as per-wave lists of (first row,
 //      mask, query) entries.  The threshold comes from the same kernel in SAMPLE
 //      mode over every S-th tile + kth_threshold_f32_kernel.
+//   1b. calls of up to 32 queries over rows of up to 512 dimensions stream an int8 copy instead (dense8_scan_kernel,
+//      sq_dense_i8.hpp: one scale per matrix, residuals measured per row at build): half the bytes, same downstream.
 //   2. dense_rerank_*_kernel (sq_dense_exact.hpp) recomputes the distance of every
 //      survivor from the ORIGINAL float32 rows in the REFERENCE arithmetic
 //      (float32 subtract, square, numpy pairwise order, correctly rounded sqrt;

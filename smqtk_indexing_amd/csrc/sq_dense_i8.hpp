@@ -1,10 +1,10 @@
-// The int8 first-stage filter of the dense L2 search (d <= 128, one query tile per call): half the bytes of the
+// The int8 first-stage filter of the dense search (L2 and cosine, d <= 512, one query tile per call): half the bytes of the
 // bfloat16 scan copy, exact integer accumulation, and an error bound that is MEASURED per row instead of assumed.
 //
 // The bf16 filter (sq_dense_scan.hpp) streams 2 d_pad + 4 bytes per row and is HBM bound: a pass over 10 M x 128 is 2.6 GB
 // and 0.39 ms at 0.82 of the peak -- the kernel is where the hardware lets it be, so the only way on is fewer bytes.  Here a
 // row is d_pad signed bytes: x' = x - c (the filter's origin, as before) quantised with ONE scale for the whole matrix,
-//     x8_k = clamp(rint(x'_k / Dx), -127, 127),      Dx = 5 rms(x'_k) / 127,
+//     x8_k = clamp(rint(x'_k / Dx), -127, 127),      Dx = clamp / 127, the clamp chosen from the data (below),
 // and the part a byte cannot hold is not bounded by a worst case but measured at build time, in float64, per row:
 //     r_row = | x' - Dx x8 |_2        (quantisation noise ~ Dx sqrt(d / 12), plus whatever the clamp cut off).
 // With the query scaled per query, Q8_k = rint(-2 q''_k / Dq), q'' = q - c, rq = |-2 q'' - Dq Q8|_2 measured the same
@@ -16,16 +16,17 @@
 //     e(row, q) = 2 r_row |q''| + |Dx x8| rq + rounding <= 2 R |q''| + (X + R) rq + rounding =: e_q
 // (Cauchy-Schwarz on the two measured residuals; R = the largest r_row of the rows that take part, X = the largest
 // |x'|).  Rows whose r_row is far above the rest (an element far beyond the clamp) would widen every query's slack:
-// they get N_row = -inf instead, pass every threshold and are simply re-ranked exactly (a matrix with more than 0.2 %
-// of such rows keeps the bf16 filter).  Everything downstream is the bf16 filter's: the sampled k-th score T_s bounds
+// they get N_row = -inf instead, pass every threshold and are simply re-ranked exactly (the clamp and R are chosen so
+// that a few hundred rows at most end up there; data no clamp suits keeps the bf16 filter).  Everything downstream is the bf16 filter's: the sampled k-th score T_s bounds
 // the true k-th score by T_s + e_q, the threshold is T' = T_s + 2 e_q, survivors leave as (first row, mask, query)
 // entries of per-wave segments, are re-ranked in the reference's float32 arithmetic from the ORIGINAL rows
 // (dense_rerank_l2_kernel), selected, and certified: a non-candidate has s > T' - e_q.  Queries that fail take the
-// middle tier and the exact path as before, so results never depend on the filter.
+// middle tier and the exact path as before, so results never depend on the filter.  Cosine: x' = x / |x|, N_row = 0, the
+// planes hold -q / |q|, e_q = R + (1 + R) rq + rounding, float64 re-rank (dense_rerank_cos_kernel).
 //
-// Layout: the copy is plain row-major int8 [n_pad][128]; a ring unit is 64 rows (8 KiB: two 32-row MFMA tiles) DMA'd as
-// 8 pieces of 8 rows, the 16-byte chunks of a row XOR-swizzled by (row >> 1) & 7 on the SOURCE side so that the
-// ds_read_b128 of a fragment (lane = row, 16 consecutive k) is conflict-free.  One 16-byte read feeds one MFMA
+// Layout: the copy is plain row-major int8 [n_pad][128 | 256 | 512]; for 128-byte rows a ring unit is 64 rows (8 KiB: two
+// 32-row MFMA tiles) DMA'd as 8 pieces of 8 rows, the 16-byte chunks of a row XOR-swizzled by (row >> 1) & 7 on the SOURCE
+// side so that the ds_read_b128 of a fragment (lane = row, 16 consecutive k) is conflict-free (wider rows: I8Geom, i8_swz).  One 16-byte read feeds one MFMA
 // (K = 32) per query plane: four reads and eight MFMAs per tile, against eight and sixteen in the bf16 kernel.
 #pragma once
 #include "sq_dense_scan.hpp"
