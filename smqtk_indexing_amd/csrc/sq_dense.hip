@@ -291,6 +291,25 @@ static int dense8_scan_launch(int row_bytes, const Dense8ScanArgs& a, hipStream_
     }
     return fail(SQ_ERR_INVALID, "int8 scan: unsupported row width %d", row_bytes);
 }
+template <int QT, bool SAMPLE>
+static int dense8_scan_mt_launch_t(const Dense8ScanArgs& a, hipStream_t st) {
+    using G = I8Geom<4>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_mt_kernel<QT, SAMPLE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dense8_scan_mt_kernel<QT, SAMPLE>), dim3((unsigned)(a.nrb * a.nqt)), dim3(G::WAVES * 64), (size_t)G::WAVES * G::NSTAGE * G::SLOT_BYTES, st, a);
+    return SQ_OK;
+}
+// one query tile per wave: dense8_scan_kernel for the row width; 2 or 4 tiles (128-byte rows): dense8_scan_mt_kernel
+template <bool SAMPLE>
+static int dense8_scan_any(int row_bytes, int qt, const Dense8ScanArgs& a, hipStream_t st) {
+    if (qt == 1) return dense8_scan_launch<SAMPLE>(row_bytes, a, st);
+    if (row_bytes == 128 && qt == 2) return dense8_scan_mt_launch_t<2, SAMPLE>(a, st);
+    if (row_bytes == 128 && qt == 4) return dense8_scan_mt_launch_t<4, SAMPLE>(a, st);
+    return fail(SQ_ERR_INVALID, "int8 scan: %d query tiles per wave over %d-byte rows", qt, row_bytes);
+}
 static int i8_waves(int row_bytes) { return row_bytes == 512 ? I8Geom<16>::WAVES : I8Geom<4>::WAVES; }
 
 // Enqueue one search (nq <= kDenseQueryChunk queries) on `st` with the workspace of slot `s`; nothing is
@@ -399,7 +418,8 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, nullptr, 0},
                                         st, s.sort_tmp));
         }
-    } else if (scan_ok && h->use8 && nq <= TILE_ROWS && h->opt.dense_int8 != 0 && kk <= (cosine ? kSelectLdsKeys128 : kSelectLdsKeys64)) {
+    } else if (scan_ok && h->use8 && h->opt.dense_int8 != 0 && kk <= (cosine ? kSelectLdsKeys128 : kSelectLdsKeys64) &&
+               (nq <= TILE_ROWS || (h->row8 == 128 && (qt == 2 || qt == 4) && nq <= h->opt.dense_int8_batch))) {
         // ---- the int8 first-stage filter (sq_dense_i8.hpp): half the bytes per row, measured error bound
         c.int8 = true;
         const int row8 = h->row8, unit_rows = i8_unit_rows(row8), spu = 2 * (unit_rows / 32), waves8 = i8_waves(row8);   // samples per unit
@@ -410,7 +430,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             // (measured at 10 M x 128, k = 100: 0.293 / 0.269 / 0.262 / 0.258 / 0.257 / 0.257 / 0.263 ms per step at 6 / 8 / 10 / 12 / 16 / 20 / 24)
             // 256- and 512-byte rows: flat from 8 to 14, best at 10 (0.471 / 0.988 ms per step at 10 M x 256 / 512); the float64 cosine
             // re-rank costs ~3.6x the float32 one per candidate: sqrt of that off the stride, as in the bf16 path
-            stride = (long long)((row8 == 128 ? 14.0 : 10.0) * sqrt((double)n / 1e7 * 100.0 / (double)kk) / (cosine ? 1.9 : 1.0) + 0.5);
+            stride = (long long)((row8 == 128 ? 14.0 : 10.0) * sqrt((double)n / 1e7 * 100.0 / (double)kk / (double)qt) / (cosine ? 1.9 : 1.0) + 0.5);
             if (stride > 16) stride = 16;
             if (stride < 1) stride = 1;
             if (stride > (long long)cap / (16ll * kk)) stride = std::max<long long>(1, (long long)cap / (16ll * kk));
@@ -418,14 +438,14 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         while (stride > 1 && (n_units / stride) * spu < 8ll * kk) stride >>= 1;
         const long long ns_units = (n_units + stride - 1) / stride;
         const long long ns = ns_units * spu;
-        SQ_TRY(s.sample.reserve((size_t)TILE_ROWS * ns * 4));
+        SQ_TRY(s.sample.reserve((size_t)nq_pad * ns * 4));
         SQ_TRY(s.keys.reserve((size_t)nq * key_stride * key_bytes));
-        SQ_TRY(s.q8.reserve((size_t)2 * TILE_ROWS * row8));
-        SQ_TRY(s.par8.reserve((size_t)TILE_ROWS * 8));
+        SQ_TRY(s.q8.reserve((size_t)2 * nq_pad * row8));
+        SQ_TRY(s.par8.reserve((size_t)nq_pad * 8));
         const int cus = cu_count(h->device);
-        int nrb = h->opt.dense_blocks > 0 ? h->opt.dense_blocks : (use_event && h->opt.dense_async_streams == 2 ? cus * 3 / 4 : cus);
+        int nrb = h->opt.dense_blocks > 0 ? h->opt.dense_blocks : (use_event && h->opt.dense_async_streams == 2 && nqt == 1 ? cus * 3 / 4 : cus);
         nrb = (nrb + 7) / 8 * 8;
-        const long long n_waves = (long long)nrb * waves8;
+        const long long n_waves = (long long)nrb * nqt * waves8;
         const u32 wave_cap = 2048;
         const int ldq = (d + 3) / 4 * 4;
         SQ_TRY(s.wave_out.reserve((size_t)n_waves * wave_cap * 8));
@@ -446,22 +466,24 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         a.wave_cap = wave_cap;
         a.sample_out = s.sample.as<float>();
         a.ns = ns;
+        a.nqt = nqt;
+        a.plane_rows = nq_pad;
         {
             // (cacheable head: 32-64 MB measured best here -- 0.244 ms per step at 10 M rows against 0.250 at the bf16 copy's 192 MB)
             const size_t copy_bytes = (size_t)h->n_pad64 * row8;
             const long long keep_mb = h->opt.dense_nt_keep_mb > 0 ? h->opt.dense_nt_keep_mb : 64;
-            a.nt = h->opt.dense_nt >= 0 ? h->opt.dense_nt : (copy_bytes > ((size_t)512 << 20) ? 1 : 0);
+            a.nt = h->opt.dense_nt >= 0 ? h->opt.dense_nt : (copy_bytes > ((size_t)512 << 20) && nqt == 1 ? 1 : 0);   // (several groups re-read the rows from L2)
             a.nt_from_row = h->opt.dense_nt == 0 ? 0x7fffffffffffffffll : h->opt.dense_nt == 1 ? 0ll : (keep_mb << 20) / row8;
         }
         int nrb_sample = nrb;
-        if (use_event && h->opt.dense_async_streams == 2 && h->opt.dense_blocks <= 0) {
+        if (use_event && h->opt.dense_async_streams == 2 && h->opt.dense_blocks <= 0 && nqt == 1) {
             int sb = h->opt.dense_sample_blocks > 0 ? h->opt.dense_sample_blocks : (h->opt.dense_sample_blocks < 0 ? nrb : cus - nrb);
             sb = (sb + 7) / 8 * 8;
             if (sb >= 8 && sb < nrb_sample) nrb_sample = sb;
         }
         if (ns_units < (long long)nrb_sample * waves8) nrb_sample = (int)(((ns_units + waves8 - 1) / waves8 + 7) / 8 * 8);
         const int wpb = 2;
-        const size_t rr_lds = ldq <= 156 ? (size_t)32 * (ldq + 4) * 4 : 0;
+        const size_t rr_lds = (qt == 1 && ldq <= 156) ? (size_t)32 * (ldq + 4) * 4 : 0;
         // The chain of six launches, eagerly or as a captured graph.  A pipelined call on a small shard is bound by the
         // HOST: a launch costs ~2.8 us of host time (tools/micro/launch_cost.hip: 19.3 us for a chain of seven, 5.6-6.3 us
         // for one hipGraphLaunch of the same chain), and a 1.25 M-row shard's whole step is ~55 us.  The slot's first
@@ -469,24 +491,24 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // later ones launch the graph; the caller's pointers travel through a pinned block (DenseCallPtrs).
         const DenseCallPtrs* ind = nullptr;
         auto chain = [&](hipStream_t cs) -> int {
-            hipLaunchKernelGGL(dense8_prep_queries_kernel, dim3(TILE_ROWS), dim3(row8), 0, cs, q, nq, d, centerp, h->dx8, h->rmax8, h->xmax8,
-                               s.q8.as<signed char>(), s.par8.as<float2>(), qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq, ind, cosine ? 1 : 0);
+            hipLaunchKernelGGL(dense8_prep_queries_kernel, dim3(nq_pad), dim3(row8), 0, cs, q, nq, d, centerp, h->dx8, h->rmax8, h->xmax8,
+                               s.q8.as<signed char>(), s.par8.as<float2>(), qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq, ind, cosine ? 1 : 0, nq_pad);
             Dense8ScanArgs b = a;
             b.unit_step = stride;   // sample pass (on the CUs the pipelined full pass leaves free)
             b.n_sel = ns_units;
             b.nrb = nrb_sample;
-            if (const int rc = dense8_scan_launch<true>(row8, b, cs)) return rc;
+            if (const int rc = dense8_scan_any<true>(row8, qt, b, cs)) return rc;
             hipLaunchKernelGGL((kth_threshold_f32_kernel<Dense8ThrPost>), dim3(nq), dim3(1024), 0, cs, a.sample_out, ns, kk, thr,
                                Dense8ThrPost{s.par8.as<float2>(), qn2});
             b.unit_step = 1;        // full pass
             b.n_sel = n_units;
             b.nrb = nrb;
             if (prof) SQ_HIP(hipEventRecord(s.ev[1], cs));
-            if (const int rc = dense8_scan_launch<false>(row8, b, cs)) return rc;
+            if (const int rc = dense8_scan_any<false>(row8, qt, b, cs)) return rc;
             if (prof) SQ_HIP(hipEventRecord(s.ev[2], cs));
             if (cosine) {
                 hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, cs, h->db, h->ld, d,
-                                   s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, TILE_ROWS, s.keys.as<K128>(), cnt,
+                                   s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<K128>(), cnt,
                                    cap, oflag, cnx, cnq, h->opt.dense_debug);
                 if (prof) SQ_HIP(hipEventRecord(s.ev[4], cs));
                 DenseFinalizeCos fin{cnt, cap, kk, h->id_base, thr, 0.0, 1, (double*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0};
@@ -495,7 +517,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                 return select_launch_t<K128>(s.keys.as<K128>(), cnt, cap, key_stride, k, nq, s.out_keys.as<K128>(), fin, cs, s.sort_tmp, 8 * stride * kk);
             }
             hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, cs, h->db, h->ld, d,
-                               s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, TILE_ROWS, s.keys.as<u64>(), cnt,
+                               s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<u64>(), cnt,
                                cap, oflag, h->opt.dense_debug);
             if (prof) SQ_HIP(hipEventRecord(s.ev[4], cs));
             DenseFinalizeL2 fin{cnt, cap, kk, h->id_base, thr, qn2, 0.0, 1, (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0};
@@ -504,13 +526,13 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             return select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(), fin, cs, s.sort_tmp, 8 * stride * kk);
         };
         c.stats.scan_launches = 2;
-        c.stats.bytes_scanned = h->n_pad64 * ((long long)row8 + 4);
+        c.stats.bytes_scanned = h->n_pad64 * ((long long)row8 + 4) * nqt;
         bool launched = false;
         if (use_event && !prof && h->opt.dense_graph != 0 && st != nullptr && st == s.own) {   // (never a capture on the caller's stream)
             // everything the captured launches were given by value: shapes, the slot's and the handle's buffers
             u64 key = 0xcbf29ce484222325ull;
             auto mix = [&key](u64 v) { key = (key ^ v) * 0x100000001b3ull; };
-            for (u64 v : {(u64)nq, (u64)k, (u64)row8, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
+            for (u64 v : {(u64)nq, (u64)k, (u64)row8, (u64)qt, (u64)nqt, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
                           (u64)h->opt.dense_debug, (u64)h->id_base, (u64)(uintptr_t)st, (u64)(uintptr_t)h->db, (u64)(uintptr_t)centerp,
                           (u64)(uintptr_t)h->scan8.p, (u64)(uintptr_t)h->nrow8.p, (u64)(uintptr_t)s.q8.p, (u64)(uintptr_t)s.par8.p,
                           (u64)(uintptr_t)s.sample.p, (u64)(uintptr_t)s.keys.p, (u64)(uintptr_t)s.wave_out.p, (u64)(uintptr_t)s.wave_cnt.p,

@@ -287,7 +287,7 @@ static __global__ __launch_bounds__(256) void dense8_flag_kernel(const float* __
 // query's own quantisation out of the bound: rq shrinks ~250-fold), the measured
 // residual rq, |q - c|^2, the score unit Dx Dq and the query's error bound e_q (all float64, rounded up where they
 // widen the bound), plus what dense_prep_queries_kernel does besides (counters, overflow flag, the aligned copy).
-//   per query p < nq_pad:  qs8[plane][p][128] int8 (plane 1 in units of Dq / 256), par[p] = {unit (Dx Dq), e_q}
+//   per query p < nq_pad (= plane_rows):  qs8[plane][p][row bytes] int8 (plane 1 in units of Dq / 256), par[p] = {unit (Dx Dq), e_q}
 // (one workgroup per query of the padded tile, one thread per byte of a plane row: blockDim.x = the copy's row bytes)
 static __global__ __launch_bounds__(512) void dense8_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
                                                                           const float* __restrict__ center, double dx, double r_max,
@@ -295,7 +295,7 @@ static __global__ __launch_bounds__(512) void dense8_prep_queries_kernel(const f
                                                                           float2* __restrict__ par, double* __restrict__ qn2,
                                                                           float* __restrict__ thr, u32* __restrict__ cnt,
                                                                           u32* __restrict__ oflag, float* __restrict__ q_al, int ldq,
-                                                                          const DenseCallPtrs* __restrict__ ind, int cosine) {
+                                                                          const DenseCallPtrs* __restrict__ ind, int cosine, int plane_rows) {
     if (ind) q = ind->q;   // (captured call graph: this launch's queries)
     const int qi = blockIdx.x, t = threadIdx.x;
     const int row_bytes = blockDim.x, nw = blockDim.x >> 6;
@@ -360,7 +360,7 @@ static __global__ __launch_bounds__(512) void dense8_prep_queries_kernel(const f
         ql8 = fminf(fmaxf(ql8, -127.f), 127.f);
     }
     qs8[(long long)qi * row_bytes + t] = (signed char)(int)qt8;
-    qs8[(long long)(TILE_ROWS + qi) * row_bytes + t] = (signed char)(int)ql8;
+    qs8[(long long)(plane_rows + qi) * row_bytes + t] = (signed char)(int)ql8;
     const double res = (double)(sc * v) - ((double)qt8 + (double)ql8 / 256.0) * dq;
     double r2 = res * res;
     for (int o = 32; o > 0; o >>= 1) r2 += __shfl_xor(r2, o);
@@ -419,6 +419,9 @@ struct Dense8ScanArgs {
     int nrb;
     int nt;                     // non-temporal stream beyond nt_from_row
     long long nt_from_row;
+    // batches of 33 .. 256 queries (dense8_scan_mt_kernel): groups of QT query tiles, workgroup -> (group, row block)
+    int nqt;                    // groups
+    int plane_rows;             // rows of one query plane: qs8 is [2][plane_rows][128]
 };
 
 // LDS chunk position (16-byte units inside a row) of source chunk c of row r: the XOR swizzle that makes the fragment reads
@@ -568,6 +571,148 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
         if (lane == 0) {
             a.wave_cnt[2 * wave_id] = wcount;
             a.wave_cnt[2 * wave_id + 1] = 0u;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- 33 .. 256 queries per call (128-byte rows)
+// QT query tiles per wave (2 for up to 64 queries, 4 beyond): the unit's A fragments are read once and meet QT sets of
+// query planes (32 QT registers per lane), so one pass over the int8 copy serves 32 QT queries -- half the bytes of the
+// bf16 multi-tile pass, which is HBM bound up to a few hundred queries (128 queries at 10 M x 128: 0.54 ms per step for 2.6 GB).
+// More than 32 QT queries: nqt groups, the workgroups of an XCD walking the groups of the same row block so that the
+// rows come from L2 again (as dense_scan_kernel does).  Everything else is dense8_scan_kernel<4, .>: units of 64 rows,
+// two tiles -- here read and scored one after the other to keep the registers under 256.
+template <int QT, bool SAMPLE>
+__global__ __launch_bounds__(512, 2) void dense8_scan_mt_kernel(Dense8ScanArgs a) {
+    using G = I8Geom<4>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r31 = lane & 31, h = lane >> 5;
+    const u32 lds_base = (u32)(uintptr_t)smem;
+    const u32 ring_base = lds_base + (u32)wave * (G::NSTAGE * G::SLOT_BYTES);
+    const unsigned char* ring_ptr = smem + wave * (G::NSTAGE * G::SLOT_BYTES);
+    const long long wave_id = (long long)blockIdx.x * G::WAVES + wave;   // unique per wave of the launch: its survivor segment
+    uint2* wout = a.wave_out + wave_id * a.wave_cap;
+    // workgroup -> (row block, group of QT query tiles)
+    const int L = blockIdx.x;
+    int grp, rb;
+    if (a.nqt > 1) {
+        const int xcd = L & 7, j = L >> 3;
+        grp = j % a.nqt;
+        rb = (j / a.nqt) * 8 + xcd;
+    } else {
+        grp = 0;
+        rb = L;
+    }
+    const int q_first = grp * QT * TILE_ROWS;   // first query of the group
+    const long long rwave = (long long)rb * G::WAVES + wave, nwaves = (long long)a.nrb * G::WAVES;
+
+    i32x4 bq[QT][4], bl[QT][4];
+    float unit_lo[QT], thr_l[QT];
+#pragma unroll
+    for (int g = 0; g < QT; ++g) {
+        const int qg = q_first + g * TILE_ROWS + r31;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bq[g][s] = *reinterpret_cast<const i32x4*>(a.qs8 + (long long)qg * G::ROW_BYTES + (2 * s + h) * 16);
+            bl[g][s] = *reinterpret_cast<const i32x4*>(a.qs8 + (long long)(a.plane_rows + qg) * G::ROW_BYTES + (2 * s + h) * 16);
+        }
+        unit_lo[g] = a.par[qg].x * 0.00390625f;
+        thr_l[g] = SAMPLE ? 0.f : a.thr[qg];
+        asm volatile("" : "+v"(unit_lo[g]), "+v"(thr_l[g]));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(bq[g][s]), "+v"(bl[g][s]));
+    }
+
+    const long long my_units = rwave < a.n_sel ? (a.n_sel - rwave + nwaves - 1) / nwaves : 0;
+    u32 voff[G::PIECES];
+#pragma unroll
+    for (int j = 0; j < G::PIECES; ++j) {
+        const int r = 8 * j + (lane >> 3);
+        voff[j] = (u32)(r * G::ROW_BYTES + i8_swz<4>(lane & 7, r) * 16);
+    }
+    const u32 voff_n = (u32)lane * 4u;
+    long long issued = 0;
+    auto issue_next = [&]() __attribute__((always_inline)) {
+        if (issued >= my_units) return;
+        const long long unit_idx = (rwave + issued * nwaves) * a.unit_step;
+        const long long row0 = unit_idx * G::UNIT_ROWS;
+        const u32 dst = ring_base + (u32)(issued % G::NSTAGE) * G::SLOT_BYTES;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan8) + row0 * G::ROW_BYTES;
+#pragma unroll
+        for (int j = 0; j < G::PIECES; ++j) {
+            if (a.nt && row0 >= a.nt_from_row)
+                glds16<true>(base, voff[j], dst + (u32)j * 1024);
+            else
+                glds16<false>(base, voff[j], dst + (u32)j * 1024);
+        }
+        glds4(a.nrow + row0, voff_n, dst + G::UNIT_BYTES);
+        ++issued;
+    };
+    for (int p = 0; p < G::NSTAGE; ++p) issue_next();
+
+    u32 wcount = 0;
+    for (long long it = 0; it < my_units; ++it) {
+        const long long unit_idx = (rwave + it * nwaves) * a.unit_step;
+        const long long row0 = unit_idx * G::UNIT_ROWS;
+        wait_units_in_flight<G::NSTAGE, G::PIECES + 1>((int)(issued - it - 1));
+        const unsigned char* sl = ring_ptr + (it % G::NSTAGE) * G::SLOT_BYTES;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r = 32 * t + r31;
+            i32x4 av[4];
+            f32x4 nr[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) av[s] = *reinterpret_cast<const i32x4*>(sl + r * G::ROW_BYTES + i8_swz<4>(2 * s + h, r) * 16);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) nr[c] = *reinterpret_cast<const f32x4*>(sl + G::UNIT_BYTES + (32 * t + 8 * c + 4 * h) * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t == 1) issue_next();   // both tiles are in registers or done: the slot is free
+#pragma unroll
+            for (int g = 0; g < QT; ++g) {
+                i32x16 acc, acl;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = acl[i] = 0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[s], bq[g][s], acc, 0, 0, 0);
+                    acl = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[s], bl[g][s], acl, 0, 0, 0);
+                }
+                float sc[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float nv = nr[i >> 2][i & 3];
+                    if constexpr (SAMPLE) nv = nv == -__builtin_inff() ? __builtin_inff() : nv;
+                    sc[i] = __fmaf_rn((float)((acc[i] << 8) + acl[i]), unit_lo[g], nv);
+                }
+                float m = sc[0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) m = fminf(m, sc[i]);
+                if constexpr (SAMPLE) {
+                    const long long sel = rwave + it * nwaves;
+                    a.sample_out[(long long)(q_first + g * TILE_ROWS + r31) * a.ns + sel * G::SAMPLES_PER_UNIT + t * 2 + h] = m;
+                } else {
+                    const u64 hit = __ballot(m <= thr_l[g]);
+                    if (hit != 0) {
+                        u32 mask = 0;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) mask |= (sc[i] <= thr_l[g] ? 1u : 0u) << i;
+                        const u64 bal = __ballot(mask != 0);
+                        if (mask) {
+                            const u32 pos = wcount + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                            if (pos < a.wave_cap) wout[pos] = make_uint2((u32)(row0 + 32 * t + 4 * h), (mask << 16) | (u32)(g * TILE_ROWS + r31));
+                        }
+                        wcount += (u32)__popcll(bal);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (!SAMPLE) {
+        if (lane == 0) {
+            a.wave_cnt[2 * wave_id] = wcount;
+            a.wave_cnt[2 * wave_id + 1] = (u32)(grp * QT);   // first query tile of the group (the re-rank's q0 / 32)
         }
     }
 }

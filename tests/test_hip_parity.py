@@ -26,6 +26,7 @@ def _reset_options():
     _lib.set_option("dense_fused_prep", 1)
     _lib.set_option("dense_int8", -1)
     _lib.set_option("dense_graph", 1)
+    _lib.set_option("dense_int8_batch", 256)
 
 
 # ------------------------------------------------------------------- Hamming
@@ -232,6 +233,41 @@ def test_dense_int8_filter_cosine(n, d, nq, k, family):
                 full = O.dense_distances(db, qs[qi], "cosine")
                 assert np.abs(full[i8[qi][mism]] - full[ri[mism]]).max() < 1e-14
             assert 777 not in i8[qi]
+    idx.close()
+
+
+@pytest.mark.parametrize("n,d,nq,k,metric", [(150_000, 128, 33, 50, "euclidean"), (120_000, 100, 64, 10, "euclidean"),
+                                              (200_000, 128, 100, 100, "euclidean"), (100_000, 64, 128, 25, "euclidean"),
+                                              (130_000, 128, 200, 100, "euclidean"), (90_000, 17, 256, 5, "euclidean"),
+                                              (110_000, 128, 70, 20, "cosine"), (80_000, 96, 129, 10, "cosine")])
+def test_dense_int8_batches_of_two_and_four_query_tiles(n, d, nq, k, metric):
+    """33 .. 256 queries over 128-byte rows: dense8_scan_mt_kernel scores 2 (up to 64 queries) or 4 query tiles per wave
+    against each int8 row unit; more than 128 queries make groups that re-read the rows.  Same answers as the bf16
+    multi-tile kernels, bit for bit, and as the oracle; beyond dense_int8_batch the bf16 kernels take the call."""
+    rng = np.random.default_rng(n + nq)
+    db, qs = _int8_family(rng, "normal", n, d, nq)
+    m = _lib.SQ_METRIC_L2 if metric == "euclidean" else _lib.SQ_METRIC_COSINE
+    idx = _lib.DenseIndex(db, metric=m)
+    tiles = -(-nq // 32)
+    qt = 2 if tiles == 2 else 4
+    groups = -(-tiles // qt)
+    d8, i8 = idx.search(qs, k)
+    st = idx.stats()
+    assert st["bytes_scanned"] == _int8_bytes(n, d) * groups, st
+    assert st["fallback_queries"] == 0 and st["mid_tier_queries"] == 0, st
+    idx.set_option("dense_int8_batch", 32)
+    d16, i16 = idx.search(qs, k)
+    assert idx.stats()["bytes_scanned"] != st["bytes_scanned"]
+    view = np.uint32 if metric == "euclidean" else np.uint64
+    np.testing.assert_array_equal(i8, i16)
+    np.testing.assert_array_equal(d8.view(view), d16.view(view))
+    for qi in range(0, nq, max(1, nq // 7)):
+        rd, ri = O.dense_topk(db, qs[qi], k, metric)
+        if metric == "euclidean":
+            np.testing.assert_array_equal(i8[qi], ri)
+            np.testing.assert_array_equal(d8[qi].view(np.uint32), rd.view(np.uint32))
+        else:
+            np.testing.assert_allclose(d8[qi], rd, rtol=1e-12, atol=1e-15)
     idx.close()
 
 
