@@ -578,7 +578,11 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
 // ---------------------------------------------------------------- 33 .. 256 queries per call (128-byte rows)
 // QT query tiles per wave (2 for up to 64 queries, 4 beyond): the unit's A fragments are read once and meet QT sets of
 // query planes (32 QT registers per lane), so one pass over the int8 copy serves 32 QT queries -- half the bytes of the
-// bf16 multi-tile pass, which is HBM bound up to a few hundred queries (128 queries at 10 M x 128: 0.54 ms per step for 2.6 GB).
+// bf16 multi-tile pass.  Measured at 10 M x 128 (tools/step_sweep.py dense_int8_batch=...): 64 queries 0.468 -> 0.315 ms per
+// step; 128 queries 0.531 -> 0.516 (four tiles: the conversion and comparison of 8 x 16 scores per lane and unit is as long
+// as the stream); 256 and 512 queries (two and four groups) 0.90 -> 1.07 and 1.62 -> 1.94 -- the bf16 kernels, whose
+// epilogue is a minimum chain on float accumulators that already hold the norms, stay ahead there.  Hence the default
+// "dense_int8_batch" = 64: two tiles only.
 // More than 32 QT queries: nqt groups, the workgroups of an XCD walking the groups of the same row block so that the
 // rows come from L2 again (as dense_scan_kernel does).  Everything else is dense8_scan_kernel<4, .>: units of 64 rows,
 // two tiles -- here read and scored one after the other to keep the registers under 256.
