@@ -98,7 +98,7 @@ def parse_args():
                     help="skip the ITQ / Hamming timings reported beside the headline metric")
     ap.add_argument("--force-collective", action="store_true",
                     help="testing: run the all-gather + merge path even with one rank (launch under torch.distributed.run)")
-    ap.add_argument("--extra-batches", type=str, default="1,128,256,1024",
+    ap.add_argument("--extra-batches", type=str, default="1,64,128,256,1024",
                     help="other total batch sizes measured after the timed region; '' to skip")
     ap.add_argument("--lsh-n", type=int, default=0, help="lsh_c3: nearest codes asked of the hash index (0 = k)")
     ap.add_argument("--fit", action="store_true",
@@ -693,7 +693,7 @@ def main() -> None:
             args.dim = 512
         if args.queries == 0:
             args.queries = 256
-        if args.extra_batches == "1,128,256,1024":
+        if args.extra_batches == "1,64,128,256,1024":
             args.extra_batches = "32"
         args.no_other_paths = True
     if args.queries == 0 and args.workload != "c5_hamming_shard":

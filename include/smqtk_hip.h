@@ -233,6 +233,7 @@ int sq_dense_search(sq_handle_t h, const float* queries, int nq, int k,
  * of the rows (128 / 256 / 512 + 4 bytes per row) and calls of up to 32 queries filter on it -- half the bytes of the bfloat16
  * pass; the results are the same bits (exact re-rank + certificate, as ever).  0 at create: no copy; 0 on a handle: the
  * copy is not used; 1: used even after its candidate lists overflowed three calls in a row (-1 goes back to bfloat16 then).
+ * Option "dense_int8_batch" (64 by default): the largest batch the int8 filter takes (128-byte rows; 32 = one query tile only).
  * Option "dense_graph" (1 by default): asynchronous int8 calls of one shape replay a captured graph (one launch per call). */
 int sq_dense_sync(sq_handle_t h);
 int sq_dense_destroy(sq_handle_t h);
