@@ -121,6 +121,21 @@ struct DenseHandle : HandleBase {
     }
 };
 
+// SQ_HOSTPROF=1 (measurement aid): host nanoseconds of an asynchronous sq_dense_search by section, printed by sq_dense_sync
+struct HostProf {
+    bool on = getenv("SQ_HOSTPROF") != nullptr;
+    long long ns[6] = {0, 0, 0, 0, 0, 0};   // entry (lookup, lock, options, device), resolve of the slot, stream / event setup, enqueue, wait-resolve, calls
+    std::chrono::steady_clock::time_point t;
+    void start() { if (on) t = std::chrono::steady_clock::now(); }
+    void lap(int i) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        ns[i] += std::chrono::duration_cast<std::chrono::nanoseconds>(now - t).count();
+        t = now;
+    }
+};
+static HostProf g_hostprof;
+
 // -------------------------------------------------------------- host driver
 static constexpr int kSelectLdsKeys64 = 16384;
 static constexpr int kSelectLdsKeys128 = 7168;
@@ -1421,12 +1436,14 @@ extern "C" int sq_dense_append(sq_handle_t hid, const float* rows, int64_t n_add
 
 extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, int k, void* out_dist, int64_t* out_idx,
                                int mem, void* stream) {
+    g_hostprof.start();
     auto* h = static_cast<DenseHandle*>(lookup_handle(hid, H_DENSE));
     if (!h) return fail(SQ_ERR_INVALID, "sq_dense_search: unknown handle");
     if (!queries || !out_dist || !out_idx || nq <= 0 || k <= 0) return fail(SQ_ERR_INVALID, "sq_dense_search: bad argument");
     std::lock_guard<std::mutex> lock(h->mu);
     h->refresh_options();
     SQ_HIP(hipSetDevice(h->device));
+    g_hostprof.lap(0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t dsz = h->metric == SQ_METRIC_COSINE ? 8 : 4;
     if (mem == SQ_MEM_DEVICE_ASYNC && nq <= kDenseQueryChunk) {
@@ -1446,6 +1463,7 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
         }
         DenseSlot& s = h->slot[h->async_calls % (unsigned)h->depth];
         SQ_TRY(dense_resolve(h, s));  // (the call `depth` back; normally resolved during an earlier call)
+        g_hostprof.lap(1);
         hipStream_t run = st;
         if (h->opt.dense_async_streams == 2) {
             // One query tile per wave (HBM bound): the two slots alternate between two streams, so neighbouring
@@ -1466,13 +1484,18 @@ extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, in
                // costs ~10 us of start latency per call, as much as a small shard's whole sample pass)
             run = owner.own;
         }
+        g_hostprof.lap(2);
         SQ_TRY(dense_enqueue(h, s, queries, nq, k, out_dist, reinterpret_cast<long long*>(out_idx), run, true));
+        g_hostprof.lap(3);
+        g_hostprof.ns[5]++;
         h->async_calls++;
         // the oldest call still in flight (depth - 1 calls back): its results are final on return -- unless the caller
         // asked not to wait here ("dense_async_wait" = 0): that call is then finished at the start of the next call (its
         // slot is the next one to be reused), and whatever the host does between the two calls overlaps the device
         if (!h->opt.dense_async_wait) return SQ_OK;
-        return dense_resolve(h, h->slot[h->async_calls % (unsigned)h->depth]);
+        const int rc_wait = dense_resolve(h, h->slot[h->async_calls % (unsigned)h->depth]);
+        g_hostprof.lap(4);
+        return rc_wait;
     }
     SQ_TRY(dense_sync_all(h));
     if (mem != SQ_MEM_HOST)
@@ -1497,6 +1520,12 @@ extern "C" int sq_dense_sync(sq_handle_t hid) {
     std::lock_guard<std::mutex> lock(h->mu);
     h->refresh_options();
     SQ_HIP(hipSetDevice(h->device));
+    if (g_hostprof.on && g_hostprof.ns[5] > 0) {
+        const double c = (double)g_hostprof.ns[5] * 1e3;
+        fprintf(stderr, "[smqtk_hip] host us per async call over %lld calls: entry %.2f | resolve of the slot %.2f | stream setup %.2f | enqueue %.2f | wait %.2f\n",
+                g_hostprof.ns[5], g_hostprof.ns[0] / c, g_hostprof.ns[1] / c, g_hostprof.ns[2] / c, g_hostprof.ns[3] / c, g_hostprof.ns[4] / c);
+        for (auto& v : g_hostprof.ns) v = 0;
+    }
     return dense_sync_all(h);
 }
 
