@@ -99,6 +99,8 @@ struct DenseHandle : HandleBase {
     double dx8 = 0.0, rmax8 = 0.0, xmax8 = 0.0;
     long long flagged8 = 0;
     int overflow8 = 0;          // calls in a row in which the int8 filter's lists overflowed (data it does not suit): it is dropped
+    float dxf8 = 0.f, inv_dxf8 = 0.f, cut8 = 0.f;   // the build's step and residual cut, for rows appended later
+    long long n8_built = 0;     // rows the clamp was chosen from (an index twice that size chooses again)
     DevBuf norms1;  // L2: |x|^2 (1 - alpha) for one query plane (`norms`: two planes)
     DevBuf zeros;   // cosine: the 32 zero "norms" every tile of an AGPR-configuration scan starts from (norm_step 0)
     static constexpr int kMaxDepth = 6;
@@ -1248,22 +1250,23 @@ static int dense8_build(DenseHandle* h) {
     double* sum_r2 = tmp.as<double>() + 1;
     u32* maxb = reinterpret_cast<u32*>(tmp.as<double>() + 2);
     u32* flagged = maxb + 2;
+    // rows beyond the chosen bound become always-candidates first; R and X are then the largest residual and the largest
+    // |x'| of the rows that REMAIN under the bound (a row 100x the rest would otherwise set X for every query)
+    double cut = best_r * best_r * (1.0 + 1e-4);   // (the choice was made in float32)
+    hipLaunchKernelGGL(dense8_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, r2row.as<float>(), h->nrow8.as<float>(), n,
+                       (float)cut, flagged, 0ll);
     hipLaunchKernelGGL(dense8_resid_stats_kernel, dim3(1024), dim3(256), 0, 0, r2row.as<float>(), h->nrow8.as<float>(), n, sum_r2, maxb);
     struct {
         double energy, sum_r2;
         u32 max_r2, max_n, flagged, pad;
     } host{};
     SQ_HIP(hipMemcpy(&host, tmp.p, sizeof(host), hipMemcpyDeviceToHost));
+    SQ_HIP(hipDeviceSynchronize());
     float max_r2, max_n;
     memcpy(&max_r2, &host.max_r2, 4);
     memcpy(&max_n, &host.max_n, 4);
-    double cut = best_r * best_r * (1.0 + 1e-4);   // (the choice was made in float32)
-    if ((double)max_r2 <= cut) cut = (double)max_r2;   // nothing beyond: R is simply the largest
-    hipLaunchKernelGGL(dense8_flag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, r2row.as<float>(), h->nrow8.as<float>(), n,
-                       (float)cut, flagged, 0ll);
-    u32 nflag = 0;
-    SQ_HIP(hipMemcpy(&nflag, flagged, 4, hipMemcpyDeviceToHost));
-    SQ_HIP(hipDeviceSynchronize());
+    const u32 nflag = host.flagged;
+    if ((double)max_r2 < cut) cut = (double)max_r2 * (1.0 + 1e-6);   // nothing near the bound: R is simply the largest
     if ((double)nflag > 4.0 * budget) return quit(SQ_OK);
     h->dx8 = dx;
     h->rmax8 = sqrt(cut) * (1.0 + 1e-6);
@@ -1274,6 +1277,15 @@ static int dense8_build(DenseHandle* h) {
                 kClip[best_c], dx, h->rmax8, kCut[best_m], h->xmax8, nflag, n);
     h->n_pad64 = n_pad64;
     h->row8 = row8;
+    h->dxf8 = ca.dx[best_c];
+    h->inv_dxf8 = ca.inv_dx[best_c];
+    {   // appended rows are flagged against R^2 itself (rounded down): R may be smaller than the bound the build flagged with
+        float c8 = (float)cut;
+        if ((double)c8 > cut) c8 = __builtin_nextafterf(c8, 0.f);
+        h->cut8 = c8;
+    }
+    h->n8_built = n;
+    h->overflow8 = 0;
     h->use8 = true;
     return quit(SQ_OK);
 }
@@ -1294,6 +1306,88 @@ static int grow_keep(DevBuf& b, size_t used, size_t need) {
     b = nb;
     return SQ_OK;
 }
+// The int8 copy after an append (h->n is the new row count; the rows are in place).  The step and the residual cut of
+// the build stay: new rows are quantised with them, rows they do not suit become always-candidates like the build's own.
+// An index that has doubled since the clamp was chosen -- or that collected too many always-candidates -- chooses again
+// from all its rows; one that had no copy (too small, or declined) tries when it has doubled since its last attempt.
+static int dense8_append(DenseHandle* h, long long n_old) {
+    const long long n = h->n;
+    if (g_opt.dense_int8 == 0 || h->d > I8_MAX_ROW_BYTES) return SQ_OK;
+    if (!h->use8) {
+        if (n >= 65536 && n >= 2 * h->n8_built) {
+            h->n8_built = n;   // (the attempt counts whether or not the build accepts the data)
+            return dense8_build(h);
+        }
+        return SQ_OK;
+    }
+    if (n >= 2 * h->n8_built) return dense8_build(h);
+    const bool cosine = h->metric == SQ_METRIC_COSINE;
+    const double* nx64 = cosine ? h->cos_nx.as<double>() : nullptr;
+    const float* centerp = (!cosine && h->center.p) ? h->center.as<float>() : nullptr;
+    const int row8 = h->row8, d = h->d;
+    const long long n_pad64 = (n + 63) / 64 * 64;
+    auto drop = [&]() {
+        h->use8 = false;
+        h->scan8.release();
+        h->nrow8.release();
+        return SQ_OK;
+    };
+    if (grow_keep(h->scan8, (size_t)h->n_pad64 * row8, (size_t)n_pad64 * row8) != SQ_OK ||
+        grow_keep(h->nrow8, (size_t)(h->n_pad64 + 64) * 4, (size_t)(n_pad64 + 64) * 4) != SQ_OK) {
+        (void)hipGetLastError();
+        return drop();
+    }
+    DevBuf tmp, r2row;
+    if (tmp.reserve(64) != SQ_OK || r2row.reserve((size_t)n_pad64 * 4) != SQ_OK) {
+        tmp.release();
+        r2row.release();
+        (void)hipGetLastError();
+        return drop();
+    }
+    auto done = [&](int rc) {
+        tmp.release();
+        r2row.release();
+        return rc;
+    };
+    const long long row_base = n_old / 64 * 64;   // the unit the old rows ended in is redone with the new ones
+    {
+        const dim3 grid((unsigned)((n_pad64 - row_base + 3) / 4)), blk(256);
+        signed char* o8 = h->scan8.as<signed char>();
+        float* nr8 = h->nrow8.as<float>();
+        float* r2p = r2row.as<float>();
+        switch (row8) {
+            case 128: hipLaunchKernelGGL(dense8_build_kernel<2>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, h->inv_dxf8, h->dxf8, o8, nr8, r2p, row_base); break;
+            case 256: hipLaunchKernelGGL(dense8_build_kernel<4>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, h->inv_dxf8, h->dxf8, o8, nr8, r2p, row_base); break;
+            default: hipLaunchKernelGGL(dense8_build_kernel<8>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, h->inv_dxf8, h->dxf8, o8, nr8, r2p, row_base); break;
+        }
+        SQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(nr8 + n_pad64), 0x7f800000, 64));
+    }
+    SQ_HIP(hipMemset(tmp.p, 0, 64));
+    double* sum_r2 = tmp.as<double>() + 1;
+    u32* maxb = reinterpret_cast<u32*>(tmp.as<double>() + 2);
+    u32* flagged = maxb + 2;
+    // the largest |x'|^2 of the new rows BEFORE their always-candidates are marked (a flagged row needs no X)
+    hipLaunchKernelGGL(dense8_flag_kernel, dim3((unsigned)((n - row_base + 255) / 256)), dim3(256), 0, 0, r2row.as<float>(), h->nrow8.as<float>(), n,
+                       h->cut8, flagged, row_base);
+    hipLaunchKernelGGL(dense8_resid_stats_kernel, dim3(256), dim3(256), 0, 0, r2row.as<float>() + row_base, h->nrow8.as<float>() + row_base,
+                       n - row_base, sum_r2, maxb);
+    struct {
+        double energy, sum_r2;
+        u32 max_r2, max_n, flagged, pad;
+    } host{};
+    SQ_HIP(hipMemcpy(&host, tmp.p, sizeof(host), hipMemcpyDeviceToHost));
+    SQ_HIP(hipDeviceSynchronize());
+    float max_n;
+    memcpy(&max_n, &host.max_n, 4);
+    if (!cosine && max_n > 0.f) h->xmax8 = std::max(h->xmax8, sqrt((double)max_n) * (1.0 + 1e-6));
+    // (the redone unit's old always-candidates are counted again: an over-estimate on the safe side)
+    h->flagged8 += host.flagged;
+    h->n_pad64 = n_pad64;
+    const double budget = std::max(256.0, 2e-5 * (double)n);
+    if ((double)h->flagged8 > 4.0 * budget) return done(dense8_build(h));   // the new rows do not look like the old ones: choose again
+    return done(SQ_OK);
+}
+
 static int dense_grow(DenseHandle* h, long long n_new) {
     const long long n_pad_new = (n_new + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
     const bool cosine = h->metric == SQ_METRIC_COSINE;
@@ -1425,13 +1519,9 @@ extern "C" int sq_dense_append(sq_handle_t hid, const float* rows, int64_t n_add
     if (e != hipSuccess) return fail(SQ_ERR_HIP, "sq_dense_append: copy failed: %s", hipGetErrorString(e));
     h->n = n_new;
     h->n_pad = (n_new + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
-    if (h->use8) {   // (the int8 copy was scaled and sized for the rows of the build: appended-to indexes keep the bf16 filter)
-        h->use8 = false;
-        h->scan8.release();
-        h->nrow8.release();
-    }
     // the tile the old rows ended in is rebuilt together with the new ones (its padding rows become real rows)
-    return dense_build_rows(h, n_old / TILE_ROWS * TILE_ROWS);
+    SQ_TRY(dense_build_rows(h, n_old / TILE_ROWS * TILE_ROWS));
+    return dense8_append(h, n_old);
 }
 
 extern "C" int sq_dense_search(sq_handle_t hid, const float* queries, int nq, int k, void* out_dist, int64_t* out_idx,

@@ -235,7 +235,8 @@ static __global__ __launch_bounds__(256) void dense8_build_kernel(const float* _
     }
 }
 
-// sum and maximum of the measured residuals r_row^2 and the largest N_row (finite rows), for the choice of R
+// sum and maximum of the measured residuals r_row^2 and the largest N_row over the rows the bound covers (finite, not
+// flagged as always-candidates: run after dense8_flag_kernel), for R and X
 static __global__ __launch_bounds__(256) void dense8_resid_stats_kernel(const float* __restrict__ r2row, const float* __restrict__ nrow,
                                                                          long long n, double* __restrict__ sum_r2,
                                                                          u32* __restrict__ max_bits) {   // [0]: max r2, [1]: max N
@@ -245,7 +246,7 @@ static __global__ __launch_bounds__(256) void dense8_resid_stats_kernel(const fl
     float m = 0.f, mn = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float nv = nrow[i];
-        if (nv < __builtin_inff()) {
+        if (nv < __builtin_inff() && nv > -__builtin_inff()) {   // (rows that take part in the bound: not padding, not always-candidates)
             const float v = r2row[i];
             acc += (double)v;
             m = fmaxf(m, v);

@@ -353,23 +353,49 @@ def test_dense_int8_heavy_tails_and_tight_clusters():
     idx.close()
 
 
-def test_dense_int8_copy_is_dropped_by_an_append():
-    """The int8 copy is scaled and sized for the rows of the build: an index that grows keeps the bf16 filter
-    (sq_dense_append rebuilds only that copy's tail)."""
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_dense_int8_copy_follows_appends(metric):
+    """sq_dense_append keeps the int8 copy: new rows are quantised with the build's step, rows it does not suit (here: a
+    block of rows 100x the rest) become always-candidates, an index that has doubled since the clamp was chosen chooses
+    again, and an index born too small gets its copy once it has grown.  After every append the answers are the oracle's
+    over all rows and the pass streams the int8 copy of the current size."""
     rng = np.random.default_rng(5)
-    n, d, k = 100_000, 96, 10
-    db = rng.standard_normal((n + 3000, d)).astype(np.float32)
+    d, k = 96, 10
+    m = _lib.SQ_METRIC_L2 if metric == "euclidean" else _lib.SQ_METRIC_COSINE
+    total = 290_000
+    db = rng.standard_normal((total, d)).astype(np.float32)
+    db[104_000:104_040] *= np.float32(100.0)                  # appended outliers
     qs = rng.standard_normal((9, d)).astype(np.float32)
-    idx = _lib.DenseIndex(np.ascontiguousarray(db[:n]))
-    idx.search(qs, k)
-    assert idx.stats()["bytes_scanned"] == _int8_bytes(n, d)
-    idx.append(np.ascontiguousarray(db[n:]))
-    dd, ii = idx.search(qs, k)
-    assert idx.stats()["bytes_scanned"] == _bf16_bytes(n + 3000, d)
-    for qi in range(len(qs)):
-        rd, ri = O.dense_topk(db, qs[qi], k)
-        np.testing.assert_array_equal(ii[qi], ri)
-        np.testing.assert_array_equal(dd[qi].view(np.uint32), rd.view(np.uint32))
+    qs[0] = db[104_010] * np.float32(1.0001)
+
+    def check(idx, n):
+        dd, ii = idx.search(qs, k)
+        st = idx.stats()
+        for qi in range(len(qs)):
+            rd, ri = O.dense_topk(db[:n], qs[qi], k, metric)
+            if metric == "euclidean":
+                np.testing.assert_array_equal(ii[qi], ri)
+                np.testing.assert_array_equal(dd[qi].view(np.uint32), rd.view(np.uint32))
+            else:
+                np.testing.assert_allclose(dd[qi], rd, rtol=1e-12, atol=1e-15)
+        return st
+
+    idx = _lib.DenseIndex(np.ascontiguousarray(db[:100_000]), metric=m)
+    assert check(idx, 100_000)["bytes_scanned"] == _int8_bytes(100_000, d)
+    n = 100_000
+    for add in (3_001, 1_039, 30_000, 80_000, 75_960):       # 104 040: the outliers are in; 214 040 > 2 x 100 000: a new clamp
+        idx.append(np.ascontiguousarray(db[n:n + add]))
+        n += add
+        st = check(idx, n)
+        assert st["bytes_scanned"] == _int8_bytes(n, d), (n, st)
+        assert st["fallback_queries"] == 0, (n, st)
+    idx.close()
+    # born below the int8 filter's minimum size
+    idx = _lib.DenseIndex(np.ascontiguousarray(db[:70_000 - 10_000]), metric=m)
+    n = 60_000
+    idx.append(np.ascontiguousarray(db[n:n + 10_000]))
+    n += 10_000
+    assert check(idx, n)["bytes_scanned"] == _int8_bytes(n, d)
     idx.close()
 
 
