@@ -99,6 +99,7 @@ struct DenseHandle : HandleBase {
     double dx8 = 0.0, rmax8 = 0.0, xmax8 = 0.0;
     long long flagged8 = 0;
     int overflow8 = 0;          // calls in a row in which the int8 filter's lists overflowed (data it does not suit): it is dropped
+    bool graph_broken = false;  // a call-graph capture failed on this handle: eager launches from then on
     float dxf8 = 0.f, inv_dxf8 = 0.f, cut8 = 0.f;   // the build's step and residual cut, for rows appended later
     long long n8_built = 0;     // rows the clamp was chosen from (an index twice that size chooses again)
     DevBuf norms1;  // L2: |x|^2 (1 - alpha) for one query plane (`norms`: two planes)
@@ -545,7 +546,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         c.stats.scan_launches = 2;
         c.stats.bytes_scanned = h->n_pad64 * ((long long)row8 + 4) * nqt;
         bool launched = false;
-        if (use_event && !prof && h->opt.dense_graph != 0 && st != nullptr && st == s.own) {   // (never a capture on the caller's stream)
+        if (use_event && !prof && h->opt.dense_graph != 0 && !h->graph_broken && st != nullptr && st == s.own) {   // (never a capture on the caller's stream)
             // everything the captured launches were given by value: shapes, the slot's and the handle's buffers
             u64 key = 0xcbf29ce484222325ull;
             auto mix = [&key](u64 v) { key = (key ^ v) * 0x100000001b3ull; };
@@ -566,23 +567,24 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                 void* ind_dev = nullptr;
                 SQ_TRY(s.call_ptrs.device_ptr(&ind_dev));
                 ind = static_cast<const DenseCallPtrs*>(ind_dev);
+                // (a capture that fails is no reason to fail the search: the handle goes back to eager launches for good)
                 hipGraph_t g = nullptr;
-                SQ_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-                const int rc = chain(st);
-                const hipError_t ec = hipStreamEndCapture(st, &g);
-                if (rc != SQ_OK || ec != hipSuccess || !g) {
-                    if (g) (void)hipGraphDestroy(g);
+                bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    const int rc = chain(st);
+                    const hipError_t ec = hipStreamEndCapture(st, &g);
+                    ok = rc == SQ_OK && ec == hipSuccess && g != nullptr;
+                }
+                if (ok) ok = hipGraphInstantiate(&s.gexec, g, nullptr, nullptr, 0) == hipSuccess;
+                if (g) (void)hipGraphDestroy(g);
+                if (!ok) {
                     (void)hipGetLastError();
-                    return fail(SQ_ERR_HIP, "sq_dense_search: capturing the call graph failed");
-                }
-                const hipError_t ei = hipGraphInstantiate(&s.gexec, g, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(g);
-                if (ei != hipSuccess) {
                     s.gexec = nullptr;
-                    return fail(SQ_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+                    h->graph_broken = true;
+                } else {
+                    s.gkey = key;
+                    if (getenv("SQ_INT8_REPORT")) fprintf(stderr, "[smqtk_hip] call graph captured (%d queries, k = %d)\n", nq, k);
                 }
-                s.gkey = key;
-                if (getenv("SQ_INT8_REPORT")) fprintf(stderr, "[smqtk_hip] call graph captured (%d queries, k = %d)\n", nq, k);
             }
             s.seen_key = key;
             if (s.gexec) {
