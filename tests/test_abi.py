@@ -35,7 +35,9 @@ def test_library_answers_without_gpu_calls():
     assert b"unknown option" in lib.sq_last_error()
     # the options the pipelined / multi-rank path sets (include/smqtk_hip.h, sq_dense_search): known, and back to defaults
     for name, default in (("dense_async_streams", 2), ("dense_async_depth", 2), ("dense_async_wait", 1),
-                          ("dense_async_order", 1), ("profile", 0)):
+                          ("dense_async_order", 1), ("profile", 0),
+                          # the int8 first-stage filter and its captured call graph (round 3)
+                          ("dense_int8", -1), ("dense_int8_batch", 64), ("dense_graph", 1), ("dense_mid_tier", 1)):
         _lib.set_option(name, default)
 
 
