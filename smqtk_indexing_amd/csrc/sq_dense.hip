@@ -502,11 +502,13 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         if (ns_units < (long long)nrb_sample * waves8) nrb_sample = (int)(((ns_units + waves8 - 1) / waves8 + 7) / 8 * 8);
         const int wpb = 2;
         const size_t rr_lds = (qt == 1 && ldq <= 156) ? (size_t)32 * (ldq + 4) * 4 : 0;
-        // The chain of six launches, eagerly or as a captured graph.  A pipelined call on a small shard is bound by the
-        // HOST: a launch costs ~2.8 us of host time (tools/micro/launch_cost.hip: 19.3 us for a chain of seven, 5.6-6.3 us
-        // for one hipGraphLaunch of the same chain), and a 1.25 M-row shard's whole step is ~55 us.  The slot's first
-        // call of a shape runs eagerly (it sizes the workspace and sets the kernels' attributes), the second captures,
-        // later ones launch the graph; the caller's pointers travel through a pinned block (DenseCallPtrs).
+        // The chain of six launches, eagerly or as a captured graph.  A launch costs ~2.8 us of host time
+        // (tools/micro/launch_cost.hip: 19.3 us for a chain of seven, 5.6-6.3 us for one hipGraphLaunch of the same chain; in
+        // this call 20 against 9.5 us, tools/host_sections.py).  It does not shorten a 1.25 M-row shard's ~55 us step -- that
+        // is the latency of the chain itself, three deep -- but frees the host thread for the gather / merge work of a
+        // sharded search.  The slot's first call of a shape runs eagerly (it sizes the workspace and sets the kernels'
+        // attributes), the second captures, later ones launch the graph; the caller's pointers travel through a pinned
+        // block (DenseCallPtrs).
         const DenseCallPtrs* ind = nullptr;
         auto chain = [&](hipStream_t cs) -> int {
             hipLaunchKernelGGL(dense8_prep_queries_kernel, dim3(nq_pad), dim3(row8), 0, cs, q, nq, d, centerp, h->dx8, h->rmax8, h->xmax8,
