@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Randomised parity run of the int8 first-stage filter: random shapes (n, d <= 512, nq <= 32, k), metrics and data
-families (ties, sparse rows, offsets, outliers); every case compares the int8 filter with the bf16 filter bit for bit and
-one query with the oracle.  usage: python3 tools/int8_fuzz.py [cases] [first seed]   (a GPU run of ~1 s per case)"""
+"""Randomised parity run of the int8 first-stage filter: random shapes (n, d <= 512, nq <= 64, k), metrics and data
+families (ties, sparse rows, offsets, outliers), a third of the cases with the last rows arriving through
+sq_dense_append; every case compares the int8 filter with the bf16 filter bit for bit and one query with the oracle.
+usage: python3 tools/int8_fuzz.py [cases] [first seed]   (a GPU run of ~1 s per case)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +17,7 @@ def run_case(seed):
     rng = np.random.default_rng(seed)
     n = int(rng.integers(66_000, 260_000))
     d = int(rng.choice([2, 3, 17, 64, 100, 128, 129, 200, 256, 300, 384, 512]))
-    nq = int(rng.integers(1, 33))
+    nq = int(rng.integers(1, 65)) if seed % 3 == 0 else int(rng.integers(1, 33))
     k = int(rng.choice([1, 2, 10, 100, 300]))
     metric = "cosine" if rng.random() < 0.35 else "euclidean"
     fam = FAMILIES[int(rng.integers(0, len(FAMILIES)))]
@@ -51,8 +52,19 @@ def run_case(seed):
         db, qs = db * np.float32(1e12), qs * np.float32(1e12)
     db, qs = np.ascontiguousarray(db, dtype=np.float32), np.ascontiguousarray(qs, dtype=np.float32)
     m = _lib.SQ_METRIC_L2 if metric == "euclidean" else _lib.SQ_METRIC_COSINE
+    appended = 0
     with np.errstate(all="ignore"):
-        idx = _lib.DenseIndex(db, metric=m)
+        if seed % 3 == 1:
+            # the last rows arrive by one or two appends (the int8 copy follows: sq_dense.hip dense8_append)
+            appended = int(rng.integers(1, n // 3))
+            idx = _lib.DenseIndex(np.ascontiguousarray(db[: n - appended]), metric=m)
+            cut = n - appended + int(rng.integers(0, appended + 1))
+            if cut > n - appended:
+                idx.append(np.ascontiguousarray(db[n - appended:cut]))
+            if cut < n:
+                idx.append(np.ascontiguousarray(db[cut:]))
+        else:
+            idx = _lib.DenseIndex(db, metric=m)
         idx.set_option("dense_int8", 1)
         d8, i8 = idx.search(qs, k)
         st8 = idx.stats()
@@ -74,7 +86,7 @@ def run_case(seed):
         else:
             ok_or = np.allclose(d8[qi, :kk], rd, rtol=1e-12, atol=1e-15, equal_nan=True)
         idx.close()
-    desc = (f"seed {seed}: n={n} d={d} nq={nq} k={k} {metric} {fam}: int8 {'ran' if int8_ran else 'declined'} "
+    desc = (f"seed {seed}: n={n}{f' (+{appended} appended)' if appended else ''} d={d} nq={nq} k={k} {metric} {fam}: int8 {'ran' if int8_ran else 'declined'} "
             f"cands/q {st8['candidates'] / nq:.0f} later tiers {st8['mid_tier_queries']}+{st8['fallback_queries']} "
             f"same={same} oracle={ok_or}")
     return bool(same and ok_or), bool(int8_ran), desc
