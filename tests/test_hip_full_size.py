@@ -61,6 +61,8 @@ def test_dense_l2_10m_x_128_properties():
     index = _lib.DenseIndex(db.data_ptr(), n=n, d=d, device_ptr=True, keepalive=db)
     dist, ids = _search_dense(index, q, k)
     assert index.stats()["fallback_queries"] == 0
+    # (the pass streamed the int8 copy: 128 + 4 bytes per row)
+    assert index.stats()["bytes_scanned"] == (-(-n // 64) * 64) * 132, index.stats()
     qh = q.cpu().numpy()
     assert ids[0, 0] == 1_234_567 and dist[0, 0] == 0.0
     assert ids[1, 0] == n - 1
@@ -96,9 +98,10 @@ def test_dense_l2_10m_x_128_properties():
 
 
 def test_dense_l2_10m_batches_of_every_kernel_agree():
-    """10 M x 128, 1024 queries: the multi-tile scans (4 query tiles per wave for 1024 and 256 queries, 2 for 64) and
-    the one-tile scan (32 queries) are different kernels behind the same exact answer -- ids and float32 distances
-    must agree bit for bit, and no query may need the exact path (also BASELINE config 2's batch, at full rows)."""
+    """10 M x 128, 1024 queries: the bf16 multi-tile scans (4 query tiles per wave for 1024 and 256 queries), the int8
+    two-tile scan (64 queries) and the int8 one-tile scan (32 queries) are different kernels -- and different filters --
+    behind the same exact answer: ids and float32 distances must agree bit for bit, and no query may need the exact path
+    (also BASELINE config 2's batch, at full rows)."""
     dev = _dev()
     n, d, k = 10_000_000, 128, 100
     g = torch.Generator(device=dev)
@@ -137,6 +140,37 @@ def test_dense_l2_10m_batches_of_every_kernel_agree():
     index.close()
 
 
+@pytest.mark.parametrize("d", [256, 512])
+def test_dense_l2_wide_rows_int8_equals_bf16(d):
+    """4 M x 256 / 512 float32: the int8 first stage over 256- and 512-byte rows (32-row ring units; four waves per
+    workgroup at 512) against the bf16 filter on the same index -- the same bits -- and the oracle's arithmetic on the
+    returned rows."""
+    dev = _dev()
+    n, k, nq = 4_000_000, 100, 32
+    g = torch.Generator(device=dev)
+    g.manual_seed(300 + d)
+    db = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for s in range(0, n, 1 << 20):
+        db[s:s + (1 << 20)].normal_(generator=g)
+    q = torch.empty((nq, d), dtype=torch.float32, device=dev).normal_(generator=g)
+    q[3] = db[3_999_999]
+    index = _lib.DenseIndex(db.data_ptr(), n=n, d=d, device_ptr=True, keepalive=db)
+    d8, i8 = _search_dense(index, q, k)
+    st = index.stats()
+    assert st["bytes_scanned"] == (-(-n // 64) * 64) * (d + 4) and st["fallback_queries"] == 0 and st["mid_tier_queries"] == 0, st
+    index.set_option("dense_int8", 0)
+    d16, i16 = _search_dense(index, q, k)
+    assert index.stats()["bytes_scanned"] == (-(-n // 32) * 32) * (2 * d + 4)
+    np.testing.assert_array_equal(i8, i16)
+    np.testing.assert_array_equal(d8.view(np.uint32), d16.view(np.uint32))
+    assert i8[3, 0] == 3_999_999 and d8[3, 0] == 0.0
+    qh = q.cpu().numpy()
+    for j in (0, 3, 31):
+        rows = db[torch.from_numpy(i8[j]).to(dev)].cpu().numpy()
+        np.testing.assert_array_equal(d8[j].view(np.uint32), O.dense_distances(rows, qh[j], "euclidean").view(np.uint32))
+    index.close()
+
+
 def test_dense_cosine_12m_x_512_shard_properties():
     """One shard of BASELINE config 4 (100 M x 512 cosine over 8 GPUs): 12.5 M x 512."""
     dev = _dev()
@@ -151,6 +185,7 @@ def test_dense_cosine_12m_x_512_shard_properties():
     index = _lib.DenseIndex(db.data_ptr(), n=n, d=d, metric=_lib.SQ_METRIC_COSINE, device_ptr=True, keepalive=db)
     dist, ids = _search_dense(index, q, k, cosine=True)
     assert index.stats()["fallback_queries"] == 0
+    assert index.stats()["bytes_scanned"] == (-(-n // 64) * 64) * 516, index.stats()   # (the int8 copy of the unit rows: 512 + 4 bytes)
     qh = q.cpu().numpy()
     assert ids[0, 0] == 7_654_321 and dist[0, 0] < 1e-6
     for j in range(q.shape[0]):
