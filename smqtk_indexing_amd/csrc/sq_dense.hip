@@ -486,6 +486,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         a.ns = ns;
         a.nqt = nqt;
         a.plane_rows = nq_pad;
+        a.debug = h->opt.dense_debug;
         {
             // (cacheable head: 32-64 MB measured best here -- 0.244 ms per step at 10 M rows against 0.250 at the bf16 copy's 192 MB)
             const size_t copy_bytes = (size_t)h->n_pad64 * row8;

@@ -423,6 +423,7 @@ struct Dense8ScanArgs {
     // batches of 33 .. 256 queries (dense8_scan_mt_kernel): groups of QT query tiles, workgroup -> (group, row block)
     int nqt;                    // groups
     int plane_rows;             // rows of one query plane: qs8 is [2][plane_rows][128]
+    int debug;                  // measurement ablations ("dense_debug"; results are garbage): 1024 = no score epilogue
 };
 
 // LDS chunk position (16-byte units inside a row) of source chunk c of row r: the XOR swizzle that makes the fragment reads
@@ -535,6 +536,10 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
                     acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t][s], bq[KH + s], acc, 0, 0, 0);
                     acl = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[t][s], bl[KH + s], acl, 0, 0, 0);
                 }
+            }
+            if (a.debug & 1024) {   // ablation: the stream and the MFMAs alone
+                if (acc[0] == 0x7fffffff && acl[5] == 0x7ffffffe) wcount += 1;
+                continue;
             }
             // scores of 32 rows x 32 queries (lane = query, register i = row (i & 3) + 8 (i >> 2) + 4 h)
             float sc[16];
