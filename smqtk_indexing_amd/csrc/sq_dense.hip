@@ -95,7 +95,8 @@ struct DenseHandle : HandleBase {
     DevBuf scan8, nrow8;
     bool use8 = false;
     int row8 = 0;               // bytes per row of the copy: 128, 256 or 512
-    long long n_pad64 = 0;
+    long long n_pad64 = 0;      // rows a pass covers (what sq_stats_t.bytes_scanned prices)
+    long long n_alloc8 = 0;     // rows the copy is allocated and padded for: a multiple of 128 (the largest ring unit)
     double dx8 = 0.0, rmax8 = 0.0, xmax8 = 0.0;
     long long flagged8 = 0;
     int overflow8 = 0;          // calls in a row in which the int8 filter's lists overflowed (data it does not suit): it is dropped
@@ -322,11 +323,23 @@ static int dense8_scan_mt_launch_t(const Dense8ScanArgs& a, hipStream_t st) {
 }
 // one query tile per wave: dense8_scan_kernel for the row width; 2 or 4 tiles (128-byte rows): dense8_scan_mt_kernel
 template <bool SAMPLE>
-static int dense8_scan_any(int row_bytes, int qt, const Dense8ScanArgs& a, hipStream_t st) {
+static int dense8_scan_any(int row_bytes, int qt, bool big, const Dense8ScanArgs& a, hipStream_t st) {
+    if (big) return dense8_scan_big_launch<SAMPLE>(a, st);
     if (qt == 1) return dense8_scan_launch<SAMPLE>(row_bytes, a, st);
     if (row_bytes == 128 && qt == 2) return dense8_scan_mt_launch_t<2, SAMPLE>(a, st);
     if (row_bytes == 128 && qt == 4) return dense8_scan_mt_launch_t<4, SAMPLE>(a, st);
     return fail(SQ_ERR_INVALID, "int8 scan: %d query tiles per wave over %d-byte rows", qt, row_bytes);
+}
+template <bool SAMPLE>
+static int dense8_scan_big_launch(const Dense8ScanArgs& a, hipStream_t st) {
+    using G = I8GeomBig;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_big_kernel<SAMPLE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dense8_scan_big_kernel<SAMPLE>), dim3((unsigned)a.nrb), dim3(G::WAVES * 64), (size_t)G::WAVES * G::NSTAGE * G::SLOT_BYTES, st, a);
+    return SQ_OK;
 }
 static int i8_waves(int row_bytes) { return row_bytes == 512 ? I8Geom<16>::WAVES : I8Geom<4>::WAVES; }
 
@@ -440,7 +453,13 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                (nq <= TILE_ROWS || (h->row8 == 128 && (qt == 2 || qt == 4) && nq <= h->opt.dense_int8_batch))) {
         // ---- the int8 first-stage filter (sq_dense_i8.hpp): half the bytes per row, measured error bound
         c.int8 = true;
-        const int row8 = h->row8, unit_rows = i8_unit_rows(row8), spu = 2 * (unit_rows / 32), waves8 = i8_waves(row8);   // samples per unit
+        // 128-byte rows, one query tile, "dense_int8_unit" = 128: ring units of 128 rows on four waves (dense8_scan_big_kernel).
+        // Alone that pass is 4 % faster than the 64-row units on eight waves (0.197 against 0.204 ms at 10 M rows); inside the
+        // pipeline, on 192 CUs beside the neighbours' kernels, it is 8 % slower (0.244 against 0.226 ms per step): not the default.
+        const int row8 = h->row8;
+        const bool big = row8 == 128 && qt == 1 && h->opt.dense_int8_unit == 128;
+        const int unit_rows = big ? I8GeomBig::UNIT_ROWS : i8_unit_rows(row8), spu = 2 * (unit_rows / 32);   // samples per unit
+        const int waves8 = big ? I8GeomBig::WAVES : i8_waves(row8);
         const long long n_units = (n + unit_rows - 1) / unit_rows;
         long long stride = h->opt.sample_stride;
         if (stride <= 0) {
@@ -518,14 +537,14 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             b.unit_step = stride;   // sample pass (on the CUs the pipelined full pass leaves free)
             b.n_sel = ns_units;
             b.nrb = nrb_sample;
-            if (const int rc = dense8_scan_any<true>(row8, qt, b, cs)) return rc;
+            if (const int rc = dense8_scan_any<true>(row8, qt, big, b, cs)) return rc;
             hipLaunchKernelGGL((kth_threshold_f32_kernel<Dense8ThrPost>), dim3(nq), dim3(1024), 0, cs, a.sample_out, ns, kk, thr,
                                Dense8ThrPost{s.par8.as<float2>(), qn2});
             b.unit_step = 1;        // full pass
             b.n_sel = n_units;
             b.nrb = nrb;
             if (prof) SQ_HIP(hipEventRecord(s.ev[1], cs));
-            if (const int rc = dense8_scan_any<false>(row8, qt, b, cs)) return rc;
+            if (const int rc = dense8_scan_any<false>(row8, qt, big, b, cs)) return rc;
             if (prof) SQ_HIP(hipEventRecord(s.ev[2], cs));
             if (cosine) {
                 hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, cs, h->db, h->ld, d,
@@ -553,7 +572,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             // everything the captured launches were given by value: shapes, the slot's and the handle's buffers
             u64 key = 0xcbf29ce484222325ull;
             auto mix = [&key](u64 v) { key = (key ^ v) * 0x100000001b3ull; };
-            for (u64 v : {(u64)nq, (u64)k, (u64)row8, (u64)qt, (u64)nqt, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
+            for (u64 v : {(u64)nq, (u64)k, (u64)row8, (u64)qt, (u64)nqt, (u64)big, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
                           (u64)h->opt.dense_debug, (u64)h->id_base, (u64)(uintptr_t)st, (u64)(uintptr_t)h->db, (u64)(uintptr_t)centerp,
                           (u64)(uintptr_t)h->scan8.p, (u64)(uintptr_t)h->nrow8.p, (u64)(uintptr_t)s.q8.p, (u64)(uintptr_t)s.par8.p,
                           (u64)(uintptr_t)s.sample.p, (u64)(uintptr_t)s.keys.p, (u64)(uintptr_t)s.wave_out.p, (u64)(uintptr_t)s.wave_cnt.p,
@@ -1165,7 +1184,7 @@ static int dense8_build(DenseHandle* h) {
     const long long n = h->n;
     const int d = h->d;
     const int row8 = i8_row_bytes(d);
-    const long long n_pad64 = (n + 63) / 64 * 64;
+    const long long n_pad64 = (n + 63) / 64 * 64, n_alloc = (n + 127) / 128 * 128;
     const float* centerp = (!cosine && h->center.p) ? h->center.as<float>() : nullptr;
     DevBuf tmp;   // [sum f64 x2 | max bits u32 x2 | flagged u32]
     DevBuf r2row;
@@ -1178,8 +1197,8 @@ static int dense8_build(DenseHandle* h) {
         }
         return rc;
     };
-    if (tmp.reserve(64) != SQ_OK || r2row.reserve((size_t)n_pad64 * 4) != SQ_OK || h->scan8.reserve((size_t)n_pad64 * row8) != SQ_OK ||
-        h->nrow8.reserve((size_t)(n_pad64 + 64) * 4) != SQ_OK) {   // (+ 64: a 32-row unit's DMA fetches 64 row terms)
+    if (tmp.reserve(64) != SQ_OK || r2row.reserve((size_t)n_alloc * 4) != SQ_OK || h->scan8.reserve((size_t)n_alloc * row8) != SQ_OK ||
+        h->nrow8.reserve((size_t)(n_alloc + 64) * 4) != SQ_OK) {   // (+ 64: a 32-row unit's DMA fetches 64 row terms)
         (void)hipGetLastError();
         return quit(SQ_OK);
     }
@@ -1241,16 +1260,16 @@ static int dense8_build(DenseHandle* h) {
     if (best_c < 0) return quit(SQ_OK);   // every clamp leaves too many rows beyond every bound (heavy tails): the bf16 filter's relative bound suits such data
     const double dx = (double)ca.dx[best_c];
     {
-        const dim3 grid((unsigned)((n_pad64 + 3) / 4)), blk(256);
+        const dim3 grid((unsigned)((n_alloc + 3) / 4)), blk(256);
         signed char* o8 = h->scan8.as<signed char>();
         float* nr8 = h->nrow8.as<float>();
         float* r2p = r2row.as<float>();
         switch (row8) {
-            case 128: hipLaunchKernelGGL(dense8_build_kernel<2>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
-            case 256: hipLaunchKernelGGL(dense8_build_kernel<4>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
-            default: hipLaunchKernelGGL(dense8_build_kernel<8>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
+            case 128: hipLaunchKernelGGL(dense8_build_kernel<2>, grid, blk, 0, 0, h->db, n, h->ld, d, n_alloc, centerp, nx64, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
+            case 256: hipLaunchKernelGGL(dense8_build_kernel<4>, grid, blk, 0, 0, h->db, n, h->ld, d, n_alloc, centerp, nx64, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
+            default: hipLaunchKernelGGL(dense8_build_kernel<8>, grid, blk, 0, 0, h->db, n, h->ld, d, n_alloc, centerp, nx64, ca.inv_dx[best_c], ca.dx[best_c], o8, nr8, r2p, 0ll); break;
         }
-        SQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(nr8 + n_pad64), 0x7f800000, 64));   // (+inf behind the last unit)
+        SQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(nr8 + n_alloc), 0x7f800000, 64));   // (+inf behind the last unit)
     }
     double* sum_r2 = tmp.as<double>() + 1;
     u32* maxb = reinterpret_cast<u32*>(tmp.as<double>() + 2);
@@ -1281,6 +1300,7 @@ static int dense8_build(DenseHandle* h) {
         fprintf(stderr, "[smqtk_hip] int8 filter: clamp %.2f rms, step %.5g, R %.5g (%.2f x the rounding residual), X %.5g, %u always-candidate rows of %lld\n",
                 kClip[best_c], dx, h->rmax8, kCut[best_m], h->xmax8, nflag, n);
     h->n_pad64 = n_pad64;
+    h->n_alloc8 = n_alloc;
     h->row8 = row8;
     h->dxf8 = ca.dx[best_c];
     h->inv_dxf8 = ca.inv_dx[best_c];
@@ -1330,20 +1350,20 @@ static int dense8_append(DenseHandle* h, long long n_old) {
     const double* nx64 = cosine ? h->cos_nx.as<double>() : nullptr;
     const float* centerp = (!cosine && h->center.p) ? h->center.as<float>() : nullptr;
     const int row8 = h->row8, d = h->d;
-    const long long n_pad64 = (n + 63) / 64 * 64;
+    const long long n_pad64 = (n + 63) / 64 * 64, n_alloc = (n + 127) / 128 * 128;
     auto drop = [&]() {
         h->use8 = false;
         h->scan8.release();
         h->nrow8.release();
         return SQ_OK;
     };
-    if (grow_keep(h->scan8, (size_t)h->n_pad64 * row8, (size_t)n_pad64 * row8) != SQ_OK ||
-        grow_keep(h->nrow8, (size_t)(h->n_pad64 + 64) * 4, (size_t)(n_pad64 + 64) * 4) != SQ_OK) {
+    if (grow_keep(h->scan8, (size_t)h->n_alloc8 * row8, (size_t)n_alloc * row8) != SQ_OK ||
+        grow_keep(h->nrow8, (size_t)(h->n_alloc8 + 64) * 4, (size_t)(n_alloc + 64) * 4) != SQ_OK) {
         (void)hipGetLastError();
         return drop();
     }
     DevBuf tmp, r2row;
-    if (tmp.reserve(64) != SQ_OK || r2row.reserve((size_t)n_pad64 * 4) != SQ_OK) {
+    if (tmp.reserve(64) != SQ_OK || r2row.reserve((size_t)n_alloc * 4) != SQ_OK) {
         tmp.release();
         r2row.release();
         (void)hipGetLastError();
@@ -1354,18 +1374,18 @@ static int dense8_append(DenseHandle* h, long long n_old) {
         r2row.release();
         return rc;
     };
-    const long long row_base = n_old / 64 * 64;   // the unit the old rows ended in is redone with the new ones
+    const long long row_base = n_old / 128 * 128;   // the unit the old rows ended in is redone with the new ones
     {
-        const dim3 grid((unsigned)((n_pad64 - row_base + 3) / 4)), blk(256);
+        const dim3 grid((unsigned)((n_alloc - row_base + 3) / 4)), blk(256);
         signed char* o8 = h->scan8.as<signed char>();
         float* nr8 = h->nrow8.as<float>();
         float* r2p = r2row.as<float>();
         switch (row8) {
-            case 128: hipLaunchKernelGGL(dense8_build_kernel<2>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, h->inv_dxf8, h->dxf8, o8, nr8, r2p, row_base); break;
-            case 256: hipLaunchKernelGGL(dense8_build_kernel<4>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, h->inv_dxf8, h->dxf8, o8, nr8, r2p, row_base); break;
-            default: hipLaunchKernelGGL(dense8_build_kernel<8>, grid, blk, 0, 0, h->db, n, h->ld, d, n_pad64, centerp, nx64, h->inv_dxf8, h->dxf8, o8, nr8, r2p, row_base); break;
+            case 128: hipLaunchKernelGGL(dense8_build_kernel<2>, grid, blk, 0, 0, h->db, n, h->ld, d, n_alloc, centerp, nx64, h->inv_dxf8, h->dxf8, o8, nr8, r2p, row_base); break;
+            case 256: hipLaunchKernelGGL(dense8_build_kernel<4>, grid, blk, 0, 0, h->db, n, h->ld, d, n_alloc, centerp, nx64, h->inv_dxf8, h->dxf8, o8, nr8, r2p, row_base); break;
+            default: hipLaunchKernelGGL(dense8_build_kernel<8>, grid, blk, 0, 0, h->db, n, h->ld, d, n_alloc, centerp, nx64, h->inv_dxf8, h->dxf8, o8, nr8, r2p, row_base); break;
         }
-        SQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(nr8 + n_pad64), 0x7f800000, 64));
+        SQ_HIP(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(nr8 + n_alloc), 0x7f800000, 64));
     }
     SQ_HIP(hipMemset(tmp.p, 0, 64));
     double* sum_r2 = tmp.as<double>() + 1;
@@ -1388,6 +1408,7 @@ static int dense8_append(DenseHandle* h, long long n_old) {
     // (the redone unit's old always-candidates are counted again: an over-estimate on the safe side)
     h->flagged8 += host.flagged;
     h->n_pad64 = n_pad64;
+    h->n_alloc8 = n_alloc;
     const double budget = std::max(256.0, 2e-5 * (double)n);
     if ((double)h->flagged8 > 4.0 * budget) return done(dense8_build(h));   // the new rows do not look like the old ones: choose again
     return done(SQ_OK);
