@@ -323,8 +323,20 @@ static int dense8_scan_mt_launch_t(const Dense8ScanArgs& a, hipStream_t st) {
 }
 // one query tile per wave: dense8_scan_kernel for the row width; 2 or 4 tiles (128-byte rows): dense8_scan_mt_kernel
 template <bool SAMPLE>
-static int dense8_scan_any(int row_bytes, int qt, bool big, const Dense8ScanArgs& a, hipStream_t st) {
-    if (big) return dense8_scan_big_launch<SAMPLE>(a, st);
+static int dense8_scan_small_launch(const Dense8ScanArgs& a, hipStream_t st) {
+    using G = I8GeomSmall;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_small_kernel<SAMPLE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dense8_scan_small_kernel<SAMPLE>), dim3((unsigned)a.nrb), dim3(G::WAVES * 64), (size_t)G::WAVES * G::NSTAGE * G::SLOT_BYTES, st, a);
+    return SQ_OK;
+}
+template <bool SAMPLE>
+static int dense8_scan_any(int row_bytes, int qt, int geom, const Dense8ScanArgs& a, hipStream_t st) {
+    if (geom == 128) return dense8_scan_big_launch<SAMPLE>(a, st);
+    if (geom == 32) return dense8_scan_small_launch<SAMPLE>(a, st);
     if (qt == 1) return dense8_scan_launch<SAMPLE>(row_bytes, a, st);
     if (row_bytes == 128 && qt == 2) return dense8_scan_mt_launch_t<2, SAMPLE>(a, st);
     if (row_bytes == 128 && qt == 4) return dense8_scan_mt_launch_t<4, SAMPLE>(a, st);
@@ -457,9 +469,9 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // Alone that pass is 4 % faster than the 64-row units on eight waves (0.197 against 0.204 ms at 10 M rows); inside the
         // pipeline, on 192 CUs beside the neighbours' kernels, it is 8 % slower (0.244 against 0.226 ms per step): not the default.
         const int row8 = h->row8;
-        const bool big = row8 == 128 && qt == 1 && h->opt.dense_int8_unit == 128;
-        const int unit_rows = big ? I8GeomBig::UNIT_ROWS : i8_unit_rows(row8), spu = 2 * (unit_rows / 32);   // samples per unit
-        const int waves8 = big ? I8GeomBig::WAVES : i8_waves(row8);
+        const int big = (row8 == 128 && qt == 1 && (h->opt.dense_int8_unit == 128 || h->opt.dense_int8_unit == 32)) ? h->opt.dense_int8_unit : 0;
+        const int unit_rows = big == 128 ? I8GeomBig::UNIT_ROWS : big == 32 ? I8GeomSmall::UNIT_ROWS : i8_unit_rows(row8), spu = 2 * (unit_rows / 32);   // samples per unit
+        const int waves8 = big == 128 ? I8GeomBig::WAVES : big == 32 ? I8GeomSmall::WAVES : i8_waves(row8);
         const long long n_units = (n + unit_rows - 1) / unit_rows;
         long long stride = h->opt.sample_stride;
         if (stride <= 0) {
