@@ -73,7 +73,6 @@ struct Options {
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
     int dense_fused_prep = 1;    // 1 = L2 searches of one query tile build the query planes inside the scan kernels (no prep launch); 0 = dense_prep_queries_kernel
     int dense_int8_batch = 64;   // largest batch the int8 filter takes (33 .. 64: two query tiles per wave, 128-byte rows; up to 256: four tiles, which only ties with the bf16 kernels; 32 = one tile only)
-    int dense_int8_unit = 64;    // rows per ring unit of the one-tile int8 pass over 128-byte rows: 64 (8 KiB, eight waves) or 128 (16 KiB, four waves: 4 % faster alone, 8 % slower inside the pipeline)
     int dense_graph = 1;         // pipelined int8 calls: the call's kernels as one captured graph launch (0 = eager launches)
     int dense_int8 = -1;         // int8 first-stage filter (L2, d <= 128, one query tile): -1 = automatic, 0 = never (bf16 filter), 1 = whenever the copy exists
     int dense_mid_tier = 1;      // 1 = queries the bf16 filter could not certify get a second, tighter filter pass (three bf16 planes of the rows built on the fly) before the exact all-rows path; 0 = straight to the exact path

@@ -103,7 +103,6 @@ int Options::*option_member(const char* name) {
         {"dense_int8", &Options::dense_int8},
         {"dense_graph", &Options::dense_graph},
         {"dense_int8_batch", &Options::dense_int8_batch},
-        {"dense_int8_unit", &Options::dense_int8_unit},
         {"dense_fused_prep", &Options::dense_fused_prep},
         {"hamming_async_depth", &Options::hamming_async_depth},
         {"hamming_async_wait", &Options::hamming_async_wait},

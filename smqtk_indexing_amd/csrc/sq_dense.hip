@@ -323,35 +323,11 @@ static int dense8_scan_mt_launch_t(const Dense8ScanArgs& a, hipStream_t st) {
 }
 // one query tile per wave: dense8_scan_kernel for the row width; 2 or 4 tiles (128-byte rows): dense8_scan_mt_kernel
 template <bool SAMPLE>
-static int dense8_scan_small_launch(const Dense8ScanArgs& a, hipStream_t st) {
-    using G = I8GeomSmall;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_small_kernel<SAMPLE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((dense8_scan_small_kernel<SAMPLE>), dim3((unsigned)a.nrb), dim3(G::WAVES * 64), (size_t)G::WAVES * G::NSTAGE * G::SLOT_BYTES, st, a);
-    return SQ_OK;
-}
-template <bool SAMPLE>
-static int dense8_scan_any(int row_bytes, int qt, int geom, const Dense8ScanArgs& a, hipStream_t st) {
-    if (geom == 128) return dense8_scan_big_launch<SAMPLE>(a, st);
-    if (geom == 32) return dense8_scan_small_launch<SAMPLE>(a, st);
+static int dense8_scan_any(int row_bytes, int qt, const Dense8ScanArgs& a, hipStream_t st) {
     if (qt == 1) return dense8_scan_launch<SAMPLE>(row_bytes, a, st);
     if (row_bytes == 128 && qt == 2) return dense8_scan_mt_launch_t<2, SAMPLE>(a, st);
     if (row_bytes == 128 && qt == 4) return dense8_scan_mt_launch_t<4, SAMPLE>(a, st);
     return fail(SQ_ERR_INVALID, "int8 scan: %d query tiles per wave over %d-byte rows", qt, row_bytes);
-}
-template <bool SAMPLE>
-static int dense8_scan_big_launch(const Dense8ScanArgs& a, hipStream_t st) {
-    using G = I8GeomBig;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_big_kernel<SAMPLE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((dense8_scan_big_kernel<SAMPLE>), dim3((unsigned)a.nrb), dim3(G::WAVES * 64), (size_t)G::WAVES * G::NSTAGE * G::SLOT_BYTES, st, a);
-    return SQ_OK;
 }
 static int i8_waves(int row_bytes) { return row_bytes == 512 ? I8Geom<16>::WAVES : I8Geom<4>::WAVES; }
 
@@ -465,13 +441,10 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                (nq <= TILE_ROWS || (h->row8 == 128 && (qt == 2 || qt == 4) && nq <= h->opt.dense_int8_batch))) {
         // ---- the int8 first-stage filter (sq_dense_i8.hpp): half the bytes per row, measured error bound
         c.int8 = true;
-        // 128-byte rows, one query tile, "dense_int8_unit" = 128: ring units of 128 rows on four waves (dense8_scan_big_kernel).
-        // Alone that pass is 4 % faster than the 64-row units on eight waves (0.197 against 0.204 ms at 10 M rows); inside the
-        // pipeline, on 192 CUs beside the neighbours' kernels, it is 8 % slower (0.244 against 0.226 ms per step): not the default.
-        const int row8 = h->row8;
-        const int big = (row8 == 128 && qt == 1 && (h->opt.dense_int8_unit == 128 || h->opt.dense_int8_unit == 32)) ? h->opt.dense_int8_unit : 0;
-        const int unit_rows = big == 128 ? I8GeomBig::UNIT_ROWS : big == 32 ? I8GeomSmall::UNIT_ROWS : i8_unit_rows(row8), spu = 2 * (unit_rows / 32);   // samples per unit
-        const int waves8 = big == 128 ? I8GeomBig::WAVES : big == 32 ? I8GeomSmall::WAVES : i8_waves(row8);
+        // (128-byte rows stream in ring units of 64 rows on eight waves.  Two other geometries were built and measured --
+        // commit 5048766: 128-row units on four waves 0.197 against 0.204 ms per pass alone but 0.244-0.251 against 0.223-0.226 ms
+        // per pipelined step; 32-row units on sixteen waves 0.236 -- and removed again.)
+        const int row8 = h->row8, unit_rows = i8_unit_rows(row8), spu = 2 * (unit_rows / 32), waves8 = i8_waves(row8);   // samples per unit
         const long long n_units = (n + unit_rows - 1) / unit_rows;
         long long stride = h->opt.sample_stride;
         if (stride <= 0) {
@@ -549,14 +522,14 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             b.unit_step = stride;   // sample pass (on the CUs the pipelined full pass leaves free)
             b.n_sel = ns_units;
             b.nrb = nrb_sample;
-            if (const int rc = dense8_scan_any<true>(row8, qt, big, b, cs)) return rc;
+            if (const int rc = dense8_scan_any<true>(row8, qt, b, cs)) return rc;
             hipLaunchKernelGGL((kth_threshold_f32_kernel<Dense8ThrPost>), dim3(nq), dim3(1024), 0, cs, a.sample_out, ns, kk, thr,
                                Dense8ThrPost{s.par8.as<float2>(), qn2});
             b.unit_step = 1;        // full pass
             b.n_sel = n_units;
             b.nrb = nrb;
             if (prof) SQ_HIP(hipEventRecord(s.ev[1], cs));
-            if (const int rc = dense8_scan_any<false>(row8, qt, big, b, cs)) return rc;
+            if (const int rc = dense8_scan_any<false>(row8, qt, b, cs)) return rc;
             if (prof) SQ_HIP(hipEventRecord(s.ev[2], cs));
             if (cosine) {
                 hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, cs, h->db, h->ld, d,
@@ -584,7 +557,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             // everything the captured launches were given by value: shapes, the slot's and the handle's buffers
             u64 key = 0xcbf29ce484222325ull;
             auto mix = [&key](u64 v) { key = (key ^ v) * 0x100000001b3ull; };
-            for (u64 v : {(u64)nq, (u64)k, (u64)row8, (u64)qt, (u64)nqt, (u64)big, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
+            for (u64 v : {(u64)nq, (u64)k, (u64)row8, (u64)qt, (u64)nqt, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
                           (u64)h->opt.dense_debug, (u64)h->id_base, (u64)(uintptr_t)st, (u64)(uintptr_t)h->db, (u64)(uintptr_t)centerp,
                           (u64)(uintptr_t)h->scan8.p, (u64)(uintptr_t)h->nrow8.p, (u64)(uintptr_t)s.q8.p, (u64)(uintptr_t)s.par8.p,
                           (u64)(uintptr_t)s.sample.p, (u64)(uintptr_t)s.keys.p, (u64)(uintptr_t)s.wave_out.p, (u64)(uintptr_t)s.wave_cnt.p,

@@ -581,280 +581,6 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
     }
 }
 
-// ---------------------------------------------------------------- 128-byte rows, 16 KiB ring units
-// The same pass over 128-byte rows with the geometry of the 512-byte rows: ring units of 128 rows (16 KiB + 512 B of row
-// terms: 18 DMA instructions per 16 KiB instead of 9 per 8 KiB), four waves per workgroup, the four tiles of a unit read
-// and scored one after the other.  Wider rows stream at 0.82 (256 B) and 0.86-0.87 (512 B) of the HBM peak where the
-// 64-row units reach 0.80: what is left at 128-byte rows is per-unit cost, not arithmetic (tools/int8_ablation.py).
-// Measured: alone 0.197 against 0.204 ms per pass at 10 M rows (0.84 of the peak) -- but 0.244 against 0.226 ms per
-// PIPELINED step, where the pass shares the device with its neighbours' kernels and one wave per SIMD has nothing to
-// hide a stall behind.  Kept as option "dense_int8_unit" = 128; the default stays the 64-row units.
-struct I8GeomBig {
-    static constexpr int ROW_BYTES = 128;
-    static constexpr int UNIT_ROWS = 128;
-    static constexpr int TILES = 4;
-    static constexpr int UNIT_BYTES = UNIT_ROWS * ROW_BYTES;   // 16 KiB
-    static constexpr int SLOT_BYTES = UNIT_BYTES + 512;        // + 128 row terms
-    static constexpr int WAVES = 4;
-    static constexpr int NSTAGE = 2;
-    static constexpr int PIECES = UNIT_BYTES / 1024;            // 16 (+ 2 for the row terms)
-    static constexpr int SAMPLES_PER_UNIT = 2 * TILES;
-};
-
-template <bool SAMPLE>
-__global__ __launch_bounds__(I8GeomBig::WAVES * 64, 1) void dense8_scan_big_kernel(Dense8ScanArgs a) {
-    using G = I8GeomBig;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r31 = lane & 31, h = lane >> 5;
-    const u32 lds_base = (u32)(uintptr_t)smem;
-    const u32 ring_base = lds_base + (u32)wave * (G::NSTAGE * G::SLOT_BYTES);
-    const unsigned char* ring_ptr = smem + wave * (G::NSTAGE * G::SLOT_BYTES);
-    const long long wave_id = (long long)blockIdx.x * G::WAVES + wave;
-    const long long nwaves = (long long)a.nrb * G::WAVES;
-    uint2* wout = a.wave_out + wave_id * a.wave_cap;
-
-    i32x4 bq[4], bl[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        bq[s] = *reinterpret_cast<const i32x4*>(a.qs8 + r31 * G::ROW_BYTES + (2 * s + h) * 16);
-        bl[s] = *reinterpret_cast<const i32x4*>(a.qs8 + (a.plane_rows + r31) * G::ROW_BYTES + (2 * s + h) * 16);
-    }
-    float unit_lo = a.par[r31].x * 0.00390625f;
-    float thr_l = SAMPLE ? 0.f : a.thr[r31];
-    asm volatile("" : "+v"(unit_lo), "+v"(thr_l));
-#pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(bq[s]), "+v"(bl[s]));
-
-    const long long my_units = wave_id < a.n_sel ? (a.n_sel - wave_id + nwaves - 1) / nwaves : 0;
-    u32 voff[G::PIECES];
-#pragma unroll
-    for (int j = 0; j < G::PIECES; ++j) {
-        const int r = 8 * j + (lane >> 3);
-        voff[j] = (u32)(r * G::ROW_BYTES + i8_swz<4>(lane & 7, r) * 16);
-    }
-    const u32 voff_n = (u32)lane * 4u;
-    long long issued = 0;
-    auto issue_next = [&]() __attribute__((always_inline)) {
-        if (issued >= my_units) return;
-        const long long unit_idx = (wave_id + issued * nwaves) * a.unit_step;
-        const long long row0 = unit_idx * G::UNIT_ROWS;
-        const u32 dst = ring_base + (u32)(issued % G::NSTAGE) * G::SLOT_BYTES;
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan8) + row0 * G::ROW_BYTES;
-#pragma unroll
-        for (int j = 0; j < G::PIECES; ++j) {
-            if (a.nt && row0 >= a.nt_from_row)
-                glds16<true>(base, voff[j], dst + (u32)j * 1024);
-            else
-                glds16<false>(base, voff[j], dst + (u32)j * 1024);
-        }
-        glds4(a.nrow + row0, voff_n, dst + G::UNIT_BYTES);
-        glds4(a.nrow + row0 + 64, voff_n, dst + G::UNIT_BYTES + 256);
-        ++issued;
-    };
-    for (int p = 0; p < G::NSTAGE; ++p) issue_next();
-
-    u32 wcount = 0;
-    for (long long it = 0; it < my_units; ++it) {
-        const long long unit_idx = (wave_id + it * nwaves) * a.unit_step;
-        const long long row0 = unit_idx * G::UNIT_ROWS;
-        wait_units_in_flight<G::NSTAGE, G::PIECES + 2>((int)(issued - it - 1));
-        const unsigned char* sl = ring_ptr + (it % G::NSTAGE) * G::SLOT_BYTES;
-#pragma unroll
-        for (int t = 0; t < G::TILES; ++t) {
-            const int r = 32 * t + r31;
-            i32x4 av[4];
-            f32x4 nr[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) av[s] = *reinterpret_cast<const i32x4*>(sl + r * G::ROW_BYTES + i8_swz<4>(2 * s + h, r) * 16);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) nr[c] = *reinterpret_cast<const f32x4*>(sl + G::UNIT_BYTES + (32 * t + 8 * c + 4 * h) * 4);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (t == G::TILES - 1) issue_next();   // the last tile is in registers: the slot is free
-            i32x16 acc, acl;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = acl[i] = 0;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[s], bq[s], acc, 0, 0, 0);
-                acl = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[s], bl[s], acl, 0, 0, 0);
-            }
-            if (a.debug & 1024) {   // ablation: the stream and the MFMAs alone
-                if (acc[0] == 0x7fffffff && acl[5] == 0x7ffffffe) wcount += 1;
-                continue;
-            }
-            float sc[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float nv = nr[i >> 2][i & 3];
-                if constexpr (SAMPLE) nv = nv == -__builtin_inff() ? __builtin_inff() : nv;
-                sc[i] = __fmaf_rn((float)((acc[i] << 8) + acl[i]), unit_lo, nv);
-            }
-            float m = sc[0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) m = fminf(m, sc[i]);
-            if constexpr (SAMPLE) {
-                const long long sel = wave_id + it * nwaves;
-                a.sample_out[(long long)r31 * a.ns + sel * G::SAMPLES_PER_UNIT + t * 2 + h] = m;
-            } else {
-                const u64 hit = __ballot(m <= thr_l);
-                if (hit != 0) {
-                    u32 mask = 0;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) mask |= (sc[i] <= thr_l ? 1u : 0u) << i;
-                    const u64 bal = __ballot(mask != 0);
-                    if (mask) {
-                        const u32 pos = wcount + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                        if (pos < a.wave_cap) wout[pos] = make_uint2((u32)(row0 + 32 * t + 4 * h), (mask << 16) | (u32)r31);
-                    }
-                    wcount += (u32)__popcll(bal);
-                }
-            }
-        }
-    }
-    if constexpr (!SAMPLE) {
-        if (lane == 0) {
-            a.wave_cnt[2 * wave_id] = wcount;
-            a.wave_cnt[2 * wave_id + 1] = 0u;
-        }
-    }
-}
-
-// ---------------------------------------------------------------- 128-byte rows, 4 KiB ring units, sixteen waves
-// The experiment in the other direction: ring units of 32 rows (one tile), sixteen waves per workgroup (four per SIMD,
-// at most 128 registers each) -- more waves to hide a stall behind when the pass shares the device ("dense_int8_unit" = 32).
-struct I8GeomSmall {
-    static constexpr int ROW_BYTES = 128;
-    static constexpr int UNIT_ROWS = 32;
-    static constexpr int TILES = 1;
-    static constexpr int UNIT_BYTES = UNIT_ROWS * ROW_BYTES;   // 4 KiB
-    static constexpr int SLOT_BYTES = UNIT_BYTES + 256;        // + the row terms (64 fetched)
-    static constexpr int WAVES = 16;
-    static constexpr int NSTAGE = 2;
-    static constexpr int PIECES = UNIT_BYTES / 1024;            // 4 (+ 1 for the row terms)
-    static constexpr int SAMPLES_PER_UNIT = 2 * TILES;
-};
-
-template <bool SAMPLE>
-__global__ __launch_bounds__(I8GeomSmall::WAVES * 64, 1) void dense8_scan_small_kernel(Dense8ScanArgs a) {
-    using G = I8GeomSmall;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r31 = lane & 31, h = lane >> 5;
-    const u32 lds_base = (u32)(uintptr_t)smem;
-    const u32 ring_base = lds_base + (u32)wave * (G::NSTAGE * G::SLOT_BYTES);
-    const unsigned char* ring_ptr = smem + wave * (G::NSTAGE * G::SLOT_BYTES);
-    const long long wave_id = (long long)blockIdx.x * G::WAVES + wave;
-    const long long nwaves = (long long)a.nrb * G::WAVES;
-    uint2* wout = a.wave_out + wave_id * a.wave_cap;
-
-    i32x4 bq[4], bl[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        bq[s] = *reinterpret_cast<const i32x4*>(a.qs8 + r31 * G::ROW_BYTES + (2 * s + h) * 16);
-        bl[s] = *reinterpret_cast<const i32x4*>(a.qs8 + (a.plane_rows + r31) * G::ROW_BYTES + (2 * s + h) * 16);
-    }
-    float unit_lo = a.par[r31].x * 0.00390625f;
-    float thr_l = SAMPLE ? 0.f : a.thr[r31];
-    asm volatile("" : "+v"(unit_lo), "+v"(thr_l));
-#pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(bq[s]), "+v"(bl[s]));
-
-    const long long my_units = wave_id < a.n_sel ? (a.n_sel - wave_id + nwaves - 1) / nwaves : 0;
-    u32 voff[G::PIECES];
-#pragma unroll
-    for (int j = 0; j < G::PIECES; ++j) {
-        const int r = 8 * j + (lane >> 3);
-        voff[j] = (u32)(r * G::ROW_BYTES + i8_swz<4>(lane & 7, r) * 16);
-    }
-    const u32 voff_n = (u32)lane * 4u;
-    long long issued = 0;
-    auto issue_next = [&]() __attribute__((always_inline)) {
-        if (issued >= my_units) return;
-        const long long unit_idx = (wave_id + issued * nwaves) * a.unit_step;
-        const long long row0 = unit_idx * G::UNIT_ROWS;
-        const u32 dst = ring_base + (u32)(issued % G::NSTAGE) * G::SLOT_BYTES;
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan8) + row0 * G::ROW_BYTES;
-#pragma unroll
-        for (int j = 0; j < G::PIECES; ++j) {
-            if (a.nt && row0 >= a.nt_from_row)
-                glds16<true>(base, voff[j], dst + (u32)j * 1024);
-            else
-                glds16<false>(base, voff[j], dst + (u32)j * 1024);
-        }
-        glds4(a.nrow + row0, voff_n, dst + G::UNIT_BYTES);
-        ++issued;
-    };
-    for (int p = 0; p < G::NSTAGE; ++p) issue_next();
-
-    u32 wcount = 0;
-    for (long long it = 0; it < my_units; ++it) {
-        const long long unit_idx = (wave_id + it * nwaves) * a.unit_step;
-        const long long row0 = unit_idx * G::UNIT_ROWS;
-        wait_units_in_flight<G::NSTAGE, G::PIECES + 1>((int)(issued - it - 1));
-        const unsigned char* sl = ring_ptr + (it % G::NSTAGE) * G::SLOT_BYTES;
-#pragma unroll
-        for (int t = 0; t < G::TILES; ++t) {
-            const int r = 32 * t + r31;
-            i32x4 av[4];
-            f32x4 nr[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) av[s] = *reinterpret_cast<const i32x4*>(sl + r * G::ROW_BYTES + i8_swz<4>(2 * s + h, r) * 16);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) nr[c] = *reinterpret_cast<const f32x4*>(sl + G::UNIT_BYTES + (32 * t + 8 * c + 4 * h) * 4);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (t == G::TILES - 1) issue_next();   // the last tile is in registers: the slot is free
-            i32x16 acc, acl;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = acl[i] = 0;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[s], bq[s], acc, 0, 0, 0);
-                acl = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[s], bl[s], acl, 0, 0, 0);
-            }
-            if (a.debug & 1024) {   // ablation: the stream and the MFMAs alone
-                if (acc[0] == 0x7fffffff && acl[5] == 0x7ffffffe) wcount += 1;
-                continue;
-            }
-            float sc[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float nv = nr[i >> 2][i & 3];
-                if constexpr (SAMPLE) nv = nv == -__builtin_inff() ? __builtin_inff() : nv;
-                sc[i] = __fmaf_rn((float)((acc[i] << 8) + acl[i]), unit_lo, nv);
-            }
-            float m = sc[0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) m = fminf(m, sc[i]);
-            if constexpr (SAMPLE) {
-                const long long sel = wave_id + it * nwaves;
-                a.sample_out[(long long)r31 * a.ns + sel * G::SAMPLES_PER_UNIT + t * 2 + h] = m;
-            } else {
-                const u64 hit = __ballot(m <= thr_l);
-                if (hit != 0) {
-                    u32 mask = 0;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) mask |= (sc[i] <= thr_l ? 1u : 0u) << i;
-                    const u64 bal = __ballot(mask != 0);
-                    if (mask) {
-                        const u32 pos = wcount + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                        if (pos < a.wave_cap) wout[pos] = make_uint2((u32)(row0 + 32 * t + 4 * h), (mask << 16) | (u32)r31);
-                    }
-                    wcount += (u32)__popcll(bal);
-                }
-            }
-        }
-    }
-    if constexpr (!SAMPLE) {
-        if (lane == 0) {
-            a.wave_cnt[2 * wave_id] = wcount;
-            a.wave_cnt[2 * wave_id + 1] = 0u;
-        }
-    }
-}
-
 // ---------------------------------------------------------------- 33 .. 256 queries per call (128-byte rows)
 // QT query tiles per wave (2 for up to 64 queries, 4 beyond): the unit's A fragments are read once and meet QT sets of
 // query planes (32 QT registers per lane), so one pass over the int8 copy serves 32 QT queries -- half the bytes of the

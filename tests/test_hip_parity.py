@@ -27,7 +27,6 @@ def _reset_options():
     _lib.set_option("dense_int8", -1)
     _lib.set_option("dense_graph", 1)
     _lib.set_option("dense_int8_batch", 64)
-    _lib.set_option("dense_int8_unit", 64)
 
 
 # ------------------------------------------------------------------- Hamming
@@ -197,16 +196,6 @@ def test_dense_int8_filter_equals_bf16_filter_and_oracle(n, d, nq, k, family):
     assert idx.stats()["bytes_scanned"] == _bf16_bytes(n, d)
     np.testing.assert_array_equal(i8, i16)
     np.testing.assert_array_equal(d8.view(np.uint32), d16.view(np.uint32))
-    if d <= 128:
-        # the other geometries of the same pass over 128-byte rows: ring units of 128 rows on four waves, of 32 rows on
-        # sixteen (default: 64 rows, eight waves)
-        idx.set_option("dense_int8", 1)
-        for unit in (128, 32):
-            idx.set_option("dense_int8_unit", unit)
-            du, iu = idx.search(qs, k)
-            assert idx.stats()["bytes_scanned"] == _int8_bytes(n, d)
-            np.testing.assert_array_equal(iu, i8)
-            np.testing.assert_array_equal(du.view(np.uint32), d8.view(np.uint32))
     for qi in range(0, nq, max(1, nq // 6)):
         rd, ri = O.dense_topk(db, qs[qi], k)
         np.testing.assert_array_equal(i8[qi], ri)

@@ -17,12 +17,11 @@ idx = _lib.DenseIndex(db.data_ptr(), n=n, d=d, device_ptr=True, keepalive=db)
 st = torch.cuda.current_stream().cuda_stream
 od = torch.empty((nq, k), dtype=torch.float32, device=dev); oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
 _lib.set_option("profile", 1)
-for unit, dbg in ((64, 0), (128, 0), (64, 1024), (128, 1024), (64, 0), (128, 0)):
-    _lib.set_option("dense_int8_unit", unit)
+for dbg in (0, 1024, 0, 1024):
     _lib.set_option("dense_debug", dbg)
     ts = []
     for i in range(12):
         idx.search_device(q.data_ptr(), nq, k, od.data_ptr(), oi.data_ptr(), st)
         ts.append(idx.stats()["scan_ms"])
-    print(f"unit rows {unit} dense_debug={dbg}: scan {sum(ts[2:]) / len(ts[2:]):.4f} ms (min {min(ts[2:]):.4f})", flush=True)
+    print(f"dense_debug={dbg}: scan {sum(ts[2:]) / len(ts[2:]):.4f} ms (min {min(ts[2:]):.4f})", flush=True)
 _lib.set_option("dense_debug", 0)
