@@ -505,7 +505,9 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             if (sb >= 8 && sb < nrb_sample) nrb_sample = sb;
         }
         if (ns_units < (long long)nrb_sample * waves8) nrb_sample = (int)(((ns_units + waves8 - 1) / waves8 + 7) / 8 * 8);
-        const int wpb = 2;
+        int wpb = 2;   // survivor segments per re-rank workgroup (128 threads each)
+        if (!cosine && h->opt.dense_rerank_segments > 0 && waves8 % h->opt.dense_rerank_segments == 0 && h->opt.dense_rerank_segments <= 4)
+            wpb = h->opt.dense_rerank_segments;
         const size_t rr_lds = (qt == 1 && ldq <= 156) ? (size_t)32 * (ldq + 4) * 4 : 0;
         // The chain of six launches, eagerly or as a captured graph.  A launch costs ~2.8 us of host time
         // (tools/micro/launch_cost.hip: 19.3 us for a chain of seven, 5.6-6.3 us for one hipGraphLaunch of the same chain; in
@@ -557,7 +559,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             // everything the captured launches were given by value: shapes, the slot's and the handle's buffers
             u64 key = 0xcbf29ce484222325ull;
             auto mix = [&key](u64 v) { key = (key ^ v) * 0x100000001b3ull; };
-            for (u64 v : {(u64)nq, (u64)k, (u64)row8, (u64)qt, (u64)nqt, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
+            for (u64 v : {(u64)nq, (u64)k, (u64)row8, (u64)qt, (u64)nqt, (u64)wpb, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
                           (u64)h->opt.dense_debug, (u64)h->id_base, (u64)(uintptr_t)st, (u64)(uintptr_t)h->db, (u64)(uintptr_t)centerp,
                           (u64)(uintptr_t)h->scan8.p, (u64)(uintptr_t)h->nrow8.p, (u64)(uintptr_t)s.q8.p, (u64)(uintptr_t)s.par8.p,
                           (u64)(uintptr_t)s.sample.p, (u64)(uintptr_t)s.keys.p, (u64)(uintptr_t)s.wave_out.p, (u64)(uintptr_t)s.wave_cnt.p,
