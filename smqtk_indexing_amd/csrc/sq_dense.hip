@@ -1169,6 +1169,7 @@ static int dense8_build(DenseHandle* h) {
     const bool cosine = h->metric == SQ_METRIC_COSINE;
     const double* nx64 = cosine ? h->cos_nx.as<double>() : nullptr;   // cosine: the copy holds the unit-length rows
     const long long n = h->n;
+    h->n8_built = n;   // (an attempt counts whether or not the data is accepted: dense8_append tries again when the index has doubled)
     const int d = h->d;
     const int row8 = i8_row_bytes(d);
     const long long n_pad64 = (n + 63) / 64 * 64, n_alloc = (n + 127) / 128 * 128;
