@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 
 #include <cstdarg>
@@ -73,6 +74,7 @@ struct Options {
     int hamming_no_permute = 0;  // 1 = keep the Hamming code array in caller order on the device (measurement)
     int dense_fused_prep = 1;    // 1 = L2 searches of one query tile build the query planes inside the scan kernels (no prep launch); 0 = dense_prep_queries_kernel
     int dense_int8_batch = 64;   // largest batch the int8 filter takes (33 .. 64: two query tiles per wave, 128-byte rows; up to 256: four tiles, which only ties with the bf16 kernels; 32 = one tile only)
+    int dense_fused = 1;         // int8 calls of one query tile as three launches (head: query prep + sample pass + threshold by the last workgroup; full pass with the re-rank as its tail; select) instead of six; 0 = the six-launch chain
     int dense_graph = 1;         // pipelined int8 calls: the call's kernels as one captured graph launch (0 = eager launches)
     int dense_int8 = -1;         // int8 first-stage filter (L2, d <= 128, one query tile): -1 = automatic, 0 = never (bf16 filter), 1 = whenever the copy exists
     int dense_mid_tier = 1;      // 1 = queries the bf16 filter could not certify get a second, tighter filter pass (three bf16 planes of the rows built on the fly) before the exact all-rows path; 0 = straight to the exact path
@@ -250,6 +252,19 @@ inline int cu_count(int device) {
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return 256;
     if (device >= 0 && device < 64) cached[device] = p.multiProcessorCount;
     return p.multiProcessorCount;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's copy of a kernel: once per (kernel,
+// device), the mask being the caller's static state for that kernel (a second GPU used from the same process otherwise
+// never gets the attribute and its launches with more than 64 KiB of LDS fail).
+inline int ensure_dyn_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done_devices) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (bit && (done_devices.load(std::memory_order_relaxed) & bit)) return SQ_OK;
+    SQ_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (bit) done_devices.fetch_or(bit, std::memory_order_relaxed);
+    return SQ_OK;
 }
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -102,6 +102,7 @@ int Options::*option_member(const char* name) {
         {"dense_mid_tier", &Options::dense_mid_tier},
         {"dense_int8", &Options::dense_int8},
         {"dense_graph", &Options::dense_graph},
+        {"dense_fused", &Options::dense_fused},
         {"dense_int8_batch", &Options::dense_int8_batch},
         {"dense_fused_prep", &Options::dense_fused_prep},
         {"hamming_async_depth", &Options::hamming_async_depth},

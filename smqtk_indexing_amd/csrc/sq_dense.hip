@@ -152,7 +152,7 @@ static constexpr int kSelectLdsKeys128 = 7168;
 template <class K, class Post>
 static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out,
                            const Post& post, hipStream_t st, DevBuf& sort_scratch, long long expect = 0) {
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_done{0};
     const int lds_max = sizeof(K) == 8 ? kSelectLdsKeys64 : kSelectLdsKeys128;
     // beyond the one-workgroup select: full sort (sq_select.hpp, "any-k sorted select"); the scratch belongs to the
     // call slot (asynchronous calls in flight, or two handles on two threads, must not share it)
@@ -164,11 +164,7 @@ static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long str
     }
     const size_t lds_full = (size_t)(lds_max + SELECT_SORT_MAX) * sizeof(K);
     const size_t lds = (size_t)(lds_keys + SELECT_SORT_MAX) * sizeof(K);
-    if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&select_topk_kernel<K, Post>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
-        attr_set = true;
-    }
+    SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&select_topk_kernel<K, Post>), (int)lds_full, attr_done));
     hipLaunchKernelGGL((select_topk_kernel<K, Post>), dim3(nq), dim3(1024), lds, st, keys, cnt, cap, stride, k, lds_keys,
                        out, post);
     return SQ_OK;
@@ -176,12 +172,8 @@ static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long str
 
 template <int WAVES, int NSTAGE, int KU, int QT, int QP, bool AB, bool SAMPLE, bool NT = false>
 static int scan_launch_t(const DenseScanArgs& a, size_t lds, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, AB, SAMPLE, NT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, AB, SAMPLE, NT>), 160 * 1024, attr_done));
     hipLaunchKernelGGL((dense_scan_kernel<WAVES, NSTAGE, KU, QT, QP, AB, SAMPLE, NT>), dim3((unsigned)(a.nrb * a.nqt)),
                        dim3(WAVES * 64), lds, st, a);
     return SQ_OK;
@@ -293,11 +285,8 @@ static hipError_t event_wait(hipEvent_t ev) {
 template <int KS, bool SAMPLE>
 static int dense8_scan_launch_t(const Dense8ScanArgs& a, hipStream_t st) {
     using G = I8Geom<KS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_kernel<KS, SAMPLE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense8_scan_kernel<KS, SAMPLE>), 160 * 1024, attr_done));
     hipLaunchKernelGGL((dense8_scan_kernel<KS, SAMPLE>), dim3((unsigned)a.nrb), dim3(G::WAVES * 64), (size_t)G::WAVES * G::NSTAGE * G::SLOT_BYTES, st, a);
     return SQ_OK;
 }
@@ -313,11 +302,8 @@ static int dense8_scan_launch(int row_bytes, const Dense8ScanArgs& a, hipStream_
 template <int QT, bool SAMPLE>
 static int dense8_scan_mt_launch_t(const Dense8ScanArgs& a, hipStream_t st) {
     using G = I8Geom<4>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense8_scan_mt_kernel<QT, SAMPLE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense8_scan_mt_kernel<QT, SAMPLE>), 160 * 1024, attr_done));
     hipLaunchKernelGGL((dense8_scan_mt_kernel<QT, SAMPLE>), dim3((unsigned)(a.nrb * a.nqt)), dim3(G::WAVES * 64), (size_t)G::WAVES * G::NSTAGE * G::SLOT_BYTES, st, a);
     return SQ_OK;
 }
@@ -328,6 +314,40 @@ static int dense8_scan_any(int row_bytes, int qt, const Dense8ScanArgs& a, hipSt
     if (row_bytes == 128 && qt == 2) return dense8_scan_mt_launch_t<2, SAMPLE>(a, st);
     if (row_bytes == 128 && qt == 4) return dense8_scan_mt_launch_t<4, SAMPLE>(a, st);
     return fail(SQ_ERR_INVALID, "int8 scan: %d query tiles per wave over %d-byte rows", qt, row_bytes);
+}
+// the three-launch form of a one-tile int8 call (sq_dense_i8.hpp): head and body per row width / metric
+template <int KS>
+static int dense8_head_launch_t(const Dense8HeadArgs& a, hipStream_t st) {
+    using G = I8Geom<KS>;
+    static std::atomic<unsigned long long> attr_done{0};
+    // (the kernel has static LDS of its own: the attribute is the ring, not the CU's 160 KiB)
+    SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense8_head_kernel<KS>), G::WAVES * G::NSTAGE * G::SLOT_BYTES, attr_done));
+    hipLaunchKernelGGL((dense8_head_kernel<KS>), dim3((unsigned)a.s.nrb), dim3(G::WAVES * 64), (size_t)G::WAVES * G::NSTAGE * G::SLOT_BYTES, st, a);
+    return SQ_OK;
+}
+static int dense8_head_launch(int row_bytes, const Dense8HeadArgs& a, hipStream_t st) {
+    switch (row_bytes) {
+        case 128: return dense8_head_launch_t<4>(a, st);
+        case 256: return dense8_head_launch_t<8>(a, st);
+        case 512: return dense8_head_launch_t<16>(a, st);
+    }
+    return fail(SQ_ERR_INVALID, "int8 head: unsupported row width %d", row_bytes);
+}
+template <int KS, bool COSINE>
+static int dense8_body_launch_t(const Dense8ScanArgs& a, const Dense8TailArgs& t, hipStream_t st) {
+    using G = I8Geom<KS>;
+    static std::atomic<unsigned long long> attr_done{0};
+    SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense8_body_kernel<KS, COSINE>), G::WAVES * G::NSTAGE * G::SLOT_BYTES, attr_done));
+    hipLaunchKernelGGL((dense8_body_kernel<KS, COSINE>), dim3((unsigned)a.nrb), dim3(G::WAVES * 64), (size_t)G::WAVES * G::NSTAGE * G::SLOT_BYTES, st, a, t);
+    return SQ_OK;
+}
+static int dense8_body_launch(int row_bytes, bool cosine, const Dense8ScanArgs& a, const Dense8TailArgs& t, hipStream_t st) {
+    switch (row_bytes) {
+        case 128: return cosine ? dense8_body_launch_t<4, true>(a, t, st) : dense8_body_launch_t<4, false>(a, t, st);
+        case 256: return cosine ? dense8_body_launch_t<8, true>(a, t, st) : dense8_body_launch_t<8, false>(a, t, st);
+        case 512: return cosine ? dense8_body_launch_t<16, true>(a, t, st) : dense8_body_launch_t<16, false>(a, t, st);
+    }
+    return fail(SQ_ERR_INVALID, "int8 body: unsupported row width %d", row_bytes);
 }
 static int i8_waves(int row_bytes) { return row_bytes == 512 ? I8Geom<16>::WAVES : I8Geom<4>::WAVES; }
 
@@ -384,7 +404,10 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
     SQ_TRY(s.q_scaled.reserve((size_t)nq_pad * d_pad * 4));
     SQ_TRY(s.out_keys.reserve((size_t)nq * k * key_bytes));
     SQ_TRY(s.status_host.reserve((size_t)(nq_pad + nq) * 4));
-    SQ_TRY(s.oflag.reserve(64));
+    if (!s.oflag.p) {   // [0] overflow flag of a call, [1] ticket counter of the fused head (self-cleaning: zero between calls)
+        SQ_TRY(s.oflag.reserve(64));
+        SQ_HIP(hipMemsetAsync(s.oflag.p, 0, 64, st));
+    }
     u32* cnt = s.cnt.as<u32>();
     float* thr = s.thr.as<float>();
     double* qn2 = s.qn2.as<double>();
@@ -460,7 +483,6 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         while (stride > 1 && (n_units / stride) * spu < 8ll * kk) stride >>= 1;
         const long long ns_units = (n_units + stride - 1) / stride;
         const long long ns = ns_units * spu;
-        SQ_TRY(s.sample.reserve((size_t)nq_pad * ns * 4));
         SQ_TRY(s.keys.reserve((size_t)nq * key_stride * key_bytes));
         SQ_TRY(s.q8.reserve((size_t)2 * nq_pad * row8));
         SQ_TRY(s.par8.reserve((size_t)nq_pad * 8));
@@ -505,6 +527,28 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             if (sb >= 8 && sb < nrb_sample) nrb_sample = sb;
         }
         if (ns_units < (long long)nrb_sample * waves8) nrb_sample = (int)(((ns_units + waves8 - 1) / waves8 + 7) / 8 * 8);
+        // Three launches instead of six (sq_dense_i8.hpp, "a call in three launches"): one query tile, and a head grid whose
+        // M = workgroups x waves x 2 lane minima per query number at least 4 k (the threshold is then within a few per cent of
+        // the k-th smallest sample) and at most 2048 (what the last workgroup's waves hold in registers).
+        bool fused = h->opt.dense_fused != 0 && qt == 1 && nqt == 1 && ns_units >= 2ll * kk;
+        if (fused) {
+            const int lanes_per_wg = waves8 * 2;
+            const int wg_min = ((4 * kk + lanes_per_wg - 1) / lanes_per_wg + 7) / 8 * 8, wg_max = 2048 / lanes_per_wg;
+            if (wg_min > wg_max || wg_min > cus)
+                fused = false;
+            else
+                nrb_sample = std::min(std::max(nrb_sample, wg_min), std::min(wg_max, (cus + 7) / 8 * 8));
+        }
+        // minima a head workgroup hands over per query: the k best of a call fall on a workgroup k / workgroups at a time
+        int keep8 = waves8 * 2;
+        if (fused) {
+            const double per_wg = (double)kk / nrb_sample;
+            if (per_wg <= 1.7 && keep8 > 4) keep8 = 4;
+            else if (per_wg <= 4.5 && keep8 > 8) keep8 = 8;
+        }
+        const long long lane_m = (long long)nrb_sample * keep8;
+        SQ_TRY(s.sample.reserve(fused ? (size_t)TILE_ROWS * lane_m * 4 : (size_t)nq_pad * ns * 4));
+        a.sample_out = s.sample.as<float>();
         int wpb = 2;   // survivor segments per re-rank workgroup (128 threads each)
         if (!cosine && h->opt.dense_rerank_segments > 0 && waves8 % h->opt.dense_rerank_segments == 0 && h->opt.dense_rerank_segments <= 4)
             wpb = h->opt.dense_rerank_segments;
@@ -518,8 +562,59 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // block (DenseCallPtrs).
         const DenseCallPtrs* ind = nullptr;
         auto chain = [&](hipStream_t cs) -> int {
-            hipLaunchKernelGGL(dense8_prep_queries_kernel, dim3(nq_pad), dim3(row8), 0, cs, q, nq, d, centerp, h->dx8, h->rmax8, h->xmax8,
-                               s.q8.as<signed char>(), s.par8.as<float2>(), qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq, ind, cosine ? 1 : 0, nq_pad);
+            if (fused) {
+                // head: query prep + sample pass (lane minima) + thresholds by the last workgroup
+                Dense8HeadArgs ha{};
+                ha.s = a;
+                ha.s.unit_step = stride;
+                ha.s.n_sel = ns_units;
+                ha.s.nrb = nrb_sample;
+                ha.q = q;
+                ha.nq = nq;
+                ha.d = d;
+                ha.center = centerp;
+                ha.dx = h->dx8;
+                ha.r_max = h->rmax8;
+                ha.x_max = h->xmax8;
+                ha.cosine = cosine ? 1 : 0;
+                ha.qn2 = qn2;
+                ha.cnt = cnt;
+                ha.oflag = oflag;
+                ha.q_al = s.q_al.as<float>();
+                ha.ldq = ldq;
+                ha.ind = ind;
+                ha.lane_min = s.sample.as<float>();
+                ha.keep = keep8;
+                ha.kk = kk;
+                if (const int rc = dense8_head_launch(row8, ha, cs)) return rc;
+                // body: the full pass; its workgroups re-rank their own survivors when the stream has drained
+                Dense8ScanArgs b = a;
+                b.unit_step = 1;
+                b.n_sel = n_units;
+                b.nrb = nrb;
+                Dense8TailArgs ta{h->db, h->ld, d, s.q_al.as<float>(), ldq, nq, s.keys.p, cnt, cap, oflag, cnx, cnq, h->opt.dense_debug};
+                if (prof) SQ_HIP(hipEventRecord(s.ev[1], cs));
+                if (const int rc = dense8_body_launch(row8, cosine, b, ta, cs)) return rc;
+                if (prof) {
+                    SQ_HIP(hipEventRecord(s.ev[2], cs));
+                    SQ_HIP(hipEventRecord(s.ev[4], cs));
+                }
+                if (cosine) {
+                    DenseFinalizeCos fin{cnt, cap, kk, h->id_base, thr, 0.0, 1, (double*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0};
+                    fin.lin = s.par8.as<float2>();
+                    fin.ind = ind;
+                    return select_launch_t<K128>(s.keys.as<K128>(), cnt, cap, key_stride, k, nq, s.out_keys.as<K128>(), fin, cs, s.sort_tmp, 8 * stride * kk);
+                }
+                DenseFinalizeL2 fin{cnt, cap, kk, h->id_base, thr, qn2, 0.0, 1, (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0};
+                fin.lin = s.par8.as<float2>();
+                fin.ind = ind;
+                return select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(), fin, cs, s.sort_tmp, 8 * stride * kk);
+            }
+            {
+                auto prep = row8 == 128 ? dense8_prep_queries_kernel<2> : (row8 == 256 ? dense8_prep_queries_kernel<4> : dense8_prep_queries_kernel<8>);
+                hipLaunchKernelGGL(prep, dim3(nq_pad / 4), dim3(64), 0, cs, q, nq, d, centerp, h->dx8, h->rmax8, h->xmax8,
+                                   s.q8.as<signed char>(), s.par8.as<float2>(), qn2, thr, cnt, oflag, s.q_al.as<float>(), ldq, ind, cosine ? 1 : 0, nq_pad);
+            }
             Dense8ScanArgs b = a;
             b.unit_step = stride;   // sample pass (on the CUs the pipelined full pass leaves free)
             b.n_sel = ns_units;
@@ -559,7 +654,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             // everything the captured launches were given by value: shapes, the slot's and the handle's buffers
             u64 key = 0xcbf29ce484222325ull;
             auto mix = [&key](u64 v) { key = (key ^ v) * 0x100000001b3ull; };
-            for (u64 v : {(u64)nq, (u64)k, (u64)row8, (u64)qt, (u64)nqt, (u64)wpb, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
+            for (u64 v : {(u64)(fused ? 1 : 0), (u64)lane_m, (u64)nq, (u64)k, (u64)row8, (u64)qt, (u64)nqt, (u64)wpb, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
                           (u64)h->opt.dense_debug, (u64)h->id_base, (u64)(uintptr_t)st, (u64)(uintptr_t)h->db, (u64)(uintptr_t)centerp,
                           (u64)(uintptr_t)h->scan8.p, (u64)(uintptr_t)h->nrow8.p, (u64)(uintptr_t)s.q8.p, (u64)(uintptr_t)s.par8.p,
                           (u64)(uintptr_t)s.sample.p, (u64)(uintptr_t)s.keys.p, (u64)(uintptr_t)s.wave_out.p, (u64)(uintptr_t)s.wave_cnt.p,
@@ -890,15 +985,9 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
         u32* m_cnt = reinterpret_cast<u32*>(m_thr + 32);
         u32* m_oflag = m_cnt + 32;
         int* m_map = reinterpret_cast<int*>(m_oflag + 16);
-        static bool attr8 = false, attr4 = false;
-        if (waves == 8 && !attr8) {
-            SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_mid_scan_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr8 = true;
-        }
-        if (waves == 4 && !attr4) {
-            SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_mid_scan_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr4 = true;
-        }
+        static std::atomic<unsigned long long> attr8{0}, attr4{0};
+        if (waves == 8) SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense_mid_scan_kernel<8>), 160 * 1024, attr8));
+        if (waves == 4) SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense_mid_scan_kernel<4>), 160 * 1024, attr4));
         // sample of true scores: every mid_stride-th row (about 64 k candidates per query pass the bound it gives)
         long long mid_stride = std::min<long long>(64, std::min<long long>((long long)cap / (8ll * kk), n / (8ll * kk)));
         if (mid_stride < 1) mid_stride = 1;
@@ -906,12 +995,8 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
         const size_t mid_sample_lds = (size_t)d * 33 * 4;
         SQ_TRY(h->mid_sample.reserve((size_t)MID_MAX_Q * mid_ns * 4));
         {
-            static bool attr_s = false;
-            if (!attr_s) {
-                SQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_mid_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           512 * 33 * 4));
-                attr_s = true;
-            }
+            static std::atomic<unsigned long long> attr_s{0};
+            SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense_mid_sample_kernel), 512 * 33 * 4, attr_s));
         }
         std::vector<int> left;
         for (size_t t0 = 0; t0 < todo.size(); t0 += MID_MAX_Q) {

@@ -516,6 +516,16 @@ struct SqLeafPair {
 static constexpr int RERANK_MAX_GROUP = 128;
 static constexpr int RERANK_STAGE_STRIDE = 68;  // floats per staged row piece: 64 + 4 (272 bytes)
 
+// The LDS a re-rank workgroup works in.  The stand-alone kernels hand in arrays of their own; the fused tail of the int8
+// full pass (sq_dense_i8.hpp: dense8_body_kernel) hands in pieces of the ring its waves have finished with.
+struct RerankLds {
+    float* qrows;   // 32 * (ldq + 4) floats when the one-tile group's queries are staged (ldq <= 156), else unused
+    u32* hist;      // [RERANK_MAX_GROUP] x 3
+    u32* base;
+    u32* fill;
+    float* stage;   // cosine, wide rows: one row stage of 32 * RERANK_STAGE_STRIDE floats per wave of the workgroup (or null)
+};
+
 template <class K, bool COSINE>
 __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long long ld, int d,
                                              const float* __restrict__ q_al, int ldq, int nq, int group_q,
@@ -523,14 +533,13 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
                                              u32 wave_cap, long long n_waves, int waves_per_block,
                                              K* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
                                              u32* __restrict__ overflow, const double* __restrict__ nx64,
-                                             const double* __restrict__ nq64, int debug) {
-    extern __shared__ __attribute__((aligned(16))) float s_qrows[];
-    __shared__ u32 s_hist[RERANK_MAX_GROUP], s_base[RERANK_MAX_GROUP], s_fill[RERANK_MAX_GROUP];
+                                             const double* __restrict__ nq64, int debug, long long w0, const RerankLds& L) {
+    float* s_qrows = L.qrows;
+    u32 *s_hist = L.hist, *s_base = L.base, *s_fill = L.fill;
     const int ldl = ldq + 4;  // LDS row stride: +16 bytes so that different query rows hit different banks
     // the 32 query vectors of a one-tile group sit in LDS while that costs little occupancy (d <= 156);
     // wider rows (66 KB at d = 512: two workgroups per CU) and larger groups read them through the cache
     const bool q_in_lds = group_q == 32 && ldq <= 156;
-    const long long w0 = (long long)blockIdx.x * waves_per_block;
     if (w0 >= n_waves) return;
     const u32 q0 = wave_cnt[2 * w0 + 1] * 32u;  // first query of the group (the same for all segments of the block)
     if (threadIdx.x < RERANK_MAX_GROUP) {
@@ -538,22 +547,35 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
         s_fill[threadIdx.x] = 0;
     }
     __syncthreads();
-    u32 total = 0;
-    for (int wi = 0; wi < waves_per_block; ++wi) {
-        const long long w = w0 + wi;
-        if (w >= n_waves) break;
-        u32 c = wave_cnt[2 * w];
-        if (c > wave_cap) {
-            if (threadIdx.x == 0) atomicOr(overflow, 1u);
-            c = wave_cap;
+    // The block's segments as ONE list of entries (entry g of the block = entry g - off[wi] of segment wi): a loop over the
+    // segments would be a chain of dependent gather round trips per segment (the fused tail has eight of them).
+    constexpr int MAXSEG = 8;
+    u32 off[MAXSEG + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int wi = 0; wi < MAXSEG; ++wi) {
+        u32 c = 0;
+        if (wi < waves_per_block && w0 + wi < n_waves) {
+            c = wave_cnt[2 * (w0 + wi)];
+            if (c > wave_cap) {
+                if (threadIdx.x == 0) atomicOr(overflow, 1u);
+                c = wave_cap;
+            }
         }
-        total += c;
-        for (u32 e = threadIdx.x; e < c; e += blockDim.x) {
-            const u32 ey = wave_out[w * wave_cap + e].y;
-            atomicAdd(&s_hist[ey & 0xffffu], (u32)__popc(ey >> 16));
-        }
+        off[wi + 1] = off[wi] + c;
     }
+    const u32 total = off[MAXSEG];
+    auto entry_at = [&](u32 g) __attribute__((always_inline)) -> const uint2* {
+        int wi = 0;
+#pragma unroll
+        for (int j = 1; j < MAXSEG; ++j) wi += g >= off[j] ? 1 : 0;
+        return wave_out + (w0 + wi) * wave_cap + (g - off[wi]);
+    };
     if (total == 0) return;  // uniform: every thread read the same counts
+    for (u32 g = threadIdx.x; g < total; g += blockDim.x) {
+        const u32 ey = entry_at(g)->y;
+        atomicAdd(&s_hist[ey & 0xffffu], (u32)__popc(ey >> 16));
+    }
     __syncthreads();
     if (threadIdx.x < group_q) {
         const u32 hcount = s_hist[threadIdx.x];
@@ -582,20 +604,15 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
         // TOGETHER, 64 elements at a time: 16 lanes per row and instruction, whole lines, into a per-wave LDS
         // stage (row stride 272 bytes: two-way bank conflicts at most), and each pair then reads its row's piece
         // from the stage.  The arithmetic and its order are untouched (scipy's two chains, one per lane).
-        __shared__ __attribute__((aligned(16))) float s_stage[4][32 * RERANK_STAGE_STRIDE];
-        if (rows_aligned && (d & 63) == 0 && blockDim.x <= 256 && !(debug & 512)) {
+        if (L.stage && rows_aligned && (d & 63) == 0 && !(debug & 512)) {
             const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, pair = lane >> 1;
-            float* stage = s_stage[wv];
-            for (int wi = 0; wi < waves_per_block; ++wi) {
-                const long long w = w0 + wi;
-                if (w >= n_waves) break;
-                u32 c = wave_cnt[2 * w];
-                c = c > wave_cap ? wave_cap : c;
+            float* stage = L.stage + wv * (32 * RERANK_STAGE_STRIDE);
+            {
                 const u32 per_round = blockDim.x / LPR;
-                for (u32 e0 = 0; e0 < c; e0 += per_round) {   // uniform trip count: the waves work in lockstep below
+                for (u32 e0 = 0; e0 < total; e0 += per_round) {   // uniform trip count: the waves work in lockstep below
                     const u32 e = e0 + threadIdx.x / LPR;
-                    const bool live = e < c;
-                    const uint2 ent = live ? wave_out[w * wave_cap + e] : make_uint2(0u, 0u);
+                    const bool live = e < total;
+                    const uint2 ent = live ? *entry_at(e) : make_uint2(0u, 0u);
                     const u32 ql = ent.y & 0xffffu;
                     const u32 qg = q0 + ql;
                     const float* qrow = q_in_lds ? s_qrows + ql * ldl : q_al + (long long)qg * ldq;
@@ -645,13 +662,9 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
             return;
         }
     }
-    for (int wi = 0; wi < waves_per_block; ++wi) {
-        const long long w = w0 + wi;
-        if (w >= n_waves) break;
-        u32 c = wave_cnt[2 * w];
-        c = c > wave_cap ? wave_cap : c;
-        for (u32 e = threadIdx.x / LPR; e < c; e += blockDim.x / LPR) {
-            const uint2 ent = wave_out[w * wave_cap + e];
+    {
+        for (u32 e = threadIdx.x / LPR; e < total; e += blockDim.x / LPR) {
+            const uint2 ent = *entry_at(e);
             const u32 ql = ent.y & 0xffffu;
             const u32 qg = q0 + ql;
             const float* qrow = q_in_lds ? s_qrows + ql * ldl : q_al + (long long)qg * ldq;
@@ -692,8 +705,11 @@ static __global__ __launch_bounds__(512) void dense_rerank_l2_kernel(
     const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt, u32 wave_cap, long long n_waves,
     int waves_per_block, int nq, int group_q, u64* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
     u32* __restrict__ overflow, int debug) {
+    extern __shared__ __attribute__((aligned(16))) float s_qrows_dyn[];
+    __shared__ u32 s_hist[RERANK_MAX_GROUP], s_base[RERANK_MAX_GROUP], s_fill[RERANK_MAX_GROUP];
     rerank_block<u64, false>(db, ld, d, q_al, ldq, nq, group_q, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block,
-                             keys, cnt, cap, overflow, nullptr, nullptr, debug);
+                             keys, cnt, cap, overflow, nullptr, nullptr, debug, (long long)blockIdx.x * waves_per_block,
+                             RerankLds{s_qrows_dyn, s_hist, s_base, s_fill, nullptr});
 }
 
 static __global__ __launch_bounds__(512) void dense_rerank_cos_kernel(
@@ -701,8 +717,12 @@ static __global__ __launch_bounds__(512) void dense_rerank_cos_kernel(
     const uint2* __restrict__ wave_out, const u32* __restrict__ wave_cnt, u32 wave_cap, long long n_waves,
     int waves_per_block, int nq, int group_q, K128* __restrict__ keys, u32* __restrict__ cnt, u32 cap,
     u32* __restrict__ overflow, const double* __restrict__ nx64, const double* __restrict__ nq64, int debug) {
+    extern __shared__ __attribute__((aligned(16))) float s_qrows_dyn[];
+    __shared__ u32 s_hist[RERANK_MAX_GROUP], s_base[RERANK_MAX_GROUP], s_fill[RERANK_MAX_GROUP];
+    __shared__ __attribute__((aligned(16))) float s_stage[4][32 * RERANK_STAGE_STRIDE];
     rerank_block<K128, true>(db, ld, d, q_al, ldq, nq, group_q, wave_out, wave_cnt, wave_cap, n_waves, waves_per_block,
-                             keys, cnt, cap, overflow, nx64, nq64, debug);
+                             keys, cnt, cap, overflow, nx64, nq64, debug, (long long)blockIdx.x * waves_per_block,
+                             RerankLds{s_qrows_dyn, s_hist, s_base, s_fill, blockDim.x <= 256 ? &s_stage[0][0] : nullptr});
 }
 
 // Plain distance vectors for sq_dense_distances (one query, n gathered rows),

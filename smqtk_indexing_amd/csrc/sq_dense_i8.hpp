@@ -289,99 +289,131 @@ static __global__ __launch_bounds__(256) void dense8_flag_kernel(const float* __
 // residual rq, |q - c|^2, the score unit Dx Dq and the query's error bound e_q (all float64, rounded up where they
 // widen the bound), plus what dense_prep_queries_kernel does besides (counters, overflow flag, the aligned copy).
 //   per query p < nq_pad (= plane_rows):  qs8[plane][p][row bytes] int8 (plane 1 in units of Dq / 256), par[p] = {unit (Dx Dq), e_q}
-// (one workgroup per query of the padded tile, one thread per byte of a plane row: blockDim.x = the copy's row bytes)
-static __global__ __launch_bounds__(512) void dense8_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
-                                                                          const float* __restrict__ center, double dx, double r_max,
-                                                                          double x_max, signed char* __restrict__ qs8,
-                                                                          float2* __restrict__ par, double* __restrict__ qn2,
-                                                                          float* __restrict__ thr, u32* __restrict__ cnt,
-                                                                          u32* __restrict__ oflag, float* __restrict__ q_al, int ldq,
-                                                                          const DenseCallPtrs* __restrict__ ind, int cosine, int plane_rows) {
+// Sixteen lanes per query -- a wave prepares FOUR queries at once (row = lane >> 4): lane l of a row owns plane bytes
+// 64 c + l + 16 e (c: 64-byte chunk of the row, e = 0 .. 3).  The stand-alone kernel below runs it with one wave per four
+// queries, the fused head of a call (dense8_head_kernel) in every workgroup.  The float64 sums are taken per 64-element
+// chunk as the butterfly (t, t ^ 32), (.., ^ 16), ... (^ 1) and then in chunk order: every caller gets the same bits.
+//   p0 / p1: this query's rows of the two planes (global or LDS); {unit, e_q} and |q''|^2 come back in every lane of the row.
+template <int EPL>   // row bytes / 64
+__device__ __forceinline__ void dense8_prep_query_row(const float* __restrict__ qrow, bool real, int d, const float* __restrict__ center,
+                                                      double dx, double r_max, double x_max, int cosine,
+                                                      signed char* __restrict__ p0, signed char* __restrict__ p1, float2& par_out,
+                                                      double& qn2_out) {
+    const int l16 = threadIdx.x & 15;
+    // L2: q'' = q - c and the planes hold -2 q''; cosine: q'' = q / |q| (float64 norm, rounded to float32) and the planes hold -q''
+    const float sc = cosine ? -1.f : -2.f;
+    float v[EPL][4];
+#pragma unroll
+    for (int c = 0; c < EPL; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = 64 * c + l16 + 16 * e;
+            float raw = 0.f, cen = 0.f;
+            if (real && t < d) {
+                raw = qrow[t];
+                if (center) cen = center[t];
+            }
+            v[c][e] = (real && t < d) ? (center ? __fsub_rn(raw, cen) : raw) : 0.f;
+        }
+    // butterfly sum of a chunk's 64 values: pairs (t, t ^ 32) and (.., ^ 16) are this lane's own four, the rest across the row
+    auto chunk_sum = [](double x0, double x1, double x2, double x3) __attribute__((always_inline)) {
+        double sacc = (x0 + x2) + (x1 + x3);
+        for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+        return sacc;
+    };
+    if (cosine) {
+        double nn = 0.0;
+#pragma unroll
+        for (int c = 0; c < EPL; ++c)
+            nn += chunk_sum((double)v[c][0] * (double)v[c][0], (double)v[c][1] * (double)v[c][1], (double)v[c][2] * (double)v[c][2],
+                            (double)v[c][3] * (double)v[c][3]);
+        const double rn = sqrt(nn);
+#pragma unroll
+        for (int c = 0; c < EPL; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[c][e] = (float)((double)v[c][e] / rn);   // (a zero query: NaN -- no scale, the exact path answers it as the reference does)
+    }
+    // |q''|^2 and the largest plane element
+    double Q = 0.0;
+    float mx = 0.f;
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) {
+        Q += chunk_sum((double)v[c][0] * (double)v[c][0], (double)v[c][1] * (double)v[c][1], (double)v[c][2] * (double)v[c][2],
+                       (double)v[c][3] * (double)v[c][3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float m = fabsf(sc * v[c][e]);
+            if (!(m == m)) m = __builtin_inff();
+            mx = fmaxf(mx, m);
+        }
+    }
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const bool ok = real && mx < 3.0e38f && mx > 0.f;   // zero / non-finite / padding queries: an all-zero plane, nothing certified by it
+    const double dq = ok ? (double)mx / 127.0 : 1.0;
+    const double inv_dq = 1.0 / dq;
+    double r2s = 0.0;
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) {
+        double r2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double w = (double)(sc * v[c][e]);
+            const double ws = w * inv_dq;   // the plane value in steps of Dq (whatever its last bit, the residual below is measured against what is stored)
+            float qt8 = 0.f, ql8 = 0.f;
+            if (ok) {
+                qt8 = fminf(fmaxf(rintf((float)ws), -127.f), 127.f);
+                // second plane: what the first leaves, in steps of Dq / 256 (the kernel joins the two integer sums by a shift)
+                ql8 = fminf(fmaxf(rintf((float)((ws - (double)qt8) * 256.0)), -127.f), 127.f);
+            }
+            const int t = 64 * c + l16 + 16 * e;
+            p0[t] = (signed char)(int)qt8;
+            p1[t] = (signed char)(int)ql8;
+            const double res = w - ((double)qt8 + (double)ql8 * 0.00390625) * dq;
+            r2[e] = res * res;
+        }
+        r2s += chunk_sum(r2[0], r2[1], r2[2], r2[3]);
+    }
+    const double rq = sqrt(r2s) * (1.0 + 1e-9);
+    const double unit = dx * dq;
+    // e_q: R |w| (the rows' measured residual; w = -2 q'' or -q'') + (X + R) rq (the query's) + the float32 evaluation of
+    // N + unit * sum (|sum| unit <= (X + R)(2 |q''| + rq): conversion, unit and fma roundings) + N's own rounding
+    const double xr = x_max + r_max, qn = sqrt(Q), wn = (cosine ? 1.0 : 2.0) * qn;   // wn: the length of what the planes hold
+    double e = r_max * wn + xr * rq + 4.0 * 5.9604644775390625e-08 * (xr * (wn + rq) + x_max * x_max);
+    e *= 1.0 + 1e-6;
+    float ef = (float)e;
+    if ((double)ef < e) ef = __uint_as_float(__float_as_uint(ef) + 1u);
+    if (!ok && real) ef = __builtin_inff();   // (a zero or non-finite query: Dense8ThrPost gives it a NaN threshold, it takes the next tier)
+    par_out = make_float2((float)unit, real ? ef : 0.f);
+    qn2_out = real ? Q : 0.0;
+}
+
+// (one 64-thread workgroup per four queries of the padded tile)
+template <int EPL>
+static __global__ __launch_bounds__(64) void dense8_prep_queries_kernel(const float* __restrict__ q, int nq, int d,
+                                                                         const float* __restrict__ center, double dx, double r_max,
+                                                                         double x_max, signed char* __restrict__ qs8,
+                                                                         float2* __restrict__ par, double* __restrict__ qn2,
+                                                                         float* __restrict__ thr, u32* __restrict__ cnt,
+                                                                         u32* __restrict__ oflag, float* __restrict__ q_al, int ldq,
+                                                                         const DenseCallPtrs* __restrict__ ind, int cosine, int plane_rows) {
+    constexpr int row_bytes = EPL * 64;
     if (ind) q = ind->q;   // (captured call graph: this launch's queries)
-    const int qi = blockIdx.x, t = threadIdx.x;
-    const int row_bytes = blockDim.x, nw = blockDim.x >> 6;
-    __shared__ double red[8];
-    __shared__ float redm[8];
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 4), t = threadIdx.x & 15;
     if (t == 0) {
         // padding queries of the tile: a NaN threshold -- no comparison passes, not even an always-candidate row's -inf
         thr[qi] = qi < nq ? -__builtin_inff() : __builtin_nanf("");
         cnt[qi] = 0u;
         if (qi == 0) *oflag = 0u;
     }
-    // L2: q'' = q - c and the planes hold -2 q''; cosine: q'' = q / |q| (float64 norm, rounded to float32) and the planes hold -q''
-    const float sc = cosine ? -1.f : -2.f;
-    float v = 0.f;
-    if (qi < nq && t < d) {
-        const float raw = q[(long long)qi * d + t];
-        v = center ? __fsub_rn(raw, center[t]) : raw;
-    }
-    if (cosine) {
-        double n2 = (double)v * (double)v;
-        for (int o = 32; o > 0; o >>= 1) n2 += __shfl_xor(n2, o);
-        if ((t & 63) == 0) red[t >> 6] = n2;
-        __syncthreads();
-        double nn = 0.0;
-        for (int w = 0; w < nw; ++w) nn += red[w];
-        __syncthreads();
-        v = (float)((double)v / sqrt(nn));   // (a zero query: NaN -- no scale, the exact path answers it as the reference does)
-    }
     if (qi < nq)
-        for (int i = t; i < ldq; i += row_bytes) q_al[(long long)qi * ldq + i] = i < d ? q[(long long)qi * d + i] : 0.f;
-    // |q''|^2 and the largest plane element
-    double a2 = (double)v * (double)v;
-    float m = fabsf(sc * v);
-    if (!(m == m)) m = __builtin_inff();
-    for (int o = 32; o > 0; o >>= 1) {
-        a2 += __shfl_xor(a2, o);
-        m = fmaxf(m, __shfl_xor(m, o));
-    }
-    if ((t & 63) == 0) {
-        red[t >> 6] = a2;
-        redm[t >> 6] = m;
-    }
-    __syncthreads();
-    double Q = 0.0;
-    float mx = 0.f;
-    for (int w = 0; w < nw; ++w) {
-        Q += red[w];
-        mx = fmaxf(mx, redm[w]);
-    }
-    __syncthreads();
-    const bool ok = qi < nq && mx < 3.0e38f && mx > 0.f;   // zero / non-finite / padding queries: an all-zero plane, nothing certified by it
-    const double dq = ok ? (double)mx / 127.0 : 1.0;
-    float qt8 = 0.f;
-    if (ok) {
-        qt8 = rintf((float)((double)(sc * v) / dq));
-        qt8 = fminf(fmaxf(qt8, -127.f), 127.f);
-    }
-    // second plane: what the first leaves, in steps of Dq / 256 (the kernel joins the two integer sums by a shift)
-    float ql8 = 0.f;
-    if (ok) {
-        ql8 = rintf((float)((((double)(sc * v) / dq) - (double)qt8) * 256.0));
-        ql8 = fminf(fmaxf(ql8, -127.f), 127.f);
-    }
-    qs8[(long long)qi * row_bytes + t] = (signed char)(int)qt8;
-    qs8[(long long)(plane_rows + qi) * row_bytes + t] = (signed char)(int)ql8;
-    const double res = (double)(sc * v) - ((double)qt8 + (double)ql8 / 256.0) * dq;
-    double r2 = res * res;
-    for (int o = 32; o > 0; o >>= 1) r2 += __shfl_xor(r2, o);
-    if ((t & 63) == 0) red[t >> 6] = r2;
-    __syncthreads();
+        for (int i = t; i < ldq; i += 16) q_al[(long long)qi * ldq + i] = i < d ? q[(long long)qi * d + i] : 0.f;
+    float2 pr;
+    double Q;
+    dense8_prep_query_row<EPL>(q + (long long)qi * d, qi < nq, d, center, dx, r_max, x_max, cosine,
+                               qs8 + (long long)qi * row_bytes, qs8 + (long long)(plane_rows + qi) * row_bytes, pr, Q);
     if (t == 0) {
-        double r2s = 0.0;
-        for (int w = 0; w < nw; ++w) r2s += red[w];
-        const double rq = sqrt(r2s) * (1.0 + 1e-9);
-        const double unit = dx * dq;
-        // e_q: R |w| (the rows' measured residual; w = -2 q'' or -q'') + (X + R) rq (the query's) + the float32 evaluation of
-        // N + unit * sum (|sum| unit <= (X + R)(2 |q''| + rq): conversion, unit and fma roundings) + N's own rounding
-        const double xr = x_max + r_max, qn = sqrt(Q), wn = (cosine ? 1.0 : 2.0) * qn;   // wn: the length of what the planes hold
-        double e = r_max * wn + xr * rq + 4.0 * 5.9604644775390625e-08 * (xr * (wn + rq) + x_max * x_max);
-        e *= 1.0 + 1e-6;
-        float ef = (float)e;
-        if ((double)ef < e) ef = __uint_as_float(__float_as_uint(ef) + 1u);
-        if (!ok && qi < nq) ef = __builtin_inff();   // (a zero or non-finite query: Dense8ThrPost gives it a NaN threshold, it takes the next tier)
-        par[qi] = make_float2((float)unit, qi < nq ? ef : 0.f);
-        qn2[qi] = qi < nq ? Q : 0.0;
+        par[qi] = pr;
+        qn2[qi] = Q;
     }
 }
 
@@ -435,10 +467,19 @@ __device__ __forceinline__ int i8_swz(int c, int r) {
     return (c & ~15) | ((c & 15) ^ (r & 15));
 }
 
-template <int KS, bool SAMPLE>
-__global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dense8_scan_kernel(Dense8ScanArgs a) {
+// What a wave does with the scores of a tile: I8_EMIT compares them with the query's threshold and appends survivors to its
+// segment; I8_SAMPLE writes the minimum of each lane's 16 rows to the sample matrix (the six-launch chain's sample pass);
+// I8_LANEMIN keeps ONE running minimum per lane over the whole pass (the fused head, dense8_head_kernel).
+enum { I8_EMIT = 0, I8_SAMPLE = 1, I8_LANEMIN = 2 };
+
+// The stream of one wave: its share of the launch's ring units through its private LDS ring, the MFMAs of the unit's tiles
+// against the query planes in registers, the score epilogue.  `wcount`: survivors appended (I8_EMIT); `smin`: the lane's
+// running minimum (I8_LANEMIN).
+template <int KS, int MODE>
+__device__ __forceinline__ void dense8_stream(const Dense8ScanArgs& a, unsigned char* smem, const i32x4 (&bq)[KS], const i32x4 (&bl)[KS],
+                                              float unit_lo, float thr_l, u32& wcount, float& smin) {
     using G = I8Geom<KS>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr bool SAMPLE = MODE != I8_EMIT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r31 = lane & 31, h = lane >> 5;
@@ -448,19 +489,6 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
     const long long wave_id = (long long)blockIdx.x * G::WAVES + wave;
     const long long nwaves = (long long)a.nrb * G::WAVES;
     uint2* wout = a.wave_out + wave_id * a.wave_cap;
-
-    // this lane's query (column r31 of the tile): its int8 planes as B fragments (k = 32 s + 16 h ..), unit and threshold
-    i32x4 bq[KS], bl[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        bq[s] = *reinterpret_cast<const i32x4*>(a.qs8 + r31 * G::ROW_BYTES + (2 * s + h) * 16);
-        bl[s] = *reinterpret_cast<const i32x4*>(a.qs8 + (TILE_ROWS + r31) * G::ROW_BYTES + (2 * s + h) * 16);
-    }
-    float unit_lo = a.par[r31].x * 0.00390625f;   // Dx Dq / 256, exact
-    float thr_l = SAMPLE ? 0.f : a.thr[r31];
-    asm volatile("" : "+v"(unit_lo), "+v"(thr_l));
-#pragma unroll
-    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(bq[s]), "+v"(bl[s]));   // complete before the ring starts
 
     const long long my_units = wave_id < a.n_sel ? (a.n_sel - wave_id + nwaves - 1) / nwaves : 0;
     // DMA piece j: bytes 1024 j .. 1024 j + 1023 of the unit's LDS image; lane -> 16 bytes at (row, chunk position), read
@@ -492,7 +520,6 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
     };
     for (int p = 0; p < G::NSTAGE; ++p) issue_next();
 
-    u32 wcount = 0;
     for (long long it = 0; it < my_units; ++it) {
         const long long unit_idx = (wave_id + it * nwaves) * a.unit_step;
         const long long row0 = unit_idx * G::UNIT_ROWS;
@@ -554,7 +581,9 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
             float m = sc[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) m = fminf(m, sc[i]);
-            if constexpr (SAMPLE) {
+            if constexpr (MODE == I8_LANEMIN) {
+                smin = fminf(smin, m);
+            } else if constexpr (MODE == I8_SAMPLE) {
                 const long long sel = wave_id + it * nwaves;
                 a.sample_out[(long long)r31 * a.ns + sel * G::SAMPLES_PER_UNIT + t * 2 + h] = m;
             } else {
@@ -573,12 +602,321 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
             }
         }
     }
+}
+
+// this lane's query (column r31 of the tile): its int8 planes as B fragments (k = 32 s + 16 h ..) from `planes`
+// ([2][32][row bytes], global or LDS), complete before the ring starts
+template <int KS>
+__device__ __forceinline__ void dense8_load_planes(const signed char* planes, i32x4 (&bq)[KS], i32x4 (&bl)[KS]) {
+    using G = I8Geom<KS>;
+    const int lane = threadIdx.x & 63, r31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        bq[s] = *reinterpret_cast<const i32x4*>(planes + r31 * G::ROW_BYTES + (2 * s + h) * 16);
+        bl[s] = *reinterpret_cast<const i32x4*>(planes + (TILE_ROWS + r31) * G::ROW_BYTES + (2 * s + h) * 16);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(bq[s]), "+v"(bl[s]));
+}
+
+template <int KS, bool SAMPLE>
+__global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dense8_scan_kernel(Dense8ScanArgs a) {
+    using G = I8Geom<KS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r31 = lane & 31;
+    i32x4 bq[KS], bl[KS];
+    dense8_load_planes<KS>(a.qs8, bq, bl);
+    float unit_lo = a.par[r31].x * 0.00390625f;   // Dx Dq / 256, exact
+    float thr_l = SAMPLE ? 0.f : a.thr[r31];
+    asm volatile("" : "+v"(unit_lo), "+v"(thr_l));
+    u32 wcount = 0;
+    float smin = 0.f;
+    dense8_stream<KS, SAMPLE ? I8_SAMPLE : I8_EMIT>(a, smem, bq, bl, unit_lo, thr_l, wcount, smin);
     if constexpr (!SAMPLE) {
         if (lane == 0) {
+            const long long wave_id = (long long)blockIdx.x * G::WAVES + wave;
             a.wave_cnt[2 * wave_id] = wcount;
             a.wave_cnt[2 * wave_id + 1] = 0u;
         }
     }
+}
+
+// ---------------------------------------------------------------- a call in three launches (one query tile)
+// A pipelined call was six dependent launches -- query prep, sample pass, k-th threshold, full pass, re-rank, select -- and on
+// a 1.25 M-row shard the pass itself is a third of that chain.  The fused form is three:
+//   head  (dense8_head_kernel): every workgroup prepares the query tile for itself (the planes never leave the CU),
+//         streams its share of the sampled units keeping ONE running minimum per lane, and the workgroup that finishes
+//         last turns the M = workgroups x waves x 2 lane minima of each query into the threshold;
+//   body  (dense8_body_kernel): the full pass, whose workgroups re-rank their own survivor segments when their waves have
+//         drained the stream (the ring's LDS becomes the re-rank's);
+//   select_topk_kernel with the finalisation, as before.
+// The threshold from lane minima: a lane's minimum is the score of an actual sampled row and different lanes hold
+// different rows, so the k-th smallest of ANY set of lane minima has >= k sampled rows at or below it -- an upper bound of
+// the k-th smallest score of the sample, hence of all rows: what the bound needs.  It is looser than the k-th smallest
+// SAMPLE only where several of the k best samples share a lane: -L ln(1 - k / L) samples instead of k for L lanes (105
+// for k = 100, L = 1024; the host sizes the grid for L >= 4 k), or where a workgroup holds more of the k best minima
+// than the `keep` it hands over (the host picks keep from k / workgroups).
+
+struct Dense8HeadArgs {
+    Dense8ScanArgs s;           // qs8 / par / thr are OUTPUTS here (written for the body by workgroup 0 / the last one)
+    const float* q;             // the caller's queries [nq][d]
+    int nq, d;
+    const float* center;
+    double dx, r_max, x_max;
+    int cosine;
+    double* qn2;
+    u32* cnt;
+    u32* oflag;                 // [0] overflow flag of the call, [1] the head's ticket counter (self-cleaning)
+    float* q_al;
+    int ldq;
+    const DenseCallPtrs* ind;
+    float* lane_min;            // [32][gridDim.x * keep]: per query, the `keep` smallest lane minima of every workgroup
+    int keep;                   // 4, 8 or 16 (<= waves x 2)
+    int kk;
+};
+
+// exact k-th smallest of each of NQ value lists vals[j * stride + 0 .. M) (M <= 64 VM) by one wave: MSB-first bisection
+// on the order-preserving keys, the count of a step = popcounts of wave ballots (no cross-lane arithmetic), leading bits
+// common to all keys skipped.  +inf when fewer than k values are finite.  A pass over a list is VM vector compares of four
+// cycles each (the reason the workgroups hand over their few smallest minima and not all of them) and a step is a chain
+// compare -> scalar popcount -> add -> select: the NQ lists are walked together so that one list's chain runs under the
+// others' compares.
+template <int VM, int NQ>
+__device__ __forceinline__ void wave_kth_smallest(const float* __restrict__ vals, long long stride, int M, int k, float (&out)[NQ]) {
+    const int lane = threadIdx.x & 63;
+    constexpr u32 KINF = 0xff800000u;   // ordered_f32(+inf)
+    u32 key[NQ][VM];
+    u32 prefix[NQ];
+    u32 xall = 0u;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        u32 kmin = KINF, kmax = 0u;
+#pragma unroll
+        for (int j = 0; j < VM; ++j) {
+            const int i = j * 64 + lane;
+            u32 kv = ordered_f32(vals[n * stride + (i < M ? i : 0)]);
+            kv = (i < M && kv < KINF) ? kv : KINF;   // (padding and NaN: as +inf)
+            key[n][j] = kv;
+            kmin = kv < kmin ? kv : kmin;
+            kmax = kv > kmax ? kv : kmax;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const u32 a = (u32)__shfl_xor((int)kmin, o), b = (u32)__shfl_xor((int)kmax, o);
+            kmin = a < kmin ? a : kmin;
+            kmax = b > kmax ? b : kmax;
+        }
+        prefix[n] = __builtin_amdgcn_readfirstlane(kmin);
+        xall |= __builtin_amdgcn_readfirstlane(kmin ^ kmax);
+    }
+    if (xall != 0u) {
+        const int top = 31 - __clz((int)xall);   // highest bit in which any list's keys differ
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) prefix[n] &= ~((2u << top) - 1u);
+        for (int b = top; b >= 0; --b) {
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                const u32 cand = prefix[n] | ((1u << b) - 1u);
+                u32 c = 0;
+#pragma unroll
+                for (int j = 0; j < VM; ++j) c += (u32)__popcll(__ballot(key[n][j] <= cand));
+                if (c < (u32)k) prefix[n] |= 1u << b;
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        // (fewer than k values at all: the walk ends on the all-ones suffix, at or above +inf)
+        float r = unordered_f32(prefix[n]);
+        if (prefix[n] >= KINF) {
+            u32 c = 0;
+#pragma unroll
+            for (int j = 0; j < VM; ++j) c += (u32)__popcll(__ballot(key[n][j] < KINF));
+            if (c < (u32)k) r = __builtin_inff();
+        }
+        out[n] = r;
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dense8_head_kernel(Dense8HeadArgs ha) {
+    using G = I8Geom<KS>;
+    constexpr int VB = G::WAVES * 2;   // lane minima per query and workgroup
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float2 s_par[TILE_ROWS];
+    __shared__ double s_qn2[TILE_ROWS];
+    __shared__ float s_lm[TILE_ROWS][16];
+    __shared__ u32 s_ticket;
+    const Dense8ScanArgs& a = ha.s;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r31 = lane & 31, h = lane >> 5;
+    const float* q = ha.ind ? ha.ind->q : ha.q;   // (captured call graph: this launch's queries)
+    const bool first = blockIdx.x == 0;
+    // ---- the query tile, prepared by this workgroup for itself: planes in LDS (where the ring will be)
+    signed char* planes = reinterpret_cast<signed char*>(smem);
+#pragma unroll
+    for (int rnd = 0; rnd < TILE_ROWS / (4 * G::WAVES); ++rnd) {
+        const int qi = rnd * 4 * G::WAVES + wave * 4 + (lane >> 4);
+        float2 pr;
+        double Q;
+        dense8_prep_query_row<KS / 2>(q + (long long)qi * ha.d, qi < ha.nq, ha.d, ha.center, ha.dx, ha.r_max, ha.x_max, ha.cosine,
+                                      planes + qi * G::ROW_BYTES, planes + (TILE_ROWS + qi) * G::ROW_BYTES, pr, Q);
+        if ((lane & 15) == 0) {
+            s_par[qi] = pr;
+            s_qn2[qi] = Q;
+        }
+        if (first) {   // what the body, the select and the host read: written once
+            if ((lane & 15) == 0) {
+                const_cast<float2*>(a.par)[qi] = pr;
+                ha.qn2[qi] = Q;
+                ha.cnt[qi] = 0u;
+                if (qi == 0) ha.oflag[0] = 0u;
+            }
+            if (qi < ha.nq)
+                for (int i = lane & 15; i < ha.ldq; i += 16) ha.q_al[(long long)qi * ha.ldq + i] = i < ha.d ? q[(long long)qi * ha.d + i] : 0.f;
+        }
+    }
+    __syncthreads();
+    i32x4 bq[KS], bl[KS];
+    dense8_load_planes<KS>(planes, bq, bl);
+    float unit_lo = s_par[r31].x * 0.00390625f;
+    asm volatile("" : "+v"(unit_lo));
+    if (first) {
+        signed char* gp = const_cast<signed char*>(a.qs8);
+        for (int i = threadIdx.x; i < 2 * TILE_ROWS * G::ROW_BYTES / 16; i += G::WAVES * 64)
+            reinterpret_cast<uint4*>(gp)[i] = reinterpret_cast<const uint4*>(planes)[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();   // the planes are in registers (and on their way to the body): the LDS is the ring's from here
+    // ---- the sample pass: one running minimum per lane
+    u32 wcount = 0;
+    float smin = __builtin_inff();
+    if (!(a.debug & 4096)) dense8_stream<KS, I8_LANEMIN>(a, smem, bq, bl, unit_lo, 0.f, wcount, smin);   // (4096: measurement, no sample pass)
+    // ---- the workgroup's VB minima per query, sorted (sixteen lanes per query: a bitonic network over shuffles); only the
+    // `keep` smallest leave.  The k best minima of a call fall on a workgroup k / workgroups at a time (Poisson): four or
+    // eight per workgroup lose next to nothing, and the last workgroup's selection is over keep / VB as many values.
+    s_lm[r31][(wave * 2 + h) & 15] = smin;
+    if (VB < 16 && wave == 0 && h == 0)
+        for (int i = VB; i < 16; ++i) s_lm[r31][i] = __builtin_inff();
+    __syncthreads();
+    const int nb = (int)gridDim.x, keep = ha.keep, M = nb * keep;
+#pragma unroll
+    for (int rnd = 0; rnd < TILE_ROWS / (4 * G::WAVES); ++rnd) {
+        const int qi = rnd * 4 * G::WAVES + wave * 4 + (lane >> 4), l16 = lane & 15;
+        float v = s_lm[qi][l16];
+#pragma unroll
+        for (int kk2 = 2; kk2 <= 16; kk2 <<= 1)
+#pragma unroll
+            for (int j = kk2 >> 1; j > 0; j >>= 1) {
+                const float o = __shfl_xor(v, j);
+                const bool up = (l16 & kk2) == 0, lower = (l16 & j) == 0;
+                v = (lower == up) ? fminf(v, o) : fmaxf(v, o);
+            }
+        if (l16 < keep) ha.lane_min[(long long)qi * M + (long long)blockIdx.x * keep + l16] = v;
+    }
+    // ---- the workgroup that arrives last turns the minima into thresholds.  An agent-scope fence is an L2 write-back /
+    // invalidate on a part whose XCDs have L2s of their own: ONE thread per workgroup pays it, behind a barrier that has
+    // collected the workgroup's stores (every wave waited for its own), not every wave.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const u32 t = atomicAdd(&ha.oflag[1], 1u);
+        if (t == gridDim.x - 1) {
+            __threadfence();
+            ha.oflag[1] = 0u;   // for the slot's next call (stream order)
+        }
+        s_ticket = t;
+    }
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    float* thr = const_cast<float*>(a.thr);
+    const Dense8ThrPost post{s_par, s_qn2};
+#pragma unroll
+    for (int rnd = 0; rnd < TILE_ROWS / (4 * G::WAVES); ++rnd) {
+        const int q0 = rnd * 4 * G::WAVES + wave * 4;   // this wave's four queries
+        float ts[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        if (q0 < ha.nq && !(a.debug & 2048)) {   // (2048: measurement, no selection)
+            const float* v = ha.lane_min + (long long)q0 * M;
+            if (M <= 256)
+                wave_kth_smallest<4, 4>(v, M, M, ha.kk, ts);
+            else if (M <= 512)
+                wave_kth_smallest<8, 4>(v, M, M, ha.kk, ts);
+            else if (M <= 1024)
+                wave_kth_smallest<16, 4>(v, M, M, ha.kk, ts);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float one[1];
+                    wave_kth_smallest<32, 1>(v + (long long)j * M, M, M, ha.kk, one);
+                    ts[j] = one[0];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // padding queries of the tile: a NaN threshold -- no comparison passes, not even an always-candidate row's -inf
+            const float t = q0 + j < ha.nq ? post(q0 + j, ts[j]) : __builtin_nanf("");
+            if (lane == 0) thr[q0 + j] = t;
+        }
+    }
+}
+
+// The re-rank's inputs that the scan does not know.
+struct Dense8TailArgs {
+    const float* db;
+    long long ld;
+    int d;
+    const float* q_al;
+    int ldq, nq;
+    void* keys;
+    u32* cnt;
+    u32 cap;
+    u32* overflow;
+    const double* nx64;
+    const double* nq64;
+    int debug;
+};
+static constexpr int I8_TAIL_QROWS_BYTES = 32 * (156 + 4) * 4;   // rerank_block stages the query tile for ldq <= 156
+static constexpr int I8_TAIL_LDS_BYTES = I8_TAIL_QROWS_BYTES + 3 * RERANK_MAX_GROUP * 4 + 8 * 32 * RERANK_STAGE_STRIDE * 4;
+
+template <int KS, bool COSINE>
+__global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dense8_body_kernel(Dense8ScanArgs a, Dense8TailArgs ta) {
+    using G = I8Geom<KS>;
+    static_assert(I8_TAIL_LDS_BYTES <= G::WAVES * G::NSTAGE * G::SLOT_BYTES, "the re-rank works in the ring's LDS");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r31 = lane & 31;
+    i32x4 bq[KS], bl[KS];
+    dense8_load_planes<KS>(a.qs8, bq, bl);
+    float unit_lo = a.par[r31].x * 0.00390625f;   // Dx Dq / 256, exact
+    float thr_l = a.thr[r31];
+    asm volatile("" : "+v"(unit_lo), "+v"(thr_l));
+    u32 wcount = 0;
+    float smin = 0.f;
+    dense8_stream<KS, I8_EMIT>(a, smem, bq, bl, unit_lo, thr_l, wcount, smin);
+    const long long w0 = (long long)blockIdx.x * G::WAVES;
+    if (lane == 0) {
+        a.wave_cnt[2 * (w0 + wave)] = wcount;
+        a.wave_cnt[2 * (w0 + wave) + 1] = 0u;
+    }
+    // ---- the tail: this workgroup's own survivor segments, re-ranked in the reference arithmetic from the original rows
+    // (workgroup scope: the segments are written and read on this CU -- an agent-scope fence would write back the L2)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();    // every wave has left the ring and its stores have landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float* fl = reinterpret_cast<float*>(smem);
+    u32* su = reinterpret_cast<u32*>(smem + I8_TAIL_QROWS_BYTES);
+    const RerankLds L{fl, su, su + RERANK_MAX_GROUP, su + 2 * RERANK_MAX_GROUP,
+                      COSINE ? reinterpret_cast<float*>(smem + I8_TAIL_QROWS_BYTES + 3 * RERANK_MAX_GROUP * 4) : nullptr};
+    using K = typename std::conditional<COSINE, K128, u64>::type;
+    rerank_block<K, COSINE>(ta.db, ta.ld, ta.d, ta.q_al, ta.ldq, ta.nq, TILE_ROWS, a.wave_out, a.wave_cnt, a.wave_cap,
+                            (long long)a.nrb * G::WAVES, G::WAVES, static_cast<K*>(ta.keys), ta.cnt, ta.cap, ta.overflow, ta.nx64,
+                            ta.nq64, ta.debug, w0, L);
 }
 
 // ---------------------------------------------------------------- 33 .. 256 queries per call (128-byte rows)
