@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--query-batches", type=int, default=8,
                     help="distinct query batches the timed steps rotate through (1 = the same queries every step)")
     ap.add_argument("--no-mid-tier", action="store_true", help="uncertified queries go straight to the exact path (measurement)")
+    ap.add_argument("--lib-options", default=os.environ.get("SQ_BENCH_OPTS", ""),
+                    help="measurement: library options set on the index, name=value,... (reported in config.lib_options)")
     ap.add_argument("--no-int8", action="store_true", help="bf16 first-stage filter only: no int8 copy is built (measurement)")
     ap.add_argument("--preroll-ms", type=float, default=30.0,
                     help="untimed pipelined steps for this long before the warm-up steps (start-up transient of the device; 0 = none)")
@@ -187,9 +189,15 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     queries = batches[0]
     torch.cuda.synchronize()
 
-    if args.no_int8:
-        _lib.set_option("dense_int8", 0)   # (read at create: the copy is not built)
-    index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=metric, device_ptr=True, id_base=r0, keepalive=db)
+    # (create-time choices are the index's own: sq_dense_create_opts -- nothing process-wide is touched)
+    index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=metric, device_ptr=True, id_base=r0, keepalive=db,
+                            options={"dense_int8": 0} if args.no_int8 else None)
+    lib_opts = {}
+    for item in args.lib_options.split(","):       # measurement: library options of the index, "name=value,..."
+        if item:
+            name_, val_ = item.split("=")
+            index.set_option(name_, int(val_))
+            lib_opts[name_] = int(val_)
     # hipEvent timing of the scan inside the library (`roofline.kernel_ms_in_pipeline`): every search on one GPU
     # (`--profile-every`), every 4th on shards -- the event records of a call cost ~10 us of a step, a tenth of a
     # 1.25 M-row shard's.  Options are per handle (sq_handle_set_option): nothing process-wide is touched.
@@ -513,6 +521,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                                        "weak: fixed rows PER GPU (the BASELINE config's shard), the same queries per step at every N"),
                 "search_calls": f"pipelined (SQ_MEM_DEVICE_ASYNC, {depth} calls in flight)" if use_async else "one blocking call per step",
                 "preroll_ms": args.preroll_ms,
+                "lib_options": lib_opts or None,
                 "results_lag_steps": results_lag,
                 "results_lag_note": "steps between a batch going in and its final (N > 1: merged) result coming out; every "
                                     "result of the timed steps is final and collected before the closing fence",

@@ -108,6 +108,8 @@ int sq_set_option(const char* name, int64_t value);
  * candidate lists, profiling ... -- the reference's contract is "implementations should be thread safe"
  * (interfaces/nearest_neighbor_index.py:22-23), and its options are per instance (constructor arguments).
  * sq_handle_reset_options drops the handle's overrides. */
+/* SQ_ERR_UNSUPPORTED where nothing would read the override: row-matrix and fit handles read no option, an ITQ model
+ * reads "itq_exact" / "dense_debug" only, "spin_wait_us" and "merge_threads" are process-wide. */
 int sq_handle_set_option(sq_handle_t h, const char* name, int64_t value);
 int sq_handle_reset_options(sq_handle_t h);
 int sq_get_stats(sq_handle_t h, sq_stats_t* out);
@@ -200,6 +202,19 @@ int sq_hamming_destroy(sq_handle_t h);
  * library pads the rows). */
 int sq_dense_create(const float* db, int64_t n, int d, int metric, int mem,
                     int64_t id_base, sq_handle_t* out);
+/* The same with options of THIS index given at create, as name / value arrays: they become the handle's overrides
+ * (sq_handle_set_option) BEFORE anything is built, so create-time choices are per index as the reference's are per
+ * instance (constructor arguments: impls/nn_index/faiss.py:182-258) -- "dense_int8" = 0: no int8 copy is built or
+ * kept (footprint 1.5x the matrix instead of 1.77x), "dense_no_center" = 1.  Two indexes of one process may differ. */
+int sq_dense_create_opts(const float* db, int64_t n, int d, int metric, int mem, int64_t id_base,
+                         const char* const* opt_names, const int64_t* opt_values, int n_opts, sq_handle_t* out);
+/* What the index keeps resident and what its build cost; out[SQ_DENSE_INFO_FIELDS] =
+ * { rows, d, bytes of the float32 rows, 1 if the library owns them (0: borrowed from the caller), bytes of the
+ *   bfloat16 scan copy, bytes of the int8 scan copy + its row terms, bytes of the row statistics, 1 if the int8 first
+ *   stage is in use, microseconds sq_dense_create took, microseconds of that spent on the int8 copy }.
+ * (The build side of FaissNearestNeighborsIndex._build_index, impls/nn_index/faiss.py:486-559.) */
+#define SQ_DENSE_INFO_FIELDS 10
+int sq_dense_info(sq_handle_t h, int64_t* out, int n_out);
 /* Append n_add rows ([n_add][d] float32, host or device) to an index that owns its matrix (created from
  * host memory); the new rows get the next row ids (id_base + old n ...).  Only the new rows cross PCIe and only
  * their statistics / scan-copy rows are built; the L2 filter keeps the origin chosen at create.
@@ -231,8 +246,10 @@ int sq_dense_search(sq_handle_t h, const float* queries, int nq, int k,
  * its internal stream behind `stream` (worth ~10 us of start latency per call on a small matrix).
  * Option "dense_int8" (-1 by default): indexes of up to 512 dimensions and at least 65536 rows also keep an int8 copy
  * of the rows (128 / 256 / 512 + 4 bytes per row) and calls of up to 32 queries filter on it -- half the bytes of the bfloat16
- * pass; the results are the same bits (exact re-rank + certificate, as ever).  0 at create: no copy; 0 on a handle: the
- * copy is not used; 1: used even after its candidate lists overflowed three calls in a row (-1 goes back to bfloat16 then).
+ * pass; the results are the same bits (exact re-rank + certificate, as ever).  0 at create (process-wide, or for one
+ * index through sq_dense_create_opts): no copy; 0 on a handle: the copy is not used; -1: after three calls in a row whose
+ * candidate lists overflowed the filter is SUSPENDED (bfloat16 answers; the copy stays and follows appends) until the
+ * index has doubled and chooses its clamp again, or until a call with 1 on the handle re-arms it; 1: never suspended.
  * Option "dense_int8_batch" (64 by default): the largest batch the int8 filter takes (128-byte rows; 32 = one query tile only).
  * Option "dense_graph" (1 by default): asynchronous int8 calls of one shape replay a captured graph (one launch per call). */
 int sq_dense_sync(sq_handle_t h);

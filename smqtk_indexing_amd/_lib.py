@@ -43,7 +43,7 @@ EXPORTS = (
     "sq_set_option", "sq_handle_set_option", "sq_handle_reset_options", "sq_get_stats", "sq_itq_hash",
     "sq_itq_model_create", "sq_itq_model_hash", "sq_itq_model_destroy",
     "sq_hamming_create", "sq_hamming_search", "sq_hamming_sync", "sq_hamming_append", "sq_hamming_remove", "sq_hamming_info", "sq_hamming_destroy",
-    "sq_dense_create", "sq_dense_append", "sq_dense_search", "sq_dense_sync", "sq_dense_destroy",
+    "sq_dense_create", "sq_dense_create_opts", "sq_dense_info", "sq_dense_append", "sq_dense_search", "sq_dense_sync", "sq_dense_destroy",
     "sq_dense_distances", "sq_merge_topk", "sq_merge_topk_strided",
     "sq_rows_create", "sq_rows_append", "sq_rows_rerank", "sq_rows_set_buckets", "sq_lsh_query", "sq_rows_destroy",
     "sq_itqfit_create", "sq_itqfit_set_mean", "sq_itqfit_cov", "sq_itqfit_project", "sq_itqfit_iterate",
@@ -95,6 +95,9 @@ def _declare(lib: ctypes.CDLL) -> None:
     lib.sq_hamming_remove.argtypes = [c_i64, c_vp, c_i64]
     lib.sq_hamming_destroy.argtypes = [c_i64]
     lib.sq_dense_create.argtypes = [c_vp, c_i64, c_int, c_int, c_int, c_i64, ctypes.POINTER(c_i64)]
+    lib.sq_dense_create_opts.argtypes = [c_vp, c_i64, c_int, c_int, c_int, c_i64, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_i64), c_int,
+                                         ctypes.POINTER(c_i64)]
+    lib.sq_dense_info.argtypes = [c_i64, ctypes.POINTER(c_i64), c_int]
     lib.sq_dense_append.argtypes = [c_i64, c_vp, c_i64, c_int]
     lib.sq_dense_search.argtypes = [c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp]
     lib.sq_dense_sync.argtypes = [c_i64]
@@ -400,7 +403,9 @@ class DenseIndex(_Handle):
     _destroy_name = "sq_dense_destroy"
 
     def __init__(self, db, n: Optional[int] = None, d: Optional[int] = None, metric: int = SQ_METRIC_L2,
-                 device_ptr: bool = False, id_base: int = 0, keepalive=None):
+                 device_ptr: bool = False, id_base: int = 0, keepalive=None, options: Optional[dict] = None):
+        """``options``: options of THIS index known at create (``sq_dense_create_opts``), e.g. ``{"dense_int8": 0}`` --
+        no int8 copy is built or kept; they stay the handle's overrides afterwards."""
         super().__init__()
         if device_ptr:
             assert n is not None and d is not None
@@ -414,9 +419,23 @@ class DenseIndex(_Handle):
             ptr, mem = _ptr(db), SQ_MEM_HOST
         self.n, self.d, self.metric, self.id_base = int(n), int(d), int(metric), int(id_base)
         h = ctypes.c_int64(0)
-        _check(load().sq_dense_create(ptr, self.n, self.d, self.metric, mem, self.id_base, ctypes.byref(h)),
-               "sq_dense_create")
+        if options:
+            names = (ctypes.c_char_p * len(options))(*[str(k_).encode() for k_ in options])
+            values = (ctypes.c_int64 * len(options))(*[int(v_) for v_ in options.values()])
+            _check(load().sq_dense_create_opts(ptr, self.n, self.d, self.metric, mem, self.id_base, names, values, len(options),
+                                               ctypes.byref(h)), "sq_dense_create_opts")
+        else:
+            _check(load().sq_dense_create(ptr, self.n, self.d, self.metric, mem, self.id_base, ctypes.byref(h)),
+                   "sq_dense_create")
         self.handle = int(h.value)
+
+    def info(self) -> dict:
+        """What the index keeps resident (bytes per copy) and what its build cost (``sq_dense_info``)."""
+        out = (ctypes.c_int64 * 10)()
+        _check(load().sq_dense_info(self.handle, out, 10), "sq_dense_info")
+        return {"rows": int(out[0]), "d": int(out[1]), "f32_rows_bytes": int(out[2]), "f32_rows_owned": bool(out[3]),
+                "bf16_copy_bytes": int(out[4]), "int8_copy_bytes": int(out[5]), "row_stats_bytes": int(out[6]),
+                "int8_in_use": bool(out[7]), "build_ms": out[8] / 1e3, "build_int8_ms": out[9] / 1e3}
 
     @property
     def dist_dtype(self):

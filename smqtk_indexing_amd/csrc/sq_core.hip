@@ -103,6 +103,7 @@ int Options::*option_member(const char* name) {
         {"dense_int8", &Options::dense_int8},
         {"dense_graph", &Options::dense_graph},
         {"dense_fused", &Options::dense_fused},
+        {"dense_tighten", &Options::dense_tighten},
         {"dense_int8_batch", &Options::dense_int8_batch},
         {"dense_fused_prep", &Options::dense_fused_prep},
         {"hamming_async_depth", &Options::hamming_async_depth},
@@ -137,6 +138,14 @@ extern "C" int sq_handle_set_option(sq_handle_t hid, const char* name, int64_t v
     if (!f) return fail(SQ_ERR_INVALID, "sq_handle_set_option: unknown option '%s'", name);
     HandleBase* h = any_handle(hid);
     if (!h) return fail(SQ_ERR_INVALID, "sq_handle_set_option: unknown handle");
+    // an override nobody would read is refused rather than silently kept: the row-matrix and fit handles read no option,
+    // an ITQ model reads "itq_exact" / "dense_debug" only, and the waits and the host merge are process-wide by nature
+    if (h->kind == H_ROWS || h->kind == H_FIT)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_handle_set_option: handles of this kind read no option");
+    if (h->kind == H_ITQ && f != &Options::itq_exact && f != &Options::dense_debug)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_handle_set_option: an ITQ model reads 'itq_exact' and 'dense_debug' only, not '%s'", name);
+    if (f == &Options::spin_wait_us || f == &Options::merge_threads)
+        return fail(SQ_ERR_UNSUPPORTED, "sq_handle_set_option: '%s' is process-wide (sq_set_option)", name);
     std::lock_guard<std::mutex> l(h->mu);
     for (auto& o : h->overrides)
         if (o.first == f) {

@@ -53,6 +53,9 @@ struct DenseCall {
 struct DenseSlot {
     DevBuf q_scaled, q_al, qn2, thr, wave_out, wave_cnt, cnt, keys, sample, out_keys, cos_nq, oflag;
     DevBuf q8, par8;              // int8 filter: the query tile's plane and {score unit, e_q}
+    DevBuf clk8;                  // measurement ("dense_debug" & 8192): the body kernel's per-workgroup clocks
+    int clk8_wgs = 0;
+    DevBuf wave_score, hist8;     // ... the fused call's tightened threshold: an entry's smallest score, the per-query histograms
     DevBuf sort_tmp;              // scratch of the any-k sorted select (k beyond the one-workgroup select): one per call in flight
     HostPinned status_host;
     // captured call graph of the int8 path ("dense_graph"): one hipGraphLaunch instead of six kernel launches per call
@@ -64,7 +67,7 @@ struct DenseSlot {
     hipStream_t own = nullptr;    // internal stream of the slot (asynchronous calls with "dense_async_streams" = 2)
     DenseCall call;
     void release() {
-        for (DevBuf* b : {&q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt, &keys, &sample, &out_keys, &cos_nq, &oflag, &sort_tmp, &q8, &par8})
+        for (DevBuf* b : {&q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt, &keys, &sample, &out_keys, &cos_nq, &oflag, &sort_tmp, &q8, &par8, &wave_score, &hist8, &clk8})
             b->release();
         status_host.release();
         call_ptrs.release();
@@ -93,7 +96,8 @@ struct DenseHandle : HandleBase {
     double xn2_max = 0.0;       // max squared row norm (error bound of the L2 filter)
     // the int8 first-stage filter (sq_dense_i8.hpp): copy, row terms, and what the build measured
     DevBuf scan8, nrow8;
-    bool use8 = false;
+    bool use8 = false;          // the int8 copy exists (and follows appends)
+    bool suspended8 = false;    // ... but automatic mode (dense_int8 = -1) leaves it alone: its lists overflowed three calls in a row.  dense_int8 = 1 re-arms it, a rebuild (the index doubled) too
     int row8 = 0;               // bytes per row of the copy: 128, 256 or 512
     long long n_pad64 = 0;      // rows a pass covers (what sq_stats_t.bytes_scanned prices)
     long long n_alloc8 = 0;     // rows the copy is allocated and padded for: a multiple of 128 (the largest ring unit)
@@ -102,6 +106,7 @@ struct DenseHandle : HandleBase {
     int overflow8 = 0;          // calls in a row in which the int8 filter's lists overflowed (data it does not suit): it is dropped
     bool graph_broken = false;  // a call-graph capture failed on this handle: eager launches from then on
     float dxf8 = 0.f, inv_dxf8 = 0.f, cut8 = 0.f;   // the build's step and residual cut, for rows appended later
+    long long build_us = 0, build8_us = 0;   // sq_dense_info: wall time of sq_dense_create / of its int8 part
     long long n8_built = 0;     // rows the clamp was chosen from (an index twice that size chooses again)
     DevBuf norms1;  // L2: |x|^2 (1 - alpha) for one query plane (`norms`: two planes)
     DevBuf zeros;   // cosine: the 32 zero "norms" every tile of an AGPR-configuration scan starts from (norm_step 0)
@@ -151,7 +156,7 @@ static constexpr int kSelectLdsKeys128 = 7168;
 // a 1024-query batch is four rounds of workgroups otherwise.
 template <class K, class Post>
 static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long stride, int k, int nq, K* out,
-                           const Post& post, hipStream_t st, DevBuf& sort_scratch, long long expect = 0) {
+                           const Post& post, hipStream_t st, DevBuf& sort_scratch, long long expect = 0, int cnt_shift = 0) {
     static std::atomic<unsigned long long> attr_done{0};
     const int lds_max = sizeof(K) == 8 ? kSelectLdsKeys64 : kSelectLdsKeys128;
     // beyond the one-workgroup select: full sort (sq_select.hpp, "any-k sorted select"); the scratch belongs to the
@@ -166,7 +171,7 @@ static int select_launch_t(const K* keys, const u32* cnt, u32 cap, long long str
     const size_t lds = (size_t)(lds_keys + SELECT_SORT_MAX) * sizeof(K);
     SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&select_topk_kernel<K, Post>), (int)lds_full, attr_done));
     hipLaunchKernelGGL((select_topk_kernel<K, Post>), dim3(nq), dim3(1024), lds, st, keys, cnt, cap, stride, k, lds_keys,
-                       out, post);
+                       out, post, cnt_shift);
     return SQ_OK;
 }
 
@@ -286,7 +291,8 @@ template <int KS, bool SAMPLE>
 static int dense8_scan_launch_t(const Dense8ScanArgs& a, hipStream_t st) {
     using G = I8Geom<KS>;
     static std::atomic<unsigned long long> attr_done{0};
-    SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense8_scan_kernel<KS, SAMPLE>), 160 * 1024, attr_done));
+    // (the kernel has a few bytes of static LDS of its own: the attribute is the ring, not the CU's 160 KiB)
+    SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense8_scan_kernel<KS, SAMPLE>), G::WAVES * G::NSTAGE * G::SLOT_BYTES, attr_done));
     hipLaunchKernelGGL((dense8_scan_kernel<KS, SAMPLE>), dim3((unsigned)a.nrb), dim3(G::WAVES * 64), (size_t)G::WAVES * G::NSTAGE * G::SLOT_BYTES, st, a);
     return SQ_OK;
 }
@@ -398,7 +404,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         }
         SQ_HIP(hipEventRecord(s.ev[0], st));
     }
-    SQ_TRY(s.cnt.reserve((size_t)nq_pad * 4));
+    SQ_TRY(s.cnt.reserve((size_t)nq_pad * 4 * 32));   // (the fused int8 call keeps its counters a cache line apart: I8_CNT_SHIFT)
     SQ_TRY(s.thr.reserve((size_t)nq_pad * 4));
     SQ_TRY(s.qn2.reserve((size_t)nq_pad * 8));
     SQ_TRY(s.q_scaled.reserve((size_t)nq_pad * d_pad * 4));
@@ -460,10 +466,14 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, nullptr, 0},
                                         st, s.sort_tmp));
         }
-    } else if (scan_ok && h->use8 && h->opt.dense_int8 != 0 && kk <= (cosine ? kSelectLdsKeys128 : kSelectLdsKeys64) &&
+    } else if (scan_ok && h->use8 && h->opt.dense_int8 != 0 && !(h->suspended8 && h->opt.dense_int8 < 0) && kk <= (cosine ? kSelectLdsKeys128 : kSelectLdsKeys64) &&
                (nq <= TILE_ROWS || (h->row8 == 128 && (qt == 2 || qt == 4) && nq <= h->opt.dense_int8_batch))) {
         // ---- the int8 first-stage filter (sq_dense_i8.hpp): half the bytes per row, measured error bound
         c.int8 = true;
+        if (h->suspended8) {   // dense_int8 = 1 on the handle: the filter is armed again (and judged again from the next calls)
+            h->suspended8 = false;
+            h->overflow8 = 0;
+        }
         // (128-byte rows stream in ring units of 64 rows on eight waves.  Two other geometries were built and measured --
         // commit 5048766: 128-row units on four waves 0.197 against 0.204 ms per pass alone but 0.244-0.251 against 0.223-0.226 ms
         // per pipelined step; 32-row units on sixteen waves 0.236 -- and removed again.)
@@ -477,6 +487,13 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             // re-rank costs ~3.6x the float32 one per candidate: sqrt of that off the stride, as in the bf16 path
             stride = (long long)((row8 == 128 ? 14.0 : 10.0) * sqrt((double)n / 1e7 * 100.0 / (double)kk / (double)qt) / (cosine ? 1.9 : 1.0) + 0.5);
             if (stride > 16) stride = 16;
+            // The fused call with the tightened threshold (sq_dense_i8.hpp): the sample only has to keep the first-level
+            // entries inside the wave segments -- what is re-ranked no longer depends on it -- so it is several times sparser
+            const bool will_tighten = h->opt.dense_fused != 0 && h->opt.dense_tighten != 0 && qt == 1 && nqt == 1;
+            if (will_tighten) {
+                stride = (long long)(40.0 * sqrt((double)n / 1e7 * 100.0 / (double)kk) + 0.5);
+                if (stride > 64) stride = 64;
+            }
             if (stride < 1) stride = 1;
             if (stride > (long long)cap / (16ll * kk)) stride = std::max<long long>(1, (long long)cap / (16ll * kk));
         }
@@ -531,6 +548,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // M = workgroups x waves x 2 lane minima per query number at least 4 k (the threshold is then within a few per cent of
         // the k-th smallest sample) and at most 2048 (what the last workgroup's waves hold in registers).
         bool fused = h->opt.dense_fused != 0 && qt == 1 && nqt == 1 && ns_units >= 2ll * kk;
+        const bool tighten = fused && h->opt.dense_tighten != 0;
         if (fused) {
             const int lanes_per_wg = waves8 * 2;
             const int wg_min = ((4 * kk + lanes_per_wg - 1) / lanes_per_wg + 7) / 8 * 8, wg_max = 2048 / lanes_per_wg;
@@ -549,6 +567,12 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         const long long lane_m = (long long)nrb_sample * keep8;
         SQ_TRY(s.sample.reserve(fused ? (size_t)TILE_ROWS * lane_m * 4 : (size_t)nq_pad * ns * 4));
         a.sample_out = s.sample.as<float>();
+        if (fused) {
+            SQ_TRY(s.wave_score.reserve((size_t)n_waves * wave_cap * 4));
+            SQ_TRY(s.hist8.reserve((size_t)I8_HIST_WORDS * 4));
+            a.wave_score = s.wave_score.as<float>();
+            a.hist = s.hist8.as<u32>();
+        }
         int wpb = 2;   // survivor segments per re-rank workgroup (128 threads each)
         if (!cosine && h->opt.dense_rerank_segments > 0 && waves8 % h->opt.dense_rerank_segments == 0 && h->opt.dense_rerank_segments <= 4)
             wpb = h->opt.dense_rerank_segments;
@@ -592,7 +616,14 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                 b.unit_step = 1;
                 b.n_sel = n_units;
                 b.nrb = nrb;
-                Dense8TailArgs ta{h->db, h->ld, d, s.q_al.as<float>(), ldq, nq, s.keys.p, cnt, cap, oflag, cnx, cnq, h->opt.dense_debug};
+                Dense8TailArgs ta{h->db, h->ld, d, s.q_al.as<float>(), ldq, nq, s.keys.p, cnt, cap, oflag, cnx, cnq, h->opt.dense_debug, qn2, kk, tighten ? 1 : 0, nullptr};
+                s.clk8_wgs = 0;
+                if ((h->opt.dense_debug & 8192) && !use_event) {   // (blocking calls only: printed by dense_resolve)
+                    if (const int rc = s.clk8.reserve((size_t)nrb * 64)) return rc;
+                    SQ_HIP(hipMemsetAsync(s.clk8.p, 0, (size_t)nrb * 64, cs));
+                    ta.clk = s.clk8.as<long long>();
+                    s.clk8_wgs = nrb;
+                }
                 if (prof) SQ_HIP(hipEventRecord(s.ev[1], cs));
                 if (const int rc = dense8_body_launch(row8, cosine, b, ta, cs)) return rc;
                 if (prof) {
@@ -603,12 +634,16 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                     DenseFinalizeCos fin{cnt, cap, kk, h->id_base, thr, 0.0, 1, (double*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0};
                     fin.lin = s.par8.as<float2>();
                     fin.ind = ind;
-                    return select_launch_t<K128>(s.keys.as<K128>(), cnt, cap, key_stride, k, nq, s.out_keys.as<K128>(), fin, cs, s.sort_tmp, 8 * stride * kk);
+                    if (tighten) fin.thr2k = a.hist + TILE_ROWS * I8_HIST_BINS;
+                    fin.cnt_shift = I8_CNT_SHIFT;
+                    return select_launch_t<K128>(s.keys.as<K128>(), cnt, cap, key_stride, k, nq, s.out_keys.as<K128>(), fin, cs, s.sort_tmp, 8 * stride * kk, I8_CNT_SHIFT);
                 }
                 DenseFinalizeL2 fin{cnt, cap, kk, h->id_base, thr, qn2, 0.0, 1, (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0};
                 fin.lin = s.par8.as<float2>();
                 fin.ind = ind;
-                return select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(), fin, cs, s.sort_tmp, 8 * stride * kk);
+                if (tighten) fin.thr2k = a.hist + TILE_ROWS * I8_HIST_BINS;
+                fin.cnt_shift = I8_CNT_SHIFT;
+                return select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(), fin, cs, s.sort_tmp, 8 * stride * kk, I8_CNT_SHIFT);
             }
             {
                 auto prep = row8 == 128 ? dense8_prep_queries_kernel<2> : (row8 == 256 ? dense8_prep_queries_kernel<4> : dense8_prep_queries_kernel<8>);
@@ -654,7 +689,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             // everything the captured launches were given by value: shapes, the slot's and the handle's buffers
             u64 key = 0xcbf29ce484222325ull;
             auto mix = [&key](u64 v) { key = (key ^ v) * 0x100000001b3ull; };
-            for (u64 v : {(u64)(fused ? 1 : 0), (u64)lane_m, (u64)nq, (u64)k, (u64)row8, (u64)qt, (u64)nqt, (u64)wpb, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
+            for (u64 v : {(u64)(fused ? 1 : 0), (u64)(tighten ? 1 : 0), (u64)(uintptr_t)s.wave_score.p, (u64)(uintptr_t)s.hist8.p, (u64)lane_m, (u64)nq, (u64)k, (u64)row8, (u64)qt, (u64)nqt, (u64)wpb, (u64)stride, (u64)nrb, (u64)nrb_sample, (u64)ns, (u64)a.nt, (u64)a.nt_from_row, (u64)n, (u64)cap,
                           (u64)h->opt.dense_debug, (u64)h->id_base, (u64)(uintptr_t)st, (u64)(uintptr_t)h->db, (u64)(uintptr_t)centerp,
                           (u64)(uintptr_t)h->scan8.p, (u64)(uintptr_t)h->nrow8.p, (u64)(uintptr_t)s.q8.p, (u64)(uintptr_t)s.par8.p,
                           (u64)(uintptr_t)s.sample.p, (u64)(uintptr_t)s.keys.p, (u64)(uintptr_t)s.wave_out.p, (u64)(uintptr_t)s.wave_cnt.p,
@@ -907,6 +942,22 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
     if (!all_fallback) {
         SQ_HIP(c.use_event ? event_wait(s.ev_done) : stream_wait(st));  // counts and status words are in hs_raw / hs now
         SQ_HIP(hipGetLastError());
+        if (s.clk8_wgs > 0 && (h->opt.dense_debug & 8192)) {   // measurement: where the body kernel's workgroups spent their time (100 MHz clock)
+            std::vector<long long> ck((size_t)s.clk8_wgs * 8);
+            SQ_HIP(hipMemcpy(ck.data(), s.clk8.p, ck.size() * 8, hipMemcpyDeviceToHost));
+            long long t0 = ck[0], tend = 0;
+            for (int w = 0; w < s.clk8_wgs; ++w) t0 = std::min(t0, ck[(size_t)w * 8]), tend = std::max(tend, ck[(size_t)w * 8 + 4]);
+            double sum[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0}, mn[5] = {1e30, 1e30, 1e30, 1e30, 1e30};
+            for (int w = 0; w < s.clk8_wgs; ++w) {
+                const long long* e = &ck[(size_t)w * 8];
+                const double v[5] = {(e[0] - t0) * 0.01, (e[1] - e[0]) * 0.01, (e[2] - e[1]) * 0.01, (e[3] - e[2]) * 0.01, (e[4] - e[3]) * 0.01};
+                for (int j = 0; j < 5; ++j) sum[j] += v[j], mx[j] = std::max(mx[j], v[j]), mn[j] = std::min(mn[j], v[j]);
+            }
+            const char* names[5] = {"start offset", "stream (first wave out)", "wave skew (all waves out)", "thresholds", "re-rank"};
+            fprintf(stderr, "[body clocks] %d workgroups, kernel span %.1f us\n", s.clk8_wgs, (tend - t0) * 0.01);
+            for (int j = 0; j < 5; ++j) fprintf(stderr, "   %-28s min %8.1f  mean %8.1f  max %8.1f us\n", names[j], mn[j], sum[j] / s.clk8_wgs, mx[j]);
+            s.clk8_wgs = 0;
+        }
         if (c.prof) {
             float t1 = 0, t2 = 0;
             SQ_HIP(hipEventElapsedTime(&t1, s.ev[1], s.ev[2]));
@@ -937,7 +988,7 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
             // (... or pass so many rows that the re-rank outweighs the bytes saved: the bf16 filter passes ~50 k of 10 M)
             const bool heavy = 2 * over > nq || cands > (long long)nq * std::max<long long>(24ll * 1024, n / 128);
             h->overflow8 = heavy ? h->overflow8 + 1 : 0;
-            if (h->overflow8 >= 3 && h->opt.dense_int8 < 0) h->use8 = false;
+            if (h->overflow8 >= 3 && h->opt.dense_int8 < 0) h->suspended8 = true;
         }
     }
     // Exact full-keys path, a group of up to 8 queries per pass over the matrix (dense_exact_group_kernel):
@@ -1250,7 +1301,9 @@ static int dense_build_rows(DenseHandle* h, long long row_base) {
 // allocate: neither is an error.
 static int dense8_build(DenseHandle* h) {
     h->use8 = false;
-    if (h->d > I8_MAX_ROW_BYTES || h->n < 65536 || g_opt.dense_int8 == 0) return SQ_OK;
+    h->suspended8 = false;
+    h->overflow8 = 0;
+    if (h->d > I8_MAX_ROW_BYTES || h->n < 65536 || h->opt.dense_int8 == 0) return SQ_OK;
     const bool cosine = h->metric == SQ_METRIC_COSINE;
     const double* nx64 = cosine ? h->cos_nx.as<double>() : nullptr;   // cosine: the copy holds the unit-length rows
     const long long n = h->n;
@@ -1410,7 +1463,7 @@ static int grow_keep(DevBuf& b, size_t used, size_t need) {
 // from all its rows; one that had no copy (too small, or declined) tries when it has doubled since its last attempt.
 static int dense8_append(DenseHandle* h, long long n_old) {
     const long long n = h->n;
-    if (g_opt.dense_int8 == 0 || h->d > I8_MAX_ROW_BYTES) return SQ_OK;
+    if (h->opt.dense_int8 == 0 || h->d > I8_MAX_ROW_BYTES) return SQ_OK;
     if (!h->use8) {
         if (n >= 65536 && n >= 2 * h->n8_built) {
             h->n8_built = n;   // (the attempt counts whether or not the build accepts the data)
@@ -1505,8 +1558,48 @@ static int dense_grow(DenseHandle* h, long long n_new) {
 
 using namespace sq;
 
+static int dense_create_impl(const float* db, int64_t n, int d, int metric, int mem, int64_t id_base,
+                             const std::vector<std::pair<int Options::*, int>>& overrides, sq_handle_t* out);
+
 extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, int mem, int64_t id_base,
                                sq_handle_t* out) {
+    return dense_create_impl(db, n, d, metric, mem, id_base, {}, out);
+}
+
+extern "C" int sq_dense_create_opts(const float* db, int64_t n, int d, int metric, int mem, int64_t id_base,
+                                    const char* const* opt_names, const int64_t* opt_values, int n_opts, sq_handle_t* out) {
+    if (n_opts < 0 || (n_opts > 0 && (!opt_names || !opt_values))) return fail(SQ_ERR_INVALID, "sq_dense_create_opts: bad option arrays");
+    std::vector<std::pair<int Options::*, int>> ov;
+    for (int i = 0; i < n_opts; ++i) {
+        int Options::*f = option_member(opt_names[i]);
+        if (!f) return fail(SQ_ERR_INVALID, "sq_dense_create_opts: unknown option '%s'", opt_names[i] ? opt_names[i] : "(null)");
+        ov.emplace_back(f, (int)opt_values[i]);
+    }
+    return dense_create_impl(db, n, d, metric, mem, id_base, ov, out);
+}
+
+// What an index keeps resident and what its build cost (bench.py's `resident_bytes` / `index_build_ms`).
+extern "C" int sq_dense_info(sq_handle_t hid, int64_t* out, int n_out) {
+    auto* h = static_cast<DenseHandle*>(lookup_handle(hid, H_DENSE));
+    if (!h) return fail(SQ_ERR_INVALID, "sq_dense_info: unknown handle");
+    if (!out || n_out < SQ_DENSE_INFO_FIELDS) return fail(SQ_ERR_INVALID, "sq_dense_info: room for %d values needed", SQ_DENSE_INFO_FIELDS);
+    std::lock_guard<std::mutex> l(h->mu);
+    out[0] = h->n;
+    out[1] = h->d;
+    out[2] = (int64_t)h->n * h->ld * 4;                                  // the float32 rows (the re-rank reads them) ...
+    out[3] = h->owned.p ? 1 : 0;                                          // ... owned by the library (1) or borrowed from the caller (0)
+    out[4] = (int64_t)h->scan.cap;                                        // bfloat16 scan copy
+    out[5] = (int64_t)(h->scan8.cap + h->nrow8.cap);                      // int8 scan copy + its row terms
+    out[6] = (int64_t)(h->norms.cap + h->norms1.cap + h->cos_nx.cap + h->center.cap + h->zeros.cap);   // row statistics
+    out[7] = h->use8 && !h->suspended8 ? 1 : 0;                                             // the int8 first stage is in use
+    out[8] = h->build_us;                                                 // sq_dense_create: wall time of the whole build
+    out[9] = h->build8_us;                                                // ... of which the int8 copy (statistics, clamp choice, copy)
+    return SQ_OK;
+}
+
+static int dense_create_impl(const float* db, int64_t n, int d, int metric, int mem, int64_t id_base,
+                             const std::vector<std::pair<int Options::*, int>>& overrides, sq_handle_t* out) {
+    const auto t_create = std::chrono::steady_clock::now();
     if (!db || !out || n <= 0 || d <= 0) return fail(SQ_ERR_INVALID, "sq_dense_create: bad argument");
     if (metric != SQ_METRIC_L2 && metric != SQ_METRIC_COSINE)
         return fail(SQ_ERR_INVALID, "sq_dense_create: unknown metric %d", metric);
@@ -1523,6 +1616,8 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
     h->d_pad = d_pad;
     h->metric = metric;
     h->id_base = id_base;
+    h->overrides = overrides;   // (create-time choices -- "dense_int8" = 0: no int8 copy -- are the handle's own)
+    h->refresh_options();
     if (hipGetDevice(&h->device) != hipSuccess) {
         delete h;
         return fail(SQ_ERR_HIP, "sq_dense_create: no HIP device");
@@ -1554,7 +1649,7 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
         h->ld = ldo;
     }
     // the filter's origin (L2): the column means (float64 sums over row blocks); rows appended later keep it
-    if (metric == SQ_METRIC_L2 && d_pad <= MAX_DPAD && !g_opt.dense_no_center) {
+    if (metric == SQ_METRIC_L2 && d_pad <= MAX_DPAD && !h->opt.dense_no_center) {
         int rc = h->center.reserve((size_t)d_pad * 4);
         if (rc != SQ_OK) return bail(rc);
         DevBuf colsum;
@@ -1586,9 +1681,14 @@ extern "C" int sq_dense_create(const float* db, int64_t n, int d, int metric, in
         }
         if (rc == SQ_OK && d_pad <= MAX_DPAD) rc = h->scan.reserve((size_t)h->n_pad * d_pad * 2);
         if (rc == SQ_OK) rc = dense_build_rows(h, 0);
+        if (rc == SQ_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(SQ_ERR_HIP, "sq_dense_create: build failed");
+        const auto t8 = std::chrono::steady_clock::now();
         if (rc == SQ_OK) rc = dense8_build(h);
+        if (rc == SQ_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(SQ_ERR_HIP, "sq_dense_create: int8 build failed");
         if (rc != SQ_OK) return bail(rc);
+        h->build8_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t8).count();
     }
+    h->build_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_create).count();
     *out = register_handle(h);
     return SQ_OK;
 }

@@ -524,6 +524,16 @@ struct RerankLds {
     u32* base;
     u32* fill;
     float* stage;   // cosine, wide rows: one row stage of 32 * RERANK_STAGE_STRIDE floats per wave of the workgroup (or null)
+    // Second-level filter (the int8 full pass's tail, sq_dense_i8.hpp "the tightened threshold"): an entry takes part only
+    // if its score -- the smallest filter score of its rows, stored beside it -- is at or below its query's thr2; the
+    // entries that pass are first compacted into `list` (all of them idle lanes otherwise: a few dozen of a few thousand).
+    const float* scores = nullptr;   // global, parallel to wave_out (or null: every entry takes part)
+    const float* thr2 = nullptr;     // LDS [group_q]
+    uint2* list = nullptr;           // LDS [list_cap]
+    u32* npass = nullptr;            // LDS counter
+    u32 list_cap = 0;
+    int cnt_shift = 0;               // the per-query candidate counters are 1 << cnt_shift words apart
+    const u32* seg_cnt = nullptr;    // LDS [waves_per_block]: the segments' entry counts (the fused tail: no global round trip; first query tile 0)
 };
 
 template <class K, bool COSINE>
@@ -541,7 +551,7 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
     // wider rows (66 KB at d = 512: two workgroups per CU) and larger groups read them through the cache
     const bool q_in_lds = group_q == 32 && ldq <= 156;
     if (w0 >= n_waves) return;
-    const u32 q0 = wave_cnt[2 * w0 + 1] * 32u;  // first query of the group (the same for all segments of the block)
+    const u32 q0 = L.seg_cnt ? 0u : wave_cnt[2 * w0 + 1] * 32u;  // first query of the group (the same for all segments of the block)
     if (threadIdx.x < RERANK_MAX_GROUP) {
         s_hist[threadIdx.x] = 0;
         s_fill[threadIdx.x] = 0;
@@ -556,7 +566,7 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
     for (int wi = 0; wi < MAXSEG; ++wi) {
         u32 c = 0;
         if (wi < waves_per_block && w0 + wi < n_waves) {
-            c = wave_cnt[2 * (w0 + wi)];
+            c = L.seg_cnt ? L.seg_cnt[wi] : wave_cnt[2 * (w0 + wi)];
             if (c > wave_cap) {
                 if (threadIdx.x == 0) atomicOr(overflow, 1u);
                 c = wave_cap;
@@ -572,15 +582,57 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
         return wave_out + (w0 + wi) * wave_cap + (g - off[wi]);
     };
     if (total == 0) return;  // uniform: every thread read the same counts
-    for (u32 g = threadIdx.x; g < total; g += blockDim.x) {
-        const u32 ey = entry_at(g)->y;
-        atomicAdd(&s_hist[ey & 0xffffu], (u32)__popc(ey >> 16));
+    const bool filtered = L.scores != nullptr;
+    auto passes = [&](u32 g, const uint2& ent) __attribute__((always_inline)) -> bool {
+        const uint2* ep = entry_at(g);
+        return L.scores[ep - wave_out] <= L.thr2[ent.y & 0xffffu];   // (an always-candidate row's -inf passes; NaN never)
+    };
+    if (filtered && threadIdx.x == 0) *L.npass = 0u;
+    if (filtered) __syncthreads();
+    if (filtered) {
+        // (four entries and their scores per thread and round trip: the tail is a chain of dependent memory latencies)
+        constexpr int PB = 4;
+        for (u32 g0 = threadIdx.x; g0 < total; g0 += blockDim.x * PB) {
+            uint2 ent[PB];
+            float sc[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const u32 g = g0 + (u32)j * blockDim.x;
+                const uint2* ep = entry_at(g < total ? g : 0u);
+                ent[j] = *ep;
+                sc[j] = L.scores[ep - wave_out];
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const u32 g = g0 + (u32)j * blockDim.x;
+                if (g < total && sc[j] <= L.thr2[ent[j].y & 0xffffu]) {   // (an always-candidate row's -inf passes; NaN never)
+                    const u32 slot = atomicAdd(L.npass, 1u);
+                    if (slot < L.list_cap) L.list[slot] = ent[j];
+                    atomicAdd(&s_hist[ent[j].y & 0xffffu], (u32)__popc(ent[j].y >> 16));
+                }
+            }
+        }
+    } else {
+        for (u32 g = threadIdx.x; g < total; g += blockDim.x) {
+            const u32 ey = entry_at(g)->y;
+            atomicAdd(&s_hist[ey & 0xffffu], (u32)__popc(ey >> 16));
+        }
     }
     __syncthreads();
+    // compact: entries 0 .. n_ent of the list; more passed than the list holds: all entries again, the others masked out
+    const bool compact = filtered && *L.npass <= L.list_cap;
+    const u32 n_ent = compact ? *L.npass : total;
+    if (n_ent == 0) return;
+    auto load_entry = [&](u32 e) __attribute__((always_inline)) -> uint2 {
+        if (compact) return L.list[e];
+        uint2 ent = *entry_at(e);
+        if (filtered && !passes(e, ent)) ent.y &= 0xffffu;
+        return ent;
+    };
     if (threadIdx.x < group_q) {
         const u32 hcount = s_hist[threadIdx.x];
         // (debug 32 / 64: measurement ablations -- no reservation / rows from a cache-resident range; results are garbage)
-        s_base[threadIdx.x] = (hcount && !(debug & 32)) ? atomicAdd(&cnt[q0 + threadIdx.x], hcount) : 0u;
+        s_base[threadIdx.x] = (hcount && !(debug & 32)) ? atomicAdd(&cnt[(long long)(q0 + threadIdx.x) << L.cnt_shift], hcount) : 0u;
     }
     if (q_in_lds) {
         const int vpr = ldq / 4;  // 16-byte vectors per query row (ldq % 4 == 0, rows 16-byte aligned)
@@ -609,10 +661,10 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
             float* stage = L.stage + wv * (32 * RERANK_STAGE_STRIDE);
             {
                 const u32 per_round = blockDim.x / LPR;
-                for (u32 e0 = 0; e0 < total; e0 += per_round) {   // uniform trip count: the waves work in lockstep below
+                for (u32 e0 = 0; e0 < n_ent; e0 += per_round) {   // uniform trip count: the waves work in lockstep below
                     const u32 e = e0 + threadIdx.x / LPR;
-                    const bool live = e < total;
-                    const uint2 ent = live ? *entry_at(e) : make_uint2(0u, 0u);
+                    const bool live = e < n_ent;
+                    const uint2 ent = live ? load_entry(e) : make_uint2(0u, 0u);
                     const u32 ql = ent.y & 0xffffu;
                     const u32 qg = q0 + ql;
                     const float* qrow = q_in_lds ? s_qrows + ql * ldl : q_al + (long long)qg * ldq;
@@ -663,8 +715,8 @@ __device__ __forceinline__ void rerank_block(const float* __restrict__ db, long 
         }
     }
     {
-        for (u32 e = threadIdx.x / LPR; e < total; e += blockDim.x / LPR) {
-            const uint2 ent = *entry_at(e);
+        for (u32 e = threadIdx.x / LPR; e < n_ent; e += blockDim.x / LPR) {
+            const uint2 ent = load_entry(e);
             const u32 ql = ent.y & 0xffffu;
             const u32 qg = q0 + ql;
             const float* qrow = q_in_lds ? s_qrows + ql * ldl : q_al + (long long)qg * ldq;
@@ -905,6 +957,8 @@ struct DenseFinalizeL2 {
     ExactGroup sel = ExactGroup{{0, 0, 0, 0, 0, 0, 0, 0}, 0};  // count > 0: query ql of the launch is sel.idx[ql], its count cnt[ql]
     const int* qmap = nullptr;  // the middle tier: query ql of the launch is qmap[ql]; cnt, thr and qn2 are the launch's own arrays
     const float2* lin = nullptr;  // the int8 filter: a non-candidate (s~ > T') has s > T' - lin[q].y (its slack is linear in |q|, not beta |q|^2)
+    const u32* thr2k = nullptr;   // the int8 full pass's tightened thresholds: ordered keys, the largest any workgroup applied (0: none did); 1 << cnt_shift words apart
+    int cnt_shift = 0;            // cnt (and thr2k) entries are 1 << cnt_shift words apart (the fused int8 call: a cache line each)
     const DenseCallPtrs* ind = nullptr;  // captured call graph: the outputs of THIS launch
     __device__ __forceinline__ void operator()(int ql, const u64* sorted, int k) const {
         const int q = qmap ? qmap[ql] : (sel.count ? sel.idx[ql] : q0 + ql);
@@ -919,13 +973,14 @@ struct DenseFinalizeL2 {
         }
         if (threadIdx.x == 0) {
             u32 st = 0;
-            const u32 c = cnt[(sel.count || qmap) ? ql : q];
+            const u32 c = cnt[(long long)((sel.count || qmap) ? ql : q) << cnt_shift];
             if (certify) {
                 if (c > cap || (overflow && *overflow)) st |= 1u;
                 if (c < (u32)kk) st |= 4u;
                 if (st == 0 && certify == 1) {
                     const double dk = (double)unordered_f32((u32)(sorted[kk - 1] >> 32));
-                    const double t = (double)thr[qa];
+                    const u32 t2k = thr2k ? thr2k[(long long)qa << cnt_shift] : 0u;
+                    const double t = t2k ? (double)unordered_f32(t2k) : (double)thr[qa];
                     const double lo2 = t + qn2[qa] * (1.0 - beta) - (lin ? (double)lin[qa].y : 0.0);  // smallest squared distance a non-candidate can have
                     const double bound = lo2 > 0.0 ? sqrt(lo2) * (1.0 - 1e-6) : 0.0;
                     if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;
@@ -953,6 +1008,8 @@ struct DenseFinalizeCos {
     int q0;
     ExactGroup sel = ExactGroup{{0, 0, 0, 0, 0, 0, 0, 0}, 0};
     const float2* lin = nullptr;          // the int8 filter: the query's own slack lin[q].y instead of `eps`
+    const u32* thr2k = nullptr;           // as DenseFinalizeL2::thr2k
+    int cnt_shift = 0;
     const DenseCallPtrs* ind = nullptr;   // captured call graph: the outputs of THIS launch
     __device__ __forceinline__ void operator()(int ql, const K128* sorted, int k) const {
         const int q = sel.count ? sel.idx[ql] : q0 + ql;
@@ -966,13 +1023,14 @@ struct DenseFinalizeCos {
         }
         if (threadIdx.x == 0) {
             u32 st = 0;
-            const u32 c = cnt[sel.count ? ql : q];
+            const u32 c = cnt[(long long)(sel.count ? ql : q) << cnt_shift];
             if (certify) {
                 if (c > cap || (overflow && *overflow)) st |= 1u;
                 if (c < (u32)kk) st |= 4u;
                 if (st == 0 && certify == 1) {
                     const double dk = unordered_f64(sorted[kk - 1].hi);
-                    const double t = (double)thr[q];  // threshold on -sim~
+                    const u32 t2k = thr2k ? thr2k[(long long)q << cnt_shift] : 0u;
+                    const double t = t2k ? (double)unordered_f32(t2k) : (double)thr[q];  // threshold on -sim~
                     // non-candidates: -sim~ > t  =>  sim < -t + eps  =>  dist > 2 acos(min(1,-t+eps))/pi
                     double smax = -t + (lin ? (double)lin[q].y : eps);
                     smax = smax > 1.0 ? 1.0 : (smax < -1.0 ? -1.0 : smax);

@@ -456,6 +456,9 @@ struct Dense8ScanArgs {
     int nqt;                    // groups
     int plane_rows;             // rows of one query plane: qs8 is [2][plane_rows][128]
     int debug;                  // measurement ablations ("dense_debug"; results are garbage): 1024 = no score epilogue
+    // the tightened threshold (dense8_body_kernel): per entry its smallest score, per query a histogram of those
+    float* wave_score;          // parallel to wave_out
+    u32* hist;                  // [32][I8_HIST_BINS] + [32] ordered keys of the largest tightened threshold applied
 };
 
 // LDS chunk position (16-byte units inside a row) of source chunk c of row r: the XOR swizzle that makes the fragment reads
@@ -470,16 +473,57 @@ __device__ __forceinline__ int i8_swz(int c, int r) {
 // What a wave does with the scores of a tile: I8_EMIT compares them with the query's threshold and appends survivors to its
 // segment; I8_SAMPLE writes the minimum of each lane's 16 rows to the sample matrix (the six-launch chain's sample pass);
 // I8_LANEMIN keeps ONE running minimum per lane over the whole pass (the fused head, dense8_head_kernel).
-enum { I8_EMIT = 0, I8_SAMPLE = 1, I8_LANEMIN = 2 };
+// I8_EMIT_H is I8_EMIT that also keeps each entry's smallest score and counts it in the query's histogram (below).
+enum { I8_EMIT = 0, I8_SAMPLE = 1, I8_LANEMIN = 2, I8_EMIT_H = 3 };
+
+// The tightened threshold.  The sampled threshold T' = T_s + 2 e_q is the k-th score of a SAMPLE plus the slack: at a
+// stride of 14 units it lets ~5 k rows per query through at 10 M x 128 where ~300 lie below the k-th score of ALL rows plus the
+// same slack -- and every one of them is a 512-byte gather for the re-rank.  The full pass knows better by the time it ends:
+// every entry it emits adds its smallest score m to a per-query histogram of I8_HIST_BINS bins of width w = e_q / 2 below T'
+// (bin j: T' - (j + 1) w < m <= T' - j w, the last bin open below; one agent-scope atomic without return per entry, ~60 per
+// wave and pass).  A workgroup whose waves have drained the stream reads the histogram as it stands: if the bins j and
+// beyond hold k entries, k different rows score at most T' - j w =: T_8, so the true k-th score is at most T_8 + e_q and a
+// row scoring above T'' = T_8 + 2 e_q is not among the k nearest: the tail re-ranks only entries with m <= T''.  The
+// histogram a workgroup sees may lack what the others have not emitted yet -- fewer counts only make T_8 larger: every
+// workgroup's T'' is valid on its own, and the select certifies against the largest one applied (kept as an ordered key beside
+// the histogram).  Always-candidate rows (score -inf) are not counted (their true score is unknown) and always pass.
+// With the second level in place the sample only has to keep the first-level entries inside the segments: it can be
+// several times sparser (host: the fused call's stride).
+static constexpr int I8_HIST_BINS = 64;
+// Per-query words every workgroup of a call updates at about the same time -- the candidate counters the re-rank reserves
+// its key ranges on and the tightened-threshold keys -- sit a cache line apart: 256 workgroups x 32 queries of atomics on ONE
+// line serialise in one memory channel (the tail's re-rank phase read 37 us on a 1.25 M-row shard, where every workgroup
+// arrives at once, against 9 us of gathers).
+static constexpr int I8_CNT_SHIFT = 5;
+static constexpr int I8_HIST_WORDS = TILE_ROWS * I8_HIST_BINS + (TILE_ROWS << I8_CNT_SHIFT);   // u32 words per call slot
+
+// A wave moves its share of the workgroup's LDS histogram (TILE_ROWS * I8_HIST_BINS words / WAVES) to the global one: the
+// bins are taken with an exchange, so entries the other waves add meanwhile are simply moved by the next flush.  One
+// global atomic per non-empty bin: a hot bin of the global histogram is added to once per workgroup and flush, not once
+// per entry (per-entry global atomics on the few bins just under T' made the pass 0.30 instead of 0.23 ms: same-address
+// atomics serialise, and the ring's counted vmcnt waits queue behind them).
+template <int WAVES>
+__device__ __forceinline__ void dense8_hist_flush(u32* lds_hist, u32* __restrict__ ghist) {
+    constexpr int PER = TILE_ROWS * I8_HIST_BINS / WAVES;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int i = 0; i < PER / 64; ++i) {
+        const int b = wave * PER + i * 64 + lane;
+        const u32 v = __hip_atomic_exchange(lds_hist + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v) __hip_atomic_fetch_add(ghist + b, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // The stream of one wave: its share of the launch's ring units through its private LDS ring, the MFMAs of the unit's tiles
 // against the query planes in registers, the score epilogue.  `wcount`: survivors appended (I8_EMIT); `smin`: the lane's
 // running minimum (I8_LANEMIN).
 template <int KS, int MODE>
 __device__ __forceinline__ void dense8_stream(const Dense8ScanArgs& a, unsigned char* smem, const i32x4 (&bq)[KS], const i32x4 (&bl)[KS],
-                                              float unit_lo, float thr_l, u32& wcount, float& smin) {
+                                              float unit_lo, float thr_l, u32& wcount, float& smin, u32* lds_ticket,
+                                              float inv_w_l = 0.f, u32* lds_hist = nullptr) {
     using G = I8Geom<KS>;
-    constexpr bool SAMPLE = MODE != I8_EMIT;
+    constexpr bool SAMPLE = MODE == I8_SAMPLE || MODE == I8_LANEMIN;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r31 = lane & 31, h = lane >> 5;
@@ -489,8 +533,23 @@ __device__ __forceinline__ void dense8_stream(const Dense8ScanArgs& a, unsigned 
     const long long wave_id = (long long)blockIdx.x * G::WAVES + wave;
     const long long nwaves = (long long)a.nrb * G::WAVES;
     uint2* wout = a.wave_out + wave_id * a.wave_cap;
+    float* wsc = MODE == I8_EMIT_H ? a.wave_score + wave_id * a.wave_cap : nullptr;
+    u32* hist_l = MODE == I8_EMIT_H ? lds_hist + r31 * I8_HIST_BINS : nullptr;   // (the workgroup's LDS copy: dense8_hist_flush)
 
-    const long long my_units = wave_id < a.n_sel ? (a.n_sel - wave_id + nwaves - 1) / nwaves : 0;
+    // Units are handed out by a ticket counter of the WORKGROUP (LDS, zeroed by the caller before a barrier): ticket t is unit
+    // (first wave of the workgroup + t % WAVES) + (t / WAVES) * nwaves of the launch -- the same units the workgroup's waves
+    // would own under a fixed split (wave w: w + it * nwaves), but a wave that runs ahead takes the next one instead of
+    // waiting at the end: with the fixed split the eight waves of a workgroup left the stream 20 - 48 us apart (of 200) and
+    // the tail -- and the CU -- waited for the last.
+    const long long wg_first = (long long)blockIdx.x * G::WAVES;
+    auto take_unit = [&]() __attribute__((always_inline)) -> long long {
+        u32 t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(lds_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        t = (u32)__builtin_amdgcn_readfirstlane((int)t);
+        const long long u = wg_first + (long long)(t % G::WAVES) + (long long)(t / G::WAVES) * nwaves;
+        return u < a.n_sel ? u : -1ll;   // (u grows with t: the first ticket beyond the launch's units ends the wave's stream)
+    };
+    const long long my_units = wave_id < a.n_sel ? (a.n_sel - wave_id + nwaves - 1) / nwaves : 0;   // (the fixed split's share: sizes the flush period)
     // DMA piece j: bytes 1024 j .. 1024 j + 1023 of the unit's LDS image; lane -> 16 bytes at (row, chunk position), read
     // from the row's source chunk swz(position)
     u32 voff[G::PIECES];
@@ -501,10 +560,18 @@ __device__ __forceinline__ void dense8_stream(const Dense8ScanArgs& a, unsigned 
         voff[j] = (u32)(r * G::ROW_BYTES + i8_swz<KS>(cpos, r) * 16);
     }
     const u32 voff_n = (u32)lane * 4u;
-    long long issued = 0;
+    static_assert(G::NSTAGE == 2, "two ring slots: the units in flight are sel_even / sel_odd");
+    long long issued = 0, sel_even = -1, sel_odd = -1;   // the selected-unit index in ring slot 0 / 1
+    bool more = true;
     auto issue_next = [&]() __attribute__((always_inline)) {
-        if (issued >= my_units) return;
-        const long long unit_idx = (wave_id + issued * nwaves) * a.unit_step;
+        if (!more) return;
+        const long long sel = take_unit();
+        if (sel < 0) {
+            more = false;
+            return;
+        }
+        if (issued & 1) sel_odd = sel; else sel_even = sel;
+        const long long unit_idx = sel * a.unit_step;
         const long long row0 = unit_idx * G::UNIT_ROWS;
         const u32 dst = ring_base + (u32)(issued % G::NSTAGE) * G::SLOT_BYTES;
         const unsigned char* base = reinterpret_cast<const unsigned char*>(a.scan8) + row0 * G::ROW_BYTES;
@@ -519,9 +586,14 @@ __device__ __forceinline__ void dense8_stream(const Dense8ScanArgs& a, unsigned 
         ++issued;
     };
     for (int p = 0; p < G::NSTAGE; ++p) issue_next();
+    // I8_EMIT_H: this wave's share of the workgroup's histogram goes to the global one eight times per pass (and once more
+    // from the tail): a workgroup that finishes early then finds at least 7/8 of everybody's entries
+    const int flush_every = (int)(my_units >> 3) > 0 ? (int)(my_units >> 3) : 1;
+    int to_flush = flush_every;
 
-    for (long long it = 0; it < my_units; ++it) {
-        const long long unit_idx = (wave_id + it * nwaves) * a.unit_step;
+    for (long long it = 0; it < issued; ++it) {   // (`issued` grows inside: issue_next)
+        const long long sel = (it & 1) ? sel_odd : sel_even;
+        const long long unit_idx = sel * a.unit_step;
         const long long row0 = unit_idx * G::UNIT_ROWS;
         wait_units_in_flight<G::NSTAGE, G::PIECES + 1>((int)(issued - it - 1));
         const unsigned char* sl = ring_ptr + (it % G::NSTAGE) * G::SLOT_BYTES;
@@ -584,7 +656,6 @@ __device__ __forceinline__ void dense8_stream(const Dense8ScanArgs& a, unsigned 
             if constexpr (MODE == I8_LANEMIN) {
                 smin = fminf(smin, m);
             } else if constexpr (MODE == I8_SAMPLE) {
-                const long long sel = wave_id + it * nwaves;
                 a.sample_out[(long long)r31 * a.ns + sel * G::SAMPLES_PER_UNIT + t * 2 + h] = m;
             } else {
                 const u64 hit = __ballot(m <= thr_l);
@@ -595,10 +666,25 @@ __device__ __forceinline__ void dense8_stream(const Dense8ScanArgs& a, unsigned 
                     const u64 bal = __ballot(mask != 0);
                     if (mask) {
                         const u32 pos = wcount + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                        if (pos < a.wave_cap) wout[pos] = make_uint2((u32)(row0 + 32 * t + 4 * h), (mask << 16) | (u32)r31);
+                        if (pos < a.wave_cap) {
+                            wout[pos] = make_uint2((u32)(row0 + 32 * t + 4 * h), (mask << 16) | (u32)r31);
+                            if constexpr (MODE == I8_EMIT_H) wsc[pos] = m;
+                        }
+                        if constexpr (MODE == I8_EMIT_H) {
+                            if (m > -__builtin_inff()) {
+                                const int bin = min((int)((thr_l - m) * inv_w_l), I8_HIST_BINS - 1);   // (m <= thr_l: never negative)
+                                __hip_atomic_fetch_add(hist_l + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
                     }
                     wcount += (u32)__popcll(bal);
                 }
+            }
+        }
+        if constexpr (MODE == I8_EMIT_H) {
+            if (--to_flush == 0) {
+                to_flush = flush_every;
+                dense8_hist_flush<G::WAVES>(lds_hist, a.hist);
             }
         }
     }
@@ -633,7 +719,10 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
     asm volatile("" : "+v"(unit_lo), "+v"(thr_l));
     u32 wcount = 0;
     float smin = 0.f;
-    dense8_stream<KS, SAMPLE ? I8_SAMPLE : I8_EMIT>(a, smem, bq, bl, unit_lo, thr_l, wcount, smin);
+    __shared__ u32 s_unit_ticket;
+    if (threadIdx.x == 0) s_unit_ticket = 0u;
+    __syncthreads();
+    dense8_stream<KS, SAMPLE ? I8_SAMPLE : I8_EMIT>(a, smem, bq, bl, unit_lo, thr_l, wcount, smin, &s_unit_ticket);
     if constexpr (!SAMPLE) {
         if (lane == 0) {
             const long long wave_id = (long long)blockIdx.x * G::WAVES + wave;
@@ -747,7 +836,8 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
     __shared__ float2 s_par[TILE_ROWS];
     __shared__ double s_qn2[TILE_ROWS];
     __shared__ float s_lm[TILE_ROWS][16];
-    __shared__ u32 s_ticket;
+    __shared__ u32 s_ticket, s_unit_ticket;
+    if (threadIdx.x == 0) s_unit_ticket = 0u;   // (the barriers of the query prep below come before its first use)
     const Dense8ScanArgs& a = ha.s;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -771,7 +861,7 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
             if ((lane & 15) == 0) {
                 const_cast<float2*>(a.par)[qi] = pr;
                 ha.qn2[qi] = Q;
-                ha.cnt[qi] = 0u;
+                ha.cnt[qi << I8_CNT_SHIFT] = 0u;
                 if (qi == 0) ha.oflag[0] = 0u;
             }
             if (qi < ha.nq)
@@ -787,13 +877,14 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
         signed char* gp = const_cast<signed char*>(a.qs8);
         for (int i = threadIdx.x; i < 2 * TILE_ROWS * G::ROW_BYTES / 16; i += G::WAVES * 64)
             reinterpret_cast<uint4*>(gp)[i] = reinterpret_cast<const uint4*>(planes)[i];
+        for (int i = threadIdx.x; i < I8_HIST_WORDS; i += G::WAVES * 64) a.hist[i] = 0u;   // the body's histogram and threshold keys
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();   // the planes are in registers (and on their way to the body): the LDS is the ring's from here
     // ---- the sample pass: one running minimum per lane
     u32 wcount = 0;
     float smin = __builtin_inff();
-    if (!(a.debug & 4096)) dense8_stream<KS, I8_LANEMIN>(a, smem, bq, bl, unit_lo, 0.f, wcount, smin);   // (4096: measurement, no sample pass)
+    if (!(a.debug & 4096)) dense8_stream<KS, I8_LANEMIN>(a, smem, bq, bl, unit_lo, 0.f, wcount, smin, &s_unit_ticket);   // (4096: measurement, no sample pass)
     // ---- the workgroup's VB minima per query, sorted (sixteen lanes per query: a bitonic network over shuffles); only the
     // `keep` smallest leave.  The k best minima of a call fall on a workgroup k / workgroups at a time (Poisson): four or
     // eight per workgroup lose next to nothing, and the last workgroup's selection is over keep / VB as many values.
@@ -878,30 +969,63 @@ struct Dense8TailArgs {
     const double* nx64;
     const double* nq64;
     int debug;
+    const double* qn2;          // |q''|^2 (Dense8ThrPost)
+    int kk;
+    int tighten;                // 0: the tail re-ranks every entry (measurement)
+    long long* clk;             // measurement ("dense_debug" & 8192): per workgroup, wall_clock64 at entry / first wave out of the stream / all waves out / thresholds done / tail done
 };
 static constexpr int I8_TAIL_QROWS_BYTES = 32 * (156 + 4) * 4;   // rerank_block stages the query tile for ldq <= 156
-static constexpr int I8_TAIL_LDS_BYTES = I8_TAIL_QROWS_BYTES + 3 * RERANK_MAX_GROUP * 4 + 8 * 32 * RERANK_STAGE_STRIDE * 4;
+static constexpr int I8_TAIL_LIST = 2048;                         // passing entries a workgroup compacts (more: uncompacted walk)
+static constexpr int I8_TAIL_RERANK_BYTES = I8_TAIL_QROWS_BYTES + 3 * RERANK_MAX_GROUP * 4 + 8 * 32 * RERANK_STAGE_STRIDE * 4;
+static constexpr int I8_TAIL_LDS_BYTES = I8_TAIL_RERANK_BYTES + I8_TAIL_LIST * 8 + TILE_ROWS * 4 + 16;
 
 template <int KS, bool COSINE>
 __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dense8_body_kernel(Dense8ScanArgs a, Dense8TailArgs ta) {
     using G = I8Geom<KS>;
     static_assert(I8_TAIL_LDS_BYTES <= G::WAVES * G::NSTAGE * G::SLOT_BYTES, "the re-rank works in the ring's LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ u32 s_hist8[TILE_ROWS * I8_HIST_BINS];
+    __shared__ u32 s_wcnt[G::WAVES];
+    __shared__ u32 s_unit_ticket;
+    // what the tail needs of the call's per-query state, fetched while nothing waits for it
+    __shared__ float s_thr1[TILE_ROWS], s_eq[TILE_ROWS];
+    __shared__ double s_qn2b[TILE_ROWS];
+    __shared__ float2 s_parb[TILE_ROWS];
+    if (threadIdx.x == 0) s_unit_ticket = 0u;
+    if (threadIdx.x < TILE_ROWS) {
+        s_thr1[threadIdx.x] = a.thr[threadIdx.x];
+        s_parb[threadIdx.x] = a.par[threadIdx.x];
+        s_eq[threadIdx.x] = a.par[threadIdx.x].y;
+        s_qn2b[threadIdx.x] = ta.qn2[threadIdx.x];
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r31 = lane & 31;
+    for (int i = threadIdx.x; i < TILE_ROWS * I8_HIST_BINS; i += G::WAVES * 64) s_hist8[i] = 0u;
+    long long* clk = ta.clk ? ta.clk + (long long)blockIdx.x * 8 : nullptr;
+    if (clk && threadIdx.x == 0) {
+        clk[0] = (long long)wall_clock64();
+        clk[1] = 0x7fffffffffffffffll;
+    }
+    __syncthreads();
     i32x4 bq[KS], bl[KS];
     dense8_load_planes<KS>(a.qs8, bq, bl);
     float unit_lo = a.par[r31].x * 0.00390625f;   // Dx Dq / 256, exact
     float thr_l = a.thr[r31];
-    asm volatile("" : "+v"(unit_lo), "+v"(thr_l));
+    // histogram bins of e_q / 2 (no usable e_q: everything in bin 0, nothing is tightened)
+    const float eq_l = a.par[r31].y;
+    float inv_w_l = (eq_l > 0.f && eq_l < __builtin_inff()) ? 2.f / eq_l : 0.f;
+    if (!(inv_w_l < 3.0e38f)) inv_w_l = 0.f;
+    asm volatile("" : "+v"(unit_lo), "+v"(thr_l), "+v"(inv_w_l));
     u32 wcount = 0;
     float smin = 0.f;
-    dense8_stream<KS, I8_EMIT>(a, smem, bq, bl, unit_lo, thr_l, wcount, smin);
+    dense8_stream<KS, I8_EMIT_H>(a, smem, bq, bl, unit_lo, thr_l, wcount, smin, &s_unit_ticket, inv_w_l, s_hist8);
     const long long w0 = (long long)blockIdx.x * G::WAVES;
     if (lane == 0) {
         a.wave_cnt[2 * (w0 + wave)] = wcount;
         a.wave_cnt[2 * (w0 + wave) + 1] = 0u;
+        s_wcnt[wave] = wcount;
+        if (clk) atomicMin((unsigned long long*)(clk + 1), (unsigned long long)wall_clock64());
     }
     // ---- the tail: this workgroup's own survivor segments, re-ranked in the reference arithmetic from the original rows
     // (workgroup scope: the segments are written and read on this CU -- an agent-scope fence would write back the L2)
@@ -909,14 +1033,94 @@ __global__ __launch_bounds__(I8Geom<KS>::WAVES * 64, KS == 16 ? 1 : 2) void dens
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();    // every wave has left the ring and its stores have landed
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (clk && threadIdx.x == 0) clk[2] = (long long)wall_clock64();
     float* fl = reinterpret_cast<float*>(smem);
     u32* su = reinterpret_cast<u32*>(smem + I8_TAIL_QROWS_BYTES);
-    const RerankLds L{fl, su, su + RERANK_MAX_GROUP, su + 2 * RERANK_MAX_GROUP,
-                      COSINE ? reinterpret_cast<float*>(smem + I8_TAIL_QROWS_BYTES + 3 * RERANK_MAX_GROUP * 4) : nullptr};
+    RerankLds L{fl, su, su + RERANK_MAX_GROUP, su + 2 * RERANK_MAX_GROUP,
+                COSINE ? reinterpret_cast<float*>(smem + I8_TAIL_QROWS_BYTES + 3 * RERANK_MAX_GROUP * 4) : nullptr};
+    // ---- the tightened thresholds of this workgroup (I8_EMIT_H above): a wave takes four queries at a time, lane = bin
+    {
+        uint2* s_list = reinterpret_cast<uint2*>(smem + I8_TAIL_RERANK_BYTES);
+        float* s_thr2 = reinterpret_cast<float*>(smem + I8_TAIL_RERANK_BYTES + I8_TAIL_LIST * 8);
+        u32* s_npass = reinterpret_cast<u32*>(s_thr2 + TILE_ROWS);
+        static_assert(I8_HIST_BINS == 64, "one lane per bin");
+        bool any = false;
+#pragma unroll
+        for (int wi = 0; wi < G::WAVES; ++wi) any = any || s_wcnt[wi] != 0u;
+        const Dense8ThrPost post{s_parb, s_qn2b};
+        // (the tail is a chain of dependent round trips on a memory system the other workgroups keep saturated: the
+        // histograms of a wave's queries are fetched together, and the workgroup's own unflushed counts are added from LDS)
+        constexpr int NQW = TILE_ROWS / G::WAVES;   // queries per wave
+        u32 hc[NQW];
+        if (ta.tighten && any) {
+#pragma unroll
+            for (int j = 0; j < NQW; ++j) {
+                const int qi = (j >> 2) * 4 * G::WAVES + wave * 4 + (j & 3);
+                hc[j] = __hip_atomic_load(a.hist + qi * I8_HIST_BINS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int j = 0; j < NQW; ++j) {
+                const int qi = (j >> 2) * 4 * G::WAVES + wave * 4 + (j & 3);
+                hc[j] += s_hist8[qi * I8_HIST_BINS + lane];
+            }
+        }
+#pragma unroll
+        for (int rnd = 0; rnd < TILE_ROWS / (4 * G::WAVES); ++rnd) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int qi = rnd * 4 * G::WAVES + wave * 4 + j;
+                const float t1 = s_thr1[qi];
+                float t2 = t1;
+                if (ta.tighten && any && qi < ta.nq && t1 < __builtin_inff() && t1 > -__builtin_inff()) {
+                    u32 c = hc[rnd * 4 + j];
+                    // suffix sums: entries in bins lane .. 63
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const u32 up = (u32)__shfl_down((int)c, o);
+                        c += lane + o < 64 ? up : 0u;
+                    }
+                    const u64 reach = __ballot(c >= (u32)ta.kk);
+                    const float eq = s_eq[qi];
+                    if (reach != 0ull && eq > 0.f && eq < __builtin_inff()) {
+                        const int jb = 63 - __clzll((long long)reach);   // the highest bin with k entries at or beyond it
+                        const float inv_w = 2.f / eq;                   // as the stream computed it
+                        if (inv_w < 3.0e38f) {
+                            // an entry of bin jb has fl(fl(T' - m) inv_w) >= jb: m <= T' - (jb / inv_w)(1 - 2^-22)
+                            const double t8 = (double)t1 - (double)jb / (double)inv_w * (1.0 - 1e-6);
+                            float t8f = (float)t8;
+                            if ((double)t8f < t8) t8f = __uint_as_float(__float_as_uint(t8f) + (t8f >= 0.f ? 1 : -1));
+                            const float cand = post(qi, t8f);
+                            if (cand < t2) t2 = cand;
+                        }
+                    }
+                    if (lane == 0) atomicMax(a.hist + TILE_ROWS * I8_HIST_BINS + (qi << I8_CNT_SHIFT), ordered_f32(t2));
+                }
+                if (lane == 0) s_thr2[qi] = t2;
+            }
+        }
+        if (ta.tighten) {
+            L.scores = a.wave_score;
+            L.thr2 = s_thr2;
+            L.list = s_list;
+            L.npass = s_npass;
+            L.list_cap = I8_TAIL_LIST;
+        }
+        L.seg_cnt = s_wcnt;
+        L.cnt_shift = I8_CNT_SHIFT;
+        __syncthreads();
+        if (clk && threadIdx.x == 0) clk[3] = (long long)wall_clock64();
+        // what the waves counted since their last flush, for the workgroups still at work (nobody here waits for it)
+        if (ta.tighten) dense8_hist_flush<G::WAVES>(s_hist8, a.hist);
+    }
     using K = typename std::conditional<COSINE, K128, u64>::type;
     rerank_block<K, COSINE>(ta.db, ta.ld, ta.d, ta.q_al, ta.ldq, ta.nq, TILE_ROWS, a.wave_out, a.wave_cnt, a.wave_cap,
                             (long long)a.nrb * G::WAVES, G::WAVES, static_cast<K*>(ta.keys), ta.cnt, ta.cap, ta.overflow, ta.nx64,
                             ta.nq64, ta.debug, w0, L);
+    if (clk) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) clk[4] = (long long)wall_clock64();
+    }
 }
 
 // ---------------------------------------------------------------- 33 .. 256 queries per call (128-byte rows)

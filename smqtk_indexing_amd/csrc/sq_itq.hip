@@ -41,6 +41,8 @@ struct ItqArgs {
     int sub32;              // x - mean in float32 (float32 rows and a float32 model mean: numpy's promotion)
     const u32* list;        // optional: only these rows (the filter's uncertain rows, sq_itq_fast.hpp)
     const u32* list_total;  // device count of `list`
+    int exact;              // option "itq_exact" of the call (the model handle's override, or the process-wide value)
+    int debug;              // option "dense_debug" of the call (ablation bits)
 };
 
 template <class T>
@@ -596,7 +598,7 @@ namespace sq {
 template <class T>
 static bool itq_wide_applies(const ItqArgs& a) {
     return a.d % 64 == 0 && a.d <= 512 && a.words <= 4 && a.n >= 32 && a.n < (1ll << 29) &&
-           (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 && !g_opt.itq_exact && (a.norm == SQ_NORM_NONE || a.norm == SQ_NORM_L2);
+           (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 && !a.exact && (a.norm == SQ_NORM_NONE || a.norm == SQ_NORM_L2);
 }
 
 template <class T>
@@ -659,10 +661,10 @@ static int itq_wide_path(const ItqArgs& a, hipStream_t st, int device) {
     wa.seg_cap = seg_cap;
     wa.n_tiles = n_tiles;
     wa.nrb = nrb;
-    wa.debug = g_opt.dense_debug & 15;
+    wa.debug = a.debug & 15;
     static DevBuf stamp_buf;   // (measurement: option dense_debug bit 16 -> phase stamps of every workgroup, printed by the host)
     wa.stamps = nullptr;
-    if (g_opt.dense_debug & 16) {
+    if (a.debug & 16) {
         SQ_TRY(stamp_buf.reserve((size_t)nrb * 64 * 8));
         SQ_HIP(hipMemsetAsync(stamp_buf.p, 0, (size_t)nrb * 64 * 8, st));
         wa.stamps = stamp_buf.as<u64>();
@@ -705,7 +707,7 @@ static int itq_launch(const ItqArgs& a0, hipStream_t st, int device) {
     if constexpr (sizeof(T) == 4) {
         const ItqFastGeom g = itq_fast_geometry(a.d, a.words);
         if (g.stages >= 2 && a.n >= 32 && a.n < (1ll << 30) && (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 &&
-            !g_opt.itq_exact && (a.norm == SQ_NORM_NONE || a.norm == SQ_NORM_L2))  // (the other orders: float64 kernel)
+            !a.exact && (a.norm == SQ_NORM_NONE || a.norm == SQ_NORM_L2))  // (the other orders: float64 kernel)
             return itq_fast_path(a, g, st, device);
     }
     if (itq_wide_applies<T>(a)) return itq_wide_path<T>(a, st, device);
@@ -756,6 +758,8 @@ extern "C" int sq_itq_hash(const void* x, int x_dtype, int64_t n, int d, const d
     a.pad = words * 64 - bits;
     a.norm = norm_ord;
     a.sub32 = (x_dtype == SQ_DTYPE_F32 && mean_dtype == SQ_DTYPE_F32) ? 1 : 0;
+    a.exact = g_opt.itq_exact;
+    a.debug = g_opt.dense_debug;
     a.d16 = (d + 15) / 16 * 16;
     if (mem == SQ_MEM_DEVICE) {
         a.x = x;
@@ -842,6 +846,7 @@ extern "C" int sq_itq_model_hash(sq_handle_t hid, const void* x, int x_dtype, in
     if (!x || !out_codes || n <= 0) return fail(SQ_ERR_INVALID, "sq_itq_model_hash: bad argument");
     if (x_dtype != SQ_DTYPE_F32 && x_dtype != SQ_DTYPE_F64) return fail(SQ_ERR_INVALID, "sq_itq_model_hash: unknown dtype %d", x_dtype);
     std::lock_guard<std::mutex> lock(h->mu);
+    h->refresh_options();   // (a per-handle "itq_exact" / "dense_debug" wins over the process-wide value)
     SQ_HIP(hipSetDevice(h->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int words = (h->bits + 63) / 64;
@@ -854,6 +859,8 @@ extern "C" int sq_itq_model_hash(sq_handle_t hid, const void* x, int x_dtype, in
     a.pad = words * 64 - h->bits;
     a.norm = h->norm;
     a.sub32 = (x_dtype == SQ_DTYPE_F32 && h->mean_dtype == SQ_DTYPE_F32) ? 1 : 0;
+    a.exact = h->opt.itq_exact;
+    a.debug = h->opt.dense_debug;
     a.d16 = (h->d + 15) / 16 * 16;
     a.mean = h->mean.as<double>();
     a.rot = h->rot.as<double>();

@@ -149,7 +149,7 @@ template <class K, class Post = SelectNoPost>
 __global__ __launch_bounds__(1024) void select_topk_kernel(const K* __restrict__ keys,
                                                             const u32* __restrict__ cnt, u32 cap,
                                                             long long stride, int k, int lds_keys,
-                                                            K* __restrict__ out, Post post = Post()) {
+                                                            K* __restrict__ out, Post post = Post(), int cnt_shift = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     K* sk = reinterpret_cast<K*>(smem_raw);
     K* so = sk + lds_keys;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const K* __restrict__
     __shared__ u64 sh_red[32];
     const int q = blockIdx.x;
     const int T = blockDim.x;
-    const u32 craw = cnt[q];
+    const u32 craw = cnt[(long long)q << cnt_shift];   // (cnt_shift: counters a cache line apart, see I8_CNT_SHIFT)
     const int M = (int)(craw < cap ? craw : cap);
     const K* src = keys + (long long)q * stride;
     K* dst = out + (long long)q * k;

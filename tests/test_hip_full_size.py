@@ -1,7 +1,8 @@
 """
-BASELINE.json's FULL per-GPU sizes on one MI355X, checked through size-independent
-properties: the oracle (numpy, one core) cannot produce a 10 M-row answer in seconds, so the
-checks are (a) structural -- ascending distances, a query that is a row finds itself first;
+BASELINE.json's FULL per-GPU sizes on one MI355X.  The headline shape (10 M x 128 L2, k = 100) is compared
+LITERALLY with the oracle over all rows for a handful of queries (about 2 s of numpy per query:
+`test_dense_l2_10m_x_128_oracle_literal`); larger batches and the other shapes are checked through
+size-independent properties: (a) structural -- ascending distances, a query that is a row finds itself first;
 (b) the returned distances recomputed by the oracle from the returned rows (a few hundred rows,
 bit-exact); (c) COMPLETENESS against a plain torch evaluation of every distance on the same
 device -- integer exact for Hamming and for ITQ's packed codes, a tolerance band around the k-th
@@ -95,6 +96,75 @@ def test_dense_l2_10m_x_128_properties():
     np.testing.assert_array_equal(md.view(np.uint32), dist.view(np.uint32))
     for h in (index, lo, hi):
         h.close()
+
+
+def test_dense_l2_10m_x_128_oracle_literal():
+    """The headline shape against the oracle itself: ids and float32 distance bits of `O.dense_topk` over ALL 10 M rows
+    (the reference's full-order equality, tests/impls/nn_index/test_lsh.py:958-961), through (a) the blocking call,
+    (b) the pipelined SQ_MEM_DEVICE_ASYNC calls with the captured graph and rotating batches exactly as bench.py drives
+    them, (c) the bf16 first stage (dense_int8 = 0).  Queries: a row, a near-duplicate of a row, four random ones."""
+    dev = _dev()
+    n, d, k, nq = 10_000_000, 128, 100, 32
+    g = torch.Generator(device=dev)
+    g.manual_seed(303)
+    db = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for s in range(0, n, 1 << 21):
+        db[s:s + (1 << 21)].normal_(generator=g)
+    nb = 4
+    batches = [torch.empty((nq, d), dtype=torch.float32, device=dev).normal_(generator=g) for _ in range(nb)]
+    batches[0][0] = db[4_321_987]
+    batches[1][7] = db[n - 3] * (1.0 + 2e-3)
+    checked = [(0, 0), (1, 7), (2, 31), (3, 16), (0, 13), (1, 0)]          # (batch, query in batch)
+    dbh = np.empty((n, d), dtype=np.float32)
+    for s in range(0, n, 1 << 21):
+        dbh[s:s + (1 << 21)] = db[s:s + (1 << 21)].cpu().numpy()
+    want = {}
+    for b, j in checked:
+        want[(b, j)] = O.dense_topk(dbh, batches[b][j].cpu().numpy(), k)
+    del dbh
+    assert want[(0, 0)][1][0] == 4_321_987 and want[(0, 0)][0][0] == 0.0 and want[(1, 7)][1][0] == n - 3
+
+    def compare(tag, b, dist, ids):
+        for (bb, j), (rd, ri) in want.items():
+            if bb != b:
+                continue
+            np.testing.assert_array_equal(ids[j], ri, err_msg=f"{tag}: ids of batch {b} query {j}")
+            np.testing.assert_array_equal(dist[j].view(np.uint32), rd.view(np.uint32), err_msg=f"{tag}: distances of batch {b} query {j}")
+
+    index = _lib.DenseIndex(db.data_ptr(), n=n, d=d, device_ptr=True, keepalive=db)
+    # (a) blocking calls
+    for b in range(nb):
+        dist, ids = _search_dense(index, batches[b], k)
+        assert index.stats()["fallback_queries"] == 0
+        assert index.stats()["bytes_scanned"] == (-(-n // 64) * 64) * 132       # the int8 first stage answered
+        compare("blocking", b, dist, ids)
+    # (b) pipelined calls, three in flight, the call graph captured: bench.py's timed loop
+    depth, steps = 3, 24
+    index.set_option("dense_graph", 1)
+    index.set_option("dense_async_depth", depth)
+    od = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(depth)]
+    oi = [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(depth)]
+    got = {}
+    for i in range(steps):
+        slot = i % depth
+        if i >= depth:       # the results of step i - depth are final once call i - 1 has returned (include/smqtk_hip.h)
+            got[(i - depth) % nb] = (od[slot].cpu().numpy().copy(), oi[slot].cpu().numpy().copy())
+        index.search_device_async(batches[i % nb].data_ptr(), nq, k, od[slot].data_ptr(), oi[slot].data_ptr(), _stream())
+    index.sync()
+    torch.cuda.synchronize()
+    for i in range(steps - depth, steps):
+        got[i % nb] = (od[i % depth].cpu().numpy().copy(), oi[i % depth].cpu().numpy().copy())
+    assert sorted(got) == list(range(nb))
+    for b in range(nb):
+        compare("pipelined+graph", b, *got[b])
+    # (c) the bf16 first stage
+    index.set_option("dense_int8", 0)
+    for b in range(nb):
+        dist, ids = _search_dense(index, batches[b], k)
+        assert index.stats()["fallback_queries"] == 0
+        assert index.stats()["bytes_scanned"] != (-(-n // 64) * 64) * 132
+        compare("bf16 filter", b, dist, ids)
+    index.close()
 
 
 def test_dense_l2_10m_batches_of_every_kernel_agree():

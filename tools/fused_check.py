@@ -40,8 +40,8 @@ for nq in nqs:
     qs = [torch.empty((nq, d), dtype=torch.float32, device=dev).normal_(generator=g) for _ in range(6)]
     qs[0][0] = db[n // 3]
     res = {}
-    for name, opts in (("fused", {"dense_fused": 1}), ("chain", {"dense_fused": 0}), ("bf16", {"dense_int8": 0})):
-        for o, v in (("dense_fused", 1), ("dense_int8", -1)):
+    for name, opts in (("fused", {"dense_fused": 1}), ("fused_untightened", {"dense_tighten": 0}), ("chain", {"dense_fused": 0}), ("bf16", {"dense_int8": 0})):
+        for o, v in (("dense_fused", 1), ("dense_int8", -1), ("dense_tighten", 1)):
             idx.set_option(o, v)
         for o, v in opts.items():
             idx.set_option(o, v)
@@ -54,7 +54,7 @@ for nq in nqs:
         print(f"nq={nq} {name}: cands/q {stt['candidates'] / nq:.0f} fallbacks {stt['fallback_queries']} mid {stt.get('mid_tier_queries')} "
               f"bytes {stt['bytes_scanned']} launches {stt['scan_launches']}")
     ref = res["bf16"]
-    for name in ("fused", "chain"):
+    for name in ("fused", "fused_untightened", "chain"):
         r = res[name]
         ok = np.array_equal(r[1], ref[1]) and np.array_equal(r[0].view(np.uint64 if metric == "cosine" else np.uint32), ref[0].view(np.uint64 if metric == "cosine" else np.uint32))
         for a, b in zip(r[2] + r[3], ref[2] + ref[3]):
