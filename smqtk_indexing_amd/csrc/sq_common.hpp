@@ -83,6 +83,8 @@ struct Options {
     int hamming_async_wait = 1;  // as dense_async_wait
     int hamming_async_order = 1; // as dense_async_order
     int hamming_ring = -1;       // Hamming stream kernel: -1 = automatic (LDS-DMA ring for arrays beyond the MALL), 0 = register loads, 1 = ring
+    int hamming_tighten = 1;     // fused Hamming searches: stream threshold from a lower sample rank than k (far fewer candidates); a bet the pick kernel checks -- a lost one redoes the call with the safe rule; 0 = the safe rank-k rule
+    int hamming_fused = 1;       // Hamming searches of up to 32 queries (64 .. 256-bit codes, k <= 2048) as three launches (head: sampled histogram + thresholds by the last workgroup; stream; pick: exact k-th distance + gather + sort per query) instead of a memset and five; 0 = the general chain
 };
 extern Options g_opt;   // process-wide defaults (sq_set_option); a handle may override any of them (sq_handle_set_option)
 // name -> member, shared by sq_set_option and sq_handle_set_option (sq_core.hip)

@@ -110,6 +110,8 @@ int Options::*option_member(const char* name) {
         {"hamming_async_wait", &Options::hamming_async_wait},
         {"hamming_async_order", &Options::hamming_async_order},
         {"hamming_ring", &Options::hamming_ring},
+        {"hamming_fused", &Options::hamming_fused},
+        {"hamming_tighten", &Options::hamming_tighten},
     };
     if (!name) return nullptr;
     for (const auto& f : kFields)

@@ -37,18 +37,25 @@ struct HammingCall {
     long long* out_idx = nullptr;
     hipStream_t st = nullptr;
     bool small = false, prof = false, use_event = false, force_fb = false;
+    bool fused = false;           // answered by hamming_pick_kernel: the mini-lists below are what a flagged query is redone from
+    int G = 0, map_rows = 0;
+    u32 S = 0;
+    long long key_stride = 0;
     u32 cap = 0;
     sq_stats_t stats{};
 };
 struct HammingSlot {
     DevBuf keys, cnt, hist, thr, out_keys, status, seg, bcnt, sort_tmp;
+    DevBuf fhist;                 // fused small-batch calls: histogram + ticket, zero between calls (sq_hamming_fused.hpp)
+    void* fhist_zeroed = nullptr; // the allocation of fhist that has been wiped once
     HostPinned status_host;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_in = nullptr, ev_done = nullptr;
     hipStream_t own = nullptr;
     HammingCall call;
     void release() {
-        for (DevBuf* b : {&keys, &cnt, &hist, &thr, &out_keys, &status, &seg, &bcnt, &sort_tmp}) b->release();
+        for (DevBuf* b : {&keys, &cnt, &hist, &thr, &out_keys, &status, &seg, &bcnt, &sort_tmp, &fhist}) b->release();
+        fhist_zeroed = nullptr;
         status_host.release();
         for (auto& e : ev)
             if (e) (void)hipEventDestroy(e), e = nullptr;
@@ -69,6 +76,7 @@ struct HammingHandle : HandleBase {
     DevBuf mut_tmp;               // scratch of the mutation kernels
     static constexpr int kMaxDepth = 4;
     HammingSlot slot[kMaxDepth];
+    bool no_fused = false;               // set while a fused call whose tightened threshold fell short is redone by the general chain
     int depth = 2;                       // asynchronous calls in flight (option hamming_async_depth, fixed while any is)
     unsigned long long async_calls = 0;  // asynchronous calls so far (slot = calls % depth)
     // shared by all calls: host-memory staging and the exact path (both synchronous)
@@ -644,6 +652,10 @@ struct HammingFinalize {
     }
 };
 
+}  // namespace sq
+#include "sq_hamming_fused.hpp"
+namespace sq {
+
 // ------------------------------------------------------------- host driver
 template <int W, int C>
 static void launch_scan(const HammingHandle* h, const u64* qs, int nq, const int* thr, u64* keys, u32* cnt, u32 cap,
@@ -824,9 +836,6 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
         // and took the exact path: 18 ms per query at 10 M codes, found by bench.py --workload lsh_c3.)
         if (h->opt.sample_stride <= 0)
             while (step > 1 && (long long)step * kk * 8 > (long long)cap) step >>= 1;
-        SQ_TRY(s.hist.reserve((size_t)nq * (bits + 1) * 4));
-        u32* hist = s.hist.as<u32>();
-        SQ_HIP(hipMemsetAsync(hist, 0, (size_t)nq * (bits + 1) * 4, st));
         const bool stream_ok = W == 1 || W == 2 || W == 4;
         // LDS-DMA ring (hamming_ring_kernel): HBM bound batches over arrays the MALL cannot hold.  Beyond ~24 queries
         // the inner loop is VALU bound and the register kernel's 32 waves per CU win.
@@ -836,9 +845,55 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
         const bool ring = ring_shape && (h->opt.hamming_ring == 1 ||
                                          (h->opt.hamming_ring < 0 && nq <= 24 && code_bytes >= ((size_t)256 << 20)) ||
                                          (h->opt.hamming_ring < 0 && !stream_ok && nq <= 64));
-        if (!stream_ok && !ring) SQ_HIP(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));  // the compaction writes cnt itself
-        hist_dispatch(h, qs, nq, bits, hist, step, st);
-        hipLaunchKernelGGL(hamming_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, hist, nq, bits, kk, thr);
+        // Small batches in three launches (sq_hamming_fused.hpp): head (sampled histogram + thresholds by the last
+        // workgroup), the stream, pick (prefix sum over the mini-lists, exact k-th distance, gather, sort, results).
+        const bool fused = h->opt.hamming_fused != 0 && !h->no_fused && stream_ok && nq <= HF_MAX_NQ && 2 * kk <= HF_SORT_CAP;
+        // The fused call's threshold: the general chain takes the smallest t whose SAMPLE count reaches k -- safe (the sample
+        // is a subset) and loose: ~step x k codes pass (7.8 k per query at 10 M x 64 bits, k = 100), and with 0.4 survivors
+        // per wave and chunk the emission path, not the popcounts, is half of the stream's time.  The pick kernel counts what
+        // the stream admitted, so the threshold may be a bet: the smallest t whose sample count reaches r, where a t that
+        // admits fewer than k codes overall would show r in a 1/step sample with probability < 1e-9 (Poisson tail:
+        // r = lambda + 7 sqrt(lambda) + 6, lambda = k / step).  A lost bet (M < k) is seen by the pick kernel and the call
+        // is redone with the safe rule (hamming_resolve); results are exact either way.
+        int thr_rank = kk;
+        if (fused && h->opt.hamming_tighten != 0) {
+            const double lambda = (double)kk / (double)step;
+            const int r = (int)ceil(lambda + 7.0 * sqrt(lambda) + 6.0);
+            if (r < thr_rank) thr_rank = r;
+            if (h->opt.hamming_tighten >= 2) thr_rank = 1;   // (testing: a bet that is usually lost -- the redo path)
+        }
+        c.fused = fused;
+        u32* hist = nullptr;
+        if (fused) {
+            const size_t words = (size_t)HF_MAX_NQ * (bits + 1);
+            SQ_TRY(s.fhist.reserve(words * 4));
+            if (s.fhist_zeroed != s.fhist.p) {   // a new allocation: wiped once, the pick kernel leaves it clean
+                SQ_HIP(hipMemsetAsync(s.fhist.p, 0, s.fhist.cap, st));
+                s.fhist_zeroed = s.fhist.p;
+            }
+            hist = s.fhist.as<u32>();
+            if (nq > 8) {   // a lane per query: no same-address LDS atomics (sq_hamming_fused.hpp)
+                const long long blocks_all2 = (n + per_block - 1) / per_block;
+                const unsigned blocks = (unsigned)((blocks_all2 + step - 1) / step);
+                const size_t lds = (size_t)32 * (bits + 1) * 4;
+                if (W == 1)
+                    hipLaunchKernelGGL((hamming_hist_by_query_kernel<1, 4>), dim3(blocks), dim3(256), lds, st, h->codes, n, qs, nq, bits, hist, step);
+                else if (W == 2)
+                    hipLaunchKernelGGL((hamming_hist_by_query_kernel<2, 2>), dim3(blocks), dim3(256), lds, st, h->codes, n, qs, nq, bits, hist, step);
+                else
+                    hipLaunchKernelGGL((hamming_hist_by_query_kernel<4, 1>), dim3(blocks), dim3(256), lds, st, h->codes, n, qs, nq, bits, hist, step);
+            } else {
+                hist_dispatch(h, qs, nq, bits, hist, step, st);
+            }
+            if (ring) hipLaunchKernelGGL(hamming_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, hist, nq, bits, thr_rank, thr);
+        } else {
+            SQ_TRY(s.hist.reserve((size_t)nq * (bits + 1) * 4));
+            hist = s.hist.as<u32>();
+            SQ_HIP(hipMemsetAsync(hist, 0, (size_t)nq * (bits + 1) * 4, st));
+            if (!stream_ok && !ring) SQ_HIP(hipMemsetAsync(cnt, 0, (size_t)nq * 4, st));  // the compaction writes cnt itself
+            hist_dispatch(h, qs, nq, bits, hist, step, st);
+            hipLaunchKernelGGL(hamming_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, hist, nq, bits, kk, thr);
+        }
         if (prof) SQ_HIP(hipEventRecord(s.ev[1], st));
         if (stream_ok || ring) {
             // streaming scan into per-(block, query) mini-lists, then a prefix-sum compaction: no global atomics
@@ -859,6 +914,18 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
             } else {
                 const long long per_chunk = 256ll * (W == 1 ? 8 : W == 2 ? 4 : 2);
                 const long long nchunks = (n + per_chunk - 1) / per_chunk;
+                if (fused && nchunks > (long long)8 * cus && 8 * cus <= 2048) {
+                    // every CU holds j workgroups that walk ceil(nchunks / (j CUs)) chunks each: the pass lasts j * that many
+                    // chunk times on the fullest CU.  10 M x 64-bit codes = 4883 chunks: 8 workgroups per CU -> 8 x 3 = 24
+                    // chunk times where 4883 / 256 = 19.1 would do; 5 per CU -> 5 x 4 = 20
+                    int best_j = 8;
+                    long long best = -1;
+                    for (int j = 8; j >= 3; --j) {
+                        const long long cost = (long long)j * ((nchunks + (long long)j * cus - 1) / ((long long)j * cus));
+                        if (best < 0 || cost < best) best = cost, best_j = j;
+                    }
+                    G = best_j * cus;
+                }
                 if ((long long)G > nchunks) G = (int)nchunks;  // short arrays: fewer, fuller mini-lists
             }
             long long want = 8ll * 128ll * kk / G;  // ~8x the expected fill of a mini-list
@@ -882,6 +949,16 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
                         case 8: SQ_TRY(ring_launch<8>(h, nt, G, qc, nqc, thr + q0, seg, bcnt, S, st)); break;
                         default: SQ_TRY(ring_launch<16>(h, nt, G, qc, nqc, thr + q0, seg, bcnt, S, st)); break;
                     }
+                } else if (fused) {
+                    if (W == 1)
+                        hipLaunchKernelGGL((hamming_body_kernel<1, 8>), dim3(G), dim3(256), 0, st, h->codes, n, h->pmul, qc, nqc, hist, bits,
+                                           thr_rank, thr, seg, bcnt, S);
+                    else if (W == 2)
+                        hipLaunchKernelGGL((hamming_body_kernel<2, 4>), dim3(G), dim3(256), 0, st, h->codes, n, h->pmul, qc, nqc, hist, bits,
+                                           thr_rank, thr, seg, bcnt, S);
+                    else
+                        hipLaunchKernelGGL((hamming_body_kernel<4, 2>), dim3(G), dim3(256), 0, st, h->codes, n, h->pmul, qc, nqc, hist, bits,
+                                           thr_rank, thr, seg, bcnt, S);
                 } else if (W == 1)
                     hipLaunchKernelGGL((hamming_stream_kernel<1, 8>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
                                        thr + q0, seg, bcnt, S);
@@ -891,17 +968,27 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
                 else
                     hipLaunchKernelGGL((hamming_stream_kernel<4, 2>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
                                        thr + q0, seg, bcnt, S);
-                hipLaunchKernelGGL(hamming_compact_kernel, dim3(nqc, COMPACT_SLICES), dim3(256), 0, st, seg, bcnt, G, nqc, S,
-                                   keys + (long long)q0 * key_stride, cnt + q0, cap, key_stride, ring ? 1 : 0, h->pmul, n);
+                if (fused) {   // (nq <= qbatch: one pass)
+                    c.G = G;
+                    c.S = S;
+                    c.map_rows = 1;   // (ring and body kernels leave physical rows in the mini-lists)
+                    c.key_stride = key_stride;
+                    if (prof) SQ_HIP(hipEventRecord(s.ev[2], st));
+                    hipLaunchKernelGGL(hamming_pick_kernel, dim3(nq), dim3(1024), 0, st, seg, bcnt, G, nq, S, bits, k, kk, thr, 1,
+                                       h->pmul, n, h->id_base, out_dist, out_idx, status, hs_dev, nq, cap, hist);
+                } else
+                    hipLaunchKernelGGL(hamming_compact_kernel, dim3(nqc, COMPACT_SLICES), dim3(256), 0, st, seg, bcnt, G, nqc, S,
+                                       keys + (long long)q0 * key_stride, cnt + q0, cap, key_stride, ring ? 1 : 0, h->pmul, n);
             }
         } else {
             scan_dispatch(h, qs, nq, thr, keys, cnt, cap, key_stride, /*mode*/ 0, st);
         }
-        if (prof) SQ_HIP(hipEventRecord(s.ev[2], st));
+        if (prof && !fused) SQ_HIP(hipEventRecord(s.ev[2], st));
         c.stats.scan_launches = 1;
         c.stats.bytes_scanned = n * W * 8;
-        SQ_TRY(select_launch(keys, cnt, cap, key_stride, k, nq, okeys, st, s.sort_tmp,
-                             HammingFinalize{cnt, cap, kk, h->id_base, out_dist, out_idx, status, hs_dev, nq}));
+        if (!fused)
+            SQ_TRY(select_launch(keys, cnt, cap, key_stride, k, nq, okeys, st, s.sort_tmp,
+                                 HammingFinalize{cnt, cap, kk, h->id_base, out_dist, out_idx, status, hs_dev, nq}));
     }
     if (prof) SQ_HIP(hipEventRecord(s.ev[3], st));
     if (use_event) {
@@ -941,6 +1028,37 @@ static int hamming_resolve(HammingHandle* h, HammingSlot& s) {
     int* thr = s.thr.as<int>();
     u64* okeys = s.out_keys.as<u64>();
     u32* status = s.status.as<u32>();
+    if (c.fused) {
+        bool short_bet = false;
+        for (int q = 0; q < nq; ++q) short_bet = short_bet || (hs[q] & 16u) != 0;
+        if (short_bet) {
+            // the tightened threshold admitted fewer than k codes for some query: the whole call again through the general
+            // chain (safe threshold), synchronously, on the same slot and stream
+            const HammingCall again = c;
+            h->no_fused = true;
+            int rc = hamming_enqueue(h, s, again.qs, nq, k, again.out_dist, again.out_idx, st, false);
+            h->no_fused = false;
+            SQ_TRY(rc);
+            SQ_TRY(hamming_resolve(h, s));
+            h->stats.fallback_queries += nq;   // (counted: it cost a second pass)
+            return SQ_OK;
+        }
+        // hamming_pick_kernel flags a query whose entries at distance <= T outnumber its sort buffer (a huge tie group): the
+        // general compaction + select answers the call from the same mini-lists
+        bool redo = false;
+        for (int q = 0; q < nq; ++q) redo = redo || (hs[q] & 8u) != 0;
+        if (redo) {
+            u32* hs_dev = nullptr;
+            SQ_TRY(s.status_host.device_ptr(reinterpret_cast<void**>(&hs_dev)));
+            hipLaunchKernelGGL(hamming_compact_kernel, dim3(nq, COMPACT_SLICES), dim3(256), 0, st, s.seg.as<u64>(), s.bcnt.as<u32>(), c.G, nq,
+                               c.S, s.keys.as<u64>(), cnt, c.cap, c.key_stride, c.map_rows, h->pmul, n);
+            SQ_TRY(select_launch(s.keys.as<u64>(), cnt, c.cap, c.key_stride, k, nq, okeys, st, s.sort_tmp,
+                                 HammingFinalize{cnt, c.cap, kk, h->id_base, c.out_dist, c.out_idx, status, hs_dev, nq}));
+            SQ_HIP(hipStreamSynchronize(st));
+            SQ_HIP(hipGetLastError());
+            h->stats.scan_launches++;
+        }
+    }
     for (int q = 0; q < nq; ++q) h->stats.candidates += hs[nq + q];
     // exact path (candidate overflow): every key of the query, radix-selected from global memory
     const bool force_fb = c.force_fb || h->opt.force_fallback != 0;

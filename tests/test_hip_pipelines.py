@@ -76,6 +76,83 @@ def test_hamming_ring_kernel_matches_oracle(w, n, nq, k):
     idx.close()
 
 
+# ------------------------------------------------------------------- Hamming small batches in three launches
+@pytest.mark.parametrize("w,n,nq,k,ring", [(1, 300_001, 1, 100, 0), (1, 1_000_003, 32, 100, 0), (2, 200_000, 17, 10, 0),
+                                           (4, 150_017, 8, 1000, 0), (1, 400_000, 5, 2048, 1), (2, 262_144, 3, 1, 1)])
+def test_hamming_fused_small_batch_matches_oracle(w, n, nq, k, ring):
+    """Head / stream / pick (sq_hamming_fused.hpp) against the oracle and against the general chain on the same index:
+    distances and rows identical, for the register stream and the ring (physical rows mapped by the pick kernel), for
+    a query that is a stored code, k = 1 and k at the fused path's limit, and repeated calls (the head kernel leaves
+    its histogram clean for the next one)."""
+    rng = np.random.default_rng(31 * w + nq + k)
+    codes = _codes(rng, n, w)
+    queries = rng.integers(0, 2 ** 64, size=(nq, w), dtype=np.uint64)
+    queries[0] = codes[len(codes) // 3]
+    idx = _lib.HammingIndex(codes, id_base=7)
+    idx.set_option("hamming_ring", ring)
+    idx.set_option("hamming_fused", 1)
+    for rep in range(3):
+        d, i = idx.search(queries, k)
+        assert idx.stats()["fallback_queries"] == 0
+        if rep == 0:
+            for qi, q in enumerate(queries):
+                rd, ri = O.hamming_topk(codes, q, k)
+                np.testing.assert_array_equal(d[qi], rd)
+                np.testing.assert_array_equal(i[qi], ri + 7)
+            d0, i0 = d, i
+        else:
+            np.testing.assert_array_equal(d, d0)
+            np.testing.assert_array_equal(i, i0)
+    cands_fused = idx.stats()["candidates"]
+    # the safe rank-k threshold instead of the tightened one: more candidates, the same answer
+    idx.set_option("hamming_tighten", 0)
+    d1, i1 = idx.search(queries, k)
+    np.testing.assert_array_equal(d1, d0)
+    np.testing.assert_array_equal(i1, i0)
+    assert idx.stats()["candidates"] >= cands_fused
+    cands_safe = idx.stats()["candidates"]
+    # a bet that is lost (threshold = the smallest distance of the sample: fewer than k codes pass for most queries): the
+    # pick kernel sees it and the call is redone by the general chain
+    idx.set_option("hamming_tighten", 2)
+    d2, i2 = idx.search(queries, k)
+    np.testing.assert_array_equal(d2, d0)
+    np.testing.assert_array_equal(i2, i0)
+    if k > 1:
+        assert idx.stats()["fallback_queries"] == nq
+    idx.set_option("hamming_tighten", 1)
+    idx.set_option("hamming_fused", 0)
+    d3, i3 = idx.search(queries, k)
+    np.testing.assert_array_equal(d3, d0)
+    np.testing.assert_array_equal(i3, i0)
+    assert idx.stats()["candidates"] == cands_safe      # the general chain: the safe threshold's mini-lists
+    idx.close()
+
+
+def test_hamming_fused_tie_group_beyond_the_sort_buffer():
+    """41 664 codes at distance exactly 3 from the query (every 64-bit word with three bits set) among 150 k random ones:
+    the pick kernel's sort buffer (4096 keys) cannot hold the tie group at the k-th distance, flags the query, and
+    the general compaction + select answers from the same mini-lists -- the lowest rows of the tie group, no exact path."""
+    rng = np.random.default_rng(8)
+    bits3 = []
+    for a in range(64):
+        for b in range(a + 1, 64):
+            for c in range(b + 1, 64):
+                bits3.append((1 << a) | (1 << b) | (1 << c))
+    codes = np.unique(np.concatenate([np.array(bits3, dtype=np.uint64),
+                                      rng.integers(0, 2 ** 64, size=150_000, dtype=np.uint64)]))[:, None]
+    queries = np.zeros((2, 1), dtype=np.uint64)
+    queries[1, 0] = np.uint64(0xffff)
+    idx = _lib.HammingIndex(codes)
+    d, i = idx.search(queries, 100)
+    assert idx.stats()["fallback_queries"] == 0
+    for qi, q in enumerate(queries):
+        rd, ri = O.hamming_topk(codes, q, 100)
+        np.testing.assert_array_equal(d[qi], rd)
+        np.testing.assert_array_equal(i[qi], ri)
+    assert (d[0] == 3).all()
+    idx.close()
+
+
 @pytest.mark.parametrize("depth,wait,ring", [(2, 1, 0), (3, 1, 1), (3, 0, 1), (4, 0, 0)])
 def test_hamming_async_calls_equal_blocking_calls(depth, wait, ring):
     """sq_hamming_search with SQ_MEM_DEVICE_ASYNC: `depth` calls in flight on the slots' own streams; call i is final when

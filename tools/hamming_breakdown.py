@@ -12,7 +12,11 @@ st = torch.cuda.current_stream().cuda_stream
 g = torch.Generator(device=dev); g.manual_seed(2)
 codes = torch.randint(-2**63, 2**63 - 1, (n, w), dtype=torch.int64, device=dev, generator=g)
 idx = _lib.HammingIndex(codes.data_ptr(), n=n, words=w, device_ptr=True, keepalive=codes)
-_lib.set_option("profile", 1)
+_lib.set_option("profile", int(os.environ.get("PROFILE", 1)))
+for item in os.environ.get("OPTS", "").split(","):      # library options of the index, name=value,...
+    if item:
+        a, b = item.split("=")
+        idx.set_option(a, int(b))
 q = torch.randint(-2**63, 2**63 - 1, (nq, w), dtype=torch.int64, device=dev, generator=g)
 od = torch.empty((nq, k), dtype=torch.int32, device=dev); oi = torch.empty((nq, k), dtype=torch.int64, device=dev)
 for r in range(int(os.environ.get("REPS", 10))):

@@ -17,7 +17,12 @@ codes = torch.unique(codes, dim=0) if w == 1 else codes          # (sorted uniqu
 idx = _lib.HammingIndex(codes.data_ptr(), n=codes.shape[0], words=w, device_ptr=True, keepalive=codes)
 st = torch.cuda.current_stream().cuda_stream
 strides = [int(x) for x in os.environ.get("STRIDES", "0").split(",")]
-for nq, stride in [(a, b) for a in (1, 32, 1024) for b in strides]:
+nqs = [int(x) for x in os.environ.get("NQS", "1,32,1024").split(",")]
+for item in os.environ.get("OPTS", "").split(","):      # library options of the index, name=value,...
+    if item:
+        a, b = item.split("=")
+        idx.set_option(a, int(b))
+for nq, stride in [(a, b) for a in nqs for b in strides]:
     _lib.set_option("sample_stride", stride)
     q = codes[torch.randint(0, codes.shape[0], (nq,), device=dev, generator=g)].contiguous() ^ 5
     od = torch.empty((nq, 100), dtype=torch.int32, device=dev)
@@ -30,4 +35,4 @@ for nq, stride in [(a, b) for a in (1, 32, 1024) for b in strides]:
     for _ in range(reps):
         idx.search_device(q.data_ptr(), nq, 100, od.data_ptr(), oi.data_ptr(), st)
     torch.cuda.synchronize()
-    print(f"n={codes.shape[0]} bits={bits} nq={nq} sample_stride={stride}: {(time.perf_counter() - t0) / reps * 1e3:.4f} ms per call, cands/q {idx.stats()['candidates'] / nq:.0f}", flush=True)
+    print(f"n={codes.shape[0]} bits={bits} nq={nq} sample_stride={stride} {os.environ.get('OPTS', '')}: {(time.perf_counter() - t0) / reps * 1e3:.4f} ms per call, cands/q {idx.stats()['candidates'] / nq:.0f}", flush=True)
