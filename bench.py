@@ -192,6 +192,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     # (create-time choices are the index's own: sq_dense_create_opts -- nothing process-wide is touched)
     index = _lib.DenseIndex(db.data_ptr(), n=n_local, d=d, metric=metric, device_ptr=True, id_base=r0, keepalive=db,
                             options={"dense_int8": 0} if args.no_int8 else None)
+    build_info = index.info()     # sq_dense_info: build time of sq_dense_create and the bytes each copy keeps resident
     lib_opts = {}
     for item in args.lib_options.split(","):       # measurement: library options of the index, "name=value,..."
         if item:
@@ -486,12 +487,16 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         tpath = os.path.join(ROOT, "profiles", "latest_traffic.json")
         if os.path.isfile(tpath) and n_local == 10_000_000 and d == 128 and not cosine:
             tj = json.load(open(tpath))
-            replay = {"hbm_bytes_per_launch": tj.get("dense8_scan_full_pass_hbm_bytes" if int8_filter else "dense_scan_full_pass_hbm_bytes"),
+            replay = {"hbm_bytes_per_launch": tj.get("dense8_body_full_pass_hbm_bytes" if (int8_filter and nq <= 32 and lib_opts.get("dense_fused", 1) != 0)
+                                                     else "dense8_scan_full_pass_hbm_bytes" if int8_filter else "dense_scan_full_pass_hbm_bytes"),
                       "file": "profiles/latest_traffic.json",
                       "note": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the committed profile"}
         achieved = streamed / (head_scan_ms * 1e-3) / 1e9 if head_scan_ms > 0 else 0.0
         qp = 2.0 if nq <= 32 else 1.0
         gather_every = (args.gather_every if args.gather_every > 0 else 4) if use_dist else None
+        fused_call = int8_filter and nq <= 32 and lib_opts.get("dense_fused", 1) != 0
+        bi = build_info
+        resident_total = (bi["f32_rows_bytes"] + bi["bf16_copy_bytes"] + bi["int8_copy_bytes"] + bi["row_stats_bytes"])
         line = {
             "metric": (f"queries/sec, exact brute-force {args.metric} kNN k={k} over {n_total}x{d} float32 (recall@{k} = 1.0 by "
                        "construction); scan HBM GB/s vs 8 TB/s peak"),
@@ -502,6 +507,14 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
+            "index_build_ms": bi["build_ms"],
+            "index_build_note": (f"sq_dense_create on this rank's {n_local} x {d} float32 rows already in HBM (column means, row statistics, "
+                                 f"bf16 scan copy, int8 scan copy: {bi['build_int8_ms']:.1f} ms of it); outside the timed region -- the "
+                                 "build side of FaissNearestNeighborsIndex._build_index, faiss.py:486-559"),
+            "resident_bytes": {"f32_rows": bi["f32_rows_bytes"], "f32_rows_owned_by_library": bi["f32_rows_owned"],
+                               "bf16_scan_copy": bi["bf16_copy_bytes"], "int8_scan_copy_and_row_terms": bi["int8_copy_bytes"],
+                               "row_statistics": bi["row_stats_bytes"], "total": resident_total,
+                               "total_over_f32_rows": resident_total / float(bi["f32_rows_bytes"]) if bi["f32_rows_bytes"] else None},
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": ("f32 results (distances bit-identical to numpy float32); filter arithmetic int8 MFMA (i32 accumulation, measured "
@@ -539,7 +552,9 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "traffic_replayed": replay,
-                "kernel": f"dense8_scan_kernel<{row8 // 32}, false> (full pass)" if int8_filter else "dense_scan_kernel (full pass)", "kernel_ms": head_scan_ms,
+                "kernel": (f"dense8_body_kernel<{row8 // 32}, false> (full pass over the int8 copy, then the exact re-rank of its survivors as the kernel's tail)" if fused_call
+                           else f"dense8_scan_kernel<{row8 // 32}, false> (full pass)" if int8_filter else "dense_scan_kernel (full pass)"),
+                "kernel_ms": head_scan_ms,
                 "kernel_ms_note": "mean hipEvent-bracketed duration (events recorded by the library on the stream the kernel is "
                                   "launched on) of the full-pass launch in BLOCKING calls right after the timed region, same "
                                   "rotating query batches: the kernel's own streaming time.  achieved = streamed bytes / this.",
