@@ -171,7 +171,12 @@ int sq_hamming_search(sq_handle_t h, const uint64_t* queries, int nq, int k,
  * handle -- or sq_hamming_sync, a mutation, the destroy -- returns; until then `queries`, `out_dist` and `out_idx`
  * stay valid and untouched.  Options "hamming_async_depth" (2 .. 4), "hamming_async_wait", "hamming_async_order" as
  * their dense_* counterparts.  The shards of BASELINE config 5 (125 M x 256-bit codes per GPU) pipeline their
- * histogram / threshold / compaction / select kernels under the neighbouring calls' scans this way. */
+ * histogram / threshold / compaction / select kernels under the neighbouring calls' scans this way.
+ * Calls of up to 32 queries over 64 .. 256-bit codes (k <= 2048) run as three launches -- sampled histogram, stream with
+ * the thresholds computed in its prologue, one pick kernel per query (option "hamming_fused", 1 by default; 0 = the general
+ * chain of five).  Their stream threshold is taken at a lower sample rank than k ("hamming_tighten", 1 by default): a bet
+ * the pick kernel checks -- a call whose threshold admitted fewer than k codes is redone with the safe rule (counted in
+ * sq_stats_t.fallback_queries); results are integer-exact either way. */
 int sq_hamming_sync(sq_handle_t h);
 /* Incremental mutation of an index that owns its device copy (created from host memory, or from a device array of
  * at least 4096 codes, which is copied): what LinearHashIndex._update_index / _remove_from_index do with a set

@@ -372,12 +372,23 @@ class HipSearcher:
     redone from the same pointer).  ``search_into`` therefore keeps a reference to the last ``lag + 1`` query
     tensors (and output tensors); callers may hand over temporaries and drop them at once."""
 
+    _live: dict = {}    # id(index) -> weak reference to the searcher whose pipeline options sit on that handle
+
     def __init__(self, index, stream_handle: int = 0, use_async: bool = False, depth: int = 2, wait: bool = True,
                  queries_ready: bool = False):
         import collections
+        import weakref
         self.index, self.stream = index, int(stream_handle)
         self.lag = 0
+        self._prefix = None
         if use_async and hasattr(index, "search_device_async"):
+            # the depth / wait / order below are written on the index's handle and read by every asynchronous call on
+            # it: a second live pipeline on the same handle would overwrite them under the first one's feet (its `lag`
+            # going stale), so it is refused; close() puts the library's defaults back
+            other = HipSearcher._live.get(id(index))
+            if other is not None and other() is not None and other().index is index and other()._prefix is not None:
+                raise RuntimeError("HipSearcher: this index already has a live asynchronous pipeline (close() it first)")
+            HipSearcher._live[id(index)] = weakref.ref(self)
             depth = min(max(int(depth), 2), 4)
             # wait=False: a call returns right after enqueueing (option *_async_wait = 0) and the wait for the oldest
             # call moves to the start of the next one: one more call of lag, and the host work between two calls (the
@@ -388,6 +399,7 @@ class HipSearcher:
             index.set_option(prefix + "_depth", depth)
             index.set_option(prefix + "_wait", 1 if wait else 0)
             index.set_option(prefix + "_order", 0 if queries_ready else 1)
+            self._prefix = prefix
             self.lag = depth - 1 if wait else depth
         self._alive = collections.deque(maxlen=self.lag + 1)   # (queries, out_d, out_i) of the calls not yet final
 
@@ -401,6 +413,20 @@ class HipSearcher:
         if self.lag:
             self.index.sync()
         self._alive.clear()
+
+    def close(self) -> None:
+        """Finish what is in flight and take the pipeline's options off the handle again (the library's defaults:
+        two calls in flight, a call returns when the oldest is final, calls ordered behind the caller's stream), so a
+        later direct ``search_device_async`` caller finds the contract of include/smqtk_hip.h."""
+        self.finish()
+        if self._prefix is not None:
+            try:
+                for name, value in (("_depth", 2), ("_wait", 1), ("_order", 1)):
+                    self.index.set_option(self._prefix + name, value)
+            except Exception:      # (the index was closed first: nothing left to restore)
+                pass
+            self._prefix = None
+            HipSearcher._live.pop(id(self.index), None)
 
 
 class PipelinedShardedSearch:
@@ -584,5 +610,7 @@ class PipelinedShardedSearch:
 
     def close(self) -> None:
         self.flush()
+        if hasattr(self.searcher, "close"):
+            self.searcher.close()
         if self.merging:
             self.merger.close()

@@ -37,7 +37,9 @@ def test_library_answers_without_gpu_calls():
     for name, default in (("dense_async_streams", 2), ("dense_async_depth", 2), ("dense_async_wait", 1),
                           ("dense_async_order", 1), ("profile", 0),
                           # the int8 first-stage filter and its captured call graph (round 3)
-                          ("dense_int8", -1), ("dense_int8_batch", 64), ("dense_graph", 1), ("dense_mid_tier", 1)):
+                          ("dense_int8", -1), ("dense_int8_batch", 64), ("dense_graph", 1), ("dense_mid_tier", 1),
+                          # the three-launch calls (round 4): dense int8 head / body / select, Hamming sample / stream / pick
+                          ("dense_fused", 1), ("dense_tighten", 1), ("hamming_fused", 1), ("hamming_tighten", 1)):
         _lib.set_option(name, default)
 
 

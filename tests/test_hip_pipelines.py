@@ -315,6 +315,18 @@ def test_pipeline_keeps_temporary_queries_alive():
         for r in (0, nq - 1):
             rd, ri = O.dense_topk(dbh, b[r], k)
             np.testing.assert_array_equal(got_i[r], ri)
+    # the pipeline's depth / wait / order sit on the handle: a second live pipeline on it is refused, close() takes
+    # them off again (a direct asynchronous caller then finds the header's contract: final when the NEXT call returns)
+    with pytest.raises(RuntimeError):
+        HipSearcher(index, _stream(), use_async=True, depth=2)
+    s.close()
+    q0 = torch.from_numpy(batches[0]).to(dev)
+    index.search_device_async(q0.data_ptr(), nq, k, outs_d[1].data_ptr(), outs_i[1].data_ptr(), _stream())
+    index.search_device_async(q0.data_ptr(), nq, k, outs_d[2].data_ptr(), outs_i[2].data_ptr(), _stream())
+    np.testing.assert_array_equal(outs_i[1].cpu().numpy(), outs_i[0].cpu().numpy())    # depth 2, wait 1: call 1 is final
+    index.sync()
+    s2 = HipSearcher(index, _stream(), use_async=True, depth=2)
+    s2.close()
     index.close()
 
 
