@@ -378,7 +378,13 @@ __global__ __launch_bounds__(HR_WAVES * 64, 1) void hamming_ring_kernel(const u6
         for (int q = 0; q < nq; ++q) {
             u64 qw[W];
 #pragma unroll
-            for (int w = 0; w < W; ++w) qw[w] = qn[w];
+            for (int w = 0; w < W; ++w) {
+                // the query word as a VECTOR operand (one v_mov per half): v_xor_b32 with a scalar source issues at 4 cycles
+                // per wave and SIMD, with vector sources at 2.5 (tools/micro/valu_rate.hip, profiles/r04_valu_issue_rates.txt)
+                u32 lo = (u32)qn[w], hi = (u32)(qn[w] >> 32);
+                asm volatile("" : "+v"(lo), "+v"(hi));
+                qw[w] = ((u64)hi << 32) | lo;
+            }
             const int t = tn;
             {
                 const int q1 = q + 1 < nq ? q + 1 : q;   // wave-uniform: scalar loads
@@ -847,7 +853,10 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
                                          (h->opt.hamming_ring < 0 && !stream_ok && nq <= 64));
         // Small batches in three launches (sq_hamming_fused.hpp): head (sampled histogram + thresholds by the last
         // workgroup), the stream, pick (prefix sum over the mini-lists, exact k-th distance, gather, sort, results).
-        const bool fused = h->opt.hamming_fused != 0 && !h->no_fused && stream_ok && nq <= HF_MAX_NQ && 2 * kk <= HF_SORT_CAP;
+        // (calls beyond 32 queries -- up to one stream launch's batch -- keep the threshold launch: hamming_body_kernel then reads
+        // the thresholds instead of computing them in its prologue)
+        const int fused_max_nq = ring ? HF_MAX_NQ : (W == 4 ? 384 : 1024);
+        const bool fused = h->opt.hamming_fused != 0 && !h->no_fused && stream_ok && nq <= fused_max_nq && 2 * kk <= HF_SORT_CAP;
         // The fused call's threshold: the general chain takes the smallest t whose SAMPLE count reaches k -- safe (the sample
         // is a subset) and loose: ~step x k codes pass (7.8 k per query at 10 M x 64 bits, k = 100), and with 0.4 survivors
         // per wave and chunk the emission path, not the popcounts, is half of the stream's time.  The pick kernel counts what
@@ -865,14 +874,14 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
         c.fused = fused;
         u32* hist = nullptr;
         if (fused) {
-            const size_t words = (size_t)HF_MAX_NQ * (bits + 1);
+            const size_t words = (size_t)(nq > HF_MAX_NQ ? nq : HF_MAX_NQ) * (bits + 1);
             SQ_TRY(s.fhist.reserve(words * 4));
             if (s.fhist_zeroed != s.fhist.p) {   // a new allocation: wiped once, the pick kernel leaves it clean
                 SQ_HIP(hipMemsetAsync(s.fhist.p, 0, s.fhist.cap, st));
                 s.fhist_zeroed = s.fhist.p;
             }
             hist = s.fhist.as<u32>();
-            if (nq > 8) {   // a lane per query: no same-address LDS atomics (sq_hamming_fused.hpp)
+            if (nq > 8 && nq <= HF_MAX_NQ) {   // a lane per query: no same-address LDS atomics (sq_hamming_fused.hpp)
                 const long long blocks_all2 = (n + per_block - 1) / per_block;
                 const unsigned blocks = (unsigned)((blocks_all2 + step - 1) / step);
                 const size_t lds = (size_t)32 * (bits + 1) * 4;
@@ -885,7 +894,7 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
             } else {
                 hist_dispatch(h, qs, nq, bits, hist, step, st);
             }
-            if (ring) hipLaunchKernelGGL(hamming_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, hist, nq, bits, thr_rank, thr);
+            if (ring || nq > HF_MAX_NQ) hipLaunchKernelGGL(hamming_thr_kernel, dim3((nq + 63) / 64), dim3(64), 0, st, hist, nq, bits, thr_rank, thr);
         } else {
             SQ_TRY(s.hist.reserve((size_t)nq * (bits + 1) * 4));
             hist = s.hist.as<u32>();
@@ -918,9 +927,14 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
                     // every CU holds j workgroups that walk ceil(nchunks / (j CUs)) chunks each: the pass lasts j * that many
                     // chunk times on the fullest CU.  10 M x 64-bit codes = 4883 chunks: 8 workgroups per CU -> 8 x 3 = 24
                     // chunk times where 4883 / 256 = 19.1 would do; 5 per CU -> 5 x 4 = 20
-                    int best_j = 8;
+                    // (at most 6 workgroups of the body kernel fit a CU: 80 VGPRs, and nq * (8 W + 8) bytes of LDS each)
+                    int jmax = 6;
+                    const size_t lds_wg = (size_t)nq * (W * 8 + 8);
+                    if (lds_wg * jmax > (size_t)160 * 1024) jmax = (int)((size_t)160 * 1024 / lds_wg);
+                    if (jmax < 3) jmax = 3;
+                    int best_j = jmax;
                     long long best = -1;
-                    for (int j = 8; j >= 3; --j) {
+                    for (int j = jmax; j >= 3; --j) {
                         const long long cost = (long long)j * ((nchunks + (long long)j * cus - 1) / ((long long)j * cus));
                         if (best < 0 || cost < best) best = cost, best_j = j;
                     }
@@ -929,6 +943,7 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
                 if ((long long)G > nchunks) G = (int)nchunks;  // short arrays: fewer, fuller mini-lists
             }
             long long want = 8ll * 128ll * kk / G;  // ~8x the expected fill of a mini-list
+            if (fused && thr_rank < kk) want = 8ll * 128ll * thr_rank / G;   // (the tightened threshold admits ~ rank x step codes)
             u32 S = 32;
             while ((long long)S < want && S < 4096u) S <<= 1;
             SQ_TRY(s.bcnt.reserve((size_t)G * nq * 4));
@@ -951,14 +966,14 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
                     }
                 } else if (fused) {
                     if (W == 1)
-                        hipLaunchKernelGGL((hamming_body_kernel<1, 8>), dim3(G), dim3(256), 0, st, h->codes, n, h->pmul, qc, nqc, hist, bits,
-                                           thr_rank, thr, seg, bcnt, S);
+                        hipLaunchKernelGGL((hamming_body_kernel<1, 8>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
+                                           nq <= HF_MAX_NQ ? hist : nullptr, bits, thr_rank, thr, seg, bcnt, S);
                     else if (W == 2)
-                        hipLaunchKernelGGL((hamming_body_kernel<2, 4>), dim3(G), dim3(256), 0, st, h->codes, n, h->pmul, qc, nqc, hist, bits,
-                                           thr_rank, thr, seg, bcnt, S);
+                        hipLaunchKernelGGL((hamming_body_kernel<2, 4>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
+                                           nq <= HF_MAX_NQ ? hist : nullptr, bits, thr_rank, thr, seg, bcnt, S);
                     else
-                        hipLaunchKernelGGL((hamming_body_kernel<4, 2>), dim3(G), dim3(256), 0, st, h->codes, n, h->pmul, qc, nqc, hist, bits,
-                                           thr_rank, thr, seg, bcnt, S);
+                        hipLaunchKernelGGL((hamming_body_kernel<4, 2>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
+                                           nq <= HF_MAX_NQ ? hist : nullptr, bits, thr_rank, thr, seg, bcnt, S);
                 } else if (W == 1)
                     hipLaunchKernelGGL((hamming_stream_kernel<1, 8>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
                                        thr + q0, seg, bcnt, S);

@@ -142,40 +142,42 @@ __device__ __forceinline__ void hf_store_key(u64* p, u64 v) {
 //   * query words and thresholds held across the lanes of a VGPR (lane l: query l) and broadcast per query with
 //     v_readlane -- no LDS reads and no scalar-memory waits in the loop;
 //   * the popcounts of a code chained through v_bcnt's accumulate operand (popc64_acc).
-// nq <= 32 (HF_MAX_NQ).  hist: the sample histogram [nq][bits + 1] of hamming_hist_kernel.
+// Batches of up to 32 queries (HF_MAX_NQ) hand over `hist`, the sample histogram [nq][bits + 1] of hamming_hist_kernel, and
+// get their thresholds in the prologue; larger ones (hist == nullptr) read them from `thr_out`, written by hamming_thr_kernel,
+// and walk the queries in groups of 64 (a lane per query of the group).  Dynamic LDS: nq * (8 W + 8) bytes.
 template <int W, int C>
 __global__ __launch_bounds__(256) void hamming_body_kernel(const u64* __restrict__ codes, long long n, RowPerm pmul,
                                                             const u64* __restrict__ qs, int nq, const u32* __restrict__ hist,
                                                             int bits, int rank, int* __restrict__ thr_out,
                                                             u64* __restrict__ seg, u32* __restrict__ bcnt, u32 S) {
     static_assert(W * 64 + 1 <= HF_PER * 64, "one wave per histogram row");
-    __shared__ u32 lcnt[HF_MAX_NQ];
-    __shared__ int lthr[HF_MAX_NQ];
+    extern __shared__ __attribute__((aligned(16))) unsigned char hbm[];
+    u64* lq = reinterpret_cast<u64*>(hbm);                      // [nq][W]
+    int* lthr = reinterpret_cast<int*>(lq + (size_t)nq * W);    // [nq]
+    u32* lcnt = reinterpret_cast<u32*>(lthr + nq);              // [nq]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long long per_chunk = 256ll * C;
     const long long nchunks = (n + per_chunk - 1) / per_chunk;
     u64 cn[C][W];
     bool validn[C];
     if ((long long)blockIdx.x < nchunks) load_codes<W, C>(codes, n, (long long)blockIdx.x * per_chunk, tid, cn, validn);
-    for (int q = wv; q < nq; q += 4) {
-        const int t = hf_wave_threshold(hist + (long long)q * (bits + 1), bits + 1, bits, rank, lane);
-        if (lane == 0) {
-            lthr[q] = t;
-            if (blockIdx.x == 0) thr_out[q] = t;
+    if (hist) {
+        for (int q = wv; q < nq; q += 4) {
+            const int t = hf_wave_threshold(hist + (long long)q * (bits + 1), bits + 1, bits, rank, lane);
+            if (lane == 0) {
+                lthr[q] = t;
+                if (blockIdx.x == 0) thr_out[q] = t;
+            }
         }
+    } else {
+        for (int i = tid; i < nq; i += 256) lthr[i] = thr_out[i];
     }
-    __shared__ u64 lq[HF_MAX_NQ * W];
-    if (tid < HF_MAX_NQ) lcnt[tid] = 0u;
-    if (tid < nq * W) lq[tid] = qs[tid];
+    for (int i = tid; i < nq; i += 256) lcnt[i] = 0u;
+    // (the queries reach the lanes through LDS: loaded from global memory straight into the registers the loop reads with
+    // v_readlane, hipcc put `s_waitcnt vmcnt(0)` at the head of the query loop -- the prefetch of the next chunk then
+    // overlapped nothing)
+    for (int i = tid; i < nq * W; i += 256) lq[i] = qs[i];
     __syncthreads();
-    u64 qv[W];
-    int tv;
-    {
-        const int ql = lane < nq ? lane : nq - 1;
-#pragma unroll
-        for (int w = 0; w < W; ++w) qv[w] = lq[ql * W + w];
-        tv = lane < nq ? lthr[ql] : -1;
-    }
     u64* myseg = seg + (long long)blockIdx.x * nq * S;
     for (long long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const long long bb = chunk * per_chunk;
@@ -189,40 +191,50 @@ __global__ __launch_bounds__(256) void hamming_body_kernel(const u64* __restrict
         }
         // the next chunk's codes travel while this one is compared with every query
         if (chunk + gridDim.x < nchunks) load_codes<W, C>(codes, n, (chunk + gridDim.x) * per_chunk, tid, cn, validn);
-        for (int q = 0; q < nq; ++q) {
-            u64 qw[W];
+        for (int g0 = 0; g0 < nq; g0 += 64) {
+            const int gn = nq - g0 < 64 ? nq - g0 : 64;
+            // lane l of every wave holds query g0 + l (W words) and its threshold
+            u64 qv[W];
+            const int ql = g0 + (lane < gn ? lane : gn - 1);
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                // the query word as a VECTOR operand (all lanes equal): v_xor_b32 with a scalar source issues at half the
-                // rate of the all-VGPR form (tools/micro/valu_rate.hip: 4 against 2-2.5 cycles per wave-instruction and SIMD)
-                u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)qv[w], q), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(qv[w] >> 32), q);
-                asm volatile("" : "+v"(lo), "+v"(hi));
-                qw[w] = ((u64)hi << 32) | lo;
-            }
-            const int t = __builtin_amdgcn_readlane(tv, q);
-            u32 dist[C];
-            u32 m = 0xffffffffu;
+            for (int w = 0; w < W; ++w) qv[w] = lq[(size_t)ql * W + w];
+            const int tv = lane < gn ? lthr[ql] : -1;
+            for (int qi = 0; qi < gn; ++qi) {
+                const int q = g0 + qi;
+                u64 qw[W];
 #pragma unroll
-            for (int i = 0; i < C; ++i) {
-                u32 dsum = 0;
-#pragma unroll
-                for (int w = 0; w < W; ++w) dsum = popc64_acc(c[i][w] ^ qw[w], dsum);
-                dist[i] = dsum;
-                m = dsum < m ? dsum : m;
-            }
-            if ((int)m <= t) {  // rare: one branch per (query, C codes); padding codes are screened inside
+                for (int w = 0; w < W; ++w) {
+                    // the query word as a VECTOR operand (all lanes equal): v_xor_b32 with a scalar source issues at half the
+                    // rate of the all-VGPR form (tools/micro/valu_rate.hip: 4 against 2-2.5 cycles per wave-instruction and SIMD)
+                    u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)qv[w], qi), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(qv[w] >> 32), qi);
+                    asm volatile("" : "+v"(lo), "+v"(hi));
+                    qw[w] = ((u64)hi << 32) | lo;
+                }
+                const int t = __builtin_amdgcn_readlane(tv, qi);
+                u32 dist[C];
+                u32 m = 0xffffffffu;
 #pragma unroll
                 for (int i = 0; i < C; ++i) {
-                    if (valid[i] && (int)dist[i] <= t) {
-                        const u32 pos = atomicAdd(&lcnt[q], 1u);
-                        if (pos < S) hf_store_key(myseg + (long long)q * S + pos, ((u64)dist[i] << 32) | (u64)(u32)code_row<W, C>(bb, tid, i));
+                    u32 dsum = 0;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) dsum = popc64_acc(c[i][w] ^ qw[w], dsum);
+                    dist[i] = dsum;
+                    m = dsum < m ? dsum : m;
+                }
+                if ((int)m <= t) {  // rare: one branch per (query, C codes); padding codes are screened inside
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        if (valid[i] && (int)dist[i] <= t) {
+                            const u32 pos = atomicAdd(&lcnt[q], 1u);
+                            if (pos < S) hf_store_key(myseg + (long long)q * S + pos, ((u64)dist[i] << 32) | (u64)(u32)code_row<W, C>(bb, tid, i));
+                        }
                     }
                 }
             }
         }
     }
     __syncthreads();
-    if (tid < nq) bcnt[(long long)blockIdx.x * nq + tid] = lcnt[tid];
+    for (int i = tid; i < nq; i += 256) bcnt[(long long)blockIdx.x * nq + i] = lcnt[i];
 }
 
 // One workgroup (1024 threads) per query over the mini-lists the stream left: seg[(g * nq + q) * S + e], fills

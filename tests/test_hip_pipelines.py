@@ -78,7 +78,8 @@ def test_hamming_ring_kernel_matches_oracle(w, n, nq, k):
 
 # ------------------------------------------------------------------- Hamming small batches in three launches
 @pytest.mark.parametrize("w,n,nq,k,ring", [(1, 300_001, 1, 100, 0), (1, 1_000_003, 32, 100, 0), (2, 200_000, 17, 10, 0),
-                                           (4, 150_017, 8, 1000, 0), (1, 400_000, 5, 2048, 1), (2, 262_144, 3, 1, 1)])
+                                           (4, 150_017, 8, 1000, 0), (1, 400_000, 5, 2048, 1), (2, 262_144, 3, 1, 1),
+                                           (1, 500_009, 100, 50, 0), (2, 300_000, 333, 10, 0), (4, 200_000, 70, 100, 0)])
 def test_hamming_fused_small_batch_matches_oracle(w, n, nq, k, ring):
     """Head / stream / pick (sq_hamming_fused.hpp) against the oracle and against the general chain on the same index:
     distances and rows identical, for the register stream and the ring (physical rows mapped by the pick kernel), for
