@@ -117,7 +117,7 @@ def cpu_baseline(dim: int, k: int, seed: int):
     sort, oracle/cpu_ref.py) timed on this host on a bounded sample of the same
     workload; scaled linearly in rows to the full database and labelled so."""
     from oracle import cpu_ref as O
-    rows, nq = 2_000_000, 32                       # ~15 s of single-thread numpy on the GPU box's host
+    rows, nq = max(20_000, 2_000_000 * 128 // max(dim, 128)), 32   # ~15 s of single-thread numpy on the GPU box's host (1 GB of rows)
     rng = np.random.default_rng(seed)
     db = rng.standard_normal((rows, dim), dtype=np.float32)
     qs = rng.standard_normal((nq, dim), dtype=np.float32)
@@ -359,7 +359,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     parity = None
     if not args.no_parity_check and world == 1:
         from oracle import cpu_ref as O
-        sub = min(n_local, 2_000_000)
+        sub = min(n_local, max(20_000, 2_000_000 * 128 // max(d, 128)))   # (1 GB of rows through the oracle)
         idx_sub = _lib.DenseIndex(db.data_ptr(), n=sub, d=d, metric=metric, device_ptr=True, keepalive=db)
         qn = queries[:2].cpu().numpy()
         gd, gi = idx_sub.search(qn, k)
@@ -598,7 +598,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
             # what SMQTK executes today -- one Python distance call per candidate row (lsh.py:511)
             from oracle import cpu_ref as O
             rng = np.random.default_rng(7)
-            rows_l = 200_000
+            rows_l = max(5_000, 200_000 * 128 // max(d, 128))
             dbl = rng.standard_normal((rows_l, d), dtype=np.float32)
             ql = rng.standard_normal(d, dtype=np.float32)
             t1 = time.perf_counter()
@@ -613,7 +613,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
             # what a vectorised CPU implementation reaches on the same sample -- |x|^2 - 2 x.q through
             # BLAS on every host thread numpy's BLAS uses, argpartition for the top k.  Not order-exact; a reported
             # baseline only (neither the oracle nor the product).
-            rows_v, nq_v = 2_000_000, 32
+            rows_v, nq_v = max(20_000, 2_000_000 * 128 // max(d, 128)), 32
             dbv = rng.standard_normal((rows_v, d), dtype=np.float32)
             qv = rng.standard_normal((nq_v, d), dtype=np.float32)
             n2 = np.einsum("ij,ij->i", dbv, dbv)

@@ -150,6 +150,13 @@ def np_pairwise_sum_f32(a: np.ndarray) -> np.float32:
     a = np.asarray(a, dtype=np.float32)
     n = a.shape[0]
     f = np.float32
+    if n > 8192:
+        # numpy's reduction iterates the array through its buffer, NPY_BUFSIZE = 8192 elements at a time: each buffer is
+        # summed pairwise and the buffers' sums are added in order (np.sum over 8300 values is NOT a pairwise split at 4144)
+        total = np_pairwise_sum_f32(a[:8192])
+        for s in range(8192, n, 8192):
+            total = f(total + np_pairwise_sum_f32(a[s:s + 8192]))
+        return total
     if n < 8:
         res = f(0.0)
         for v in a:

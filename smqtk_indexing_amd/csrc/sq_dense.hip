@@ -32,6 +32,7 @@
 #include "sq_dense_scan.hpp"
 #include "sq_dense_mid.hpp"
 #include "sq_dense_i8.hpp"
+#include "sq_dense_wide.hpp"
 
 namespace sq {
 
@@ -238,6 +239,15 @@ static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, int qt, int
 
 template <bool SAMPLE>
 static int scan_launch(const Options& o, const DenseScanArgs& a, int d_pad, int qt, int qp, hipStream_t st) {
+    if (d_pad > RING_MAX_DPAD) {   // rows beyond the ring kernels: one query tile per wave, fragments straight from global memory
+        if (qt != 1) return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d takes one query tile per wave", d_pad);
+        const dim3 grid((unsigned)(a.nrb * a.nqt)), block(WIDE_WAVES * 64);
+        if (qp == 2)
+            hipLaunchKernelGGL((dense_wide_scan_kernel<2, SAMPLE>), grid, block, 0, st, a, d_pad / KT);
+        else
+            hipLaunchKernelGGL((dense_wide_scan_kernel<1, SAMPLE>), grid, block, 0, st, a, d_pad / KT);
+        return SQ_OK;
+    }
     const ScanGeom g = scan_geometry(o, d_pad, qt, qp);
     if (g.stages < 2 || ((qt > 1 || qp == 1) && g.waves == 4 && g.stages != 4))
         return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d qt=%d leaves no room for the LDS ring", d_pad, qt);
@@ -261,7 +271,7 @@ static double dense_eps_b(int d_pad) { return (3.0 * d_pad + 8.0) * 1.1920928955
 // many as the register budget allows (four at d_pad = 128, two beyond).
 static int scan_query_tiles(const Options& o, int d_pad, int nqt) {
     const int ku = d_pad / KT;
-    if (nqt <= 1) return 1;
+    if (nqt <= 1 || d_pad > RING_MAX_DPAD) return 1;   // (sq_dense_wide.hpp: one tile per wave)
     int want = nqt >= 3 ? 4 : 2;
     if (o.dense_qt == 1 || o.dense_qt == 2 || o.dense_qt == 4) want = o.dense_qt;
     if (ku >= 2 && want > 2) want = 2;  // four tiles of a 256-wide row spill past 512 registers
@@ -378,7 +388,8 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
     const int qt = scan_query_tiles(h->opt, d_pad, (nq + TILE_ROWS - 1) / TILE_ROWS);  // query tiles per wave
     // query planes: the multi-tile configuration is MFMA bound, so it drops q_lo (half the MFMAs, twice the
     // product bound: ~1.4x more rows pass the filter) unless asked otherwise
-    const int qp = (qt > 1 && (h->opt.dense_qplanes != 2 || d_pad > KT)) ? 1 : 2;
+    // (rows beyond the ring kernels, sq_dense_wide.hpp: two planes unless option dense_qplanes = 1 -- half the query bytes read from L2 per row tile, twice the slack)
+    const int qp = ((qt > 1 && (h->opt.dense_qplanes != 2 || d_pad > KT)) || (d_pad > RING_MAX_DPAD && h->opt.dense_qplanes == 1)) ? 1 : 2;
     const int group_q = qt * TILE_ROWS;                                           // queries per scan workgroup
     const int nqt = (nq + group_q - 1) / group_q;                                 // groups of qt query tiles
     const int nq_pad = nqt * group_q;
@@ -783,7 +794,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // (DenseScanArgs::raw_q, DenseThrPost).  The head of a call is then sample pass -> threshold: on a 1.25 M-row
         // shard the three-launch head (prep 6-27 us beside the neighbours' kernels, sample, threshold) no longer
         // fitted under the previous call's 59 us scan, and the scans did not run back to back.
-        const bool fused_prep = !cosine && qt == 1 && qp == 2 && h->opt.dense_fused_prep != 0;
+        const bool fused_prep = !cosine && qt == 1 && qp == 2 && h->opt.dense_fused_prep != 0 && d_pad <= RING_MAX_DPAD;
         const float* centerp = h->center.p ? h->center.as<float>() : nullptr;
         if (!fused_prep)
             hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, q, nq, d, d_pad, h->metric, qs,

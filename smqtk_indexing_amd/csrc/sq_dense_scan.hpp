@@ -39,7 +39,8 @@ static constexpr int TILE_ROWS = 32;                   // rows per MFMA tile
 static constexpr int UNIT_BYTES = TILE_ROWS * KT * 2;  // 8 KiB: 32 rows x 256 bytes
 static constexpr int NORM_BYTES = 256;                 // per ring slot: |x|^2 of the tile's 32 rows (64 lanes x 4 B)
 static constexpr int SLOT_BYTES = UNIT_BYTES + NORM_BYTES;
-static constexpr int MAX_DPAD = 512;
+static constexpr int RING_MAX_DPAD = 512;   // widest padded row of the ring kernels (dense_scan_kernel: query tile in registers / LDS)
+static constexpr int MAX_DPAD = 8192;       // widest padded row with a scan copy at all (beyond the ring kernels: sq_dense_wide.hpp)
 
 // --------------------------------------------------------------- bf16 split
 __device__ __forceinline__ u32 bf16_bits_rn(float x) {

@@ -56,8 +56,27 @@ __device__ __forceinline__ int pw_split(int m) {
     return m2 - (m2 % 8);
 }
 
+// numpy's add-reduce walks an array through its iterator's buffer: NPY_BUFSIZE = 8192 elements at a time, each buffer
+// summed pairwise as above and the buffers' sums added in order -- np.sum of 8300 float32 values is
+// pairwise(a[:8192]) + pairwise(a[8192:]), not a pairwise split at 4144 (found with 8300-dimensional rows in round 4;
+// oracle/cpu_ref.py:np_pairwise_sum_f32 restates it, tests/test_oracle_golden.py pins it against np.sum).
+static constexpr int PW_BUFSIZE = 8192;
+
+template <class T, class L>
+__device__ __forceinline__ T pw_tree_buffer(L&& leaf, const int base, const int n);
+
 template <class T, class L>
 __device__ __forceinline__ T pw_tree(L&& leaf, int n) {
+    if (n <= PW_BUFSIZE) return pw_tree_buffer<T>(leaf, 0, n);
+    T total = pw_tree_buffer<T>(leaf, 0, PW_BUFSIZE);
+    for (int s = PW_BUFSIZE; s < n; s += PW_BUFSIZE) total = add_rn(total, pw_tree_buffer<T>(leaf, s, n - s < PW_BUFSIZE ? n - s : PW_BUFSIZE));
+    return total;
+}
+
+// one buffer: elements [base, base + n), n <= 8192
+template <class T, class L>
+__device__ __forceinline__ T pw_tree_buffer(L&& leaf0, const int base, const int n) {
+    auto leaf = [&](int off, int m) { return leaf0(base + off, m); };
     if (n <= 128) return leaf(0, n);
     T st[PW_MAX_DEPTH];
 #pragma unroll

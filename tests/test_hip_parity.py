@@ -789,12 +789,39 @@ def test_dense_async_call_graph(graph):
         idx.close()
 
 
-def test_dense_wide_rows_exact_path():
-    """d beyond the scan kernel's LDS budget: exact path, numpy pairwise recursion (d > 128)."""
+@pytest.mark.parametrize("metric,n,d,nq,k,qplanes", [("euclidean", 70_000, 1000, 2, 5, 0), ("euclidean", 80_000, 2048, 32, 100, 0),
+                                                    ("euclidean", 66_000, 4096, 40, 10, 0), ("cosine", 70_000, 2048, 7, 10, 0),
+                                                    ("euclidean", 70_003, 1500, 33, 20, 1), ("euclidean", 66_001, 8192, 3, 3, 0)])
+def test_dense_rows_wider_than_512_dimensions(metric, n, d, nq, k, qplanes):
+    """Rows beyond the ring kernels' 512 padded dimensions (the reference's own examples index 2048- and 4096-d descriptors,
+    docs/examples/caffe_build_index.rst:35): dense_wide_scan_kernel filters them from the bf16 copy -- fragments straight
+    from global memory, one query tile per wave, several tiles as groups -- and the exact re-rank (numpy's pairwise recursion
+    at d > 128) answers; ids and float32 distance bits equal the oracle's, no query on the exact path."""
+    rng = np.random.default_rng(d + nq)
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    db += rng.standard_normal((1, d)).astype(np.float32)              # a common offset: the filter works around the column means
+    qs = (db[rng.integers(0, n, nq)] + np.float32(0.5) * rng.standard_normal((nq, d))).astype(np.float32)
+    qs[0] = db[4242]
+    if qplanes:
+        _lib.set_option("dense_qplanes", qplanes)
+    try:
+        idx = _dense_check(db, qs, k, metric)
+    finally:
+        _lib.set_option("dense_qplanes", 0)
+    st = idx.stats()
+    assert st["fallback_queries"] == 0, st
+    d_pad = -(-d // 128) * 128
+    assert st["bytes_scanned"] == (-(-n // 32) * 32) * (d_pad * 2 + (4 if metric == "euclidean" else 0)), st
+    idx.close()
+
+
+def test_dense_rows_beyond_the_scan_copy_take_the_exact_path():
+    """d beyond every filter (padded rows above 8192 dimensions): the exact path, numpy pairwise recursion."""
     rng = np.random.default_rng(8)
-    db = rng.standard_normal((70_000, 1000)).astype(np.float32)
-    qs = rng.standard_normal((2, 1000)).astype(np.float32)
-    _dense_check(db, qs, 5, "euclidean")
+    db = rng.standard_normal((66_000, 8300)).astype(np.float32)
+    qs = rng.standard_normal((2, 8300)).astype(np.float32)
+    idx = _dense_check(db, qs, 5, "euclidean")
+    assert idx.stats()["fallback_queries"] == 2
 
 
 @pytest.mark.parametrize("d", [1, 5, 8, 9, 127, 128, 129, 200, 300, 1024, 4100])

@@ -150,7 +150,8 @@ def test_dense_nn_golden(golden):
 
 def test_pairwise_sum_restatement():
     rng = np.random.default_rng(5)
-    for n in (1, 7, 8, 9, 100, 128, 129, 200, 256, 300, 512, 1000, 4096):
+    # (beyond 8192 elements numpy sums its iterator's 8192-element buffers one after the other)
+    for n in (1, 7, 8, 9, 100, 128, 129, 200, 256, 300, 512, 1000, 4096, 8192, 8193, 8300, 16384, 20000):
         a = np.square(rng.standard_normal(n).astype(np.float32) * 7)
         assert O.np_pairwise_sum_f32(a).tobytes() == np.sum(a).tobytes(), n
 
