@@ -204,7 +204,10 @@ int sq_hamming_destroy(sq_handle_t h);
  * summation order and sqrt); cosine distances are float64.
  * With SQ_MEM_DEVICE the matrix is borrowed (row stride d; the pointer must
  * be 16-byte aligned and d % 4 == 0, otherwise pass host memory and the
- * library pads the rows). */
+ * library pads the rows).
+ * Any d: rows of up to 8192 padded dimensions are filtered from a bfloat16 copy (up to 512: the ring kernels, and an
+ * int8 copy for small batches; beyond: dense_wide_scan_kernel, the widths of the reference's own examples --
+ * 2048- / 4096-dimensional descriptors, docs/examples/caffe_build_index.rst:35); wider rows take the exact path. */
 int sq_dense_create(const float* db, int64_t n, int d, int metric, int mem,
                     int64_t id_base, sq_handle_t* out);
 /* The same with options of THIS index given at create, as name / value arrays: they become the handle's overrides

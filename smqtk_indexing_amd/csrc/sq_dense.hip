@@ -779,8 +779,10 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // and the pipelined step drops from 0.50 to 0.46 ms (tools/step_sweep.py dense_blocks=...).
         // (one query tile per wave only: the multi-tile configurations are MFMA bound and want every CU)
         int nrb = h->opt.dense_blocks > 0 ? h->opt.dense_blocks : (use_event && h->opt.dense_async_streams == 2 && nqt == 1 ? cus * 3 / 4 : cus);
+        // (the wide kernel, 122 registers and 32 KB of LDS: two eight-wave workgroups per CU -- twice the row bytes in flight)
+        if (d_pad > RING_MAX_DPAD && h->opt.dense_blocks <= 0) nrb = 2 * cus;
         nrb = (nrb + 7) / 8 * 8;
-        const int wv = scan_geometry(h->opt, d_pad, qt, qp).waves;
+        const int wv = d_pad > RING_MAX_DPAD ? WIDE_WAVES : scan_geometry(h->opt, d_pad, qt, qp).waves;
         // survivors leave the scan as per-wave segments; the re-rank kernel turns them into per-query key lists
         const long long n_waves = (long long)nrb * nqt * wv;
         const u32 wave_cap = 2048;

@@ -5,25 +5,28 @@
 // query took the exact path, a pass over the float32 matrix per 8 queries.  dense_scan_kernel keeps the query tile's
 // fragments in registers or in LDS, which ends at d_pad = 512 (32 queries x d_pad x 2 planes x 2 bytes: 512 KB at 4096).
 // Here a wave owns a 32-row tile and walks its k-units (128 columns = 256 bytes of the bfloat16 scan copy per row) with
-// the accumulators of ONE query tile in registers; the row fragments AND the query fragments of a k-unit are plain global
-// loads straight into the MFMA operand registers, the next unit's requested before this unit's sixteen
-// v_mfma_f32_32x32x16_bf16.  The scan copy is stored in fragment order, so a lane's 16 bytes are a lane's operand;
-// the query planes (512 KB for 32 queries at 4096 dimensions) stay in L2.  Same inputs, outputs and error bound as
+// the accumulators of ONE query tile in registers; the row fragments of a k-unit are plain global loads straight into
+// the MFMA operand registers (the scan copy is stored in fragment order: a lane's 16 bytes are a lane's operand), the
+// next unit's requested before this unit's sixteen v_mfma_f32_32x32x16_bf16; the query tile's fragments of the unit --
+// the same for all eight waves of a workgroup -- pass through a double-buffered LDS copy, one barrier per unit; the query
+// planes themselves (512 KB for 32 queries at 4096 dimensions) stay in L2.  Same inputs, outputs and error bound as
 // dense_scan_kernel's one-tile configuration (DenseScanArgs; scores = n' + x_hi (q_hi + q_lo)): the
 // sample pass, the threshold, the exact re-rank, the select and the certification around it are unchanged.
-// No LDS, no ring: the compiler's own counted waits order the loads (a DMA ring as in dense_scan_kernel would need the
-// query unit staged per wave: 16 KB per stage beside the rows' 8).
+// No DMA ring: the compiler's own counted waits order the loads.
 #pragma once
 #include "sq_dense_scan.hpp"
 
 namespace sq {
 
-static constexpr int WIDE_WAVES = 4;
+static constexpr int WIDE_WAVES = 8;
 
+// LDS: two buffers of the query tile's fragments of ONE k-unit: [plane][query 0..31][16 chunks of 16 bytes, chunk c at
+// position c ^ (query & 15): the fragment reads of 16 consecutive queries then hit 16 different bank groups].
 template <int QP, bool SAMPLE>
 __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void dense_wide_scan_kernel(DenseScanArgs a, int ku) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) unsigned char qbuf[2][QP * TILE_ROWS * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r31 = lane & 31, h = lane >> 5;
     const long long wave_id = (long long)blockIdx.x * WIDE_WAVES + wave;   // unique per wave of the launch
     uint2* wout = a.wave_out + wave_id * a.wave_cap;
@@ -43,25 +46,39 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void dense_wide_scan_kernel(Den
     const size_t dpad = (size_t)ku * KT;
     const int qglob = qt * TILE_ROWS + r31;
     const float thr_l = SAMPLE ? 0.f : ((a.debug & 4) ? -__builtin_inff() : a.thr[qglob]);
-    // this lane's query: per k-unit 256 bytes of q_hi then 256 of q_lo, chunk 2 s + h of each = k-step s
-    const unsigned char* qrow = reinterpret_cast<const unsigned char*>(a.qs) + (size_t)qglob * dpad * 4 + (size_t)h * 16;
+    // The query tile's fragments of a k-unit are the same for the eight waves of the workgroup (and for every row tile):
+    // thread t brings chunk (t & 15) of query (t >> 4) of each plane -- 16 threads read 256 contiguous bytes -- and all
+    // waves read their fragments from the LDS copy.  (Every wave loading its own fragments from L2 -- the first version --
+    // moved 2 x the rows' bytes through the L2 fabric and ran the pass at 0.34 of the HBM peak.)
+    const int lq = tid >> 4, lc = tid & 15;
+    const unsigned char* qsrc = reinterpret_cast<const unsigned char*>(a.qs) + (size_t)(qt * TILE_ROWS + lq) * dpad * 4 + (size_t)lc * 16;
+    const u32 qdst = (u32)(lq * 256 + ((lc ^ (lq & 15)) * 16));
     u32 tail_mask = 0;   // rows of the last, partial tile that exist (bit i <-> accumulator register i of this lane)
     {
         const int nvalid = (int)(a.n - (a.n_tiles - 1) * TILE_ROWS);
 #pragma unroll
         for (int i = 0; i < 16; ++i) tail_mask |= ((i & 3) + 8 * (i >> 2) + 4 * h < nvalid ? 1u : 0u) << i;
     }
+    // rounds of the WORKGROUP (its first wave has the most tiles): every wave walks them all -- the barriers are the
+    // workgroup's -- and skips the arithmetic of a round it has no tile in
+    const long long wg_first = (long long)rb * WIDE_WAVES;
+    const long long rounds = wg_first < a.n_sel ? (a.n_sel - wg_first + nwaves - 1) / nwaves : 0;
+    if (rounds > 0) {   // unit 0 of the query tile
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(qsrc), v1;
+        if constexpr (QP == 2) v1 = *reinterpret_cast<const f32x4*>(qsrc + 256);
+        *reinterpret_cast<f32x4*>(qbuf[0] + qdst) = v0;
+        if constexpr (QP == 2) *reinterpret_cast<f32x4*>(qbuf[0] + TILE_ROWS * 256 + qdst) = v1;
+    }
     u32 wcount = 0;
-    for (long long sel = gw; sel < a.n_sel; sel += nwaves) {
-        const long long row0 = sel * a.tile_step * TILE_ROWS;
+    int step = 0;   // (round, k-unit) steps so far: buffer step & 1 holds this step's query fragments
+    for (long long it = 0; it < rounds; ++it) {
+        const long long sel = gw + it * nwaves;
+        const bool active = sel < a.n_sel;
+        const long long row0 = (active ? sel : 0) * a.tile_step * TILE_ROWS;
         const unsigned char* arow = reinterpret_cast<const unsigned char*>(a.scan) + (size_t)(row0 + r31) * dpad * 2 + (size_t)h * 16;
-        f32x4 av[8], bh[8], bl[QP == 2 ? 8 : 1];
+        f32x4 av[8];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            av[g] = *reinterpret_cast<const f32x4*>(arow + g * 32);
-            bh[g] = *reinterpret_cast<const f32x4*>(qrow + g * 32);
-            if constexpr (QP == 2) bl[g] = *reinterpret_cast<const f32x4*>(qrow + 256 + g * 32);
-        }
+        for (int g = 0; g < 8; ++g) av[g] = *reinterpret_cast<const f32x4*>(arow + g * 32);
         // the accumulator starts from the rows' stored norms n' (0 for cosine): score = n' + x . q'
         f32x16 acc;
         if (a.norms) {
@@ -75,28 +92,40 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void dense_wide_scan_kernel(Den
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         }
-        for (int kc = 0; kc < ku; ++kc) {
-            f32x4 an[8], bhn[8], bln[QP == 2 ? 8 : 1];
-            const int kn = kc + 1 < ku ? kc + 1 : kc;   // (the last unit re-requests itself: no branch around the loads)
+        for (int kc = 0; kc < ku; ++kc, ++step) {
+            // requests of the NEXT step: the row fragments of this tile's next unit (the last unit re-requests itself: no
+            // branch around the loads) and the workgroup's share of the next query unit (the next round starts at unit 0)
+            f32x4 an[8], nq0, nq1;
+            const int kn = kc + 1 < ku ? kc + 1 : kc;
+            const int kq = kc + 1 < ku ? kc + 1 : 0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) an[g] = *reinterpret_cast<const f32x4*>(arow + (size_t)kn * 256 + g * 32);
+            nq0 = *reinterpret_cast<const f32x4*>(qsrc + (size_t)kq * 512);
+            if constexpr (QP == 2) nq1 = *reinterpret_cast<const f32x4*>(qsrc + (size_t)kq * 512 + 256);
+            __syncthreads();   // this step's buffer is complete; nobody still reads the other one
+            const unsigned char* qb = qbuf[step & 1];
+            f32x4 bh[8], bl[QP == 2 ? 8 : 1];
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                an[g] = *reinterpret_cast<const f32x4*>(arow + (size_t)kn * 256 + g * 32);
-                bhn[g] = *reinterpret_cast<const f32x4*>(qrow + (size_t)kn * 512 + g * 32);
-                if constexpr (QP == 2) bln[g] = *reinterpret_cast<const f32x4*>(qrow + (size_t)kn * 512 + 256 + g * 32);
+                const u32 at = (u32)(r31 * 256 + (((2 * g + h) ^ (r31 & 15)) * 16));
+                bh[g] = *reinterpret_cast<const f32x4*>(qb + at);
+                if constexpr (QP == 2) bl[g] = *reinterpret_cast<const f32x4*>(qb + TILE_ROWS * 256 + at);
             }
+            if (active) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, av[s]);
-                if constexpr (QP == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bl[s]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bh[s]), acc, 0, 0, 0);
+                for (int s = 0; s < 8; ++s) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, av[s]);
+                    if constexpr (QP == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bl[s]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bh[s]), acc, 0, 0, 0);
+                }
             }
+            unsigned char* qn = qbuf[(step + 1) & 1];
+            *reinterpret_cast<f32x4*>(qn + qdst) = nq0;
+            if constexpr (QP == 2) *reinterpret_cast<f32x4*>(qn + TILE_ROWS * 256 + qdst) = nq1;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                av[g] = an[g];
-                bh[g] = bhn[g];
-                if constexpr (QP == 2) bl[g] = bln[g];
-            }
+            for (int g = 0; g < 8; ++g) av[g] = an[g];
         }
+        if (!active) continue;
         // ---- tile complete: scores for 32 rows x 32 queries (lane = query, register i = row (i & 3) + 8 (i >> 2) + 4 h)
         const bool is_tail = row0 + TILE_ROWS > a.n;   // wave-uniform: the last, partial tile
         if constexpr (SAMPLE) {
