@@ -327,6 +327,9 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     # ms_per_step -- and is reported separately as kernel_ms_in_pipeline.  roofline.achieved / frac use THIS one.
     index.sync() if use_async else None
     index.set_option("profile", 1)
+    # (the fused int8 call re-ranks inside the full-pass kernel: its per-workgroup clocks split the kernel's duration into
+    # the stream and the tail -- sq_stats_t.rerank_ms then is the tail; measurement bit of option dense_debug)
+    index.set_option("dense_debug", lib_opts.get("dense_debug", 0) | 8192)
     od1 = torch.empty((nq, k), dtype=ddt, device=dev)
     oi1 = torch.empty((nq, k), dtype=torch.int64, device=dev)
     al, al_rr = [], []
@@ -340,6 +343,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
     head_scan_ms = float(np.mean(al[4:]))
     alone_rerank_ms = float(np.mean(al_rr[4:]))
     index.set_option("profile", prof_every)
+    index.set_option("dense_debug", lib_opts.get("dense_debug", 0))
     head_cands = float(np.mean(cands)) / nq if cands else None
     head_fb = int(np.sum(fallbacks)) if fallbacks else 0
     head_mid = int(np.sum(mids)) if mids else 0
@@ -562,6 +566,11 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 "kernel_ms_in_pipeline_note": "the same bracket INSIDE the timed region: with pipelined calls the scan shares the "
                                               "device with the neighbouring calls' short kernels (and runs on 3/4 of the CUs to "
                                               "leave them room), so this can exceed ms_per_step; not used for achieved / frac",
+                "pass_ms": (head_scan_ms - alone_rerank_ms) if fused_call else None,
+                "frac_pass": (streamed / ((head_scan_ms - alone_rerank_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if (fused_call and head_scan_ms > alone_rerank_ms > 0) else None,
+                "pass_note": "fused int8 call: the kernel's duration minus its tail (thresholds + exact re-rank of its survivors), the tail "
+                             "measured by the kernel's own per-workgroup clocks (wall_clock64: from the last wave leaving the stream "
+                             "to the last workgroup done); frac_pass = streamed bytes / pass_ms / peak -- the stream alone; frac prices the whole kernel",
                 "rerank_kernel_ms": alone_rerank_ms, "rerank_kernel_ms_in_pipeline": pipe_rerank_ms,
                 "rerank_note": "exact re-rank of the survivors; its rows are cold (distinct query batches: ~3.3 k x nq rows of "
                                "512 B gathered from HBM per step)",

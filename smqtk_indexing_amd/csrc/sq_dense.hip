@@ -955,7 +955,8 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
     if (!all_fallback) {
         SQ_HIP(c.use_event ? event_wait(s.ev_done) : stream_wait(st));  // counts and status words are in hs_raw / hs now
         SQ_HIP(hipGetLastError());
-        if (s.clk8_wgs > 0 && (h->opt.dense_debug & 8192)) {   // measurement: where the body kernel's workgroups spent their time (100 MHz clock)
+        double clk_tail_ms = -1.0;
+        if (s.clk8_wgs > 0 && (h->opt.dense_debug & 8192)) {   // measurement: where the body kernel's workgroups spent their time (100 MHz clock; + 16384: printed)
             std::vector<long long> ck((size_t)s.clk8_wgs * 8);
             SQ_HIP(hipMemcpy(ck.data(), s.clk8.p, ck.size() * 8, hipMemcpyDeviceToHost));
             long long t0 = ck[0], tend = 0;
@@ -967,8 +968,15 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
                 for (int j = 0; j < 5; ++j) sum[j] += v[j], mx[j] = std::max(mx[j], v[j]), mn[j] = std::min(mn[j], v[j]);
             }
             const char* names[5] = {"start offset", "stream (first wave out)", "wave skew (all waves out)", "thresholds", "re-rank"};
-            fprintf(stderr, "[body clocks] %d workgroups, kernel span %.1f us\n", s.clk8_wgs, (tend - t0) * 0.01);
-            for (int j = 0; j < 5; ++j) fprintf(stderr, "   %-28s min %8.1f  mean %8.1f  max %8.1f us\n", names[j], mn[j], sum[j] / s.clk8_wgs, mx[j]);
+            if (h->opt.dense_debug & 16384) {
+                fprintf(stderr, "[body clocks] %d workgroups, kernel span %.1f us\n", s.clk8_wgs, (tend - t0) * 0.01);
+                for (int j = 0; j < 5; ++j) fprintf(stderr, "   %-28s min %8.1f  mean %8.1f  max %8.1f us\n", names[j], mn[j], sum[j] / s.clk8_wgs, mx[j]);
+            }
+            // the kernel's own split for sq_stats_t (set below when the call was timed): the part after the last wave of any
+            // workgroup has left the stream is the tail (thresholds + re-rank)
+            long long stream_end = 0;
+            for (int w = 0; w < s.clk8_wgs; ++w) stream_end = std::max(stream_end, ck[(size_t)w * 8 + 2]);
+            clk_tail_ms = (double)(tend - stream_end) * 1e-5;
             s.clk8_wgs = 0;
         }
         if (c.prof) {
@@ -988,6 +996,9 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
                 float t3 = 0;
                 SQ_HIP(hipEventElapsedTime(&t3, s.ev[2], s.ev[4]));
                 h->stats.rerank_ms = t3;
+                // the fused int8 call re-ranks inside the full-pass kernel: with its clocks recorded (dense_debug & 8192) the
+                // tail's share of scan_ms is reported as rerank_ms
+                if (clk_tail_ms >= 0.0) h->stats.rerank_ms = clk_tail_ms;
             }
         }
         for (int qi = 0; qi < nq; ++qi) h->stats.candidates += hs_raw[qi];

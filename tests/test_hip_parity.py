@@ -458,9 +458,15 @@ def test_dense_exact_path_two_level_select(metric):
         rd, ri = O.dense_topk(z, z[1], 50, "cosine")
         np.testing.assert_allclose(d[0], rd, rtol=1e-12, atol=1e-15)
     _lib.set_option("force_fallback", 0)
-    wide = rng.standard_normal((70_000, 700)).astype(np.float32)   # wider than the MFMA scan: exact path only
+    wide = rng.standard_normal((70_000, 700)).astype(np.float32)   # wider than the ring kernels: dense_wide_scan_kernel (round 4)
     idx = _dense_check(wide, wide[:2] + 0.01, 20, metric)
-    assert idx.stats()["fallback_queries"] == 2
+    assert idx.stats()["fallback_queries"] == 0
+    _lib.set_option("force_fallback", 1)                            # ... and its exact path (the group kernel at d = 700)
+    try:
+        idx = _dense_check(wide, wide[:2] + 0.01, 20, metric)
+        assert idx.stats()["fallback_queries"] == 2
+    finally:
+        _lib.set_option("force_fallback", 0)
 
 
 @pytest.mark.parametrize("metric", ["euclidean", "cosine"])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Measurement helper: where the workgroups of the fused int8 full pass (dense8_body_kernel) spend their time -- the
-library prints per-workgroup clock statistics for blocking calls under "dense_debug" = 8192.
+library prints per-workgroup clock statistics for blocking calls under "dense_debug" = 8192 | 16384.
 usage: N=10000000 NQ=32 [OPTS=name=v,...] python3 tools/body_clocks.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +24,7 @@ od = torch.empty((nq, k), dtype=torch.float32, device=dev); oi = torch.empty((nq
 for i in range(6):
     idx.search_device(qs[i % 4].data_ptr(), nq, k, od.data_ptr(), oi.data_ptr(), st)
 torch.cuda.synchronize()
-idx.set_option("dense_debug", 8192)
+idx.set_option("dense_debug", 8192 | 16384)
 idx.set_option("profile", 1)
 for i in range(3):
     idx.search_device(qs[i % 4].data_ptr(), nq, k, od.data_ptr(), oi.data_ptr(), st)
