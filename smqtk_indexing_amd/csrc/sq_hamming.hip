@@ -872,6 +872,11 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
             if (h->opt.hamming_tighten >= 2) thr_rank = 1;   // (testing: a bet that is usually lost -- the redo path)
         }
         c.fused = fused;
+        // the stream of a fused call: hamming_body_kernel (queries broadcast with v_readlane: two instructions per query word
+        // and chunk -- 128- and 256-bit codes beyond 32 queries measure 4-35 % slower with it than with the LDS-broadcast
+        // stream kernel, tools/hamming_width_sweep.sh) or, for those, hamming_stream_kernel between the tightened threshold
+        // and the pick kernel
+        const bool body_kernel = fused && !ring && (W == 1 || nq <= HF_MAX_NQ);
         u32* hist = nullptr;
         if (fused) {
             const size_t words = (size_t)(nq > HF_MAX_NQ ? nq : HF_MAX_NQ) * (bits + 1);
@@ -964,7 +969,7 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
                         case 8: SQ_TRY(ring_launch<8>(h, nt, G, qc, nqc, thr + q0, seg, bcnt, S, st)); break;
                         default: SQ_TRY(ring_launch<16>(h, nt, G, qc, nqc, thr + q0, seg, bcnt, S, st)); break;
                     }
-                } else if (fused) {
+                } else if (body_kernel) {
                     if (W == 1)
                         hipLaunchKernelGGL((hamming_body_kernel<1, 8>), dim3(G), dim3(256), lds, st, h->codes, n, h->pmul, qc, nqc,
                                            nq <= HF_MAX_NQ ? hist : nullptr, bits, thr_rank, thr, seg, bcnt, S);
@@ -986,10 +991,10 @@ static int hamming_enqueue(HammingHandle* h, HammingSlot& s, const u64* qs, int 
                 if (fused) {   // (nq <= qbatch: one pass)
                     c.G = G;
                     c.S = S;
-                    c.map_rows = 1;   // (ring and body kernels leave physical rows in the mini-lists)
+                    c.map_rows = (ring || body_kernel) ? 1 : 0;   // (ring and body kernels leave physical rows in the mini-lists)
                     c.key_stride = key_stride;
                     if (prof) SQ_HIP(hipEventRecord(s.ev[2], st));
-                    hipLaunchKernelGGL(hamming_pick_kernel, dim3(nq), dim3(1024), 0, st, seg, bcnt, G, nq, S, bits, k, kk, thr, 1,
+                    hipLaunchKernelGGL(hamming_pick_kernel, dim3(nq), dim3(1024), 0, st, seg, bcnt, G, nq, S, bits, k, kk, thr, (ring || body_kernel) ? 1 : 0,
                                        h->pmul, n, h->id_base, out_dist, out_idx, status, hs_dev, nq, cap, hist);
                 } else
                     hipLaunchKernelGGL(hamming_compact_kernel, dim3(nqc, COMPACT_SLICES), dim3(256), 0, st, seg, bcnt, G, nqc, S,
