@@ -87,9 +87,9 @@ def parse_args():
     ap.add_argument("--async-wait", type=int, default=-1,
                     help="several GPUs: 1 = a search call returns when the oldest call in flight is final, 0 = right after "
                          "enqueueing (option dense_async_wait): the gather / merge bookkeeping between two calls then overlaps "
-                         "the device, at one more call of lag.  -1 (default): 0 for runs of more than 40 steps, 1 for shorter "
-                         "ones, where the extra call in flight only lengthens the drain inside the timed region (one-rank "
-                         "proxy, 1.25 M-row shard, 20 steps: 0.122 against 0.130 ms per step)")
+                         "the device, at one more call of lag.  -1 (default): 0 (round 4, three-launch calls: the one-rank proxy "
+                         "of the 8-GPU step reads 0.082 against 0.090 ms per step at 20 steps and 0.065 against 0.068 at 100; "
+                         "with round 3's six-launch calls short runs were better off with 1)")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="several GPUs: steps per all-gather (PipelinedShardedSearch gather_every); 0 = 4: a collective "
                          "with its pinned copy and merge hand-off costs about as much host time as a 1.25 M-row shard "
@@ -240,7 +240,7 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
                 # host merge (rank 0, a worker thread) run under the searches of the following batches
                 self.pipe = PipelinedShardedSearch(index, nq_, k, ddt, merge_on=0, device=dev, use_async=use_async, depth=depth,
                                                    gather_every=args.gather_every if args.gather_every > 0 else 4,
-                                                   wait=bool(args.async_wait if args.async_wait >= 0 else (1 if args.steps <= 40 else 0)),
+                                                   wait=bool(args.async_wait if args.async_wait >= 0 else 0),
                                                    queries_ready=True)   # (the queries were generated and synchronised long ago)
             else:
                 self.od = [torch.empty((nq_, k), dtype=ddt, device=dev) for _ in range(depth)]   # one per call in flight
