@@ -21,9 +21,8 @@ the kernels of step i + 1 are enqueued while step i runs and the status words of
 read one call later, so the device never waits for the host; every step's results are final
 and every merge is collected before the closing fence (`--sync-search`: one blocking call per
 step, the round-1 behaviour).  One process per GPU (torch.distributed / RCCL); rank 0 prints
-ONE JSON line.  Three searches are in flight (`--async-depth`: the short kernels of a call -- query
-prep, sample pass, threshold, re-rank, select -- overlap two neighbours' scans: 0.256 against 0.273 ms
-per step at 10 M rows with the int8 filter); with several ranks a search call returns
+ONE JSON line.  Two searches are in flight on one GPU, three on shards (`--async-depth`: the short kernels
+of a call -- head, select -- overlap the neighbours' passes); with several ranks a search call returns
 right after enqueueing (`--async-wait 0`: the gather / merge bookkeeping overlaps the device), four
 steps share one all-gather (`--gather-every`: the collective's fixed cost is that of a whole step on
 a 1.25 M-row shard) and the library's timing events are taken on every 4th search; results come
@@ -82,8 +81,8 @@ def parse_args():
     ap.add_argument("--sync-search", action="store_true", help="one blocking search call per step (no pipelining)")
     ap.add_argument("--async-streams", type=int, default=0, help="option dense_async_streams (0 = library default)")
     ap.add_argument("--async-depth", type=int, default=0,
-                    help="asynchronous searches in flight (option dense_async_depth); 0 = 3 "
-                         "(the short kernels of a call overlap two neighbours' scans, DESIGN.md sections 4.1b and 5)")
+                    help="asynchronous searches in flight (option dense_async_depth); 0 = 2 on one GPU, 3 on shards "
+                         "(the short kernels of a shard's call overlap two neighbours' passes, DESIGN.md sections 4.1b and 5)")
     ap.add_argument("--async-wait", type=int, default=-1,
                     help="several GPUs: 1 = a search call returns when the oldest call in flight is final, 0 = right after "
                          "enqueueing (option dense_async_wait): the gather / merge bookkeeping between two calls then overlaps "
@@ -210,7 +209,10 @@ def bruteforce(args, torch, dist, _lib, world, rank, dev, use_dist, emit):
         index.set_option("dense_mid_tier", 0)
     stream = torch.cuda.current_stream().cuda_stream
     use_async = not args.sync_search
-    depth = args.async_depth if args.async_depth > 0 else 3
+    # calls in flight: 3 on shards (the short kernels of a 1.25 M-row shard's call overlap two neighbours' passes: one-rank proxy
+    # 0.065 against 0.081 ms per step), 2 on one GPU since round 4 (three launches per call: 0.229-0.232 against 0.235-0.238 ms
+    # per step at 20 steps, equal at 100 -- profiles/r04_async_depth.txt)
+    depth = args.async_depth if args.async_depth > 0 else (3 if use_dist else 2)
     depth = min(max(depth, 2), 4)
     if use_async:
         index.set_option("dense_async_depth", depth)
