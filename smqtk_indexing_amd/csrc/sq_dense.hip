@@ -33,6 +33,7 @@
 #include "sq_dense_mid.hpp"
 #include "sq_dense_i8.hpp"
 #include "sq_dense_wide.hpp"
+#include "sq_dense_tighten.hpp"
 
 namespace sq {
 
@@ -57,6 +58,8 @@ struct DenseSlot {
     DevBuf clk8;                  // measurement ("dense_debug" & 8192): the body kernel's per-workgroup clocks
     int clk8_wgs = 0;
     DevBuf wave_score, hist8;     // ... the fused call's tightened threshold: an entry's smallest score, the per-query histograms
+    DevBuf tg;                    // the wide-row path's second-level threshold (sq_dense_tighten.hpp): [hist | raw thresholds | T'' | keys of T'']
+    void* tg_zeroed = nullptr;    // the allocation of tg that has been wiped once (its histogram is zero between calls)
     DevBuf sort_tmp;              // scratch of the any-k sorted select (k beyond the one-workgroup select): one per call in flight
     HostPinned status_host;
     // captured call graph of the int8 path ("dense_graph"): one hipGraphLaunch instead of six kernel launches per call
@@ -68,7 +71,7 @@ struct DenseSlot {
     hipStream_t own = nullptr;    // internal stream of the slot (asynchronous calls with "dense_async_streams" = 2)
     DenseCall call;
     void release() {
-        for (DevBuf* b : {&q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt, &keys, &sample, &out_keys, &cos_nq, &oflag, &sort_tmp, &q8, &par8, &wave_score, &hist8, &clk8})
+        for (DevBuf* b : {&q_scaled, &q_al, &qn2, &thr, &wave_out, &wave_cnt, &cnt, &keys, &sample, &out_keys, &cos_nq, &oflag, &sort_tmp, &q8, &par8, &wave_score, &hist8, &clk8, &tg})
             b->release();
         status_host.release();
         call_ptrs.release();
@@ -791,6 +794,22 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         SQ_TRY(s.wave_cnt.reserve((size_t)n_waves * 8));
         SQ_TRY(s.q_al.reserve((size_t)nq * ldq * 4));
         u32* oflag = s.oflag.as<u32>();
+        // rows beyond the ring kernels: a second-level threshold between the pass and the re-rank (sq_dense_tighten.hpp)
+        const bool wide_tighten = d_pad > RING_MAX_DPAD && h->opt.dense_tighten != 0 && nq_pad <= TG_MAX_Q;
+        u32 *tg_hist = nullptr, *tg_thr2k = nullptr;
+        float *tg_traw = nullptr, *tg_thr2 = nullptr;
+        if (wide_tighten) {
+            SQ_TRY(s.wave_score.reserve((size_t)n_waves * wave_cap * 4));
+            SQ_TRY(s.tg.reserve((size_t)TG_MAX_Q * (TG_BINS + 3) * 4));
+            if (s.tg_zeroed != s.tg.p) {   // a new allocation: wiped once, dense_tighten_thr_kernel leaves the histogram clean
+                SQ_HIP(hipMemsetAsync(s.tg.p, 0, s.tg.cap, st));
+                s.tg_zeroed = s.tg.p;
+            }
+            tg_hist = s.tg.as<u32>();
+            tg_traw = reinterpret_cast<float*>(tg_hist + TG_MAX_Q * TG_BINS);
+            tg_thr2 = tg_traw + TG_MAX_Q;
+            tg_thr2k = reinterpret_cast<u32*>(tg_thr2 + TG_MAX_Q);
+        }
         // L2, one query tile per wave (the HBM-bound configuration a pipelined step runs): no prep launch -- the scan
         // kernels build the planes of their query tile themselves and the threshold kernel's prologue does the rest
         // (DenseScanArgs::raw_q, DenseThrPost).  The head of a call is then sample pass -> threshold: on a 1.25 M-row
@@ -853,8 +872,9 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             if (work < (long long)nrb * wv) a.nrb = (int)(((work + wv - 1) / wv + 7) / 8 * 8);
         }
         SQ_TRY(scan_launch<true>(h->opt, a, d_pad, qt, qp, st));
+        DenseThrPost tp{qn2, cosine ? 1 : 0, filter_bound(cosine ? 1 : 0, eps_a, eps_b, h->xn2_max)};
         {
-            DenseThrPost tp{qn2, cosine ? 1 : 0, filter_bound(cosine ? 1 : 0, eps_a, eps_b, h->xn2_max)};
+            tp.traw_out = tg_traw;
             if (fused_prep) {
                 tp.raw_q = q;
                 tp.nq = nq;
@@ -875,8 +895,18 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         a.n_sel = n_tiles;
         a.nrb = nrb;
         if (prof) SQ_HIP(hipEventRecord(s.ev[1], st));
+        a.wave_score = wide_tighten ? s.wave_score.as<float>() : nullptr;
         SQ_TRY(scan_launch<false>(h->opt, a, d_pad, qt, qp, st));
         if (prof) SQ_HIP(hipEventRecord(s.ev[2], st));
+        if (wide_tighten) {
+            DenseThrPost tp2 = tp;   // (the same slack rule, nothing else)
+            tp2.traw_out = nullptr;
+            tp2.raw_q = nullptr;
+            hipLaunchKernelGGL(dense_tighten_hist_kernel, dim3(64), dim3(256), 0, st, a.wave_out, a.wave_score, a.wave_cnt, wave_cap, n_waves,
+                               (const float*)thr, (const float*)tg_traw, nq_pad, tg_hist);
+            hipLaunchKernelGGL((dense_tighten_thr_kernel<DenseThrPost>), dim3((nq_pad + 63) / 64), dim3(64), 0, st, tg_hist, (const float*)thr,
+                               (const float*)tg_traw, nq, nq_pad, kk, tp2, tg_thr2, tg_thr2k);
+        }
         c.stats.scan_launches = 2;
         c.stats.bytes_scanned = h->n_pad * ((long long)d_pad * 2 + (cosine ? 0 : 4));
         // exact re-rank of the survivors (wave segments -> per-query keys), select, certify
@@ -891,23 +921,33 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         const size_t rr_lds = (qt == 1 && ldq <= 156) ? (size_t)32 * (ldq + 4) * 4 : 0;  // the query tile in LDS (rerank_block)
         const unsigned gxr = (unsigned)((n_waves + wpb - 1) / wpb);
         if (cosine) {
-            hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, s.q_al.as<float>(),
-                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<K128>(), cnt,
-                               cap, oflag, cnx, cnq, h->opt.dense_debug);
+            if (wide_tighten)
+                hipLaunchKernelGGL((dense_rerank_filtered_kernel<K128, true>), dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d,
+                                   s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<K128>(), cnt,
+                                   cap, oflag, cnx, cnq, h->opt.dense_debug, (const float*)a.wave_score, (const float*)tg_thr2);
+            else
+                hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, s.q_al.as<float>(),
+                                   ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<K128>(), cnt,
+                                   cap, oflag, cnx, cnq, h->opt.dense_debug);
             if (prof) SQ_HIP(hipEventRecord(s.ev[4], st));
-            SQ_TRY(select_launch_t<K128>(s.keys.as<K128>(), cnt, cap, key_stride, k, nq, s.out_keys.as<K128>(),
-                                         DenseFinalizeCos{cnt, cap, kk, h->id_base, thr, eps_a + eps_b, 1, (double*)out_dist,
-                                                          out_idx, hs_dev, hs_raw_dev, oflag, 0},
-                                         st, s.sort_tmp));
+            DenseFinalizeCos fin{cnt, cap, kk, h->id_base, thr, eps_a + eps_b, 1, (double*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0};
+            if (wide_tighten) fin.thr2k = tg_thr2k;
+            SQ_TRY(select_launch_t<K128>(s.keys.as<K128>(), cnt, cap, key_stride, k, nq, s.out_keys.as<K128>(), fin, st, s.sort_tmp));
         } else {
-            hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, s.q_al.as<float>(),
-                               ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<u64>(), cnt,
-                               cap, oflag, h->opt.dense_debug);
+            if (wide_tighten)
+                hipLaunchKernelGGL((dense_rerank_filtered_kernel<u64, false>), dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d,
+                                   s.q_al.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<u64>(), cnt,
+                                   cap, oflag, (const double*)nullptr, (const double*)nullptr, h->opt.dense_debug, (const float*)a.wave_score,
+                                   (const float*)tg_thr2);
+            else
+                hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3(gxr), dim3(rr_threads), rr_lds, st, h->db, h->ld, d, s.q_al.as<float>(),
+                                   ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, nq, group_q, s.keys.as<u64>(), cnt,
+                                   cap, oflag, h->opt.dense_debug);
             if (prof) SQ_HIP(hipEventRecord(s.ev[4], st));
-            SQ_TRY(select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(),
-                                        DenseFinalizeL2{cnt, cap, kk, h->id_base, thr, qn2, 0.5 * eps_a + eps_b, 1,
-                                                        (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0},
-                                        st, s.sort_tmp, 4 * stride * kk));   // ~2.7 stride k candidates per query on N(0,1) data
+            DenseFinalizeL2 fin{cnt, cap, kk, h->id_base, thr, qn2, 0.5 * eps_a + eps_b, 1, (float*)out_dist, out_idx, hs_dev, hs_raw_dev, oflag, 0};
+            if (wide_tighten) fin.thr2k = tg_thr2k;
+            SQ_TRY(select_launch_t<u64>(s.keys.as<u64>(), cnt, cap, key_stride, k, nq, s.out_keys.as<u64>(), fin, st, s.sort_tmp,
+                                        4 * stride * kk));   // ~2.7 stride k candidates per query on N(0,1) data
         }
     } else {
         c.all_fallback = true;  // rows wider than the MFMA scan covers: exact path for every query

@@ -874,6 +874,7 @@ struct DenseThrPost {
     u32* cnt = nullptr;
     u32* oflag = nullptr;
     float* q_al = nullptr;
+    float* traw_out = nullptr;   // optional: the threshold before the slack (sq_dense_tighten.hpp sizes its histogram bins with it)
     __device__ __forceinline__ void prologue(int q, double* red) const {
         if (!raw_q) return;
         const int T = blockDim.x;
@@ -902,6 +903,7 @@ struct DenseThrPost {
         __syncthreads();  // qn2[q] is read by the thread that publishes the threshold
     }
     __device__ __forceinline__ float operator()(int q, float t) const {
+        if (traw_out) traw_out[q] = t;
         if (!(t < __builtin_inff())) return t;
         double slack;
         if (cosine) {

@@ -266,6 +266,7 @@ struct DenseScanArgs {
     const float* raw_q;     // [raw_nq][raw_d] float32
     int raw_nq, raw_d;
     const float* center;    // [d_pad] or nullptr
+    float* wave_score;      // optional, parallel to wave_out: each entry's smallest filter score (sq_dense_wide.hpp -> sq_dense_tighten.hpp)
 };
 
 typedef __attribute__((address_space(3))) u32 lds_u32;

@@ -135,9 +135,10 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void dense_wide_scan_kernel(Den
                 if (!is_tail || ((tail_mask >> i) & 1u)) ml = fminf(ml, acc[i]);
             a.sample_out[(long long)qglob * a.ns + sel * 2 + h] = ml;
         } else {
-            float m = acc[0];
+            float m = __builtin_inff();   // (the rows that exist: a padding row's score is no row's)
 #pragma unroll
-            for (int i = 1; i < 16; ++i) m = fminf(m, acc[i]);
+            for (int i = 0; i < 16; ++i)
+                if (!is_tail || ((tail_mask >> i) & 1u)) m = fminf(m, acc[i]);
             const u64 hit = __ballot(m <= thr_l);
             if (hit != 0) {
                 u32 mask = le_mask16(acc, thr_l);
@@ -145,7 +146,10 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 2) void dense_wide_scan_kernel(Den
                 const u64 bal = __ballot(mask != 0);
                 if (mask) {
                     const u32 pos = wcount + __builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                    if (pos < a.wave_cap) wout[pos] = make_uint2((u32)(row0 + 4 * h), (mask << 16) | (u32)r31);
+                    if (pos < a.wave_cap) {
+                        wout[pos] = make_uint2((u32)(row0 + 4 * h), (mask << 16) | (u32)r31);
+                        if (a.wave_score) a.wave_score[wave_id * a.wave_cap + pos] = m;   // (second-level threshold: sq_dense_tighten.hpp)
+                    }
                 }
                 wcount += (u32)__popcll(bal);
             }
