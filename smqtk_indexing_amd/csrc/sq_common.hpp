@@ -75,7 +75,7 @@ struct Options {
     int dense_fused_prep = 1;    // 1 = L2 searches of one query tile build the query planes inside the scan kernels (no prep launch); 0 = dense_prep_queries_kernel
     int dense_int8_batch = 64;   // largest batch the int8 filter takes (33 .. 64: two query tiles per wave, 128-byte rows; up to 256: four tiles, which only ties with the bf16 kernels; 32 = one tile only)
     int dense_fused = 1;         // int8 calls of one query tile as three launches (head: query prep + sample pass + threshold by the last workgroup; full pass with the re-rank as its tail; select) instead of six; 0 = the six-launch chain
-    int dense_tighten = 1;       // fused int8 calls: the full pass histograms its entries' scores and its tail re-ranks only those under the tightened threshold (sq_dense_i8.hpp); 0 = every entry is re-ranked (measurement)
+    int dense_tighten = 1;       // fused int8 calls: the full pass histograms its entries' scores and its tail re-ranks only those under the tightened threshold (sq_dense_i8.hpp); rows beyond 512 dimensions: the second-level threshold of sq_dense_tighten.hpp between the pass and the re-rank; 0 = every entry is re-ranked (measurement)
     int dense_graph = 1;         // pipelined int8 calls: the call's kernels as one captured graph launch (0 = eager launches)
     int dense_int8 = -1;         // int8 first-stage filter (L2, d <= 128, one query tile): -1 = automatic, 0 = never (bf16 filter), 1 = whenever the copy exists
     int dense_mid_tier = 1;      // 1 = queries the bf16 filter could not certify get a second, tighter filter pass (three bf16 planes of the rows built on the fly) before the exact all-rows path; 0 = straight to the exact path

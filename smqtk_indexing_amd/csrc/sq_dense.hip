@@ -794,21 +794,24 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         SQ_TRY(s.wave_cnt.reserve((size_t)n_waves * 8));
         SQ_TRY(s.q_al.reserve((size_t)nq * ldq * 4));
         u32* oflag = s.oflag.as<u32>();
-        // rows beyond the ring kernels: a second-level threshold between the pass and the re-rank (sq_dense_tighten.hpp)
-        const bool wide_tighten = d_pad > RING_MAX_DPAD && h->opt.dense_tighten != 0 && nq_pad <= TG_MAX_Q;
+        // rows beyond the ring kernels: a second-level threshold between the pass and the re-rank (sq_dense_tighten.hpp).
+        // (The ring kernels do not store their entries' scores: the few instructions that would in dense_scan_kernel's
+        // emission path changed the answers of its hand-scheduled multi-tile builds -- one query of a hundred lost the
+        // survivors of its last row tiles -- and were taken out again; tools/tighten_debug.py.)
+        const bool wide_tighten = h->opt.dense_tighten != 0 && d_pad > RING_MAX_DPAD && group_q <= TG_MAX_GROUP && nq_pad <= TG_CAP_Q;
         u32 *tg_hist = nullptr, *tg_thr2k = nullptr;
         float *tg_traw = nullptr, *tg_thr2 = nullptr;
         if (wide_tighten) {
             SQ_TRY(s.wave_score.reserve((size_t)n_waves * wave_cap * 4));
-            SQ_TRY(s.tg.reserve((size_t)TG_MAX_Q * (TG_BINS + 3) * 4));
+            SQ_TRY(s.tg.reserve((size_t)TG_CAP_Q * (TG_BINS + 3) * 4));   // (fixed layout: the histogram region never meets old thresholds)
             if (s.tg_zeroed != s.tg.p) {   // a new allocation: wiped once, dense_tighten_thr_kernel leaves the histogram clean
                 SQ_HIP(hipMemsetAsync(s.tg.p, 0, s.tg.cap, st));
                 s.tg_zeroed = s.tg.p;
             }
             tg_hist = s.tg.as<u32>();
-            tg_traw = reinterpret_cast<float*>(tg_hist + TG_MAX_Q * TG_BINS);
-            tg_thr2 = tg_traw + TG_MAX_Q;
-            tg_thr2k = reinterpret_cast<u32*>(tg_thr2 + TG_MAX_Q);
+            tg_traw = reinterpret_cast<float*>(tg_hist + (size_t)TG_CAP_Q * TG_BINS);
+            tg_thr2 = tg_traw + TG_CAP_Q;
+            tg_thr2k = reinterpret_cast<u32*>(tg_thr2 + TG_CAP_Q);
         }
         // L2, one query tile per wave (the HBM-bound configuration a pipelined step runs): no prep launch -- the scan
         // kernels build the planes of their query tile themselves and the threshold kernel's prologue does the rest
@@ -902,8 +905,8 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
             DenseThrPost tp2 = tp;   // (the same slack rule, nothing else)
             tp2.traw_out = nullptr;
             tp2.raw_q = nullptr;
-            hipLaunchKernelGGL(dense_tighten_hist_kernel, dim3(64), dim3(256), 0, st, a.wave_out, a.wave_score, a.wave_cnt, wave_cap, n_waves,
-                               (const float*)thr, (const float*)tg_traw, nq_pad, tg_hist);
+            hipLaunchKernelGGL(dense_tighten_hist_kernel, dim3(nqt > 4 ? 16 : 64, nqt), dim3(256), 0, st, a.wave_out, a.wave_score, a.wave_cnt,
+                               wave_cap, n_waves, (const float*)thr, (const float*)tg_traw, group_q, tg_hist);
             hipLaunchKernelGGL((dense_tighten_thr_kernel<DenseThrPost>), dim3((nq_pad + 63) / 64), dim3(64), 0, st, tg_hist, (const float*)thr,
                                (const float*)tg_traw, nq, nq_pad, kk, tp2, tg_thr2, tg_thr2k);
         }

@@ -17,36 +17,40 @@
 namespace sq {
 
 static constexpr int TG_BINS = 64;
-static constexpr int TG_MAX_Q = 128;   // queries of a call (padded): the histogram of a workgroup is 32 KB of LDS
+static constexpr int TG_MAX_GROUP = 128;   // queries of a scan workgroup's group (32 x query tiles per wave)
+static constexpr int TG_CAP_Q = 4096 + 128;  // padded queries of a call (larger batches run in chunks of 4096)
 
-// hist: [nq_pad][TG_BINS], zero on entry (dense_tighten_thr_kernel wipes it)
+// hist: [nq_pad][TG_BINS], zero on entry (dense_tighten_thr_kernel wipes it).  Grid (slices, groups): block (x, g) walks
+// every gridDim.x-th wave segment of query group g (a segment's queries are its group's: wave_cnt[2 w + 1] = the group's
+// first query tile) with an LDS histogram of the group's queries.
 static __global__ __launch_bounds__(256) void dense_tighten_hist_kernel(const uint2* __restrict__ wave_out, const float* __restrict__ wave_score,
                                                                         const u32* __restrict__ wave_cnt, u32 wave_cap, long long n_waves,
                                                                         const float* __restrict__ thr, const float* __restrict__ traw,
-                                                                        int nq_pad, u32* __restrict__ hist) {
-    __shared__ u32 lh[TG_MAX_Q * TG_BINS];
-    for (int i = threadIdx.x; i < nq_pad * TG_BINS; i += 256) lh[i] = 0u;
+                                                                        int group_q, u32* __restrict__ hist) {
+    __shared__ u32 lh[TG_MAX_GROUP * TG_BINS];
+    const u32 g0 = (u32)blockIdx.y * (u32)group_q;   // the group's first query
+    for (int i = threadIdx.x; i < group_q * TG_BINS; i += 256) lh[i] = 0u;
     __syncthreads();
     for (long long w = blockIdx.x; w < n_waves; w += gridDim.x) {
+        if (wave_cnt[2 * w + 1] * 32u != g0) continue;   // (uniform)
         u32 c = wave_cnt[2 * w];
         if (c > wave_cap) c = wave_cap;
-        const u32 q0 = wave_cnt[2 * w + 1] * 32u;
         const uint2* seg = wave_out + w * wave_cap;
         const float* sc = wave_score + w * wave_cap;
         for (u32 e = threadIdx.x; e < c; e += 256) {
-            const u32 q = q0 + (seg[e].y & 0xffffu);
-            const float t1 = thr[q], wbin = (t1 - traw[q]) * 0.03125f;
+            const u32 ql = seg[e].y & 0xffffu;
+            const float t1 = thr[g0 + ql], wbin = (t1 - traw[g0 + ql]) * 0.03125f;
             int bin = 0;
             if (wbin > 0.f && wbin < __builtin_inff()) {
                 const float f = (t1 - sc[e]) / wbin;   // (m <= T': never negative; NaN -> bin 0)
                 bin = f >= (float)(TG_BINS - 1) ? TG_BINS - 1 : (f > 0.f ? (int)f : 0);
             }
-            atomicAdd(&lh[q * TG_BINS + bin], 1u);
+            atomicAdd(&lh[ql * TG_BINS + bin], 1u);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nq_pad * TG_BINS; i += 256)
-        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+    for (int i = threadIdx.x; i < group_q * TG_BINS; i += 256)
+        if (lh[i]) atomicAdd(&hist[(size_t)g0 * TG_BINS + i], lh[i]);
 }
 
 // one thread per query; thr2: the tightened thresholds, thr2k: their ordered keys (DenseFinalize*::thr2k)
