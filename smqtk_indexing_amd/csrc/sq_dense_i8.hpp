@@ -123,9 +123,11 @@ struct Dense8ClipArgs {
 template <int EPL>
 static __global__ __launch_bounds__(256) void dense8_clip_stats_kernel(const float* __restrict__ db, long long n, long long ld, int d,
                                                                         const float* __restrict__ center, const double* __restrict__ nx64,
-                                                                        Dense8ClipArgs ca, u32* __restrict__ counts) {
+                                                                        Dense8ClipArgs ca, u32* __restrict__ counts, int row_step) {
     const int lane = threadIdx.x & 63;
-    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    // (row_step > 1: every row_step-th row -- the counts only CHOOSE the clamp; the copy's own residuals are measured row by
+    // row by the build kernel and rows beyond the chosen bound are flagged from those)
+    const long long wave0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * row_step, nw = (long long)gridDim.x * 4 * row_step;
     u32 cnt[I8_NCLIP][I8_NCUT];
 #pragma unroll
     for (int c = 0; c < I8_NCLIP; ++c)
