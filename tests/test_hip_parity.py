@@ -118,9 +118,9 @@ def test_hamming_k_larger_than_n_and_id_base():
 
 
 # --------------------------------------------------------------------- dense
-def _dense_check(db, qs, k, metric="euclidean", exact_dist=True):
+def _dense_check(db, qs, k, metric="euclidean", exact_dist=True, options=None):
     m = _lib.SQ_METRIC_L2 if metric == "euclidean" else _lib.SQ_METRIC_COSINE
-    idx = _lib.DenseIndex(db, metric=m)
+    idx = _lib.DenseIndex(db, metric=m, options=options)      # (options: this index's own, sq_dense_create_opts)
     d, i = idx.search(qs, k)
     for qi, q in enumerate(qs):
         rd, ri = O.dense_topk(db, q, k, metric)
@@ -417,9 +417,9 @@ def test_dense_middle_tier_certifies_what_the_bf16_filter_cannot(d, family):
         off[0] = 100.0                                     # clusters at +-100 e_0, spread 0.5: |x - c| = 100 for every row
         db = (0.5 * db + np.where(np.arange(n)[:, None] % 2 == 0, off, -off)).astype(np.float32)
         qs[6:] = (0.5 * qs[6:] + off).astype(np.float32)
-    _lib.set_option("dense_int8", 0)                      # (the tiers behind the bf16 filter are the subject)
-    idx = _dense_check(db, qs, k)
-    st = idx.stats()
+    idx = _dense_check(db, qs, k, options={"dense_int8": 0})   # (the tiers behind the bf16 filter are the subject: this index
+    st = idx.stats()                                           #  keeps no int8 copy -- its own choice, nothing process-wide)
+    assert idx.info()["int8_copy_bytes"] == 0
     assert st["mid_tier_queries"] > 0, st
     assert st["fallback_queries"] <= st["mid_tier_queries"] // 4, st           # the tier certifies (almost) all it takes
     mid = st["mid_tier_queries"]
