@@ -797,7 +797,9 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // rows beyond the ring kernels: a second-level threshold between the pass and the re-rank (sq_dense_tighten.hpp).
         // (The ring kernels do not store their entries' scores: the few instructions that would in dense_scan_kernel's
         // emission path changed the answers of its hand-scheduled multi-tile builds -- one query of a hundred lost the
-        // survivors of its last row tiles -- and were taken out again; tools/tighten_debug.py.)
+        // survivors of its last row tiles -- and were taken out again; tools/tighten_debug.py.  In the compiler-scheduled
+        // one-tile builds alone they were correct but not worth it: 10 M x 128 without the int8 copy, 3.3 k -> 2.1 k rows
+        // re-ranked per query, 0.424 -> 0.451 ms per step: two more launches against 512-byte gathers.)
         const bool wide_tighten = h->opt.dense_tighten != 0 && d_pad > RING_MAX_DPAD && group_q <= TG_MAX_GROUP && nq_pad <= TG_CAP_Q;
         u32 *tg_hist = nullptr, *tg_thr2k = nullptr;
         float *tg_traw = nullptr, *tg_thr2 = nullptr;
