@@ -12,7 +12,9 @@
 // planes themselves (512 KB for 32 queries at 4096 dimensions) stay in L2.  Same inputs, outputs and error bound as
 // dense_scan_kernel's one-tile configuration (DenseScanArgs; scores = n' + x_hi (q_hi + q_lo)): the
 // sample pass, the threshold, the exact re-rank, the select and the certification around it are unchanged.
-// No DMA ring: the compiler's own counted waits order the loads.
+// No DMA ring: the compiler's own counted waits order the loads.  (Non-temporal row loads were tried: 2.63 instead of 1.57-1.68 ms
+// per pass -- a wave's load touches 32 bytes of 32 different rows and the other three quarters of each line are wanted by its
+// next three loads: without the caches every line is fetched four times.)
 #pragma once
 #include "sq_dense_scan.hpp"
 
