@@ -243,12 +243,18 @@ static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, int qt, int
 template <bool SAMPLE>
 static int scan_launch(const Options& o, const DenseScanArgs& a, int d_pad, int qt, int qp, hipStream_t st) {
     if (d_pad > RING_MAX_DPAD) {   // rows beyond the ring kernels: one query tile per wave, fragments straight from global memory
-        if (qt != 1) return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d takes one query tile per wave", d_pad);
+        if (qt != 1 && qt != 2) return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d takes one or two query tiles per wave", d_pad);
         const dim3 grid((unsigned)(a.nrb * a.nqt)), block(WIDE_WAVES * 64);
-        if (qp == 2)
-            hipLaunchKernelGGL((dense_wide_scan_kernel<2, SAMPLE>), grid, block, 0, st, a, d_pad / KT);
-        else
-            hipLaunchKernelGGL((dense_wide_scan_kernel<1, SAMPLE>), grid, block, 0, st, a, d_pad / KT);
+        if (qt == 2) {
+            if (qp == 2)
+                hipLaunchKernelGGL((dense_wide_scan_kernel<2, 2, SAMPLE>), grid, block, 0, st, a, d_pad / KT);
+            else
+                hipLaunchKernelGGL((dense_wide_scan_kernel<1, 2, SAMPLE>), grid, block, 0, st, a, d_pad / KT);
+        } else if (qp == 2) {
+            hipLaunchKernelGGL((dense_wide_scan_kernel<2, 1, SAMPLE>), grid, block, 0, st, a, d_pad / KT);
+        } else {
+            hipLaunchKernelGGL((dense_wide_scan_kernel<1, 1, SAMPLE>), grid, block, 0, st, a, d_pad / KT);
+        }
         return SQ_OK;
     }
     const ScanGeom g = scan_geometry(o, d_pad, qt, qp);
@@ -274,7 +280,8 @@ static double dense_eps_b(int d_pad) { return (3.0 * d_pad + 8.0) * 1.1920928955
 // many as the register budget allows (four at d_pad = 128, two beyond).
 static int scan_query_tiles(const Options& o, int d_pad, int nqt) {
     const int ku = d_pad / KT;
-    if (nqt <= 1 || d_pad > RING_MAX_DPAD) return 1;   // (sq_dense_wide.hpp: one tile per wave)
+    if (nqt <= 1) return 1;
+    if (d_pad > RING_MAX_DPAD) return o.dense_qt == 1 ? 1 : 2;   // (sq_dense_wide.hpp: two tiles per wave for batches beyond 32 queries)
     int want = nqt >= 3 ? 4 : 2;
     if (o.dense_qt == 1 || o.dense_qt == 2 || o.dense_qt == 4) want = o.dense_qt;
     if (ku >= 2 && want > 2) want = 2;  // four tiles of a 256-wide row spill past 512 registers
@@ -392,7 +399,8 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
     // query planes: the multi-tile configuration is MFMA bound, so it drops q_lo (half the MFMAs, twice the
     // product bound: ~1.4x more rows pass the filter) unless asked otherwise
     // (rows beyond the ring kernels, sq_dense_wide.hpp: two planes unless option dense_qplanes = 1 -- half the query bytes read from L2 per row tile, twice the slack)
-    const int qp = ((qt > 1 && (h->opt.dense_qplanes != 2 || d_pad > KT)) || (d_pad > RING_MAX_DPAD && h->opt.dense_qplanes == 1)) ? 1 : 2;
+    const int qp = d_pad > RING_MAX_DPAD ? (h->opt.dense_qplanes == 1 ? 1 : 2)
+                                        : ((qt > 1 && (h->opt.dense_qplanes != 2 || d_pad > KT)) ? 1 : 2);
     const int group_q = qt * TILE_ROWS;                                           // queries per scan workgroup
     const int nqt = (nq + group_q - 1) / group_q;                                 // groups of qt query tiles
     const int nq_pad = nqt * group_q;
@@ -783,7 +791,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
         // (one query tile per wave only: the multi-tile configurations are MFMA bound and want every CU)
         int nrb = h->opt.dense_blocks > 0 ? h->opt.dense_blocks : (use_event && h->opt.dense_async_streams == 2 && nqt == 1 ? cus * 3 / 4 : cus);
         // (the wide kernel, 122 registers and 32 KB of LDS: two eight-wave workgroups per CU -- twice the row bytes in flight)
-        if (d_pad > RING_MAX_DPAD && h->opt.dense_blocks <= 0) nrb = 2 * cus;
+        if (d_pad > RING_MAX_DPAD && h->opt.dense_blocks <= 0) nrb = qt == 1 ? 2 * cus : cus;   // (two tiles per wave: one workgroup per CU)
         nrb = (nrb + 7) / 8 * 8;
         const int wv = d_pad > RING_MAX_DPAD ? WIDE_WAVES : scan_geometry(h->opt, d_pad, qt, qp).waves;
         // survivors leave the scan as per-wave segments; the re-rank kernel turns them into per-query key lists
