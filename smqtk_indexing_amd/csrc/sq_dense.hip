@@ -243,9 +243,14 @@ static int scan_launch_ku(const DenseScanArgs& a, const ScanGeom& g, int qt, int
 template <bool SAMPLE>
 static int scan_launch(const Options& o, const DenseScanArgs& a, int d_pad, int qt, int qp, hipStream_t st) {
     if (d_pad > RING_MAX_DPAD) {   // rows beyond the ring kernels: one query tile per wave, fragments straight from global memory
-        if (qt != 1 && qt != 2) return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d takes one or two query tiles per wave", d_pad);
+        if (qt != 1 && qt != 2 && qt != 4) return fail(SQ_ERR_UNSUPPORTED, "dense scan: d_pad=%d takes one, two or four query tiles per wave", d_pad);
         const dim3 grid((unsigned)(a.nrb * a.nqt)), block(WIDE_WAVES * 64);
-        if (qt == 2) {
+        if (qt == 4) {
+            if (qp == 2)
+                hipLaunchKernelGGL((dense_wide_scan_kernel<2, 4, SAMPLE>), grid, block, 0, st, a, d_pad / KT);
+            else
+                hipLaunchKernelGGL((dense_wide_scan_kernel<1, 4, SAMPLE>), grid, block, 0, st, a, d_pad / KT);
+        } else if (qt == 2) {
             if (qp == 2)
                 hipLaunchKernelGGL((dense_wide_scan_kernel<2, 2, SAMPLE>), grid, block, 0, st, a, d_pad / KT);
             else
@@ -281,7 +286,10 @@ static double dense_eps_b(int d_pad) { return (3.0 * d_pad + 8.0) * 1.1920928955
 static int scan_query_tiles(const Options& o, int d_pad, int nqt) {
     const int ku = d_pad / KT;
     if (nqt <= 1) return 1;
-    if (d_pad > RING_MAX_DPAD) return o.dense_qt == 1 ? 1 : 2;   // (sq_dense_wide.hpp: two tiles per wave for batches beyond 32 queries)
+    if (d_pad > RING_MAX_DPAD) {   // (sq_dense_wide.hpp: two tiles per wave for batches beyond 32 queries, four beyond 64)
+        if (o.dense_qt == 1 || o.dense_qt == 2 || o.dense_qt == 4) return o.dense_qt;
+        return nqt >= 3 ? 4 : 2;
+    }
     int want = nqt >= 3 ? 4 : 2;
     if (o.dense_qt == 1 || o.dense_qt == 2 || o.dense_qt == 4) want = o.dense_qt;
     if (ku >= 2 && want > 2) want = 2;  // four tiles of a 256-wide row spill past 512 registers

@@ -24,8 +24,9 @@ static constexpr int WIDE_WAVES = 8;
 
 // LDS: two buffers of the query tiles' fragments of ONE k-unit: [tile][plane][query 0..31][16 chunks of 16 bytes, chunk c at
 // position c ^ (query & 15): the fragment reads of 16 consecutive queries then hit 16 different bank groups].
-// QT query tiles per wave (1, or 2 for batches beyond 32 queries: a row tile's fragments meet two sets of query fragments,
-// so a pass over the copy serves 64 queries -- half the passes of a large batch; 16 more accumulators per lane).
+// QT query tiles per wave (1; 2 / 4 for batches beyond 32 / 64 queries: a row tile's fragments meet QT sets of query
+// fragments, so a pass over the copy serves 32 QT queries -- a half / a quarter of the passes of a large batch; 16 more
+// accumulators per lane and tile, 16 KB more LDS per tile and buffer).
 template <int QP, int QT, bool SAMPLE>
 __global__ __launch_bounds__(WIDE_WAVES * 64, QT == 1 ? 2 : 1) void dense_wide_scan_kernel(DenseScanArgs a, int ku) {
     constexpr int TILE_BYTES = QP * TILE_ROWS * 256;   // one query tile's fragments of a k-unit
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, QT == 1 ? 2 : 1) void dense_wide_s
         if (a.norms) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x4 nv = *reinterpret_cast<const f32x4*>(a.norms + row0 + 8 * c + 4 * h);
+                // (norm_step 0: the cosine call of a multi-tile batch hands over 32 zeros for every tile, as to the ring kernels)
+                const f32x4 nv = *reinterpret_cast<const f32x4*>(a.norms + row0 * a.norm_step + 8 * c + 4 * h);
 #pragma unroll
                 for (int t = 0; t < QT; ++t)
 #pragma unroll

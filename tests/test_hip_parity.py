@@ -797,11 +797,12 @@ def test_dense_async_call_graph(graph):
 
 @pytest.mark.parametrize("metric,n,d,nq,k,qplanes", [("euclidean", 70_000, 1000, 2, 5, 0), ("euclidean", 80_000, 2048, 32, 100, 0),
                                                     ("euclidean", 66_000, 4096, 40, 10, 0), ("cosine", 70_000, 2048, 7, 10, 0),
-                                                    ("euclidean", 70_003, 1500, 33, 20, 1), ("euclidean", 66_001, 8192, 3, 3, 0)])
+                                                    ("euclidean", 70_003, 1500, 33, 20, 1), ("euclidean", 66_001, 8192, 3, 3, 0),
+                                                    ("euclidean", 66_000, 1024, 100, 10, 0), ("cosine", 66_000, 640, 130, 5, 0)])
 def test_dense_rows_wider_than_512_dimensions(metric, n, d, nq, k, qplanes):
     """Rows beyond the ring kernels' 512 padded dimensions (the reference's own examples index 2048- and 4096-d descriptors,
     docs/examples/caffe_build_index.rst:35): dense_wide_scan_kernel filters them from the bf16 copy -- fragments straight
-    from global memory, one query tile per wave, several tiles as groups -- and the exact re-rank (numpy's pairwise recursion
+    from global memory, one, two or four query tiles per wave by batch size -- and the exact re-rank (numpy's pairwise recursion
     at d > 128) answers; ids and float32 distance bits equal the oracle's, no query on the exact path."""
     rng = np.random.default_rng(d + nq)
     db = rng.standard_normal((n, d)).astype(np.float32)
