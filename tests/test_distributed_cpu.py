@@ -296,3 +296,48 @@ def test_shard_range_covers_rows():
             spans = [shard_range(n, w, r) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_hip_searcher_owns_the_handle_options_until_closed():
+    """HipSearcher writes a pipeline's depth / wait / order onto the index handle (sq_handle_set_option): a second live
+    asynchronous pipeline on the same handle is refused, close() puts the library's defaults (2 / 1 / 1) back and frees the
+    handle for the next pipeline; a blocking searcher touches nothing.  (Host logic only: a recording stand-in for the index.)"""
+    from smqtk_indexing_amd.distributed import HipSearcher
+
+    class FakeIndex:
+        async_option_prefix = "dense_async"
+
+        def __init__(self):
+            self.options, self.synced = [], 0
+
+        def set_option(self, name, value):
+            self.options.append((name, value))
+
+        def search_device_async(self, *a):
+            pass
+
+        def search_device(self, *a):
+            pass
+
+        def sync(self):
+            self.synced += 1
+
+    idx = FakeIndex()
+    s = HipSearcher(idx, 0, use_async=True, depth=3, wait=False, queries_ready=True)
+    assert s.lag == 3
+    assert idx.options == [("dense_async_depth", 3), ("dense_async_wait", 0), ("dense_async_order", 0)]
+    with pytest.raises(RuntimeError):
+        HipSearcher(idx, 0, use_async=True)
+    blocking = HipSearcher(idx, 0, use_async=False)            # no options of its own: allowed beside the pipeline
+    assert blocking.lag == 0 and len(idx.options) == 3
+    s.close()
+    assert idx.synced == 1
+    assert idx.options[3:] == [("dense_async_depth", 2), ("dense_async_wait", 1), ("dense_async_order", 1)]
+    s.close()                                                   # idempotent
+    assert len(idx.options) == 6
+    s2 = HipSearcher(idx, 0, use_async=True, depth=9)           # the handle is free again; depth clamps to 4
+    assert s2.lag == 3 and idx.options[6] == ("dense_async_depth", 4)
+    s2.close()
+    other = FakeIndex()                                         # pipelines on two handles do not meet
+    a, b = HipSearcher(idx, 0, use_async=True), HipSearcher(other, 0, use_async=True)
+    a.close(), b.close()
