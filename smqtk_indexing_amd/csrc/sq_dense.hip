@@ -121,13 +121,15 @@ struct DenseHandle : HandleBase {
     // workspace shared by all calls: host-memory staging, the exact path (runs synchronously), index build
     DevBuf q_dev, out_dist_dev, out_idx_dev, big_keys, fb_sample, fb_keys, fb_out, scratch, fb_cnt, fb_sort;
     DevBuf mid_q, mid_planes, mid_small, mid_qal, mid_wave_out, mid_wave_cnt, mid_keys, mid_out, mid_sample;  // the middle tier (synchronous)
+    DevBuf mid_cos_center, mid_cos_rows;   // cosine tier: column means c [d_pad], [2][mid_cos_ld] float32 1/|x| and x.c/|x| (built at first use)
+    long long mid_cos_n = -1, mid_cos_ld = 0;   // rows mid_cos_rows covers (an append makes it stale)
     PinnedStage stage;
     hipEvent_t ev_ref = nullptr;   // SQ_TRACE (measurement aid): the origin of the printed call timelines
     ~DenseHandle() override {
         if (ev_ref) (void)hipEventDestroy(ev_ref);
         for (DevBuf* b : {&owned, &scan, &scan8, &nrow8, &norms, &norms1, &zeros, &center, &cos_nx, &q_dev, &out_dist_dev, &out_idx_dev, &big_keys,
                           &fb_sample, &fb_keys, &fb_out, &scratch, &fb_cnt, &fb_sort, &mid_q, &mid_planes, &mid_small, &mid_qal,
-                          &mid_wave_out, &mid_wave_cnt, &mid_keys, &mid_out, &mid_sample})
+                          &mid_wave_out, &mid_wave_cnt, &mid_keys, &mid_out, &mid_sample, &mid_cos_center, &mid_cos_rows})
             b->release();
         for (auto& sl : slot) sl.release();
         stage.release();
@@ -1091,8 +1093,8 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
     if (todo.empty()) return SQ_OK;
     // ---- middle tier (sq_dense_mid.hpp): the uncertified queries of a filtered L2 call, 32 per pass over the float32
     // rows, scored with 64 times less slack; whatever it certifies is final, the rest goes on to the exact path
-    if (!all_fallback && !small && !force_fb && !cosine && h->opt.dense_mid_tier != 0 && d % 64 == 0 && d <= 512 &&
-        (reinterpret_cast<uintptr_t>(h->db) & 15u) == 0 && (h->ld & 3) == 0 && h->norms.p != nullptr) {
+    if (!all_fallback && !small && !force_fb && h->opt.dense_mid_tier != 0 && d % 64 == 0 && d <= 512 &&
+        (reinterpret_cast<uintptr_t>(h->db) & 15u) == 0 && (h->ld & 3) == 0 && (cosine ? h->cos_nx.p != nullptr : h->norms.p != nullptr)) {
         const int d_pad = h->d_pad;
         const int ldq = (d + 3) / 4 * 4;
         const double eps_b_mid = (4.0 * d_pad + 8.0) * 1.1920928955078125e-07;
@@ -1110,20 +1112,50 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
         SQ_TRY(h->mid_q.reserve((size_t)MID_MAX_Q * d * 4));
         SQ_TRY(h->mid_planes.reserve((size_t)MID_MAX_Q * d_pad * 4));
         // [qn2 f64 x32][thr f32 x32][cnt u32 x32][oflag u32 x16][qmap i32 x32]
-        SQ_TRY(h->mid_small.reserve(32 * 8 + 32 * 4 + 32 * 4 + 64 + 32 * 4));
+        // cosine adds [cnq f64 x32][qw f32 x32][lin float2 x32]
+        SQ_TRY(h->mid_small.reserve(32 * 8 + 32 * 4 + 32 * 4 + 64 + 32 * 4 + 32 * 8 + 32 * 4 + 32 * 8));
         SQ_TRY(h->mid_qal.reserve((size_t)MID_MAX_Q * ldq * 4));
         SQ_TRY(h->mid_wave_out.reserve((size_t)n_waves * wave_cap * 8));
         SQ_TRY(h->mid_wave_cnt.reserve((size_t)n_waves * 8));
-        SQ_TRY(h->mid_keys.reserve((size_t)MID_MAX_Q * cap * 8));
-        SQ_TRY(h->mid_out.reserve((size_t)MID_MAX_Q * k * 8));
+        SQ_TRY(h->mid_keys.reserve((size_t)MID_MAX_Q * cap * key_bytes));
+        SQ_TRY(h->mid_out.reserve((size_t)MID_MAX_Q * k * key_bytes));
         double* m_qn2 = h->mid_small.as<double>();
         float* m_thr = reinterpret_cast<float*>(m_qn2 + 32);
         u32* m_cnt = reinterpret_cast<u32*>(m_thr + 32);
         u32* m_oflag = m_cnt + 32;
         int* m_map = reinterpret_cast<int*>(m_oflag + 16);
-        static std::atomic<unsigned long long> attr8{0}, attr4{0};
-        if (waves == 8) SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense_mid_scan_kernel<8>), 160 * 1024, attr8));
-        if (waves == 4) SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense_mid_scan_kernel<4>), 160 * 1024, attr4));
+        double* m_cnq = reinterpret_cast<double*>(m_map + 32);
+        float* m_qw = reinterpret_cast<float*>(m_cnq + 32);
+        float2* m_lin = reinterpret_cast<float2*>(m_qw + 32);
+        static std::atomic<unsigned long long> attr8{0}, attr4{0}, attr8c{0}, attr4c{0};
+        if (waves == 8 && !cosine) SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense_mid_scan_kernel<8, false>), 160 * 1024, attr8));
+        if (waves == 4 && !cosine) SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense_mid_scan_kernel<4, false>), 160 * 1024, attr4));
+        if (waves == 8 && cosine) SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense_mid_scan_kernel<8, true>), 160 * 1024, attr8c));
+        if (waves == 4 && cosine) SQ_TRY(ensure_dyn_lds(reinterpret_cast<const void*>(&dense_mid_scan_kernel<4, true>), 160 * 1024, attr4c));
+        if (cosine && h->mid_cos_n != n) {
+            // the cosine tier's origin and per-row terms (sq_dense_mid.hpp), once per index and again after an append
+            if (!h->mid_cos_center.p) {
+                SQ_TRY(h->mid_cos_center.reserve((size_t)d_pad * 4));
+                DevBuf colsum;
+                SQ_TRY(colsum.reserve((size_t)d * 8));
+                SQ_HIP(hipMemsetAsync(colsum.p, 0, (size_t)d * 8, st));
+                const long long rpb = 512;
+                hipLaunchKernelGGL(dense_colsum_kernel, dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, st, h->db, n, h->ld, d, rpb,
+                                   colsum.as<double>());
+                hipLaunchKernelGGL(dense_center_kernel, dim3((d_pad + 255) / 256), dim3(256), 0, st, colsum.as<double>(), n, d, d_pad,
+                                   h->mid_cos_center.as<float>());
+                const hipError_t e = stream_wait(st);
+                colsum.release();
+                SQ_HIP(e);
+            }
+            h->mid_cos_ld = (n + 63) / 64 * 64;
+            SQ_TRY(h->mid_cos_rows.reserve((size_t)h->mid_cos_ld * 2 * 4));
+            hipLaunchKernelGGL(dense_mid_cos_rows_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, h->db, n, h->ld, d,
+                               (const float*)h->mid_cos_center.as<float>(), (const double*)h->cos_nx.as<double>(),
+                               h->mid_cos_rows.as<float>(), h->mid_cos_ld);
+            SQ_HIP(hipGetLastError());
+            h->mid_cos_n = n;
+        }
         // sample of true scores: every mid_stride-th row (about 64 k candidates per query pass the bound it gives)
         long long mid_stride = std::min<long long>(64, std::min<long long>((long long)cap / (8ll * kk), n / (8ll * kk)));
         if (mid_stride < 1) mid_stride = 1;
@@ -1140,14 +1172,27 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
             sel.count = (int)std::min<size_t>(MID_MAX_Q, todo.size() - t0);
             for (int j = 0; j < MID_MAX_Q; ++j) sel.idx[j] = todo[t0 + (size_t)(j < sel.count ? j : 0)];
             hipLaunchKernelGGL(dense_mid_gather_kernel, dim3(MID_MAX_Q), dim3(128), 0, st, q, d, sel, h->mid_q.as<float>(), m_map);
-            hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(MID_MAX_Q), dim3(256), 0, st, h->mid_q.as<float>(), sel.count, d, d_pad,
-                               h->metric, h->mid_planes.as<uint4>(), m_qn2, m_thr, m_cnt, m_oflag, h->mid_qal.as<float>(), ldq,
-                               h->center.p ? h->center.as<float>() : nullptr);
-            hipLaunchKernelGGL(dense_mid_sample_kernel, dim3((unsigned)((mid_ns + 7) / 8)), dim3(256), mid_sample_lds, st, h->db, h->ld, d, n,
-                               mid_stride, mid_ns, (const float*)h->mid_q.as<float>(), (const double*)m_qn2, h->mid_sample.as<float>());
-            hipLaunchKernelGGL((kth_threshold_f32_kernel<DenseMidThrPost>), dim3(sel.count), dim3(1024), 0, st, h->mid_sample.as<float>(),
-                               mid_ns, kk, m_thr,
-                               DenseMidThrPost{m_map, (const float*)out_dist, (const u32*)hs_dev, k, kk, m_qn2, fb_mid.beta});
+            if (cosine) {
+                hipLaunchKernelGGL(dense_mid_cos_queries_kernel, dim3(MID_MAX_Q), dim3(256), 0, st, h->mid_q.as<float>(), sel.count, d, d_pad,
+                                   (const float*)h->mid_cos_center.as<float>(), eps_b_mid, h->mid_planes.as<uint4>(), m_qn2, m_thr, m_cnt,
+                                   m_oflag, h->mid_qal.as<float>(), ldq, m_qw, m_lin);
+                hipLaunchKernelGGL(dense_cos_qnorm_kernel, dim3(1), dim3(64), 0, st, (const float*)h->mid_q.as<float>(), sel.count, d, m_cnq);
+                hipLaunchKernelGGL(dense_mid_cos_sample_kernel, dim3((unsigned)((mid_ns + 7) / 8)), dim3(256), mid_sample_lds, st, h->db, h->ld,
+                                   d, n, mid_stride, mid_ns, (const float*)h->mid_q.as<float>(), (const double*)m_qn2,
+                                   (const double*)h->cos_nx.as<double>(), h->mid_sample.as<float>());
+                hipLaunchKernelGGL((kth_threshold_f32_kernel<DenseMidCosThrPost>), dim3(sel.count), dim3(1024), 0, st,
+                                   h->mid_sample.as<float>(), mid_ns, kk, m_thr,
+                                   DenseMidCosThrPost{m_map, (const double*)out_dist, (const u32*)hs_dev, k, kk, (const float2*)m_lin});
+            } else {
+                hipLaunchKernelGGL(dense_prep_queries_kernel, dim3(MID_MAX_Q), dim3(256), 0, st, h->mid_q.as<float>(), sel.count, d, d_pad,
+                                   h->metric, h->mid_planes.as<uint4>(), m_qn2, m_thr, m_cnt, m_oflag, h->mid_qal.as<float>(), ldq,
+                                   h->center.p ? h->center.as<float>() : nullptr);
+                hipLaunchKernelGGL(dense_mid_sample_kernel, dim3((unsigned)((mid_ns + 7) / 8)), dim3(256), mid_sample_lds, st, h->db, h->ld, d, n,
+                                   mid_stride, mid_ns, (const float*)h->mid_q.as<float>(), (const double*)m_qn2, h->mid_sample.as<float>());
+                hipLaunchKernelGGL((kth_threshold_f32_kernel<DenseMidThrPost>), dim3(sel.count), dim3(1024), 0, st, h->mid_sample.as<float>(),
+                                   mid_ns, kk, m_thr,
+                                   DenseMidThrPost{m_map, (const float*)out_dist, (const u32*)hs_dev, k, kk, m_qn2, fb_mid.beta});
+            }
             DenseMidArgs a{};
             a.x = h->db;
             a.n = n;
@@ -1164,19 +1209,39 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
             a.wave_cap = wave_cap;
             a.n_tiles = n_tiles;
             a.nrb = nrb;
-            if (waves == 8)
-                hipLaunchKernelGGL((dense_mid_scan_kernel<8>), dim3(nrb), dim3(512), mid_lds, st, a);
-            else
-                hipLaunchKernelGGL((dense_mid_scan_kernel<4>), dim3(nrb), dim3(256), mid_lds, st, a);
+            a.rowstat = cosine ? h->mid_cos_rows.as<float>() : nullptr;
+            a.rowstat_ld = h->mid_cos_ld;
+            a.qw = m_qw;
+            if (cosine) {
+                if (waves == 8)
+                    hipLaunchKernelGGL((dense_mid_scan_kernel<8, true>), dim3(nrb), dim3(512), mid_lds, st, a);
+                else
+                    hipLaunchKernelGGL((dense_mid_scan_kernel<4, true>), dim3(nrb), dim3(256), mid_lds, st, a);
+            } else if (waves == 8) {
+                hipLaunchKernelGGL((dense_mid_scan_kernel<8, false>), dim3(nrb), dim3(512), mid_lds, st, a);
+            } else {
+                hipLaunchKernelGGL((dense_mid_scan_kernel<4, false>), dim3(nrb), dim3(256), mid_lds, st, a);
+            }
             const int wpb = 2;
             const size_t rr_lds = ldq <= 156 ? (size_t)32 * (ldq + 4) * 4 : 0;
-            hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, st, h->db, h->ld, d,
-                               h->mid_qal.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, sel.count, TILE_ROWS,
-                               h->mid_keys.as<u64>(), m_cnt, cap, m_oflag, 0);
-            DenseFinalizeL2 fin{m_cnt, cap, kk, h->id_base, m_thr, m_qn2, fb_mid.beta, 1, (float*)out_dist, out_idx, hs_dev, nullptr, m_oflag, 0};
-            fin.qmap = m_map;
-            SQ_TRY(select_launch_t<u64>(h->mid_keys.as<u64>(), m_cnt, cap, (long long)cap, k, sel.count, h->mid_out.as<u64>(), fin, st,
-                                        h->fb_sort));
+            if (cosine) {
+                hipLaunchKernelGGL(dense_rerank_cos_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, st, h->db, h->ld,
+                                   d, h->mid_qal.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, sel.count, TILE_ROWS,
+                                   h->mid_keys.as<K128>(), m_cnt, cap, m_oflag, cnx, (const double*)m_cnq, 0);
+                DenseFinalizeCos fin{m_cnt, cap, kk, h->id_base, m_thr, 0.0, 1, (double*)out_dist, out_idx, hs_dev, nullptr, m_oflag, 0};
+                fin.qmap = m_map;
+                fin.lin = m_lin;
+                SQ_TRY(select_launch_t<K128>(h->mid_keys.as<K128>(), m_cnt, cap, (long long)cap, k, sel.count, h->mid_out.as<K128>(), fin, st,
+                                             h->fb_sort));
+            } else {
+                hipLaunchKernelGGL(dense_rerank_l2_kernel, dim3((unsigned)((n_waves + wpb - 1) / wpb)), dim3(128 * wpb), rr_lds, st, h->db, h->ld, d,
+                                   h->mid_qal.as<float>(), ldq, a.wave_out, a.wave_cnt, wave_cap, n_waves, wpb, sel.count, TILE_ROWS,
+                                   h->mid_keys.as<u64>(), m_cnt, cap, m_oflag, 0);
+                DenseFinalizeL2 fin{m_cnt, cap, kk, h->id_base, m_thr, m_qn2, fb_mid.beta, 1, (float*)out_dist, out_idx, hs_dev, nullptr, m_oflag, 0};
+                fin.qmap = m_map;
+                SQ_TRY(select_launch_t<u64>(h->mid_keys.as<u64>(), m_cnt, cap, (long long)cap, k, sel.count, h->mid_out.as<u64>(), fin, st,
+                                            h->fb_sort));
+            }
             h->stats.scan_launches++;
             h->stats.bytes_scanned += n * (long long)d * 4;
             h->stats.mid_tier_queries += sel.count;

@@ -1013,8 +1013,10 @@ struct DenseFinalizeCos {
     const u32* thr2k = nullptr;           // as DenseFinalizeL2::thr2k
     int cnt_shift = 0;
     const DenseCallPtrs* ind = nullptr;   // captured call graph: the outputs of THIS launch
+    const int* qmap = nullptr;            // the middle tier: query ql of the launch is qmap[ql]; cnt, thr and lin are the launch's own arrays
     __device__ __forceinline__ void operator()(int ql, const K128* sorted, int k) const {
-        const int q = sel.count ? sel.idx[ql] : q0 + ql;
+        const int q = qmap ? qmap[ql] : (sel.count ? sel.idx[ql] : q0 + ql);
+        const int qa = qmap ? ql : q;  // index into thr / lin
         double* out_dist = ind ? static_cast<double*>(ind->out_dist) : this->out_dist;
         long long* out_idx = ind ? ind->out_idx : this->out_idx;
         for (int j = threadIdx.x; j < k; j += blockDim.x) {
@@ -1025,16 +1027,16 @@ struct DenseFinalizeCos {
         }
         if (threadIdx.x == 0) {
             u32 st = 0;
-            const u32 c = cnt[(long long)(sel.count ? ql : q) << cnt_shift];
+            const u32 c = cnt[(long long)((sel.count || qmap) ? ql : q) << cnt_shift];
             if (certify) {
                 if (c > cap || (overflow && *overflow)) st |= 1u;
                 if (c < (u32)kk) st |= 4u;
                 if (st == 0 && certify == 1) {
                     const double dk = unordered_f64(sorted[kk - 1].hi);
-                    const u32 t2k = thr2k ? thr2k[(long long)q << cnt_shift] : 0u;
-                    const double t = t2k ? (double)unordered_f32(t2k) : (double)thr[q];  // threshold on -sim~
+                    const u32 t2k = thr2k ? thr2k[(long long)qa << cnt_shift] : 0u;
+                    const double t = t2k ? (double)unordered_f32(t2k) : (double)thr[qa];  // threshold on -sim~
                     // non-candidates: -sim~ > t  =>  sim < -t + eps  =>  dist > 2 acos(min(1,-t+eps))/pi
-                    double smax = -t + (lin ? (double)lin[q].y : eps);
+                    double smax = -t + (lin ? (double)lin[qa].y : eps);
                     smax = smax > 1.0 ? 1.0 : (smax < -1.0 ? -1.0 : smax);
                     const double bound = 2.0 * acos(smax) / 3.141592653589793 - 1e-9;
                     if (!(t == (double)__builtin_inff()) && !(dk < bound)) st |= 2u;

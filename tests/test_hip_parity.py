@@ -433,6 +433,56 @@ def test_dense_middle_tier_certifies_what_the_bf16_filter_cannot(d, family):
     idx.close()
 
 
+@pytest.mark.parametrize("d,offset,int8", [(64, 50.0, -1), (128, 50.0, -1), (256, 8.0, 0), (512, 50.0, -1), (128, 20.0, 0)])
+def test_dense_cosine_middle_tier_offset_data(d, offset, int8):
+    """Cosine over descriptors that share a large offset (tools/int8_fuzz.py's "cosine offset" family: every similarity
+    within 1e-3 of 1, all rows inside the first filters' slack -- the round-3 review found every such query on the exact
+    all-rows path).  The cosine middle tier (sq_dense_mid.hpp: unit rows split into two bf16 planes on the fly, scores
+    taken about the column means so the error scales with |q - c|/|q|) certifies them; answers match the oracle's
+    restatement of metrics.cosine_distance (smqtk_indexing/utils/metrics.py:120-137) with and without the tier.
+    Also in the mix: zero rows and a row holding inf (NaN distance: last), a zero query, a query about the origin."""
+    rng = np.random.default_rng(700 + d + int(offset))
+    n, k = 200_000, 25
+    off = (offset * rng.standard_normal(d)).astype(np.float32)
+    db = (rng.standard_normal((n, d)).astype(np.float32) + off).astype(np.float32)
+    db[5] = 0.0
+    db[70_001] = 0.0
+    db[123_456, 3] = np.inf
+    qs = (rng.standard_normal((12, d)).astype(np.float32) + off).astype(np.float32)
+    qs[3] = db[777]                                        # a stored row: distance 0 (or an ulp) first
+    qs[10] = rng.standard_normal(d).astype(np.float32)      # about the origin, far from every row's direction
+    qs[11] = 0.0                                           # every distance NaN: rows in id order
+    options = {"dense_int8": int8} if int8 >= 0 else None
+    idx = _dense_check(db, qs, k, "cosine", options=options)
+    st = idx.stats()
+    assert st["mid_tier_queries"] >= 9, st
+    assert st["fallback_queries"] <= 3, st                  # (the zero query has nothing to certify; at most two more)
+    mid = st["mid_tier_queries"]
+    d1, i1 = idx.search(qs, k)
+    idx.set_option("dense_mid_tier", 0)
+    d0, i0 = idx.search(qs, k)
+    assert idx.stats()["fallback_queries"] >= mid and idx.stats()["mid_tier_queries"] == 0
+    np.testing.assert_array_equal(i0, i1)
+    np.testing.assert_array_equal(d0.view(np.uint64), d1.view(np.uint64))
+    # rows appended later are covered too (the tier's per-row terms are rebuilt for the grown index)
+    idx.set_option("dense_mid_tier", 1)
+    extra = (rng.standard_normal((5_000, d)).astype(np.float32) + off).astype(np.float32)
+    extra[17] = qs[0] * np.float32(3.0)                     # the same direction as query 0: distance ~0, must come first
+    idx.append(extra)
+    d2, i2 = idx.search(qs[:4], k)
+    assert idx.stats()["mid_tier_queries"] > 0
+    both = np.concatenate([db, extra])
+    for qi in range(4):
+        rd, ri = O.dense_topk(both, qs[qi], k, "cosine")
+        np.testing.assert_allclose(d2[qi], rd, rtol=1e-12, atol=1e-15)
+        mism = i2[qi] != ri
+        if mism.any():
+            full = O.dense_distances(both, qs[qi], "cosine")
+            assert np.abs(full[i2[qi][mism]] - full[ri[mism]]).max() < 1e-14
+    assert i2[0, 0] == n + 17 or d2[0, 0] == d2[0, 1]
+    idx.close()
+
+
 @pytest.mark.parametrize("metric", ["euclidean", "cosine"])
 def test_dense_exact_path_two_level_select(metric):
     """The exact path (forced here; also what rows wider than the scan covers take) selects in two
