@@ -49,6 +49,7 @@ struct DenseCall {
     long long* out_idx = nullptr;
     hipStream_t st = nullptr;     // the stream the call's kernels were enqueued on
     bool small = false, all_fallback = false, prof = false, use_event = false, int8 = false;
+    bool mid_direct = false;    // no first filter ran (it is suspended: DenseHandle::first_suspended): every query starts at the middle tier
     u32 cap = 0;                  // candidate-list length the call was enqueued with
     sq_stats_t stats{};
 };
@@ -123,6 +124,13 @@ struct DenseHandle : HandleBase {
     DevBuf mid_q, mid_planes, mid_small, mid_qal, mid_wave_out, mid_wave_cnt, mid_keys, mid_out, mid_sample;  // the middle tier (synchronous)
     DevBuf mid_cos_center, mid_cos_rows;   // cosine tier: column means c [d_pad], [2][mid_cos_ld] float32 1/|x| and x.c/|x| (built at first use)
     long long mid_cos_n = -1, mid_cos_ld = 0;   // rows mid_cos_rows covers (an append makes it stale)
+    // The first filters' candidate lists overflowed for most queries of three calls in a row (descriptors sharing a large
+    // offset under cosine, one tight cluster: every row inside the slack): calls go straight to the middle tier -- the
+    // overflowing pass, its re-rank of `cap` rows per query and its select bought nothing (2 M x 128 cosine, 32 queries:
+    // 5.6 of a 5.8 ms call).  The first filter is tried again every 256 such calls.
+    int overflow16 = 0;
+    bool first_suspended = false;
+    unsigned direct_calls = 0;
     PinnedStage stage;
     hipEvent_t ev_ref = nullptr;   // SQ_TRACE (measurement aid): the origin of the printed call timelines
     ~DenseHandle() override {
@@ -387,6 +395,13 @@ static int dense8_body_launch(int row_bytes, bool cosine, const Dense8ScanArgs& 
 }
 static int i8_waves(int row_bytes) { return row_bytes == 512 ? I8Geom<16>::WAVES : I8Geom<4>::WAVES; }
 
+// Shapes the middle tier covers (sq_dense_mid.hpp)
+static bool dense_mid_shape_ok(const DenseHandle* h) {
+    const bool cosine = h->metric == SQ_METRIC_COSINE;
+    return h->d % 64 == 0 && h->d <= 512 && (reinterpret_cast<uintptr_t>(h->db) & 15u) == 0 && (h->ld & 3) == 0 &&
+           (cosine ? h->cos_nx.p != nullptr : h->norms.p != nullptr);
+}
+
 // Enqueue one search (nq <= kDenseQueryChunk queries) on `st` with the workspace of slot `s`; nothing is
 // waited for.  dense_resolve() finishes the call: it waits for the kernels, reads the status words and
 // sends uncertified queries down the exact path.
@@ -498,6 +513,10 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                                                         (float*)out_dist, out_idx, hs_dev, hs_raw_dev, nullptr, 0},
                                         st, s.sort_tmp));
         }
+    } else if (scan_ok && h->first_suspended && h->opt.dense_mid_tier != 0 && !h->opt.force_fallback && dense_mid_shape_ok(h) &&
+               ++h->direct_calls % 256u != 0) {
+        c.all_fallback = true;   // (nothing enqueued: dense_resolve starts every query at the middle tier)
+        c.mid_direct = true;
     } else if (scan_ok && h->use8 && h->opt.dense_int8 != 0 && !(h->suspended8 && h->opt.dense_int8 < 0) && kk <= (cosine ? kSelectLdsKeys128 : kSelectLdsKeys64) &&
                (nq <= TILE_ROWS || (h->row8 == 128 && (qt == 2 || qt == 4) && nq <= h->opt.dense_int8_batch))) {
         // ---- the int8 first-stage filter (sq_dense_i8.hpp): half the bytes per row, measured error bound
@@ -1076,6 +1095,11 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
             const bool heavy = 2 * over > nq || cands > (long long)nq * std::max<long long>(24ll * 1024, n / 128);
             h->overflow8 = heavy ? h->overflow8 + 1 : 0;
             if (h->overflow8 >= 3 && h->opt.dense_int8 < 0) h->suspended8 = true;
+        } else if (!small) {
+            int over = 0;
+            for (int qi = 0; qi < nq; ++qi) over += (hs[qi] & 1u) ? 1 : 0;
+            h->overflow16 = 2 * over > nq ? h->overflow16 + 1 : 0;
+            h->first_suspended = h->overflow16 >= 3;
         }
     }
     // Exact full-keys path, a group of up to 8 queries per pass over the matrix (dense_exact_group_kernel):
@@ -1093,8 +1117,9 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
     if (todo.empty()) return SQ_OK;
     // ---- middle tier (sq_dense_mid.hpp): the uncertified queries of a filtered L2 call, 32 per pass over the float32
     // rows, scored with 64 times less slack; whatever it certifies is final, the rest goes on to the exact path
-    if (!all_fallback && !small && !force_fb && h->opt.dense_mid_tier != 0 && d % 64 == 0 && d <= 512 &&
-        (reinterpret_cast<uintptr_t>(h->db) & 15u) == 0 && (h->ld & 3) == 0 && (cosine ? h->cos_nx.p != nullptr : h->norms.p != nullptr)) {
+    if (c.mid_direct)
+        for (int qi = 0; qi < nq; ++qi) hs[qi] = 1u;   // (no first-filter result to take a bound from: DenseMid*ThrPost)
+    if ((!all_fallback || c.mid_direct) && !small && !force_fb && h->opt.dense_mid_tier != 0 && dense_mid_shape_ok(h)) {
         const int d_pad = h->d_pad;
         const int ldq = (d + 3) / 4 * 4;
         const double eps_b_mid = (4.0 * d_pad + 8.0) * 1.1920928955078125e-07;
