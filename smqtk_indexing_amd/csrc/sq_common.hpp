@@ -78,7 +78,7 @@ struct Options {
     int dense_tighten = 1;       // fused int8 calls: the full pass histograms its entries' scores and its tail re-ranks only those under the tightened threshold (sq_dense_i8.hpp); rows beyond 512 dimensions: the second-level threshold of sq_dense_tighten.hpp between the pass and the re-rank; 0 = every entry is re-ranked (measurement)
     int dense_graph = 1;         // pipelined int8 calls: the call's kernels as one captured graph launch (0 = eager launches)
     int dense_int8 = -1;         // int8 first-stage filter (L2, d <= 128, one query tile): -1 = automatic, 0 = never (bf16 filter), 1 = whenever the copy exists
-    int dense_mid_tier = 1;      // 1 = queries the bf16 filter could not certify get a second, tighter filter pass (three bf16 planes of the rows built on the fly) before the exact all-rows path; 0 = straight to the exact path
+    int dense_mid_tier = 1;      // 1 = queries the first filter could not certify get a second, tighter filter pass (L2 and cosine: bf16 planes of the float32 rows built on the fly) before the exact all-rows path, and calls start there once the first filter's lists overflow call after call; 0 = straight to the exact path
     int hamming_async_depth = 2; // asynchronous Hamming searches in flight (2..4), as dense_async_depth
     int hamming_async_wait = 1;  // as dense_async_wait
     int hamming_async_order = 1; // as dense_async_order
