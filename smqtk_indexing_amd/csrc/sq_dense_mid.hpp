@@ -338,8 +338,8 @@ static __global__ __launch_bounds__(256) void dense_mid_cos_rows_kernel(const fl
 }
 
 // The pass's queries for the cosine tier (one workgroup per query slot, the layout of dense_prep_queries_kernel):
-// planes of q' = -(q - c)/|q|, w = -1/|q|, the query's slack
-//     eps = (2^-14 + eps_b) |q - c|/|q| (1 + 1e-5) + 1e-6 (1 + |c|/|q|)
+// planes of q' = -(q_s - c)/|q_s|, w = -1/|q_s| (q_s: the query at the length closest to c), the query's slack
+//     eps = (2^-14 + eps_b) |q_s - c|/|q_s| (1 + 1e-5) + 1e-6 (1 + |c|/|q_s|)
 // (bf16 three-product error and float32 accumulation of the q' term; the float32 roundings of x^, q', u, w and of the
 // final fma), the float32 copy the re-rank reads, and the per-call state (threshold, counters, overflow flag).
 static __global__ __launch_bounds__(256) void dense_mid_cos_queries_kernel(const float* __restrict__ q, int nq, int d, int d_pad,
@@ -357,34 +357,53 @@ static __global__ __launch_bounds__(256) void dense_mid_cos_queries_kernel(const
     }
     if (qi < nq)
         for (int i = threadIdx.x; i < ldq; i += 256) q_al[(long long)qi * ldq + i] = i < d ? q[(long long)qi * d + i] : 0.f;
-    double a_q = 0.0, a_d = 0.0, a_c = 0.0;
+    // cosine does not see the query's length: the query is taken at the length that makes |q_s - c|/|q_s| smallest,
+    // q_s = s q with s = |c|^2/(q.c) (q_s - c perpendicular to c: the ratio is the sine of the angle between q and c, and
+    // |c|/|q_s| its cosine); a query at more than 90 degrees from c is taken so long that c does not matter (ratio -> 1)
+    double a_q = 0.0, a_qc = 0.0, a_c = 0.0;
     if (qi < nq)
         for (int i = threadIdx.x; i < d; i += 256) {
             const double v = (double)q[(long long)qi * d + i], c = (double)center[i];
             a_q += v * v;
-            a_d += (v - c) * (v - c);
+            a_qc += v * c;
             a_c += c * c;
         }
     for (int o = 32; o > 0; o >>= 1) {
         a_q += __shfl_xor(a_q, o);
-        a_d += __shfl_xor(a_d, o);
+        a_qc += __shfl_xor(a_qc, o);
         a_c += __shfl_xor(a_c, o);
     }
     if ((threadIdx.x & 63) == 0) {
         red[0][threadIdx.x >> 6] = a_q;
-        red[1][threadIdx.x >> 6] = a_d;
+        red[1][threadIdx.x >> 6] = a_qc;
         red[2][threadIdx.x >> 6] = a_c;
     }
     __syncthreads();
     const double tq = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    const double td = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double tqc = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const double tc = red[2][0] + red[2][1] + red[2][2] + red[2][3];
     const bool ok = qi < nq && tq > 0.0 && tq < 1e300;
-    const double scale = ok ? -1.0 / sqrt(tq) : 0.0;
+    double sq = 1.0;
+    if (ok && tqc > 0.0 && tc > 0.0) sq = tc / tqc;
+    else if (ok && tc > 0.0) sq = 1e3 * sqrt(tc / tq);
+    if (!(sq > 1e-30 && sq < 1e30)) sq = 1.0;
+    const double len = ok ? sq * sqrt(tq) : 0.0;       // |q_s|
+    const double scale = ok ? -1.0 / len : 0.0;
+    __syncthreads();
+    double a_d = 0.0;                                  // |q_s - c|^2, summed directly (the expanded form cancels)
+    if (ok)
+        for (int i = threadIdx.x; i < d; i += 256) {
+            const double t = (double)q[(long long)qi * d + i] * sq - (double)center[i];
+            a_d += t * t;
+        }
+    for (int o = 32; o > 0; o >>= 1) a_d += __shfl_xor(a_d, o);
+    if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = a_d;
+    __syncthreads();
+    const double td = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     if (threadIdx.x == 0) {
-        qn2[qi] = qi < nq ? tq : 0.0;
+        qn2[qi] = qi < nq ? tq : 0.0;                  // (the TRUE |q|^2: the sampled scores divide by it)
         qw[qi] = (float)scale;
-        const double rd = ok ? sqrt(td / tq) : 0.0, rc = ok ? sqrt(tc / tq) : 0.0;
+        const double rd = ok ? sqrt(td) / len : 0.0, rc = ok ? sqrt(tc) / len : 0.0;
         const double eps = (6.103515625e-05 + eps_b) * rd * (1.0 + 1e-5) + 1e-6 * (1.0 + rc);
         lin[qi] = make_float2(0.f, ok ? (float)(eps * (1.0 + 1e-6)) : __builtin_inff());   // (a zero / non-finite query: nothing certifies)
     }
@@ -400,7 +419,7 @@ static __global__ __launch_bounds__(256) void dense_mid_cos_queries_kernel(const
             for (int e = 0; e < 2; ++e) {
                 const int k = k0 + j + e;
                 float x = 0.f;
-                if (ok && k < d) x = (float)(((double)q[(long long)qi * d + k] - (double)center[k]) * scale);
+                if (ok && k < d) x = (float)(((double)q[(long long)qi * d + k] * sq - (double)center[k]) * scale);
                 u32 hi, lo;
                 bf16_split(x, hi, lo);
                 half[e] = p ? lo : hi;

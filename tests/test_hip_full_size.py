@@ -1,7 +1,8 @@
 """
 BASELINE.json's FULL per-GPU sizes on one MI355X.  The headline shape (10 M x 128 L2, k = 100) is compared
 LITERALLY with the oracle over all rows for a handful of queries (about 2 s of numpy per query:
-`test_dense_l2_10m_x_128_oracle_literal`); larger batches and the other shapes are checked through
+`test_dense_l2_10m_x_128_oracle_literal`; cosine over offset descriptors through the middle tier:
+`test_dense_cosine_10m_x_128_offset_oracle_literal`); larger batches and the other shapes are checked through
 size-independent properties: (a) structural -- ascending distances, a query that is a row finds itself first;
 (b) the returned distances recomputed by the oracle from the returned rows (a few hundred rows,
 bit-exact); (c) COMPLETENESS against a plain torch evaluation of every distance on the same
@@ -164,6 +165,78 @@ def test_dense_l2_10m_x_128_oracle_literal():
         assert index.stats()["fallback_queries"] == 0
         assert index.stats()["bytes_scanned"] != (-(-n // 64) * 64) * 132
         compare("bf16 filter", b, dist, ids)
+    index.close()
+
+
+def test_dense_cosine_10m_x_128_offset_oracle_literal():
+    """Cosine at the headline size over descriptors that share a 50-sigma offset (every list of the first filters
+    overflows) against the oracle itself over ALL 10 M rows (metrics.cosine_distance, smqtk_indexing/utils/metrics.py:120-137:
+    float64 distances within 1e-12, ids equal wherever the reference's distances differ): through the cosine middle tier behind
+    the overflowing first filters, then -- the filters suspended after three such calls -- with calls starting at the tier,
+    blocking and pipelined (SQ_MEM_DEVICE_ASYNC, three calls in flight).  Queries: a stored row scaled by 2.5 (distance 0
+    up to rounding), three random ones about the same offset."""
+    dev = _dev()
+    n, d, k, nq = 10_000_000, 128, 100, 32
+    g = torch.Generator(device=dev)
+    g.manual_seed(404)
+    off = torch.empty((d,), dtype=torch.float32, device=dev).normal_(generator=g) * 50.0
+    db = torch.empty((n, d), dtype=torch.float32, device=dev)
+    for s in range(0, n, 1 << 21):
+        db[s:s + (1 << 21)].normal_(generator=g).add_(off)
+    nb = 2
+    batches = [torch.empty((nq, d), dtype=torch.float32, device=dev).normal_(generator=g).add_(off) for _ in range(nb)]
+    batches[0][5] = db[7_654_321] * 2.5
+    checked = [(0, 5), (0, 0), (1, 31), (1, 9)]
+    dbh = np.empty((n, d), dtype=np.float32)
+    for s in range(0, n, 1 << 21):
+        dbh[s:s + (1 << 21)] = db[s:s + (1 << 21)].cpu().numpy()
+    want = {}
+    full = {}
+    for b, j in checked:
+        dist_all = O.dense_distances(dbh, batches[b][j].cpu().numpy(), "cosine")
+        order = np.argsort(dist_all, kind="stable")[:k]
+        want[(b, j)] = (dist_all[order], order.astype(np.int64))
+        full[(b, j)] = dist_all
+    del dbh
+    assert want[(0, 5)][1][0] == 7_654_321 and want[(0, 5)][0][0] < 1e-7
+
+    def compare(tag, b, dist, ids):
+        for (bb, j), (rd, ri) in want.items():
+            if bb != b:
+                continue
+            np.testing.assert_allclose(dist[j], rd, rtol=1e-12, atol=1e-15, err_msg=f"{tag}: distances of batch {b} query {j}")
+            mism = ids[j] != ri
+            if mism.any():   # only among distances the reference itself cannot tell apart
+                assert np.abs(full[(bb, j)][ids[j][mism]] - full[(bb, j)][ri[mism]]).max() < 1e-14, f"{tag}: ids of batch {b} query {j}"
+
+    index = _lib.DenseIndex(db.data_ptr(), n=n, d=d, metric=_lib.SQ_METRIC_COSINE, device_ptr=True, keepalive=db)
+    # (a) blocking calls: the first ones run the (overflowing) first filters in front of the tier, the later ones start at it
+    direct = 0
+    for i in range(10):
+        b = i % nb
+        dist, ids = _search_dense(index, batches[b], k, cosine=True)
+        st = index.stats()
+        assert st["mid_tier_queries"] == nq and st["fallback_queries"] == 0, st
+        direct += st["candidates"] == 0
+        compare(f"blocking call {i}", b, dist, ids)
+    assert direct >= 3 and st["candidates"] == 0 and st["bytes_scanned"] == n * d * 4      # one pass over the float32 rows
+    # (b) pipelined calls, three in flight
+    depth, steps = 3, 12
+    index.set_option("dense_async_depth", depth)
+    od = [torch.empty((nq, k), dtype=torch.float64, device=dev) for _ in range(depth)]
+    oi = [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(depth)]
+    got = {}
+    for i in range(steps):
+        slot = i % depth
+        if i >= depth:
+            got[(i - depth) % nb] = (od[slot].cpu().numpy().copy(), oi[slot].cpu().numpy().copy())
+        index.search_device_async(batches[i % nb].data_ptr(), nq, k, od[slot].data_ptr(), oi[slot].data_ptr(), _stream())
+    index.sync()
+    torch.cuda.synchronize()
+    for i in range(steps - depth, steps):
+        got[i % nb] = (od[i % depth].cpu().numpy().copy(), oi[i % depth].cpu().numpy().copy())
+    for b in range(nb):
+        compare("pipelined", b, *got[b])
     index.close()
 
 
