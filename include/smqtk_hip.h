@@ -262,8 +262,8 @@ int sq_dense_search(sq_handle_t h, const float* queries, int nq, int k,
  * Option "dense_graph" (1 by default): asynchronous int8 calls of one shape replay a captured graph (one launch per call).
  * Option "dense_mid_tier" (1 by default): queries the first filter cannot certify take a second, tighter filter over the
  * float32 rows (L2 and cosine, d % 64 == 0, d <= 512, 16-byte aligned rows) before the exact all-rows path; after three calls
- * in a row in which most candidate lists overflowed, calls skip the first filter and start there (it is tried again every
- * 256 calls).  0: uncertified queries go straight to the exact path.  Answers are the same bits either way
+ * in a row in which most candidate lists overflowed, calls skip the first filter and start there (it is tried again after
+ * 16 such calls, then 32, 64 ... 1024 while it keeps overflowing; the first probe that does not overflow re-arms it).  0: uncertified queries go straight to the exact path.  Answers are the same bits either way
  * (metrics.py:73-86, 120-137 arithmetic in the re-rank; every tier certifies or hands on). */
 int sq_dense_sync(sq_handle_t h);
 int sq_dense_destroy(sq_handle_t h);

@@ -127,10 +127,12 @@ struct DenseHandle : HandleBase {
     // The first filters' candidate lists overflowed for most queries of three calls in a row (descriptors sharing a large
     // offset under cosine, one tight cluster: every row inside the slack): calls go straight to the middle tier -- the
     // overflowing pass, its re-rank of `cap` rows per query and its select bought nothing (2 M x 128 cosine, 32 queries:
-    // 5.6 of a 5.8 ms call).  The first filter is tried again every 256 such calls.
+    // 5.6 of a 5.8 ms call).  The first filter is tried again after 16 such calls, then 32, 64 ... 1024 while it keeps
+    // overflowing (a burst of atypical queries costs sixteen slower calls, data of that geometry a probe in a thousand);
+    // the first probe that does not overflow re-arms it.
     int overflow16 = 0;
     bool first_suspended = false;
-    unsigned direct_calls = 0;
+    unsigned direct_calls = 0, probe_interval = 16;
     PinnedStage stage;
     hipEvent_t ev_ref = nullptr;   // SQ_TRACE (measurement aid): the origin of the printed call timelines
     ~DenseHandle() override {
@@ -514,7 +516,7 @@ static int dense_enqueue(DenseHandle* h, DenseSlot& s, const float* q, int nq, i
                                         st, s.sort_tmp));
         }
     } else if (scan_ok && h->first_suspended && h->opt.dense_mid_tier != 0 && !h->opt.force_fallback && dense_mid_shape_ok(h) &&
-               ++h->direct_calls % 256u != 0) {
+               ++h->direct_calls % h->probe_interval != 0) {
         c.all_fallback = true;   // (nothing enqueued: dense_resolve starts every query at the middle tier)
         c.mid_direct = true;
     } else if (scan_ok && h->use8 && h->opt.dense_int8 != 0 && !(h->suspended8 && h->opt.dense_int8 < 0) && kk <= (cosine ? kSelectLdsKeys128 : kSelectLdsKeys64) &&
@@ -1095,11 +1097,26 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
             const bool heavy = 2 * over > nq || cands > (long long)nq * std::max<long long>(24ll * 1024, n / 128);
             h->overflow8 = heavy ? h->overflow8 + 1 : 0;
             if (h->overflow8 >= 3 && h->opt.dense_int8 < 0) h->suspended8 = true;
-        } else if (!small) {
+        }
+        if (!small && (!c.int8 || h->opt.dense_int8 > 0)) {   // (an int8 stage in automatic mode suspends itself first, above)
             int over = 0;
             for (int qi = 0; qi < nq; ++qi) over += (hs[qi] & 1u) ? 1 : 0;
-            h->overflow16 = 2 * over > nq ? h->overflow16 + 1 : 0;
-            h->first_suspended = h->overflow16 >= 3;
+            const bool heavy = 2 * over > nq;
+            if (h->first_suspended) {          // this call was a probe
+                if (heavy) {
+                    h->probe_interval = std::min(1024u, 2u * h->probe_interval);
+                } else {
+                    h->first_suspended = false;
+                    h->overflow16 = 0;
+                    h->probe_interval = 16u;
+                }
+            } else {
+                h->overflow16 = heavy ? h->overflow16 + 1 : 0;
+                if (h->overflow16 >= 3) {
+                    h->first_suspended = true;
+                    h->direct_calls = 0;
+                }
+            }
         }
     }
     // Exact full-keys path, a group of up to 8 queries per pass over the matrix (dense_exact_group_kernel):

@@ -494,6 +494,40 @@ def test_dense_cosine_middle_tier_offset_data(d, offset, int8):
     idx.close()
 
 
+def test_dense_suspended_first_filter_is_rearmed():
+    """Three calls whose candidate lists all overflow (zero queries under cosine: every row scores the same) suspend the first
+    filter; ordinary queries then start at the middle tier, the sixteenth such call probes the first filter again, finds
+    it working and re-arms it.  Answers match the oracle in every state."""
+    rng = np.random.default_rng(909)
+    n, d, k = 100_000, 64, 10
+    db = rng.standard_normal((n, d)).astype(np.float32)
+    good = rng.standard_normal((8, d)).astype(np.float32)
+    zero = np.zeros((8, d), dtype=np.float32)
+    idx = _lib.DenseIndex(db, metric=_lib.SQ_METRIC_COSINE, options={"dense_int8": 0})
+    want = [O.dense_topk(db, q, k, "cosine") for q in good]
+
+    def check():
+        dist, ids = idx.search(good, k)
+        for qi in range(len(good)):
+            np.testing.assert_allclose(dist[qi], want[qi][0], rtol=1e-12, atol=1e-15)
+            np.testing.assert_array_equal(ids[qi], want[qi][1])
+        return idx.stats()
+
+    st = check()
+    assert st["candidates"] > 0 and st["mid_tier_queries"] == 0, st          # the first filter answers
+    for _ in range(3):
+        idx.search(zero, k)
+        assert idx.stats()["candidates"] == 8 * n
+    for i in range(15):
+        st = check()
+        assert st["candidates"] == 0 and st["mid_tier_queries"] == 8 and st["fallback_queries"] == 0, (i, st)
+    st = check()                                                              # the probe
+    assert st["candidates"] > 0 and st["mid_tier_queries"] == 0, st
+    st = check()                                                              # re-armed
+    assert st["candidates"] > 0 and st["mid_tier_queries"] == 0, st
+    idx.close()
+
+
 @pytest.mark.parametrize("metric", ["euclidean", "cosine"])
 def test_dense_exact_path_two_level_select(metric):
     """The exact path (forced here; also what rows wider than the scan covers take) selects in two
