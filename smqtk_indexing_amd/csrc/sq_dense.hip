@@ -400,7 +400,7 @@ static int i8_waves(int row_bytes) { return row_bytes == 512 ? I8Geom<16>::WAVES
 // Shapes the middle tier covers (sq_dense_mid.hpp)
 static bool dense_mid_shape_ok(const DenseHandle* h) {
     const bool cosine = h->metric == SQ_METRIC_COSINE;
-    return h->d % 64 == 0 && h->d <= 512 && (reinterpret_cast<uintptr_t>(h->db) & 15u) == 0 && (h->ld & 3) == 0 &&
+    return h->d <= 512 && (reinterpret_cast<uintptr_t>(h->db) & 15u) == 0 && (h->ld & 3) == 0 && h->ld >= (h->d + 3) / 4 * 4 && h->n >= 32 &&
            (cosine ? h->cos_nx.p != nullptr : h->norms.p != nullptr);
 }
 

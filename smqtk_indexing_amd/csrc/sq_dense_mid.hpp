@@ -17,7 +17,7 @@
 // evaluates the TRUE scores of every 64th row in float64 -- their k-th smallest bounds the k-th smallest of all rows
 // with no filter error in it -- and, when the first filter's candidate list was complete, the k-th exact distance
 // found there is used if it is smaller.
-// Shapes: d % 64 == 0, d <= 512, rows 16-byte aligned (everything else keeps the exact path).
+// Shapes: d <= 512, rows 16-byte aligned with a stride of whole 16-byte chunks (everything else keeps the exact path).
 //
 // Cosine (round 4; metrics.cosine_similarity, smqtk_indexing/utils/metrics.py:89-137): the same stream with the rows
 // scaled to unit length in registers (x^ = x / |x|, float32) and the score taken about the column means c of the rows,
@@ -43,7 +43,7 @@ static constexpr double kEpsAMid = 1.220703125e-04;
 struct DenseMidArgs {
     const float* x;        // [n][ld] float32 rows
     long long n, ld;
-    int d;                 // d % 64 == 0
+    int d;                 // <= 512 (the last 64-float unit of a row may be partial)
     const float* center;   // [d_pad] or nullptr
     const float* norms;    // [n_pad] the first filter's stored norms n' = RD(|x'|^2 (1 - alpha1))
     float norm_scale;      // c1 = (1 - alpha_mid) / (1 - alpha1), rounded down
@@ -75,7 +75,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_mid_scan_kernel(D
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r31 = lane & 31, h = lane >> 5;
-    const int D = a.d, DPAD = a.d_pad, KU = D / 64;
+    const int D = a.d, DPAD = a.d_pad, KU = (D + 63) / 64;
+    // rows that do not fill their last 64-float unit: the lanes whose 16-byte source chunk lies beyond the row fetch the
+    // unit's first chunk instead (in bounds; the query planes are zero there, so a finite value contributes nothing and a
+    // non-finite one belongs to a row whose score is NaN anyway)
+    const int tail_chunks = (D & 63) ? ((D & 63) + 3) / 4 : 16;
     // LDS: [query planes 32 x DPAD*4][centre DPAD*4][rings]
     const u32 q_bytes = (u32)TILE_ROWS * DPAD * 4, c_bytes = (u32)DPAD * 4;
     const u32 lds_base = (u32)(uintptr_t)smem;
@@ -119,8 +123,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void dense_mid_scan_kernel(D
         if (row0 + 32 > a.n) row0 = a.n - 32;   // the last tile: the window moves back, rows below `shift` are masked out
         const u32 dst = ring_base + (u32)iss_slot * MID_SLOT_BYTES;
         const unsigned char* base = reinterpret_cast<const unsigned char*>(a.x) + row0 * a.ld * 4 + iss_kc * 256;
+        if (tail_chunks < 16 && iss_kc == KU - 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) glds16<true>(base, voff[j], dst + (u32)j * 1024);
+            for (int j = 0; j < 8; ++j) {
+                const int sc = (lane & 15) ^ ((4 * j + (lane >> 4)) & 15);
+                glds16<true>(base, sc < tail_chunks ? voff[j] : voff[j] - (u32)sc * 16u, dst + (u32)j * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) glds16<true>(base, voff[j], dst + (u32)j * 1024);
+        }
         if (iss_kc == 0) glds4((COS ? a.rowstat : a.norms) + row0, voff_norm, dst + MID_UNIT_BYTES);
         ++issued;
         if (++iss_kc == KU) {
