@@ -261,7 +261,7 @@ int sq_dense_search(sq_handle_t h, const float* queries, int nq, int k,
  * Option "dense_int8_batch" (64 by default): the largest batch the int8 filter takes (128-byte rows; 32 = one query tile only).
  * Option "dense_graph" (1 by default): asynchronous int8 calls of one shape replay a captured graph (one launch per call).
  * Option "dense_mid_tier" (1 by default): queries the first filter cannot certify take a second, tighter filter over the
- * float32 rows (L2 and cosine, d % 64 == 0, d <= 512, 16-byte aligned rows) before the exact all-rows path; after three calls
+ * float32 rows (L2 and cosine, d <= 512, 16-byte aligned rows) before the exact all-rows path; after three calls
  * in a row in which most candidate lists overflowed, calls skip the first filter and start there (it is tried again after
  * 16 such calls, then 32, 64 ... 1024 while it keeps overflowing; the first probe that does not overflow re-arms it).  0: uncertified queries go straight to the exact path.  Answers are the same bits either way
  * (metrics.py:73-86, 120-137 arithmetic in the re-rank; every tier certifies or hands on). */
