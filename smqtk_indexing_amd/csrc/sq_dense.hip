@@ -1105,6 +1105,7 @@ static int dense_resolve(DenseHandle* h, DenseSlot& s) {
             if (h->first_suspended) {          // this call was a probe
                 if (heavy) {
                     h->probe_interval = std::min(1024u, 2u * h->probe_interval);
+                    h->direct_calls = 0;   // (the next probe a whole interval from here)
                 } else {
                     h->first_suspended = false;
                     h->overflow16 = 0;

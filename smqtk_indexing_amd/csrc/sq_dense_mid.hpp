@@ -281,7 +281,17 @@ static __global__ __launch_bounds__(256) void dense_mid_sample_kernel(const floa
     const long long row = i * stride < n ? i * stride : n - 1;
     const float* x = db + row * ld;
     double acc = 0.0;
-    for (int k = 0; k < d; ++k) {
+    int k = 0;
+    for (; k + 4 <= d; k += 4) {   // (rows are 16-byte aligned with a stride of whole chunks: dense_mid_shape_ok)
+        const float4 xv = *reinterpret_cast<const float4*>(x + k);
+        const double t0 = (double)xv.x - (double)lq[k * 33 + j], t1 = (double)xv.y - (double)lq[(k + 1) * 33 + j];
+        const double t2 = (double)xv.z - (double)lq[(k + 2) * 33 + j], t3 = (double)xv.w - (double)lq[(k + 3) * 33 + j];
+        acc = fma(t0, t0, acc);
+        acc = fma(t1, t1, acc);
+        acc = fma(t2, t2, acc);
+        acc = fma(t3, t3, acc);
+    }
+    for (; k < d; ++k) {
         const double t = (double)x[k] - (double)lq[k * 33 + j];
         acc = fma(t, t, acc);
     }
@@ -462,7 +472,15 @@ static __global__ __launch_bounds__(256) void dense_mid_cos_sample_kernel(const 
     const long long row = i * stride < n ? i * stride : n - 1;
     const float* x = db + row * ld;
     double acc = 0.0;
-    for (int k = 0; k < d; ++k) acc = fma((double)x[k], (double)lq[k * 33 + j], acc);
+    int k = 0;
+    for (; k + 4 <= d; k += 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + k);
+        acc = fma((double)xv.x, (double)lq[k * 33 + j], acc);
+        acc = fma((double)xv.y, (double)lq[(k + 1) * 33 + j], acc);
+        acc = fma((double)xv.z, (double)lq[(k + 2) * 33 + j], acc);
+        acc = fma((double)xv.w, (double)lq[(k + 3) * 33 + j], acc);
+    }
+    for (; k < d; ++k) acc = fma((double)x[k], (double)lq[k * 33 + j], acc);
     const double sc = -acc / sqrt(nx64[row] * qn2_mid[j]) + 1e-12;
     float r = (float)sc;
     if ((double)r < sc) r = __uint_as_float(__float_as_uint(r) + (r >= 0.f ? 1 : -1));
